@@ -1,0 +1,908 @@
+/* jb_oracle.c — CPU fp64 RESTATEMENT of the Jitterbug hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under jitterbug_amd/ may import, link or
+ * execute this file; it is the checker for the HIP path (tests/, smoke(),
+ * bench.py's cpu_baseline leg).
+ *
+ * PARITY PIN STATUS: the physics part (substep) is "parity unpinned" against
+ * the reference's MuJoCo 2.0: the reference ships no golden vectors or tests
+ * and MuJoCo/dm_control are absent from /root/reference and from this image
+ * (SURVEY.md §8c).  It is pinned only by the closed-form known-answer tests of
+ * SURVEY.md §8(c) (tests/test_oracle_kat.py) and by internal cross-checks
+ * (independent numpy dynamics, conservation laws, KKT of the contact solve).
+ * The observation / reward / reset parts follow the reference's own Python
+ * line by line and are pinned by the KATs derived from that text.
+ *
+ * What is restated, and from where:
+ *  - model tables: include/jitterbug_model.h   (reference: jitterbug.xml:1-148)
+ *  - substep     : MuJoCo 2.0 forward dynamics + Euler step as driven by
+ *                  dm_control Physics.step() (mj_step2 then mj_step1), reached
+ *                  from reference jitterbug.py:84-90 (control.Environment, 50
+ *                  substeps per control step).  Third-party; pipeline restated
+ *                  from MuJoCo's published documentation / source:
+ *                  kinematics -> joint-space inertia M -> bias (Coriolis,
+ *                  centrifugal, gravity) -> passive spring/damper -> actuator
+ *                  -> plane collisions -> pyramidal soft contacts (solref /
+ *                  solimp impedance, diagApprox regulariser) -> convex contact
+ *                  problem (MuJoCo: Newton; here: its dual by PGS run to
+ *                  convergence, same unique optimum) -> semi-implicit Euler with
+ *                  implicit joint damping.
+ *  - accessors   : reference jitterbug.py:180-317
+ *  - reset       : reference jitterbug.py:601-666 (RNG replaced by Philox4x32-10
+ *                  counter streams keyed (seed, env, episode))
+ *  - observation : reference jitterbug.py:673-763, tables :324-372
+ *  - reward      : reference jitterbug.py:840-925 + dm_control rewards.tolerance
+ *
+ * Algorithmic choice: the dynamics are assembled by the projection (Kane)
+ * form  M = sum_b m Jv^T Jv + Jw^T I Jw,  bias_k = sum_b Jv_k.F_b + Jw_k.N_b
+ * in world axes — deliberately NOT the root-frame composite-body / Schur
+ * scheme the HIP kernel uses, so that agreement between the two is evidence.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#include "../include/jitterbug_model.h"
+
+#define NB JB_NBODY
+#define NV JB_NV
+#define NQ JB_NQ
+#define NH JB_NHINGE
+#define MAXCON 64
+#define MAXROW (4 * MAXCON)
+#define WARM_SIZE (JB_NGEOM * 16 + JB_NV)   /* pyramid forces by (geom,slot,edge) + last qacc */
+
+static const int PARENT[NB] = {-1, 0, 1, 0, 3, 0, 5, 0, 7, 0};
+
+typedef struct {
+    int contacts;        /* 1: plane contacts on                                   */
+    int implicit_damp;   /* 1: Euler treats joint damping implicitly (MuJoCo)      */
+    int solver_iters;    /* max PGS sweeps                                          */
+    double solver_tol;   /* stop when max |df| * scale < tol (0: run all sweeps)   */
+    int warmstart;       /* 1: start PGS from the forces in the warm buffer        */
+    int feet_only;       /* 1: only the 4 foot spheres collide                     */
+    int solver;          /* 0: dual PGS, 1: primal Newton with exact line search   */
+                         /*    (MuJoCo 2.0's default solver; same unique optimum)  */
+} jbo_opts;
+
+typedef struct {
+    int ncon_last, ncon_max;
+    int sweeps_total, sweeps_max;
+    int nsolve;
+    int overflow;
+    double resid_max;
+} jbo_stats;
+
+/* ------------------------------------------------------------------ small math */
+static inline void cross3(double* o, const double* a, const double* b) {
+    double x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+    o[0] = x; o[1] = y; o[2] = z;
+}
+static inline double dot3(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+static inline void matvec3(double* o, const double* R, const double* v) {
+    double x = R[0] * v[0] + R[1] * v[1] + R[2] * v[2];
+    double y = R[3] * v[0] + R[4] * v[1] + R[5] * v[2];
+    double z = R[6] * v[0] + R[7] * v[1] + R[8] * v[2];
+    o[0] = x; o[1] = y; o[2] = z;
+}
+static inline void matTvec3(double* o, const double* R, const double* v) {
+    double x = R[0] * v[0] + R[3] * v[1] + R[6] * v[2];
+    double y = R[1] * v[0] + R[4] * v[1] + R[7] * v[2];
+    double z = R[2] * v[0] + R[5] * v[1] + R[8] * v[2];
+    o[0] = x; o[1] = y; o[2] = z;
+}
+static inline void matmul3(double* o, const double* A, const double* B) {
+    double t[9];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) t[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+    memcpy(o, t, sizeof t);
+}
+/* mju_quat2Mat (used by reference jitterbug.py:200,270,287,300) */
+static void quat2mat(double* R, const double* q) {
+    double w = q[0], x = q[1], y = q[2], z = q[3];
+    R[0] = w * w + x * x - y * y - z * z; R[1] = 2 * (x * y - w * z);           R[2] = 2 * (x * z + w * y);
+    R[3] = 2 * (x * y + w * z);           R[4] = w * w - x * x + y * y - z * z; R[5] = 2 * (y * z - w * x);
+    R[6] = 2 * (x * z - w * y);           R[7] = 2 * (y * z + w * x);           R[8] = w * w - x * x - y * y + z * z;
+}
+static void rodrigues(double* R, const double* e, double th) {
+    double c = cos(th), s = sin(th), v = 1 - c;
+    R[0] = c + e[0] * e[0] * v;        R[1] = e[0] * e[1] * v - e[2] * s; R[2] = e[0] * e[2] * v + e[1] * s;
+    R[3] = e[1] * e[0] * v + e[2] * s; R[4] = c + e[1] * e[1] * v;        R[5] = e[1] * e[2] * v - e[0] * s;
+    R[6] = e[2] * e[0] * v - e[1] * s; R[7] = e[2] * e[1] * v + e[0] * s; R[8] = c + e[2] * e[2] * v;
+}
+
+/* ------------------------------------------------------------------ kinematics */
+typedef struct {
+    double R[NB][9], t[NB][3];      /* reference (root@qpos0) coords -> world: X = R x0 + t */
+    double com[NB][3], Iw[NB][9];   /* world COM and inertia tensor about it, world axes */
+    double anchor[NB][3], axis[NB][3]; /* world hinge anchor/axis of body b's own hinge (b>=1) */
+    double mass[NB];
+} Kin;
+
+static void kinematics(const double* P, double* qpos, Kin* k) {
+    /* MuJoCo normalises the free-joint quaternion in place (mj_kinematics). */
+    double* q = qpos + 3;
+    double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    if (n < 1e-15) { q[0] = 1; q[1] = q[2] = q[3] = 0; } else { for (int i = 0; i < 4; i++) q[i] /= n; }
+    quat2mat(k->R[0], q);
+    for (int i = 0; i < 3; i++) k->t[0][i] = qpos[i];
+    for (int b = 1; b < NB; b++) {
+        const double* H = P + JB_P_HINGE + (b - 1) * JB_HINGE_STRIDE;
+        int p = PARENT[b];
+        double Rj[9], tmp[3], a_rot[3];
+        rodrigues(Rj, H + JB_H_AXIS, qpos[7 + (b - 1)]);
+        matmul3(k->R[b], k->R[p], Rj);
+        matvec3(a_rot, Rj, H + JB_H_ANCHOR);
+        for (int i = 0; i < 3; i++) tmp[i] = H[JB_H_ANCHOR + i] - a_rot[i];
+        matvec3(k->t[b], k->R[p], tmp);
+        for (int i = 0; i < 3; i++) k->t[b][i] += k->t[p][i];
+        matvec3(k->anchor[b], k->R[p], H + JB_H_ANCHOR);
+        for (int i = 0; i < 3; i++) k->anchor[b][i] += k->t[p][i];
+        matvec3(k->axis[b], k->R[p], H + JB_H_AXIS);
+    }
+    for (int b = 0; b < NB; b++) {
+        const double* B = P + JB_P_BODY + b * JB_BODY_STRIDE;
+        k->mass[b] = B[JB_B_MASS];
+        matvec3(k->com[b], k->R[b], B + JB_B_COM);
+        for (int i = 0; i < 3; i++) k->com[b][i] += k->t[b][i];
+        const double* ii = B + JB_B_INERTIA;
+        double I0[9] = {ii[0], ii[3], ii[4], ii[3], ii[1], ii[5], ii[4], ii[5], ii[2]}, T[9], Rt[9];
+        matmul3(T, k->R[b], I0);
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Rt[3 * i + j] = k->R[b][3 * j + i];
+        matmul3(k->Iw[b], T, Rt);
+    }
+}
+
+/* Jacobian columns of body b for world point x: Jv (3xNV), Jw (3xNV), column-major by dof */
+static void jacobian(const Kin* k, int b, const double* x, double Jv[NV][3], double Jw[NV][3]) {
+    memset(Jv, 0, sizeof(double) * NV * 3);
+    memset(Jw, 0, sizeof(double) * NV * 3);
+    for (int j = 0; j < 3; j++) Jv[j][j] = 1.0;            /* root translation: world axes */
+    double r[3];
+    for (int j = 0; j < 3; j++) {                          /* root rotation: body-local axes through root origin */
+        double e[3] = {k->R[0][j], k->R[0][3 + j], k->R[0][6 + j]};
+        for (int i = 0; i < 3; i++) { Jw[3 + j][i] = e[i]; r[i] = x[i] - k->t[0][i]; }
+        cross3(Jv[3 + j], e, r);
+    }
+    for (int a = b; a > 0; a = PARENT[a]) {
+        int d = 5 + a;
+        for (int i = 0; i < 3; i++) { Jw[d][i] = k->axis[a][i]; r[i] = x[i] - k->anchor[a][i]; }
+        cross3(Jv[d], k->axis[a], r);
+    }
+}
+
+/* M (NVxNV row-major), bias (Coriolis+centrifugal+gravity) in MuJoCo dof coordinates */
+static void dynamics(const double* P, const Kin* k, const double* qvel, double* M, double* bias) {
+    static const double zero3[3] = {0, 0, 0};
+    double Jv[NB][NV][3], Jw[NB][NV][3];
+    memset(M, 0, sizeof(double) * NV * NV);
+    for (int b = 0; b < NB; b++) {
+        jacobian(k, b, k->com[b], Jv[b], Jw[b]);
+        for (int i = 0; i < NV; i++) {
+            double IJw[3];
+            matvec3(IJw, k->Iw[b], Jw[b][i]);
+            for (int j = 0; j <= i; j++)
+                M[i * NV + j] += k->mass[b] * dot3(Jv[b][i], Jv[b][j]) + dot3(IJw, Jw[b][j]);
+        }
+    }
+    for (int i = 0; i < NV; i++) for (int j = 0; j < i; j++) M[j * NV + i] = M[i * NV + j];
+
+    /* velocity-product accelerations with qacc = 0, gravity folded in as -g at the root */
+    const double* g = P + JB_P_GRAVITY;
+    double w[NB][3], al[NB][3], ref[NB][3], Aref[NB][3];
+    matvec3(w[0], k->R[0], qvel + 3);
+    memcpy(al[0], zero3, sizeof zero3);
+    for (int i = 0; i < 3; i++) { ref[0][i] = k->t[0][i]; Aref[0][i] = -g[i]; }
+    memset(bias, 0, sizeof(double) * NV);
+    for (int b = 0; b < NB; b++) {
+        if (b > 0) {
+            int p = PARENT[b];
+            double qd = qvel[5 + b], r[3], t1[3], t2[3];
+            for (int i = 0; i < 3; i++) w[b][i] = w[p][i] + k->axis[b][i] * qd;
+            cross3(t1, w[p], k->axis[b]);
+            for (int i = 0; i < 3; i++) al[b][i] = al[p][i] + t1[i] * qd;
+            for (int i = 0; i < 3; i++) { r[i] = k->anchor[b][i] - ref[p][i]; ref[b][i] = k->anchor[b][i]; }
+            cross3(t1, al[p], r);
+            cross3(t2, w[p], r); cross3(t2, w[p], t2);
+            for (int i = 0; i < 3; i++) Aref[b][i] = Aref[p][i] + t1[i] + t2[i];
+        }
+        double r[3], t1[3], t2[3], ac[3], F[3], N[3], Iw_[3], Ial[3];
+        for (int i = 0; i < 3; i++) r[i] = k->com[b][i] - ref[b][i];
+        cross3(t1, al[b], r);
+        cross3(t2, w[b], r); cross3(t2, w[b], t2);
+        for (int i = 0; i < 3; i++) { ac[i] = Aref[b][i] + t1[i] + t2[i]; F[i] = k->mass[b] * ac[i]; }
+        matvec3(Iw_, k->Iw[b], w[b]);
+        matvec3(Ial, k->Iw[b], al[b]);
+        cross3(t1, w[b], Iw_);
+        for (int i = 0; i < 3; i++) N[i] = Ial[i] + t1[i];
+        for (int d = 0; d < NV; d++) bias[d] += dot3(Jv[b][d], F) + dot3(Jw[b][d], N);
+    }
+}
+
+/* dense Cholesky A = L L^T (lower, in place), n<=NV; returns 0 on success */
+static int chol(double* A, int n, int ld) {
+    for (int j = 0; j < n; j++) {
+        double s = A[j * ld + j];
+        for (int k = 0; k < j; k++) s -= A[j * ld + k] * A[j * ld + k];
+        if (!(s > 0)) return -1;
+        double d = sqrt(s);
+        A[j * ld + j] = d;
+        for (int i = j + 1; i < n; i++) {
+            double t = A[i * ld + j];
+            for (int k = 0; k < j; k++) t -= A[i * ld + k] * A[j * ld + k];
+            A[i * ld + j] = t / d;
+        }
+    }
+    return 0;
+}
+static void chol_solve(const double* L, int n, int ld, double* x) {
+    for (int i = 0; i < n; i++) { double s = x[i]; for (int k = 0; k < i; k++) s -= L[i * ld + k] * x[k]; x[i] = s / L[i * ld + i]; }
+    for (int i = n - 1; i >= 0; i--) { double s = x[i]; for (int k = i + 1; k < n; k++) s -= L[k * ld + i] * x[k]; x[i] = s / L[i * ld + i]; }
+}
+
+/* ------------------------------------------------------------------ collisions */
+typedef struct { double dist, pos[3]; int body, geom, slot; } Contact;
+
+/* All against the floor plane z=0 with normal +z (reference: jitterbug.xml:30).
+ * Restates MuJoCo's mjc_PlaneSphere / mjc_PlaneCylinder / mjc_PlaneBox /
+ * mjc_PlaneConvex(ellipsoid support point).  A contact exists when dist < 0
+ * (margin 0). */
+static int add_contact(Contact* c, int n, double dist, const double* pos, int body, int geom, int slot) {
+    if (n >= MAXCON) return n;
+    c[n].dist = dist; c[n].pos[0] = pos[0]; c[n].pos[1] = pos[1]; c[n].pos[2] = pos[2];
+    c[n].body = body; c[n].geom = geom; c[n].slot = slot;
+    return n + 1;
+}
+static int collide(const double* P, const Kin* k, int feet_only, Contact* con, int* overflow) {
+    static const double nz[3] = {0, 0, 1};
+    int n = 0;
+    for (int g = 0; g < JB_NGEOM; g++) {
+        const double* G = P + JB_P_GEOM + g * JB_GEOM_STRIDE;
+        int type = (int)G[JB_G_TYPE], b = (int)G[JB_G_BODY];
+        if (feet_only && !(g >= 4 && g < 20 && ((g - 4) & 3) == 3)) continue;
+        double c[3], Rg[9], pos[3];
+        matvec3(c, k->R[b], G + JB_G_CENTER);
+        for (int i = 0; i < 3; i++) c[i] += k->t[b][i];
+        matmul3(Rg, k->R[b], G + JB_G_ROT);
+        const double* sz = G + JB_G_SIZE;
+        int n0 = n;
+        if (type == JB_GEOM_SPHERE) {
+            double dist = c[2] - sz[0];
+            if (dist < 0) { for (int i = 0; i < 3; i++) pos[i] = c[i] - nz[i] * (sz[0] + 0.5 * dist); n = add_contact(con, n, dist, pos, b, g, 0); }
+        } else if (type == JB_GEOM_ELLIPSOID) {
+            /* support point of the ellipsoid in direction -n */
+            double dl[3], mnz[3] = {0, 0, -1}, s[3], sw[3];
+            matTvec3(dl, Rg, mnz);
+            double den = sqrt(sz[0] * sz[0] * dl[0] * dl[0] + sz[1] * sz[1] * dl[1] * dl[1] + sz[2] * sz[2] * dl[2] * dl[2]);
+            for (int i = 0; i < 3; i++) s[i] = sz[i] * sz[i] * dl[i] / den;
+            matvec3(sw, Rg, s);
+            for (int i = 0; i < 3; i++) sw[i] += c[i];
+            double dist = sw[2];
+            if (dist < 0) { for (int i = 0; i < 3; i++) pos[i] = sw[i] - nz[i] * 0.5 * dist; n = add_contact(con, n, dist, pos, b, g, 0); }
+        } else if (type == JB_GEOM_BOX) {
+            int cnt = 0;
+            for (int v = 0; v < 8 && cnt < 4; v++) {
+                double l[3] = {(v & 1 ? sz[0] : -sz[0]), (v & 2 ? sz[1] : -sz[1]), (v & 4 ? sz[2] : -sz[2])}, vec[3];
+                matvec3(vec, Rg, l);
+                double dist = c[2] + vec[2];
+                if (dist < 0) {
+                    for (int i = 0; i < 3; i++) pos[i] = c[i] + vec[i] - nz[i] * 0.5 * dist;
+                    n = add_contact(con, n, dist, pos, b, g, cnt); cnt++;
+                }
+            }
+        } else { /* cylinder */
+            double axis[3] = {Rg[2], Rg[5], Rg[8]}, vec[3];
+            double prjaxis = axis[2];
+            if (prjaxis > 0) { for (int i = 0; i < 3; i++) axis[i] = -axis[i]; prjaxis = -prjaxis; }
+            double dist0 = c[2];
+            for (int i = 0; i < 3; i++) vec[i] = axis[i] * prjaxis - nz[i];
+            double len2 = dot3(vec, vec);
+            if (len2 >= 1e-30) { double s = sz[0] / sqrt(len2); for (int i = 0; i < 3; i++) vec[i] *= s; }
+            else { vec[0] = Rg[0] * sz[0]; vec[1] = Rg[3] * sz[0]; vec[2] = Rg[6] * sz[0]; }
+            double prjvec = vec[2];
+            double ax[3] = {axis[0] * sz[1], axis[1] * sz[1], axis[2] * sz[1]};
+            prjaxis *= sz[1];
+            double d1 = dist0 + prjaxis + prjvec;
+            if (d1 < 0) {
+                for (int i = 0; i < 3; i++) pos[i] = c[i] + vec[i] + ax[i] - nz[i] * 0.5 * d1;
+                n = add_contact(con, n, d1, pos, b, g, 0);
+                double d2 = dist0 - prjaxis + prjvec;
+                if (d2 < 0) {
+                    for (int i = 0; i < 3; i++) pos[i] = c[i] + vec[i] - ax[i] - nz[i] * 0.5 * d2;
+                    n = add_contact(con, n, d2, pos, b, g, 1);
+                }
+                double prjvec1 = -0.5 * prjvec, d3 = dist0 + prjaxis + prjvec1;
+                if (d3 < 0) {
+                    double vec1[3];
+                    cross3(vec1, vec, ax);
+                    double l = sqrt(dot3(vec1, vec1));
+                    if (l > 1e-300) { double s = sz[0] * sqrt(3.0) * 0.5 / l; for (int i = 0; i < 3; i++) vec1[i] *= s; }
+                    for (int i = 0; i < 3; i++) pos[i] = c[i] + vec1[i] + ax[i] - 0.5 * vec[i] - nz[i] * 0.5 * d3;
+                    n = add_contact(con, n, d3, pos, b, g, 2);
+                    for (int i = 0; i < 3; i++) pos[i] = c[i] - vec1[i] + ax[i] - 0.5 * vec[i] - nz[i] * 0.5 * d3;
+                    n = add_contact(con, n, d3, pos, b, g, 3);
+                }
+            }
+        }
+        if (n == MAXCON && n0 != n) *overflow = 1;
+    }
+    return n;
+}
+
+/* impedance d(r) (MuJoCo solimp, 5-parameter form) */
+static double impedance(const double* solimp, double r) {
+    double d0 = solimp[0], dw = solimp[1], width = solimp[2], mid = solimp[3], pw = solimp[4];
+    double x = fabs(r) / width, y;
+    if (x >= 1) return dw;
+    if (x <= 0) return d0;
+    if (pw == 1) y = x;
+    else if (x <= mid) y = pow(x / mid, pw) * mid;           /* a x^p, a = 1/mid^(p-1) */
+    else y = 1 - pow((1 - x) / (1 - mid), pw) * (1 - mid);   /* 1 - b (1-x)^p        */
+    return d0 + y * (dw - d0);
+}
+
+/* debug taps for the tests */
+typedef struct {
+    int ncon, nrow;
+    double con_dist[MAXCON], con_pos[MAXCON][3];
+    int con_geom[MAXCON];
+    double f[MAXROW], aref[MAXROW], Rdiag[MAXROW], jar[MAXROW];   /* jar = J qacc - aref at the solution */
+    double M[NV * NV], bias[NV], tau[NV], qacc_smooth[NV], qacc[NV], qfrc_constraint[NV];
+} jbo_debug;
+
+/* ------------------------------------------------------------------ one substep */
+/* warm: optional [WARM_SIZE]: pyramid forces keyed by (geom, contact slot, edge), then the last qacc */
+static void substep(const double* P, double* qpos, double* qvel, double ctrl, const jbo_opts* o,
+                    double* warm, jbo_stats* st, jbo_debug* dbg) {
+    Kin k;
+    double M[NV * NV], L[NV * NV], bias[NV], tau[NV], qacc_s[NV], qfc[NV];
+    const double h = P[JB_P_TIMESTEP];
+    kinematics(P, qpos, &k);
+    dynamics(P, &k, qvel, M, bias);
+
+    /* passive (spring + damper, springref = 0) and actuator (general: gain*ctrl + bias) */
+    for (int d = 0; d < NV; d++) tau[d] = -bias[d];
+    for (int j = 0; j < NH; j++) {
+        const double* H = P + JB_P_HINGE + j * JB_HINGE_STRIDE;
+        tau[6 + j] += -H[JB_H_STIFFNESS] * qpos[7 + j] - H[JB_H_DAMPING] * qvel[6 + j];
+    }
+    double u = ctrl;
+    if (u < P[JB_P_CTRLRANGE]) u = P[JB_P_CTRLRANGE];
+    if (u > P[JB_P_CTRLRANGE + 1]) u = P[JB_P_CTRLRANGE + 1];
+    {
+        double gear = P[JB_P_GEAR], len = gear * qpos[15], vel = gear * qvel[14];
+        double force = P[JB_P_GAIN] * u + P[JB_P_BIASPRM] + P[JB_P_BIASPRM + 1] * len + P[JB_P_BIASPRM + 2] * vel;
+        tau[14] += gear * force;
+    }
+
+    memset(qfc, 0, sizeof qfc);
+    Contact con[MAXCON];
+    int ncon = 0, overflow = 0;
+    if (o->contacts) ncon = collide(P, &k, o->feet_only, con, &overflow);
+    if (dbg) { dbg->ncon = ncon; dbg->nrow = 0; memcpy(dbg->M, M, sizeof M); memcpy(dbg->bias, bias, sizeof bias); memcpy(dbg->tau, tau, sizeof tau); }
+
+    if (ncon > 0 || dbg) {
+        memcpy(L, M, sizeof M);
+        chol(L, NV, NV);
+        memcpy(qacc_s, tau, sizeof tau);
+        chol_solve(L, NV, NV, qacc_s);
+        if (dbg) memcpy(dbg->qacc_smooth, qacc_s, sizeof qacc_s);
+    }
+    if (ncon > 0) {
+        const int nr = 4 * ncon;
+        const double mu = P[JB_P_FRICTION] * sqrt(1.0 / P[JB_P_IMPRATIO]);
+        const double* solref = P + JB_P_SOLREF;
+        const double* solimp = P + JB_P_SOLIMP;
+        double tc = solref[0] < 2 * h ? 2 * h : solref[0];
+        double dmax = solimp[1];
+        double Kk = 1.0 / (dmax * dmax * tc * tc * solref[1] * solref[1]);
+        double Bb = 2.0 / (dmax * tc);
+        /* rows */
+        double (*J)[NV] = malloc(sizeof(double) * NV * nr);
+        double (*MJ)[NV] = malloc(sizeof(double) * NV * nr);
+        double* A = malloc(sizeof(double) * nr * nr);
+        double *b = malloc(sizeof(double) * nr), *Rr = malloc(sizeof(double) * nr), *f = malloc(sizeof(double) * nr), *aref = malloc(sizeof(double) * nr);
+        for (int c = 0; c < ncon; c++) {
+            double Jv[NV][3], Jw[NV][3];
+            jacobian(&k, con[c].body, con[c].pos, Jv, Jw);
+            /* contact frame: x = normal (0,0,1); MuJoCo mju_makeFrame -> y = (0,1,0), z = x cross y = (-1,0,0) */
+            double imp = impedance(solimp, con[c].dist);
+            double tran = P[JB_P_BODY + con[c].body * JB_BODY_STRIDE + JB_B_INVW_TRAN];   /* + world body: 0 */
+            double fr = P[JB_P_FRICTION];
+            double dA = tran + fr * fr * tran;
+            double R0 = (1 - imp) / imp * dA;
+            if (R0 < 1e-15) R0 = 1e-15;
+            double Rpy = 2 * mu * mu * R0;
+            for (int e = 0; e < 4; e++) {
+                int r = 4 * c + e;
+                double sgn = (e & 1) ? -1.0 : 1.0;
+                double vel = 0;
+                for (int d = 0; d < NV; d++) {
+                    double jn = Jv[d][2];
+                    double jt = (e < 2) ? Jv[d][1] : -Jv[d][0];
+                    J[r][d] = jn + sgn * mu * jt;
+                    vel += J[r][d] * qvel[d];
+                }
+                Rr[r] = Rpy;
+                aref[r] = -Bb * vel - Kk * imp * con[c].dist;
+                for (int d = 0; d < NV; d++) MJ[r][d] = J[r][d];
+                chol_solve(L, NV, NV, MJ[r]);
+                double a0 = 0;
+                for (int d = 0; d < NV; d++) a0 += J[r][d] * qacc_s[d];
+                b[r] = a0 - aref[r];
+                f[r] = (warm && o->warmstart) ? warm[(con[c].geom * 4 + con[c].slot) * 4 + e] : 0.0;
+            }
+        }
+        for (int i = 0; i < nr; i++)
+            for (int j = 0; j < nr; j++) { double s = 0; for (int d = 0; d < NV; d++) s += J[i][d] * MJ[j][d]; A[i * nr + j] = s; }
+        int sweeps = 0;
+        double resid = 0;
+        if (o->solver == 0) {
+            /* projected Gauss-Seidel on the dual  min 1/2 f'(A+R)f + f'b, f>=0 */
+            for (int it = 0; it < o->solver_iters; it++) {
+                double maxd = 0;
+                for (int i = 0; i < nr; i++) {
+                    double s = b[i] + Rr[i] * f[i];
+                    for (int j = 0; j < nr; j++) s += A[i * nr + j] * f[j];
+                    double fn = f[i] - s / (A[i * nr + i] + Rr[i]);
+                    if (fn < 0) fn = 0;
+                    double dd = fabs(fn - f[i]) * (A[i * nr + i] + Rr[i]);   /* in acceleration units */
+                    if (dd > maxd) maxd = dd;
+                    f[i] = fn;
+                }
+                sweeps++;
+                resid = maxd;
+                if (o->solver_tol > 0 && maxd < o->solver_tol) break;
+            }
+        } else {
+            /* primal Newton (MuJoCo's default solver):
+             *   min_x 1/2 (x-xs)' M (x-xs) + sum_i 1/(2 R_i) min(0, J_i x - aref_i)^2
+             * exact Hessian on the active set + exact line search on the
+             * piecewise-quadratic cost.  Warm start: previous qacc (qacc_warmstart)
+             * if its cost is lower than that of qacc_smooth. */
+            double x[NV], g[NV], p[NV], H[NV * NV], Mp[NV];
+            double *r = malloc(sizeof(double) * nr), *sj = malloc(sizeof(double) * nr), *bp = malloc(sizeof(double) * nr);
+            int* idx = malloc(sizeof(int) * nr);
+            memcpy(x, qacc_s, sizeof x);
+            if (warm && o->warmstart) {
+                double cw = 0, cs = 0, dx[NV];
+                const double* xw = warm + JB_NGEOM * 16;
+                for (int d = 0; d < NV; d++) dx[d] = xw[d] - qacc_s[d];
+                for (int i = 0; i < NV; i++) for (int j = 0; j < NV; j++) cw += 0.5 * dx[i] * M[i * NV + j] * dx[j];
+                for (int i = 0; i < nr; i++) {
+                    double rw = -aref[i], rs = -aref[i];
+                    for (int d = 0; d < NV; d++) { rw += J[i][d] * xw[d]; rs += J[i][d] * qacc_s[d]; }
+                    if (rw < 0) cw += 0.5 * rw * rw / Rr[i];
+                    if (rs < 0) cs += 0.5 * rs * rs / Rr[i];
+                }
+                if (cw < cs) memcpy(x, xw, sizeof x);
+            }
+            for (int it = 0; it < (o->solver_iters < 100 ? o->solver_iters : 100); it++) {
+                /* gradient and Hessian */
+                for (int i = 0; i < NV; i++) { double s = -tau[i]; for (int j = 0; j < NV; j++) s += M[i * NV + j] * x[j]; g[i] = s; }
+                memcpy(H, M, sizeof H);
+                for (int i = 0; i < nr; i++) {
+                    double ri = -aref[i];
+                    for (int d = 0; d < NV; d++) ri += J[i][d] * x[d];
+                    r[i] = ri;
+                    if (ri < 0) {
+                        double Di = 1.0 / Rr[i];
+                        for (int d = 0; d < NV; d++) {
+                            g[d] += Di * ri * J[i][d];
+                            for (int e2 = 0; e2 <= d; e2++) H[d * NV + e2] += Di * J[i][d] * J[i][e2];
+                        }
+                    }
+                }
+                for (int i = 0; i < NV; i++) for (int j = 0; j < i; j++) H[j * NV + i] = H[i * NV + j];
+                chol(H, NV, NV);
+                for (int d = 0; d < NV; d++) p[d] = -g[d];
+                chol_solve(H, NV, NV, p);
+                /* exact line search: phi'(a) = c0 + a c1 + sum_i D_i min(0, r_i + a s_i) s_i = 0 */
+                double c0 = 0, c1 = 0;
+                for (int i = 0; i < NV; i++) { double s = 0; for (int j = 0; j < NV; j++) s += M[i * NV + j] * p[j]; Mp[i] = s; }
+                for (int i = 0; i < NV; i++) { double s = -tau[i]; for (int j = 0; j < NV; j++) s += M[i * NV + j] * x[j]; c0 += s * p[i]; c1 += p[i] * Mp[i]; }
+                int nb = 0;
+                double slope = c1, icpt = c0;        /* phi'(a) = icpt + slope a on the current segment */
+                for (int i = 0; i < nr; i++) {
+                    double si = 0; for (int d = 0; d < NV; d++) si += J[i][d] * p[d];
+                    sj[i] = si;
+                    if (r[i] < 0) { slope += si * si / Rr[i]; icpt += r[i] * si / Rr[i]; }
+                    if ((r[i] < 0 && si > 0) || (r[i] >= 0 && si < 0)) { bp[nb] = -r[i] / si; idx[nb] = i; nb++; }
+                }
+                for (int i = 1; i < nb; i++) {      /* insertion sort of the breakpoints */
+                    double a = bp[i]; int ii = idx[i], j = i - 1;
+                    while (j >= 0 && bp[j] > a) { bp[j + 1] = bp[j]; idx[j + 1] = idx[j]; j--; }
+                    bp[j + 1] = a; idx[j + 1] = ii;
+                }
+                double alpha = 0;
+                int found = 0;
+                for (int kbp = 0; kbp <= nb; kbp++) {
+                    double a_hi = (kbp < nb) ? bp[kbp] : INFINITY;
+                    double a0 = -icpt / slope;
+                    if (a0 <= a_hi) { alpha = a0; found = 1; break; }
+                    int i = idx[kbp];              /* row i toggles at a_hi */
+                    /* row enters the active set when s<0 (residual decreasing), leaves when s>0 */
+                    double Di = 1.0 / Rr[i], sgn;
+                    sgn = (sj[i] < 0) ? 1.0 : -1.0;
+                    slope += sgn * Di * sj[i] * sj[i];
+                    icpt += sgn * Di * r[i] * sj[i];
+                }
+                if (!found) alpha = 1.0;
+                double maxstep = 0;
+                for (int d = 0; d < NV; d++) { double dx = alpha * p[d]; x[d] += dx; double sc = fabs(dx) * M[d * NV + d]; if (sc > maxstep) maxstep = sc; }
+                sweeps++;
+                resid = maxstep;
+                if (maxstep <= o->solver_tol) break;
+            }
+            for (int i = 0; i < nr; i++) {
+                double ri = -aref[i];
+                for (int d = 0; d < NV; d++) ri += J[i][d] * x[d];
+                f[i] = ri < 0 ? -ri / Rr[i] : 0.0;
+            }
+            if (warm) memcpy(warm + JB_NGEOM * 16, x, sizeof x);
+            free(r); free(sj); free(bp); free(idx);
+        }
+        if (st) {
+            st->sweeps_total += sweeps; if (sweeps > st->sweeps_max) st->sweeps_max = sweeps;
+            st->nsolve++; if (resid > st->resid_max) st->resid_max = resid;
+        }
+        for (int d = 0; d < NV; d++) { double s = 0; for (int r = 0; r < nr; r++) s += J[r][d] * f[r]; qfc[d] = s; }
+        if (warm) {
+            memset(warm, 0, sizeof(double) * JB_NGEOM * 16);
+            for (int c = 0; c < ncon; c++) for (int e = 0; e < 4; e++) warm[(con[c].geom * 4 + con[c].slot) * 4 + e] = f[4 * c + e];
+        }
+        if (dbg) {
+            dbg->nrow = nr;
+            double qa[NV];
+            for (int d = 0; d < NV; d++) qa[d] = tau[d] + qfc[d];
+            chol_solve(L, NV, NV, qa);
+            memcpy(dbg->qacc, qa, sizeof qa);
+            for (int c = 0; c < ncon; c++) { dbg->con_dist[c] = con[c].dist; dbg->con_geom[c] = con[c].geom; memcpy(dbg->con_pos[c], con[c].pos, sizeof(double) * 3); }
+            for (int r = 0; r < nr; r++) {
+                double s = 0; for (int d = 0; d < NV; d++) s += J[r][d] * qa[d];
+                dbg->f[r] = f[r]; dbg->aref[r] = aref[r]; dbg->Rdiag[r] = Rr[r]; dbg->jar[r] = s - aref[r];
+            }
+        }
+        free(J); free(MJ); free(A); free(b); free(Rr); free(f); free(aref);
+    } else if (warm) {
+        memset(warm, 0, sizeof(double) * JB_NGEOM * 16);
+    }
+    if (st) { st->ncon_last = ncon; if (ncon > st->ncon_max) st->ncon_max = ncon; if (overflow) st->overflow = 1; }
+    if (dbg) memcpy(dbg->qfrc_constraint, qfc, sizeof qfc);
+
+    /* Euler, implicit in joint damping:  (M + h diag(b)) qacc = qfrc_smooth + qfrc_constraint */
+    double qacc[NV];
+    memcpy(L, M, sizeof M);
+    if (o->implicit_damp)
+        for (int j = 0; j < NH; j++) L[(6 + j) * NV + 6 + j] += h * P[JB_P_HINGE + j * JB_HINGE_STRIDE + JB_H_DAMPING];
+    chol(L, NV, NV);
+    for (int d = 0; d < NV; d++) qacc[d] = tau[d] + qfc[d];
+    chol_solve(L, NV, NV, qacc);
+    if (dbg && ncon == 0) memcpy(dbg->qacc, qacc, sizeof qacc);
+
+    /* mj_advance: velocity first, then position with the NEW velocity */
+    for (int d = 0; d < NV; d++) qvel[d] += h * qacc[d];
+    for (int i = 0; i < 3; i++) qpos[i] += h * qvel[i];
+    {   /* mju_quatIntegrate: q <- q * exp(h w / 2), w body-local */
+        double w[3] = {qvel[3], qvel[4], qvel[5]};
+        double nrm = sqrt(dot3(w, w));
+        if (nrm > 1e-15) {
+            double ang = h * nrm, s = sin(0.5 * ang) / nrm, c = cos(0.5 * ang);
+            double dq[4] = {c, w[0] * s, w[1] * s, w[2] * s}, *q = qpos + 3;
+            double r0 = q[0] * dq[0] - q[1] * dq[1] - q[2] * dq[2] - q[3] * dq[3];
+            double r1 = q[0] * dq[1] + q[1] * dq[0] + q[2] * dq[3] - q[3] * dq[2];
+            double r2 = q[0] * dq[2] - q[1] * dq[3] + q[2] * dq[0] + q[3] * dq[1];
+            double r3 = q[0] * dq[3] + q[1] * dq[2] - q[2] * dq[1] + q[3] * dq[0];
+            double n = sqrt(r0 * r0 + r1 * r1 + r2 * r2 + r3 * r3);
+            q[0] = r0 / n; q[1] = r1 / n; q[2] = r2 / n; q[3] = r3 / n;
+        }
+    }
+    for (int j = 0; j < NH; j++) qpos[7 + j] += h * qvel[6 + j];
+}
+
+/* ------------------------------------------------------------------ public: physics */
+void jbo_default_opts(jbo_opts* o) {
+    o->contacts = 1; o->implicit_damp = 1; o->solver_iters = 20000; o->solver_tol = 1e-12; o->warmstart = 1; o->feet_only = 0; o->solver = 1;
+}
+
+/* nsub substeps with constant ctrl (reference: control.Environment.step, 50 substeps) */
+void jbo_step_physics(const double* P, double* qpos, double* qvel, double ctrl, int nsub, const jbo_opts* o,
+                      double* warm, jbo_stats* st) {
+    for (int s = 0; s < nsub; s++) substep(P, qpos, qvel, ctrl, o, warm, st, NULL);
+    /* trailing mj_step1: normalise quaternion so derived quantities match the state */
+    double* q = qpos + 3;
+    double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    for (int i = 0; i < 4; i++) q[i] /= n;
+}
+
+/* forward dynamics only, with taps (qpos/qvel not advanced) */
+void jbo_forward_debug(const double* P, const double* qpos, const double* qvel, double ctrl, const jbo_opts* o, jbo_debug* dbg) {
+    double q[NQ], v[NV];
+    memcpy(q, qpos, sizeof q); memcpy(v, qvel, sizeof v);
+    substep(P, q, v, ctrl, o, NULL, NULL, dbg);
+}
+int jbo_debug_size(void) { return (int)sizeof(jbo_debug); }
+int jbo_maxcon(void) { return MAXCON; }
+
+/* total momentum (linear P, angular L about world origin) and energies, for the conservation tests */
+void jbo_momentum_energy(const double* P, const double* qpos_in, const double* qvel, double* out /*[8]: P3 L3 T V*/) {
+    Kin k; double qpos[NQ];
+    memcpy(qpos, qpos_in, sizeof qpos);
+    kinematics(P, qpos, &k);
+    double lin[3] = {0, 0, 0}, ang[3] = {0, 0, 0}, T = 0, V = 0;
+    for (int b = 0; b < NB; b++) {
+        double Jv[NV][3], Jw[NV][3], vc[3] = {0, 0, 0}, w[3] = {0, 0, 0}, Iw_[3], t[3];
+        jacobian(&k, b, k.com[b], Jv, Jw);
+        for (int d = 0; d < NV; d++) for (int i = 0; i < 3; i++) { vc[i] += Jv[d][i] * qvel[d]; w[i] += Jw[d][i] * qvel[d]; }
+        matvec3(Iw_, k.Iw[b], w);
+        cross3(t, k.com[b], vc);
+        for (int i = 0; i < 3; i++) { lin[i] += k.mass[b] * vc[i]; ang[i] += Iw_[i] + k.mass[b] * t[i]; }
+        T += 0.5 * k.mass[b] * dot3(vc, vc) + 0.5 * dot3(w, Iw_);
+        V -= k.mass[b] * dot3(P + JB_P_GRAVITY, k.com[b]);
+    }
+    for (int j = 0; j < NH; j++) V += 0.5 * P[JB_P_HINGE + j * JB_HINGE_STRIDE + JB_H_STIFFNESS] * qpos[7 + j] * qpos[7 + j];
+    for (int i = 0; i < 3; i++) { out[i] = lin[i]; out[3 + i] = ang[i]; }
+    out[6] = T; out[7] = V;
+}
+
+/* ------------------------------------------------------------------ RNG: Philox4x32-10 */
+static inline void philox_round(uint32_t* c, const uint32_t* k) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k[0], n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k[1], n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+void jbo_philox(uint64_t seed, uint64_t env, uint32_t episode, uint32_t stream, uint32_t out[4]) {
+    uint32_t c[4] = {(uint32_t)env, (uint32_t)(env >> 32), episode, stream};
+    uint32_t k[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    for (int r = 0; r < 10; r++) {
+        philox_round(c, k);
+        k[0] += 0x9E3779B9u; k[1] += 0xBB67AE85u;
+    }
+    memcpy(out, c, sizeof(uint32_t) * 4);
+}
+static inline double u01(uint32_t x) { return (double)(x >> 8) * (1.0 / 16777216.0); }   /* [0,1), 24 bits: exact in fp32 too */
+
+/* ------------------------------------------------------------------ reset (reference jitterbug.py:601-666) */
+void jbo_reset(const double* P, int task, int random_pose, uint64_t seed, uint64_t env, uint32_t episode,
+               double* qpos, double* qvel, double* target /*[3]: tx ty psi*/) {
+    uint32_t r0[4], r1[4];
+    jbo_philox(seed, env, episode, 0, r0);
+    jbo_philox(seed, env, episode, 1, r1);
+    const double TWO_PI = 2.0 * M_PI;
+    double angle = u01(r0[0]) * TWO_PI;              /* :609 */
+    double radius = 0.05 + u01(r0[1]) * (0.2 - 0.05); /* :610 */
+    double yaw = u01(r0[2]) * TWO_PI;                /* :611 */
+    memset(qpos, 0, sizeof(double) * NQ);
+    memset(qvel, 0, sizeof(double) * NV);
+    for (int i = 0; i < 3; i++) qpos[i] = P[JB_P_ROOTPOS0 + i];
+    qpos[3] = 1.0;
+    target[0] = target[1] = target[2] = 0.0;
+    if (task == JB_TASK_FACE_DIRECTION || task == JB_TASK_MOVE_IN_DIRECTION) target[2] = yaw;       /* :618-630 */
+    else if (task == JB_TASK_MOVE_TO_POSITION) { target[0] = radius * cos(angle); target[1] = radius * sin(angle); } /* :632-639 */
+    else if (task == JB_TASK_MOVE_TO_POSE) { target[0] = radius * cos(angle); target[1] = radius * sin(angle); target[2] = yaw; } /* :641-648 */
+    if (random_pose) {                                /* :653-664 */
+        double th = u01(r0[3]) * TWO_PI;
+        double ax = u01(r1[0]) * 0.05 - 0.025, ay = u01(r1[1]) * 0.05 - 0.025, az = 1.0;
+        double n = sqrt(ax * ax + ay * ay + az * az);
+        double s = sin(0.5 * th);
+        qpos[3] = cos(0.5 * th); qpos[4] = s * ax / n; qpos[5] = s * ay / n; qpos[6] = s * az / n;
+    }
+}
+
+/* ------------------------------------------------------------------ observation / reward */
+static double wrap_pi(double a) {           /* reference jitterbug.py:235-238, 313-316: (-pi, pi] */
+    while (a > M_PI) a -= 2 * M_PI;
+    while (a <= -M_PI) a += 2 * M_PI;
+    return a;
+}
+static inline double norm_(double v, double lo, double hi) { return (v - lo) / (hi - lo) * 2.0 - 1.0; }   /* :668-671 */
+
+static void target_quat(double psi, double* q) { q[0] = cos(0.5 * psi); q[1] = 0; q[2] = 0; q[3] = sin(0.5 * psi); }
+
+static double angle_to_target(const double* qpos, double psi) {   /* :192-208, 262-273, 305-317 */
+    double R[9], Rt[9], tq[4];
+    quat2mat(R, qpos + 3);
+    double yaw = atan2(R[3], R[0]) - M_PI / 2;
+    target_quat(psi, tq);
+    quat2mat(Rt, tq);
+    double tyaw = atan2(Rt[3], Rt[0]);
+    return wrap_pi(tyaw - yaw);
+}
+static void target_in_jb_frame(const double* P, const double* qpos, const double* target, double* out) {   /* :275-290 */
+    double R[9], d[3] = {target[0] - qpos[0], target[1] - qpos[1], P[JB_P_TARGETZ] - qpos[2]};
+    quat2mat(R, qpos + 3);
+    matTvec3(out, R, d);
+}
+static void vel_in_target_frame(const double* qvel, double psi, double* out) {   /* :292-303; framelinvel == qvel[0:3] */
+    double Rt[9], tq[4];
+    target_quat(psi, tq);
+    quat2mat(Rt, tq);
+    matTvec3(out, Rt, qvel);
+}
+
+int jbo_obs_dim(int task) { static const int d[JB_NTASK] = {15, 16, 19, 18, 19}; return (task >= 0 && task < JB_NTASK) ? d[task] : -1; }
+
+/* reference jitterbug.py:673-763 (un-encoded observation dict, flattened in dict order) */
+void jbo_observation(const double* P, int task, const double* qpos, const double* qvel, const double* target, double* obs) {
+    obs[0] = norm_(qpos[0], -2, 2); obs[1] = norm_(qpos[1], -2, 2); obs[2] = norm_(qpos[2], 0, 0.1);
+    for (int i = 0; i < 4; i++) obs[3 + i] = norm_(qpos[3 + i], -1, 1);
+    for (int i = 0; i < 3; i++) obs[7 + i] = norm_(qvel[i], -1, 1);
+    for (int i = 0; i < 3; i++) obs[10 + i] = norm_(qvel[3 + i], -35, 35);
+    obs[13] = norm_(wrap_pi(qpos[15] + M_PI / 2), -M_PI, M_PI);       /* :222-239 */
+    obs[14] = norm_(qvel[14], -180, 180);
+    double t3[3];
+    switch (task) {
+    case JB_TASK_MOVE_FROM_ORIGIN: break;
+    case JB_TASK_FACE_DIRECTION:
+        obs[15] = norm_(angle_to_target(qpos, target[2]), -M_PI, M_PI); break;
+    case JB_TASK_MOVE_IN_DIRECTION:
+        obs[15] = norm_(angle_to_target(qpos, target[2]), -M_PI, M_PI);
+        vel_in_target_frame(qvel, target[2], t3);
+        for (int i = 0; i < 3; i++) obs[16 + i] = norm_(t3[i], -1, 1);
+        break;
+    case JB_TASK_MOVE_TO_POSITION:
+        target_in_jb_frame(P, qpos, target, t3);
+        obs[15] = norm_(t3[0], -3, 3); obs[16] = norm_(t3[1], -3, 3); obs[17] = norm_(t3[2], -0.1, 0.1); break;
+    case JB_TASK_MOVE_TO_POSE:
+        target_in_jb_frame(P, qpos, target, t3);
+        obs[15] = norm_(t3[0], -3, 3); obs[16] = norm_(t3[1], -3, 3); obs[17] = norm_(t3[2], -0.1, 0.1);
+        obs[18] = norm_(angle_to_target(qpos, target[2]), -M_PI, M_PI); break;
+    }
+}
+
+/* dm_control utils/rewards.tolerance restated (third-party; reference call sites jitterbug.py:846-889) */
+static double sigmoid_(double x, double value_at_1, int kind /*0 gaussian 1 cosine 2 linear*/) {
+    if (kind == 0) { double scale = sqrt(-2 * log(value_at_1)); return exp(-0.5 * (x * scale) * (x * scale)); }
+    if (kind == 1) { double scale = acos(2 * value_at_1 - 1) / M_PI, sx = x * scale; return fabs(sx) < 1 ? (1 + cos(M_PI * sx)) / 2 : 0.0; }
+    { double scale = 1 - value_at_1, sx = x * scale; return fabs(sx) < 1 ? 1 - sx : 0.0; }
+}
+static double tolerance(double x, double lo, double hi, double margin, double value_at_margin, int kind) {
+    int in_bounds = (lo <= x) && (x <= hi);
+    if (margin == 0) return in_bounds ? 1.0 : 0.0;
+    double d = (x < lo ? lo - x : x - hi) / margin;
+    return in_bounds ? 1.0 : sigmoid_(d, value_at_margin, kind);
+}
+
+double jbo_reward(const double* P, int task, const double* qpos, const double* qvel, const double* target) {
+    double R[9], t3[3], r = 0;
+    quat2mat(R, qpos + 3);
+    double upright = tolerance(R[8], 1, 1, 0.5, 0.1, 0);                                   /* :882-889 */
+    double pos_r = 0, head_r = 0, vel_r = 0;
+    target_in_jb_frame(P, qpos, target, t3);
+    pos_r = tolerance(sqrt(dot3(t3, t3)), 0, 0, 0.05, 0.1, 0);                             /* :868-880 */
+    head_r = tolerance(angle_to_target(qpos, target[2]), 0, 0, M_PI / 2, 0.0, 1);          /* :840-852 */
+    vel_in_target_frame(qvel, target[2], t3);
+    vel_r = tolerance(t3[0], 0.1, INFINITY, 0.1, 0.0, 2);                                  /* :854-866 */
+    switch (task) {                                                                        /* :891-925 */
+    case JB_TASK_MOVE_FROM_ORIGIN: r = 1 - pos_r; break;
+    case JB_TASK_FACE_DIRECTION: r = head_r; break;
+    case JB_TASK_MOVE_IN_DIRECTION: r = vel_r; break;
+    case JB_TASK_MOVE_TO_POSITION: r = pos_r; break;
+    case JB_TASK_MOVE_TO_POSE: r = pos_r * head_r; break;
+    }
+    return r * upright;
+}
+void jbo_reward_terms(const double* P, const double* qpos, const double* qvel, const double* target, double* out /*P,H,V,U*/) {
+    double R[9], t3[3];
+    quat2mat(R, qpos + 3);
+    target_in_jb_frame(P, qpos, target, t3);
+    out[0] = tolerance(sqrt(dot3(t3, t3)), 0, 0, 0.05, 0.1, 0);
+    out[1] = tolerance(angle_to_target(qpos, target[2]), 0, 0, M_PI / 2, 0.0, 1);
+    vel_in_target_frame(qvel, target[2], t3);
+    out[2] = tolerance(t3[0], 0.1, INFINITY, 0.1, 0.0, 2);
+    out[3] = tolerance(R[8], 1, 1, 0.5, 0.1, 0);
+}
+double jbo_tolerance(double x, double lo, double hi, double margin, double vam, int kind) { return tolerance(x, lo, hi, margin, vam, kind); }
+
+/* ------------------------------------------------------------------ batch environment (CPU baseline + lockstep oracle) */
+typedef struct {
+    int n, task, random_pose, nsub, step_limit, per_env_model;
+    uint64_t seed, env_offset;
+    jbo_opts opts;
+    double* P;          /* [NPARAM] or [n, NPARAM] */
+    double *qpos, *qvel, *target, *warm;
+    int *step_count; uint32_t* episode;
+    jbo_stats stats;
+} jbo_env;
+
+static const double* envP(const jbo_env* e, int i) { return e->per_env_model ? e->P + (size_t)i * JB_NPARAM : e->P; }
+
+jbo_env* jbo_env_create(int n, int task, int random_pose, int nsub, int step_limit, uint64_t seed, uint64_t env_offset,
+                        const double* P, int per_env_model, const jbo_opts* opts) {
+    jbo_env* e = calloc(1, sizeof *e);
+    e->n = n; e->task = task; e->random_pose = random_pose; e->nsub = nsub; e->step_limit = step_limit;
+    e->seed = seed; e->env_offset = env_offset; e->per_env_model = per_env_model; e->opts = *opts;
+    size_t np = per_env_model ? (size_t)n * JB_NPARAM : JB_NPARAM;
+    e->P = malloc(sizeof(double) * np); memcpy(e->P, P, sizeof(double) * np);
+    e->qpos = calloc((size_t)n * NQ, sizeof(double)); e->qvel = calloc((size_t)n * NV, sizeof(double));
+    e->target = calloc((size_t)n * 3, sizeof(double)); e->warm = calloc((size_t)n * WARM_SIZE, sizeof(double));
+    e->step_count = calloc(n, sizeof(int)); e->episode = calloc(n, sizeof(uint32_t));
+    return e;
+}
+void jbo_env_destroy(jbo_env* e) {
+    if (!e) return;
+    free(e->P); free(e->qpos); free(e->qvel); free(e->target); free(e->warm); free(e->step_count); free(e->episode); free(e);
+}
+static void env_reset_one(jbo_env* e, int i) {
+    jbo_reset(envP(e, i), e->task, e->random_pose, e->seed, e->env_offset + (uint64_t)i, e->episode[i],
+              e->qpos + (size_t)i * NQ, e->qvel + (size_t)i * NV, e->target + (size_t)i * 3);
+    memset(e->warm + (size_t)i * WARM_SIZE, 0, sizeof(double) * WARM_SIZE);
+    e->step_count[i] = 0;
+}
+/* mask nullable (= all). Each reset consumes one episode index. obs nullable. */
+void jbo_env_reset(jbo_env* e, const uint8_t* mask, double* obs) {
+    int D = jbo_obs_dim(e->task);
+    for (int i = 0; i < e->n; i++) {
+        if (mask && !mask[i]) continue;
+        env_reset_one(e, i);
+        e->episode[i]++;
+    }
+    if (obs) for (int i = 0; i < e->n; i++)
+        jbo_observation(envP(e, i), e->task, e->qpos + (size_t)i * NQ, e->qvel + (size_t)i * NV, e->target + (size_t)i * 3, obs + (size_t)i * D);
+}
+/* one control step for every env; auto_reset: VecEnv semantics (obs of the new episode is returned on done) */
+void jbo_env_step(jbo_env* e, const double* action, double* obs, double* reward, uint8_t* done, int auto_reset, int nthreads) {
+    int D = jbo_obs_dim(e->task);
+    jbo_stats agg; memset(&agg, 0, sizeof agg);
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#pragma omp parallel
+#endif
+    {
+        jbo_stats st; memset(&st, 0, sizeof st);
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 8)
+#endif
+        for (int i = 0; i < e->n; i++) {
+            double* qp = e->qpos + (size_t)i * NQ; double* qv = e->qvel + (size_t)i * NV; double* tg = e->target + (size_t)i * 3;
+            jbo_step_physics(envP(e, i), qp, qv, action[i], e->nsub, &e->opts, e->warm + (size_t)i * WARM_SIZE, &st);
+            e->step_count[i]++;
+            if (reward) reward[i] = jbo_reward(envP(e, i), e->task, qp, qv, tg);
+            int d = e->step_count[i] >= e->step_limit;
+            if (done) done[i] = (uint8_t)d;
+            if (d && auto_reset) { env_reset_one(e, i); e->episode[i]++; }
+            if (obs) jbo_observation(envP(e, i), e->task, qp, qv, tg, obs + (size_t)i * D);
+        }
+#ifdef _OPENMP
+#pragma omp critical
+#endif
+        {
+            agg.sweeps_total += st.sweeps_total; agg.nsolve += st.nsolve;
+            if (st.sweeps_max > agg.sweeps_max) agg.sweeps_max = st.sweeps_max;
+            if (st.ncon_max > agg.ncon_max) agg.ncon_max = st.ncon_max;
+            if (st.resid_max > agg.resid_max) agg.resid_max = st.resid_max;
+            agg.overflow |= st.overflow;
+        }
+    }
+    e->stats = agg;
+}
+void jbo_env_get_state(const jbo_env* e, double* qpos, double* qvel, double* target) {
+    if (qpos) memcpy(qpos, e->qpos, sizeof(double) * (size_t)e->n * NQ);
+    if (qvel) memcpy(qvel, e->qvel, sizeof(double) * (size_t)e->n * NV);
+    if (target) memcpy(target, e->target, sizeof(double) * (size_t)e->n * 3);
+}
+void jbo_env_set_state(jbo_env* e, const double* qpos, const double* qvel, const double* target) {
+    if (qpos) memcpy(e->qpos, qpos, sizeof(double) * (size_t)e->n * NQ);
+    if (qvel) memcpy(e->qvel, qvel, sizeof(double) * (size_t)e->n * NV);
+    if (target) memcpy(e->target, target, sizeof(double) * (size_t)e->n * 3);
+    memset(e->warm, 0, sizeof(double) * (size_t)e->n * WARM_SIZE);
+}
+void jbo_env_get_counters(const jbo_env* e, int* step_count, uint32_t* episode) {
+    if (step_count) memcpy(step_count, e->step_count, sizeof(int) * e->n);
+    if (episode) memcpy(episode, e->episode, sizeof(uint32_t) * e->n);
+}
+void jbo_env_stats(const jbo_env* e, jbo_stats* out) { *out = e->stats; }
+int jbo_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+int jbo_warm_size(void) { return WARM_SIZE; }

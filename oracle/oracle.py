@@ -1,0 +1,229 @@
+"""ctypes wrapper around the CPU fp64 oracle (oracle/jb_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py.  Nothing under jitterbug_amd/ imports this.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libjb_oracle.so")
+
+NQ, NV, NGEOM = 16, 15, 22
+NPARAM = 612
+WARM_SIZE = NGEOM * 16 + NV
+MAXCON = 64
+MAXROW = 4 * MAXCON
+TASKS = ("move_from_origin", "face_direction", "move_in_direction", "move_to_position", "move_to_pose")
+OBS_DIM = (15, 16, 19, 18, 19)
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "jb_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s"], stdout=subprocess.DEVNULL)
+    return _SO
+
+
+class Opts(C.Structure):
+    _fields_ = [("contacts", C.c_int), ("implicit_damp", C.c_int), ("solver_iters", C.c_int),
+                ("solver_tol", C.c_double), ("warmstart", C.c_int), ("feet_only", C.c_int), ("solver", C.c_int)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("ncon_last", C.c_int), ("ncon_max", C.c_int), ("sweeps_total", C.c_int), ("sweeps_max", C.c_int),
+                ("nsolve", C.c_int), ("overflow", C.c_int), ("resid_max", C.c_double)]
+
+
+class Debug(C.Structure):
+    _fields_ = [("ncon", C.c_int), ("nrow", C.c_int),
+                ("con_dist", C.c_double * MAXCON), ("con_pos", (C.c_double * 3) * MAXCON), ("con_geom", C.c_int * MAXCON),
+                ("f", C.c_double * MAXROW), ("aref", C.c_double * MAXROW), ("Rdiag", C.c_double * MAXROW), ("jar", C.c_double * MAXROW),
+                ("M", C.c_double * (NV * NV)), ("bias", C.c_double * NV), ("tau", C.c_double * NV),
+                ("qacc_smooth", C.c_double * NV), ("qacc", C.c_double * NV), ("qfrc_constraint", C.c_double * NV)]
+
+
+_lib = None
+_dp = C.POINTER(C.c_double)
+
+
+def _p(a):
+    return a.ctypes.data_as(_dp)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_SO)
+        L.jbo_default_opts.argtypes = [C.POINTER(Opts)]
+        L.jbo_step_physics.argtypes = [_dp, _dp, _dp, C.c_double, C.c_int, C.POINTER(Opts), _dp, C.POINTER(Stats)]
+        L.jbo_forward_debug.argtypes = [_dp, _dp, _dp, C.c_double, C.POINTER(Opts), C.POINTER(Debug)]
+        L.jbo_momentum_energy.argtypes = [_dp, _dp, _dp, _dp]
+        L.jbo_philox.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
+        L.jbo_reset.argtypes = [_dp, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_uint32, _dp, _dp, _dp]
+        L.jbo_observation.argtypes = [_dp, C.c_int, _dp, _dp, _dp, _dp]
+        L.jbo_reward.argtypes = [_dp, C.c_int, _dp, _dp, _dp]
+        L.jbo_reward.restype = C.c_double
+        L.jbo_reward_terms.argtypes = [_dp, _dp, _dp, _dp, _dp]
+        L.jbo_tolerance.argtypes = [C.c_double] * 5 + [C.c_int]
+        L.jbo_tolerance.restype = C.c_double
+        L.jbo_env_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64, _dp, C.c_int, C.POINTER(Opts)]
+        L.jbo_env_create.restype = C.c_void_p
+        L.jbo_env_destroy.argtypes = [C.c_void_p]
+        L.jbo_env_reset.argtypes = [C.c_void_p, C.c_void_p, _dp]
+        L.jbo_env_step.argtypes = [C.c_void_p, _dp, _dp, _dp, C.c_void_p, C.c_int, C.c_int]
+        L.jbo_env_get_state.argtypes = [C.c_void_p, _dp, _dp, _dp]
+        L.jbo_env_set_state.argtypes = [C.c_void_p, _dp, _dp, _dp]
+        L.jbo_env_get_counters.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.jbo_env_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
+        assert L.jbo_debug_size() == C.sizeof(Debug), (L.jbo_debug_size(), C.sizeof(Debug))
+        _lib = L
+    return _lib
+
+
+def default_opts(**kw):
+    o = Opts()
+    lib().jbo_default_opts(C.byref(o))
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+def task_id(task):
+    return TASKS.index(task) if isinstance(task, str) else int(task)
+
+
+def step_physics(P, qpos, qvel, ctrl, nsub=50, opts=None, warm=None, stats=None):
+    """Advance ONE env in place by nsub substeps. Returns (qpos, qvel) (new arrays)."""
+    P = np.ascontiguousarray(P, dtype=np.float64)
+    q = np.array(qpos, dtype=np.float64).copy()
+    v = np.array(qvel, dtype=np.float64).copy()
+    opts = opts or default_opts()
+    lib().jbo_step_physics(_p(P), _p(q), _p(v), float(ctrl), int(nsub), C.byref(opts),
+                           _p(warm) if warm is not None else None, C.byref(stats) if stats is not None else None)
+    return q, v
+
+
+def forward_debug(P, qpos, qvel, ctrl=0.0, opts=None):
+    P = np.ascontiguousarray(P, dtype=np.float64)
+    q = np.ascontiguousarray(qpos, dtype=np.float64)
+    v = np.ascontiguousarray(qvel, dtype=np.float64)
+    d = Debug()
+    lib().jbo_forward_debug(_p(P), _p(q), _p(v), float(ctrl), C.byref(opts or default_opts()), C.byref(d))
+    out = dict(ncon=d.ncon, nrow=d.nrow,
+               M=np.array(d.M).reshape(NV, NV), bias=np.array(d.bias), tau=np.array(d.tau),
+               qacc_smooth=np.array(d.qacc_smooth), qacc=np.array(d.qacc), qfrc_constraint=np.array(d.qfrc_constraint),
+               con_dist=np.array(d.con_dist[:d.ncon]), con_geom=np.array(d.con_geom[:d.ncon]),
+               con_pos=np.array([list(d.con_pos[i]) for i in range(d.ncon)]).reshape(d.ncon, 3),
+               f=np.array(d.f[:d.nrow]), aref=np.array(d.aref[:d.nrow]), R=np.array(d.Rdiag[:d.nrow]), jar=np.array(d.jar[:d.nrow]))
+    return out
+
+
+def momentum_energy(P, qpos, qvel):
+    out = np.zeros(8)
+    lib().jbo_momentum_energy(_p(np.ascontiguousarray(P, dtype=np.float64)), _p(np.ascontiguousarray(qpos, dtype=np.float64)),
+                              _p(np.ascontiguousarray(qvel, dtype=np.float64)), _p(out))
+    return dict(P=out[0:3], L=out[3:6], T=out[6], V=out[7])
+
+
+def philox(seed, env, episode, stream):
+    out = (C.c_uint32 * 4)()
+    lib().jbo_philox(seed, env, episode, stream, out)
+    return np.array(list(out), dtype=np.uint32)
+
+
+def reset(P, task, random_pose, seed, env, episode):
+    P = np.ascontiguousarray(P, dtype=np.float64)
+    q, v, t = np.zeros(NQ), np.zeros(NV), np.zeros(3)
+    lib().jbo_reset(_p(P), task_id(task), int(random_pose), seed, env, episode, _p(q), _p(v), _p(t))
+    return q, v, t
+
+
+def observation(P, task, qpos, qvel, target):
+    P = np.ascontiguousarray(P, dtype=np.float64)
+    t = task_id(task)
+    obs = np.zeros(OBS_DIM[t])
+    lib().jbo_observation(_p(P), t, _p(np.ascontiguousarray(qpos, dtype=np.float64)), _p(np.ascontiguousarray(qvel, dtype=np.float64)),
+                          _p(np.ascontiguousarray(target, dtype=np.float64)), _p(obs))
+    return obs
+
+
+def reward(P, task, qpos, qvel, target):
+    P = np.ascontiguousarray(P, dtype=np.float64)
+    return lib().jbo_reward(_p(P), task_id(task), _p(np.ascontiguousarray(qpos, dtype=np.float64)),
+                            _p(np.ascontiguousarray(qvel, dtype=np.float64)), _p(np.ascontiguousarray(target, dtype=np.float64)))
+
+
+def reward_terms(P, qpos, qvel, target):
+    out = np.zeros(4)
+    lib().jbo_reward_terms(_p(np.ascontiguousarray(P, dtype=np.float64)), _p(np.ascontiguousarray(qpos, dtype=np.float64)),
+                           _p(np.ascontiguousarray(qvel, dtype=np.float64)), _p(np.ascontiguousarray(target, dtype=np.float64)), _p(out))
+    return dict(P=out[0], H=out[1], V=out[2], U=out[3])
+
+
+def tolerance(x, bounds=(0.0, 0.0), margin=0.0, value_at_margin=0.1, sigmoid="gaussian"):
+    kind = dict(gaussian=0, cosine=1, linear=2)[sigmoid]
+    return lib().jbo_tolerance(float(x), float(bounds[0]), float(bounds[1]), float(margin), float(value_at_margin), kind)
+
+
+class OracleEnv:
+    """Batch of N oracle environments in lockstep (fp64, OpenMP over envs)."""
+
+    def __init__(self, n, task="move_from_origin", P=None, random_pose=True, nsub=50, step_limit=1000, seed=0,
+                 env_offset=0, opts=None, per_env_model=False):
+        self.n = int(n)
+        self.task = task_id(task)
+        self.D = OBS_DIM[self.task]
+        P = np.ascontiguousarray(P, dtype=np.float64)
+        self.opts = opts or default_opts()
+        self._h = lib().jbo_env_create(self.n, self.task, int(random_pose), int(nsub), int(step_limit), seed, env_offset,
+                                       _p(P), int(per_env_model), C.byref(self.opts))
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().jbo_env_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def reset(self, mask=None):
+        obs = np.zeros((self.n, self.D))
+        m = None
+        if mask is not None:
+            m = np.ascontiguousarray(mask, dtype=np.uint8)
+        lib().jbo_env_reset(self._h, m.ctypes.data if m is not None else None, _p(obs))
+        return obs
+
+    def step(self, action, auto_reset=True, nthreads=0):
+        a = np.ascontiguousarray(np.broadcast_to(np.asarray(action, dtype=np.float64).reshape(-1), (self.n,)), dtype=np.float64)
+        obs = np.zeros((self.n, self.D))
+        rew = np.zeros(self.n)
+        done = np.zeros(self.n, dtype=np.uint8)
+        lib().jbo_env_step(self._h, _p(a), _p(obs), _p(rew), done.ctypes.data, int(auto_reset), int(nthreads))
+        return obs, rew, done
+
+    def get_state(self):
+        q, v, t = np.zeros((self.n, NQ)), np.zeros((self.n, NV)), np.zeros((self.n, 3))
+        lib().jbo_env_get_state(self._h, _p(q), _p(v), _p(t))
+        return q, v, t
+
+    def set_state(self, qpos=None, qvel=None, target=None):
+        def prep(a, w):
+            return None if a is None else _p(np.ascontiguousarray(np.asarray(a, dtype=np.float64).reshape(self.n, w)))
+        lib().jbo_env_set_state(self._h, prep(qpos, NQ), prep(qvel, NV), prep(target, 3))
+
+    def counters(self):
+        sc = np.zeros(self.n, dtype=np.int32)
+        ep = np.zeros(self.n, dtype=np.uint32)
+        lib().jbo_env_get_counters(self._h, sc.ctypes.data, ep.ctypes.data)
+        return sc, ep
+
+    def stats(self):
+        s = Stats()
+        lib().jbo_env_stats(self._h, C.byref(s))
+        return s
