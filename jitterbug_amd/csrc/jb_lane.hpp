@@ -1,0 +1,137 @@
+// jb_lane.hpp — lane-value abstraction for the Jitterbug simulator.
+//
+// The simulator maps ONE ENVIRONMENT TO FOUR LANES (a "quad"): lane l of the quad
+// owns leg l (reference: jitterbug.xml:52-103, four structurally identical
+// two-hinge legs); root-body and motor quantities are replicated in the four
+// lanes; sums over legs are quad all-reductions.  The math in jb_sim.hpp is
+// written once against the small vocabulary below:
+//
+//   device  (hipcc, gfx950):  V = float, mask = bool, quad_sum = 2 DPP quad_perm adds,
+//                             any_lane = wave ballot.
+//   host    (g++, tests only): V = Quad<T> (4 components = the 4 lanes), which lets
+//                             tests/ run the very same source in fp32/fp64 against
+//                             the oracle without a GPU.  The host instantiation is
+//                             test infrastructure, not a product path.
+#pragma once
+#include <cmath>
+#include <cstdint>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define JB_HD __host__ __device__ __forceinline__
+#define JB_D __device__ __forceinline__
+#else
+#define JB_HD inline
+#define JB_D inline
+#endif
+
+namespace jb {
+
+// ----------------------------------------------------------------------------- scalar lanes (device)
+#if defined(__HIPCC__)
+JB_D float dpp_quad_xor1(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, false));  // quad_perm [1,0,3,2]
+}
+JB_D float dpp_quad_xor2(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, false));  // quad_perm [2,3,0,1]
+}
+JB_D float quad_sum(float x) {
+    x += dpp_quad_xor1(x);
+    x += dpp_quad_xor2(x);
+    return x;
+}
+JB_D unsigned quad_sum_u(unsigned x) {
+    x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, false);
+    x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xF, 0xF, false);
+    return x;
+}
+JB_D bool any_lane(bool m) { return __builtin_amdgcn_ballot_w64(m) != 0ull; }
+#endif
+
+JB_HD float sel(bool m, float a, float b) { return m ? a : b; }
+JB_HD double sel(bool m, double a, double b) { return m ? a : b; }
+JB_HD unsigned selu(bool m, unsigned a, unsigned b) { return m ? a : b; }
+JB_HD bool lt(float a, float b) { return a < b; }
+JB_HD bool lt(double a, double b) { return a < b; }
+JB_HD bool gt(float a, float b) { return a > b; }
+JB_HD bool gt(double a, double b) { return a > b; }
+JB_HD bool mand(bool a, bool b) { return a && b; }
+JB_HD bool mor(bool a, bool b) { return a || b; }
+JB_HD bool mnot(bool a) { return !a; }
+JB_HD unsigned mbit(bool a) { return a ? 1u : 0u; }
+JB_HD bool neq_u(unsigned a, unsigned b) { return a != b; }
+JB_HD float vsqrt(float x) { return sqrtf(x); }
+JB_HD double vsqrt(double x) { return sqrt(x); }
+JB_HD float vabs(float x) { return fabsf(x); }
+JB_HD double vabs(double x) { return fabs(x); }
+JB_HD float vsin(float x) { return sinf(x); }
+JB_HD double vsin(double x) { return sin(x); }
+JB_HD float vcos(float x) { return cosf(x); }
+JB_HD double vcos(double x) { return cos(x); }
+JB_HD float vmin(float a, float b) { return fminf(a, b); }
+JB_HD double vmin(double a, double b) { return fmin(a, b); }
+JB_HD float vmax(float a, float b) { return fmaxf(a, b); }
+JB_HD double vmax(double a, double b) { return fmax(a, b); }
+JB_HD float vfloor(float a) { return floorf(a); }
+JB_HD double vfloor(double a) { return floor(a); }
+
+template <typename V> struct lane_traits;            // ::mask, ::uint, ::real
+template <> struct lane_traits<float> { using mask = bool; using uint = unsigned; using real = float; };
+template <> struct lane_traits<double> { using mask = bool; using uint = unsigned; using real = double; };
+
+// ----------------------------------------------------------------------------- Quad<T>: host emulation of 4 lanes
+#if !defined(__HIPCC__)
+struct Mask4 { bool v[4]; };
+struct UQuad { uint32_t v[4]; };
+template <typename T> struct Quad {
+    T v[4];
+    Quad() = default;
+    Quad(T s) { v[0] = v[1] = v[2] = v[3] = s; }
+    Quad(T a, T b, T c, T d) { v[0] = a; v[1] = b; v[2] = c; v[3] = d; }
+    Quad& operator+=(const Quad& o) { for (int i = 0; i < 4; i++) v[i] += o.v[i]; return *this; }
+    Quad& operator-=(const Quad& o) { for (int i = 0; i < 4; i++) v[i] -= o.v[i]; return *this; }
+    Quad& operator*=(const Quad& o) { for (int i = 0; i < 4; i++) v[i] *= o.v[i]; return *this; }
+};
+#define JB_QBIN(op) \
+    template <typename T> inline Quad<T> operator op(const Quad<T>& a, const Quad<T>& b) { Quad<T> r; for (int i = 0; i < 4; i++) r.v[i] = a.v[i] op b.v[i]; return r; } \
+    template <typename T> inline Quad<T> operator op(const Quad<T>& a, T b) { Quad<T> r; for (int i = 0; i < 4; i++) r.v[i] = a.v[i] op b; return r; } \
+    template <typename T> inline Quad<T> operator op(T a, const Quad<T>& b) { Quad<T> r; for (int i = 0; i < 4; i++) r.v[i] = a op b.v[i]; return r; }
+JB_QBIN(+) JB_QBIN(-) JB_QBIN(*) JB_QBIN(/)
+#undef JB_QBIN
+template <typename T> inline Quad<T> operator-(const Quad<T>& a) { Quad<T> r; for (int i = 0; i < 4; i++) r.v[i] = -a.v[i]; return r; }
+template <typename T> inline Quad<T> quad_sum(const Quad<T>& x) { return Quad<T>((x.v[0] + x.v[1]) + (x.v[2] + x.v[3])); }
+inline UQuad quad_sum_u(const UQuad& x) { uint32_t s = (x.v[0] + x.v[1]) + (x.v[2] + x.v[3]); return UQuad{{s, s, s, s}}; }
+inline bool any_lane(const Mask4& m) { return m.v[0] || m.v[1] || m.v[2] || m.v[3]; }
+inline bool any_lane(bool m) { return m; }
+inline float quad_sum(float x) { return x; }
+inline double quad_sum(double x) { return x; }
+template <typename T> inline Quad<T> sel(const Mask4& m, const Quad<T>& a, const Quad<T>& b) { Quad<T> r; for (int i = 0; i < 4; i++) r.v[i] = m.v[i] ? a.v[i] : b.v[i]; return r; }
+inline UQuad selu(const Mask4& m, const UQuad& a, const UQuad& b) { UQuad r; for (int i = 0; i < 4; i++) r.v[i] = m.v[i] ? a.v[i] : b.v[i]; return r; }
+template <typename T> inline Mask4 lt(const Quad<T>& a, const Quad<T>& b) { Mask4 r; for (int i = 0; i < 4; i++) r.v[i] = a.v[i] < b.v[i]; return r; }
+template <typename T> inline Mask4 gt(const Quad<T>& a, const Quad<T>& b) { Mask4 r; for (int i = 0; i < 4; i++) r.v[i] = a.v[i] > b.v[i]; return r; }
+inline Mask4 mand(const Mask4& a, const Mask4& b) { Mask4 r; for (int i = 0; i < 4; i++) r.v[i] = a.v[i] && b.v[i]; return r; }
+inline Mask4 mor(const Mask4& a, const Mask4& b) { Mask4 r; for (int i = 0; i < 4; i++) r.v[i] = a.v[i] || b.v[i]; return r; }
+inline Mask4 mnot(const Mask4& a) { Mask4 r; for (int i = 0; i < 4; i++) r.v[i] = !a.v[i]; return r; }
+inline UQuad mbit(const Mask4& a) { UQuad r; for (int i = 0; i < 4; i++) r.v[i] = a.v[i] ? 1u : 0u; return r; }
+inline Mask4 neq_u(const UQuad& a, const UQuad& b) { Mask4 r; for (int i = 0; i < 4; i++) r.v[i] = a.v[i] != b.v[i]; return r; }
+inline UQuad operator*(const UQuad& a, uint32_t b) { UQuad r; for (int i = 0; i < 4; i++) r.v[i] = a.v[i] * b; return r; }
+inline UQuad operator+(const UQuad& a, const UQuad& b) { UQuad r; for (int i = 0; i < 4; i++) r.v[i] = a.v[i] + b.v[i]; return r; }
+inline UQuad operator+(const UQuad& a, uint32_t b) { UQuad r; for (int i = 0; i < 4; i++) r.v[i] = a.v[i] + b; return r; }
+#define JB_QUN(name, fn) template <typename T> inline Quad<T> name(const Quad<T>& a) { Quad<T> r; for (int i = 0; i < 4; i++) r.v[i] = fn(a.v[i]); return r; }
+JB_QUN(vsqrt, vsqrt) JB_QUN(vabs, vabs) JB_QUN(vsin, vsin) JB_QUN(vcos, vcos) JB_QUN(vfloor, vfloor)
+#undef JB_QUN
+template <typename T> inline Quad<T> vmin(const Quad<T>& a, const Quad<T>& b) { Quad<T> r; for (int i = 0; i < 4; i++) r.v[i] = vmin(a.v[i], b.v[i]); return r; }
+template <typename T> inline Quad<T> vmax(const Quad<T>& a, const Quad<T>& b) { Quad<T> r; for (int i = 0; i < 4; i++) r.v[i] = vmax(a.v[i], b.v[i]); return r; }
+template <typename T> struct lane_traits<Quad<T>> { using mask = Mask4; using uint = UQuad; using real = T; };
+#endif
+
+// unsigned helpers
+JB_HD unsigned umulv(unsigned a, unsigned b) { return a * b; }
+JB_HD unsigned vtou(float a) { return (unsigned)a; }
+JB_HD unsigned vtou(double a) { return (unsigned)a; }
+#if !defined(__HIPCC__)
+inline UQuad umulv(const UQuad& a, const UQuad& b) { UQuad r; for (int i = 0; i < 4; i++) r.v[i] = a.v[i] * b.v[i]; return r; }
+template <typename T> inline UQuad vtou(const Quad<T>& a) { UQuad r; for (int i = 0; i < 4; i++) r.v[i] = (uint32_t)a.v[i]; return r; }
+#endif
+
+}  // namespace jb

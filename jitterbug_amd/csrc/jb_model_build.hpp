@@ -1,0 +1,124 @@
+// jb_model_build.hpp — compiled parameter table (include/jitterbug_model.h) -> per-lane constant table (jb_sim.hpp LM_*).
+// Host-side, plain C++.  Used by the HIP library's host code and by the host test harness.
+#pragma once
+#include <cmath>
+
+#include "../../include/jitterbug_model.h"
+#include "jb_sim.hpp"
+
+namespace jb {
+
+// returns 0 on success, <0 when the table asks for something the kernel does not implement
+template <typename T> inline int build_lane_model(const double* P, int leg, T* out) {
+    for (int i = 0; i < LM_COUNT; i++) out[i] = T(0);
+    auto body = [&](int b) { return P + JB_P_BODY + b * JB_BODY_STRIDE; };
+    auto hinge = [&](int h) { return P + JB_P_HINGE + h * JB_HINGE_STRIDE; };
+    auto geom = [&](int g) { return P + JB_P_GEOM + g * JB_GEOM_STRIDE; };
+    auto put3 = [&](int at, const double* v) { for (int i = 0; i < 3; i++) out[at + i] = T(v[i]); };
+    auto put3d = [&](int at, const double* v, const double* ref) { for (int i = 0; i < 3; i++) out[at + i] = T(v[i] - ref[i]); };
+    auto norm3d = [&](const double* v, const double* ref) { double s = 0; for (int i = 0; i < 3; i++) s += (v[i] - ref[i]) * (v[i] - ref[i]); return std::sqrt(s); };
+    const double zero3[3] = {0, 0, 0};
+
+    const double h = P[JB_P_TIMESTEP];
+    out[LM_H] = T(h);
+    put3(LM_GRAV, P + JB_P_GRAVITY);
+    double tc = P[JB_P_SOLREF] < 2 * h ? 2 * h : P[JB_P_SOLREF], dr = P[JB_P_SOLREF + 1], dmax = P[JB_P_SOLIMP + 1];
+    if (!(P[JB_P_SOLREF] > 0)) return -1;
+    out[LM_KK] = T(1.0 / (dmax * dmax * tc * tc * dr * dr));
+    out[LM_BB] = T(2.0 / (dmax * tc));
+    out[LM_IMP_D0] = T(P[JB_P_SOLIMP]); out[LM_IMP_DW] = T(P[JB_P_SOLIMP + 1]); out[LM_IMP_IW] = T(1.0 / P[JB_P_SOLIMP + 2]);
+    out[LM_IMP_MID] = T(P[JB_P_SOLIMP + 3]); out[LM_IMP_POW] = T(P[JB_P_SOLIMP + 4]);
+    if (P[JB_P_SOLIMP + 4] != 2.0) return -2;
+    out[LM_MU] = T(P[JB_P_FRICTION] * std::sqrt(1.0 / P[JB_P_IMPRATIO]));
+    out[LM_FR2] = T(P[JB_P_FRICTION] * P[JB_P_FRICTION]);
+    out[LM_GEAR] = T(P[JB_P_GEAR]); out[LM_GAIN] = T(P[JB_P_GAIN]);
+    put3(LM_BIAS, P + JB_P_BIASPRM);
+    out[LM_CTRL_LO] = T(P[JB_P_CTRLRANGE]); out[LM_CTRL_HI] = T(P[JB_P_CTRLRANGE + 1]);
+    double mtot = 0;
+    for (int b = 0; b < JB_NBODY; b++) mtot += body(b)[JB_B_MASS];
+    out[LM_MTOT] = T(mtot);
+    out[LM_TARGET_Z] = T(P[JB_P_TARGETZ]); out[LM_ROOT_Z0] = T(P[JB_P_ROOTPOS0 + 2]); out[LM_LANE] = T(leg);
+
+    // root body
+    out[LM_M0] = T(body(0)[JB_B_MASS]); put3(LM_C0, body(0) + JB_B_COM);
+    for (int i = 0; i < 6; i++) out[LM_I0 + i] = T(body(0)[JB_B_INERTIA + i]);
+    out[LM_TRAN0] = T(body(0)[JB_B_INVW_TRAN]);
+    // motor body
+    const double* am = hinge(8) + JB_H_ANCHOR;
+    out[LM_MM] = T(body(9)[JB_B_MASS]); put3(LM_AM, am); put3(LM_EM, hinge(8) + JB_H_AXIS);
+    put3d(LM_DCM, body(9) + JB_B_COM, am);
+    for (int i = 0; i < 6; i++) out[LM_IM + i] = T(body(9)[JB_B_INERTIA + i]);
+    out[LM_TRANM] = T(body(9)[JB_B_INVW_TRAN]);
+    // own leg
+    const int bu = 1 + 2 * leg, bl = 2 + 2 * leg, hs = 2 * leg, hk = 2 * leg + 1;
+    const double* a1 = hinge(hs) + JB_H_ANCHOR;
+    const double* a2 = hinge(hk) + JB_H_ANCHOR;
+    put3(LM_A1, a1); put3(LM_E1, hinge(hs) + JB_H_AXIS); put3d(LM_DA2, a2, a1); put3(LM_E2, hinge(hk) + JB_H_AXIS);
+    put3d(LM_DC1, body(bu) + JB_B_COM, a1); put3d(LM_DC2, body(bl) + JB_B_COM, a2);
+    for (int i = 0; i < 6; i++) { out[LM_I1 + i] = T(body(bu)[JB_B_INERTIA + i]); out[LM_I2 + i] = T(body(bl)[JB_B_INERTIA + i]); }
+    out[LM_M1] = T(body(bu)[JB_B_MASS]); out[LM_M2] = T(body(bl)[JB_B_MASS]);
+    out[LM_K1] = T(hinge(hs)[JB_H_STIFFNESS]); out[LM_B1] = T(hinge(hs)[JB_H_DAMPING]);
+    out[LM_K2] = T(hinge(hk)[JB_H_STIFFNESS]); out[LM_B2] = T(hinge(hk)[JB_H_DAMPING]);
+    out[LM_TRAN1] = T(body(bu)[JB_B_INVW_TRAN]); out[LM_TRAN2] = T(body(bl)[JB_B_INVW_TRAN]);
+    if (hinge(8)[JB_H_DAMPING] != 0.0 || hinge(8)[JB_H_STIFFNESS] != 0.0) return -3;   // motor hinge: no passive terms in the model
+    const double *gu = geom(4 + 4 * leg), *gt = geom(5 + 4 * leg), *gl = geom(6 + 4 * leg), *gf = geom(7 + 4 * leg);
+    if ((int)gu[JB_G_TYPE] != JB_GEOM_CYLINDER || (int)gt[JB_G_TYPE] != JB_GEOM_SPHERE || (int)gl[JB_G_TYPE] != JB_GEOM_CYLINDER || (int)gf[JB_G_TYPE] != JB_GEOM_SPHERE) return -4;
+    auto put_cyl = [&](int at_d, int at_ax, int at_xa, int at_r, int at_h, const double* g, const double* ref) {
+        put3d(at_d, g + JB_G_CENTER, ref);
+        const double* Rg = g + JB_G_ROT;
+        out[at_ax] = T(Rg[2]); out[at_ax + 1] = T(Rg[5]); out[at_ax + 2] = T(Rg[8]);
+        out[at_xa] = T(Rg[0]); out[at_xa + 1] = T(Rg[3]); out[at_xa + 2] = T(Rg[6]);
+        out[at_r] = T(g[JB_G_SIZE]); out[at_h] = T(g[JB_G_SIZE + 1]);
+    };
+    put3d(LM_DFOOT, gf + JB_G_CENTER, a2); out[LM_FOOT_R] = T(gf[JB_G_SIZE]);
+    put_cyl(LM_LC_D, LM_LC_AX, LM_LC_XA, LM_LC_R, LM_LC_H, gl, a2);
+    put_cyl(LM_UC_D, LM_UC_AX, LM_UC_XA, LM_UC_R, LM_UC_H, gu, a1);
+    put3d(LM_DTIP, gt + JB_G_CENTER, a1); out[LM_TIP_R] = T(gt[JB_G_SIZE]);
+    double bleg = norm3d(gu + JB_G_CENTER, a1) + std::sqrt(gu[JB_G_SIZE] * gu[JB_G_SIZE] + gu[JB_G_SIZE + 1] * gu[JB_G_SIZE + 1]);
+    double btip = norm3d(gt + JB_G_CENTER, a1) + gt[JB_G_SIZE];
+    out[LM_BOUND_LEG] = T((bleg > btip ? bleg : btip) + 1e-4);
+
+    // lane-assigned root / motor-body geoms; disabled slots get finite, harmless geometry
+    out[LM_XB_EN] = T(0); out[LM_XC_EN] = T(0); out[LM_XE_EN] = T(0); out[LM_X_ONM] = T(0);
+    for (int i = 0; i < 9; i++) { out[LM_XB_R + i] = T(i % 4 == 0); out[LM_XE_R + i] = T(i % 4 == 0); }
+    out[LM_XC_AX + 2] = T(1); out[LM_XC_XA] = T(1);
+    out[LM_XE_S] = out[LM_XE_S + 1] = out[LM_XE_S + 2] = T(1);
+    double bound = 0;
+    auto put_box = [&](const double* g) {
+        out[LM_XB_EN] = T(1); put3(LM_XB_C, g + JB_G_CENTER);
+        for (int i = 0; i < 9; i++) out[LM_XB_R + i] = T(g[JB_G_ROT + i]);
+        put3(LM_XB_S, g + JB_G_SIZE);
+        double b = norm3d(g + JB_G_CENTER, zero3) + norm3d(g + JB_G_SIZE, zero3);
+        if (b > bound) bound = b;
+    };
+    auto put_xcyl = [&](const double* g, const double* ref) {
+        out[LM_XC_EN] = T(1);
+        put_cyl(LM_XC_C, LM_XC_AX, LM_XC_XA, LM_XC_R, LM_XC_H, g, zero3);
+        double b = norm3d(g + JB_G_CENTER, ref) + std::sqrt(g[JB_G_SIZE] * g[JB_G_SIZE] + g[JB_G_SIZE + 1] * g[JB_G_SIZE + 1]);
+        if (b > bound) bound = b;
+    };
+    auto put_ell = [&](const double* g, const double* ref) {
+        out[LM_XE_EN] = T(1); put3(LM_XE_C, g + JB_G_CENTER);
+        for (int i = 0; i < 9; i++) out[LM_XE_R + i] = T(g[JB_G_ROT + i]);
+        put3(LM_XE_S, g + JB_G_SIZE);
+        double mx = g[JB_G_SIZE];
+        for (int i = 1; i < 3; i++) if (g[JB_G_SIZE + i] > mx) mx = g[JB_G_SIZE + i];
+        double b = norm3d(g + JB_G_CENTER, ref) + mx;
+        if (b > bound) bound = b;
+    };
+    if (leg == 0) { if ((int)geom(0)[JB_G_TYPE] != JB_GEOM_BOX) return -5; put_box(geom(0)); }
+    if (leg == 1) { if ((int)geom(1)[JB_G_TYPE] != JB_GEOM_BOX) return -5; put_box(geom(1)); }
+    if (leg == 2) {
+        if ((int)geom(2)[JB_G_TYPE] != JB_GEOM_CYLINDER || (int)geom(3)[JB_G_TYPE] != JB_GEOM_ELLIPSOID) return -5;
+        put_xcyl(geom(2), zero3); put_ell(geom(3), zero3);
+    }
+    if (leg == 3) {
+        if ((int)geom(20)[JB_G_TYPE] != JB_GEOM_CYLINDER || (int)geom(21)[JB_G_TYPE] != JB_GEOM_ELLIPSOID) return -5;
+        put_xcyl(geom(20), am); put_ell(geom(21), am);
+        out[LM_X_ONM] = T(1);
+    }
+    out[LM_BOUND_X] = T(bound + 1e-4);
+    return 0;
+}
+
+}  // namespace jb

@@ -1,0 +1,785 @@
+// jb_sim.hpp — the Jitterbug substep, written once for device lanes and the host test harness.
+//
+// Replaces, for one physics substep of one environment, what the reference runs
+// inside MuJoCo 2.0 through dm_control's Physics.step() (reference call chain:
+// jitterbug.py:84-90 control.Environment -> 50 x mj_step2/mj_step1 on
+// jitterbug.xml).  This is a from-scratch formulation specialised to the
+// Jitterbug topology (free root + four 2-hinge legs + one motor hinge):
+//
+//   * everything is expressed in the ROOT BODY FRAME about the root origin, so
+//     leg kinematics depend only on that leg's two hinge angles;
+//   * joint-space inertia by composite rigid bodies:  M = [Arr Br; Br^T C] with
+//     Arr 6x6 (whole robot as one rigid body), per-branch coupling Br (6x2 per
+//     leg, 6x1 motor) and per-branch blocks C (2x2 / 1x1) — the star topology
+//     makes the joint block block-diagonal;
+//   * bias forces by a Newton-Euler pass with the root acceleration pinned to
+//     MuJoCo's qacc=0 convention (world-frame linear acceleration of the root
+//     origin = 0), gravity folded in as a fictitious root acceleration;
+//   * linear solves by eliminating each branch (2x2) onto the root: a 6x6 Schur
+//     complement, Cholesky-factored redundantly by the four lanes of a quad;
+//   * soft contacts exactly as MuJoCo poses them (pyramidal cone, solref/solimp
+//     impedance, diagApprox regulariser) and solved in the PRIMAL like MuJoCo's
+//     Newton solver:  H = M + sum_c B_c^T W_c B_c  has the same star sparsity as
+//     M, so each Newton iteration is one more Schur solve; iterations stop when
+//     the active set repeats (the minimiser of a piecewise quadratic is then
+//     exact);
+//   * semi-implicit Euler with implicit joint damping (M + h diag(b)).
+//
+// Lane mapping: 4 lanes per environment, lane l owns leg l; see jb_lane.hpp.
+// Unknown ordering used internally: y = [alpha(3) (root angular accel, body
+// frame) ; a(3) = R^T d/dt(v_world) ; leg joint accels (2, lane-private) ;
+// motor accel (1, replicated)].
+#pragma once
+#include <type_traits>
+
+#include "jb_lane.hpp"
+
+namespace jb {
+
+// ----------------------------------------------------------------------------- lane model table
+// Index map of the per-lane constant table.  Filled by jb_build_lane_model()
+// (host) from the compiled parameter table of include/jitterbug_model.h.
+enum LM : int {
+    LM_H = 0, LM_GRAV = 1 /*3*/, LM_KK = 4, LM_BB = 5, LM_IMP_D0 = 6, LM_IMP_DW = 7, LM_IMP_IW /*1/width*/ = 8, LM_IMP_MID = 9, LM_IMP_POW = 10,
+    LM_MU = 11, LM_FR2 = 12, LM_GEAR = 13, LM_GAIN = 14, LM_BIAS = 15 /*3*/, LM_CTRL_LO = 18, LM_CTRL_HI = 19, LM_MTOT = 20,
+    // root body
+    LM_M0 = 21, LM_C0 = 22 /*3*/, LM_I0 = 25 /*6*/, LM_TRAN0 = 31,
+    // motor ("mass") body
+    LM_MM = 32, LM_AM = 33 /*3*/, LM_EM = 36 /*3*/, LM_DCM = 39 /*3: com - anchor*/, LM_IM = 42 /*6*/, LM_TRANM = 48,
+    // own leg
+    LM_A1 = 49 /*3*/, LM_E1 = 52 /*3*/, LM_DA2 = 55 /*3: knee anchor - a1*/, LM_E2 = 58 /*3*/, LM_DC1 = 61 /*3*/, LM_I1 = 64 /*6*/, LM_M1 = 70,
+    LM_DC2 = 71 /*3: com2 - knee anchor*/, LM_I2 = 74 /*6*/, LM_M2 = 80, LM_K1 = 81, LM_B1 = 82, LM_K2 = 83, LM_B2 = 84, LM_TRAN1 = 85, LM_TRAN2 = 86,
+    LM_DFOOT = 87 /*3*/, LM_FOOT_R = 90,
+    LM_LC_D = 91 /*3: lower cylinder centre - knee anchor*/, LM_LC_AX = 94 /*3*/, LM_LC_XA = 97 /*3*/, LM_LC_R = 100, LM_LC_H = 101,
+    LM_UC_D = 102 /*3: upper cylinder centre - a1*/, LM_UC_AX = 105 /*3*/, LM_UC_XA = 108 /*3*/, LM_UC_R = 111, LM_UC_H = 112,
+    LM_DTIP = 113 /*3*/, LM_TIP_R = 116,
+    // lane-assigned geoms of the root / motor body (lane 0: coreBody1 box, lane 1: coreBody2 box,
+    // lane 2: screw1 cylinder + screw2 ellipsoid, lane 3: threadMass cylinder + mass ellipsoid on the motor body)
+    LM_XB_EN = 117, LM_XB_C = 118 /*3*/, LM_XB_R = 121 /*9*/, LM_XB_S = 130 /*3*/,
+    LM_XC_EN = 133, LM_XC_C = 134 /*3*/, LM_XC_AX = 137 /*3*/, LM_XC_XA = 140 /*3*/, LM_XC_R = 143, LM_XC_H = 144,
+    LM_XE_EN = 145, LM_XE_C = 146 /*3*/, LM_XE_R = 149 /*9*/, LM_XE_S = 158 /*3*/,
+    LM_X_ONM = 161 /*1: the lane's cylinder+ellipsoid sit on the motor body*/,
+    LM_BOUND_LEG = 162 /* bounding radius of upper cylinder + tip about a1 */, LM_BOUND_X = 163 /* bounding radius of lane geoms about their reference point */,
+    LM_TARGET_Z = 164, LM_ROOT_Z0 = 165, LM_LANE = 166 /* 0..3: which leg this lane owns */,
+    LM_COUNT = 168
+};
+
+template <typename V> struct LaneModel { V c[LM_COUNT]; };
+
+template <typename V> struct Vec3 { V x, y, z; };
+template <typename V> JB_HD Vec3<V> v3(const V& x, const V& y, const V& z) { Vec3<V> r; r.x = x; r.y = y; r.z = z; return r; }
+template <typename V> JB_HD Vec3<V> ldv3(const LaneModel<V>& m, int i) { return v3(m.c[i], m.c[i + 1], m.c[i + 2]); }
+template <typename V> JB_HD Vec3<V> operator+(const Vec3<V>& a, const Vec3<V>& b) { return v3<V>(a.x + b.x, a.y + b.y, a.z + b.z); }
+template <typename V> JB_HD Vec3<V> operator-(const Vec3<V>& a, const Vec3<V>& b) { return v3<V>(a.x - b.x, a.y - b.y, a.z - b.z); }
+template <typename V> JB_HD Vec3<V> operator-(const Vec3<V>& a) { return v3<V>(-a.x, -a.y, -a.z); }
+template <typename V> JB_HD Vec3<V> operator*(const Vec3<V>& a, const V& s) { return v3<V>(a.x * s, a.y * s, a.z * s); }
+template <typename V> JB_HD V dot(const Vec3<V>& a, const Vec3<V>& b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+template <typename V> JB_HD Vec3<V> cross(const Vec3<V>& a, const Vec3<V>& b) {
+    return v3<V>(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+template <typename V, typename MKT> JB_HD Vec3<V> sel_v3(const MKT& k, const Vec3<V>& a, const Vec3<V>& b) { return v3<V>(sel(k, a.x, b.x), sel(k, a.y, b.y), sel(k, a.z, b.z)); }
+template <typename V> JB_HD typename lane_traits<V>::uint zero_u() { return mbit(lt(V(1), V(0))); }
+template <typename V> JB_HD Vec3<V> qsum(const Vec3<V>& a) { return v3<V>(quad_sum(a.x), quad_sum(a.y), quad_sum(a.z)); }
+
+// 3x3 general matrix (row major) and symmetric 3x3 (xx yy zz xy xz yz)
+template <typename V> struct Mat3 { V m[9]; };
+template <typename V> struct Sym3 { V xx, yy, zz, xy, xz, yz; };
+template <typename V> JB_HD Vec3<V> mul(const Mat3<V>& R, const Vec3<V>& v) {
+    return v3<V>(R.m[0] * v.x + R.m[1] * v.y + R.m[2] * v.z, R.m[3] * v.x + R.m[4] * v.y + R.m[5] * v.z, R.m[6] * v.x + R.m[7] * v.y + R.m[8] * v.z);
+}
+template <typename V> JB_HD Vec3<V> mulT(const Mat3<V>& R, const Vec3<V>& v) {
+    return v3<V>(R.m[0] * v.x + R.m[3] * v.y + R.m[6] * v.z, R.m[1] * v.x + R.m[4] * v.y + R.m[7] * v.z, R.m[2] * v.x + R.m[5] * v.y + R.m[8] * v.z);
+}
+template <typename V> JB_HD Mat3<V> mul(const Mat3<V>& A, const Mat3<V>& B) {
+    Mat3<V> C;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) C.m[3 * i + j] = A.m[3 * i] * B.m[j] + A.m[3 * i + 1] * B.m[3 + j] + A.m[3 * i + 2] * B.m[6 + j];
+    return C;
+}
+template <typename V> JB_HD Vec3<V> mul(const Sym3<V>& S, const Vec3<V>& v) {
+    return v3<V>(S.xx * v.x + S.xy * v.y + S.xz * v.z, S.xy * v.x + S.yy * v.y + S.yz * v.z, S.xz * v.x + S.yz * v.y + S.zz * v.z);
+}
+template <typename V> JB_HD Sym3<V> ldsym(const LaneModel<V>& m, int i) {
+    Sym3<V> s; s.xx = m.c[i]; s.yy = m.c[i + 1]; s.zz = m.c[i + 2]; s.xy = m.c[i + 3]; s.xz = m.c[i + 4]; s.yz = m.c[i + 5]; return s;
+}
+template <typename V> JB_HD Sym3<V> operator+(const Sym3<V>& a, const Sym3<V>& b) {
+    Sym3<V> s; s.xx = a.xx + b.xx; s.yy = a.yy + b.yy; s.zz = a.zz + b.zz; s.xy = a.xy + b.xy; s.xz = a.xz + b.xz; s.yz = a.yz + b.yz; return s;
+}
+template <typename V> JB_HD Sym3<V> qsum(const Sym3<V>& a) {
+    Sym3<V> s; s.xx = quad_sum(a.xx); s.yy = quad_sum(a.yy); s.zz = quad_sum(a.zz); s.xy = quad_sum(a.xy); s.xz = quad_sum(a.xz); s.yz = quad_sum(a.yz); return s;
+}
+// R S R^T for symmetric S
+template <typename V> JB_HD Sym3<V> rotate(const Mat3<V>& R, const Sym3<V>& S) {
+    V t[9];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        t[3 * i + 0] = R.m[3 * i] * S.xx + R.m[3 * i + 1] * S.xy + R.m[3 * i + 2] * S.xz;
+        t[3 * i + 1] = R.m[3 * i] * S.xy + R.m[3 * i + 1] * S.yy + R.m[3 * i + 2] * S.yz;
+        t[3 * i + 2] = R.m[3 * i] * S.xz + R.m[3 * i + 1] * S.yz + R.m[3 * i + 2] * S.zz;
+    }
+    Sym3<V> o;
+    o.xx = t[0] * R.m[0] + t[1] * R.m[1] + t[2] * R.m[2];
+    o.yy = t[3] * R.m[3] + t[4] * R.m[4] + t[5] * R.m[5];
+    o.zz = t[6] * R.m[6] + t[7] * R.m[7] + t[8] * R.m[8];
+    o.xy = t[0] * R.m[3] + t[1] * R.m[4] + t[2] * R.m[5];
+    o.xz = t[0] * R.m[6] + t[1] * R.m[7] + t[2] * R.m[8];
+    o.yz = t[3] * R.m[6] + t[4] * R.m[7] + t[5] * R.m[8];
+    return o;
+}
+// inertia about the origin of a body with COM inertia I, mass m, COM c:  I + m (|c|^2 1 - c c^T)
+template <typename V> JB_HD Sym3<V> about_origin(const Sym3<V>& I, const V& m, const Vec3<V>& c) {
+    Sym3<V> o;
+    V cx2 = c.x * c.x, cy2 = c.y * c.y, cz2 = c.z * c.z;
+    o.xx = I.xx + m * (cy2 + cz2); o.yy = I.yy + m * (cx2 + cz2); o.zz = I.zz + m * (cx2 + cy2);
+    o.xy = I.xy - m * c.x * c.y; o.xz = I.xz - m * c.x * c.z; o.yz = I.yz - m * c.y * c.z;
+    return o;
+}
+// Rodrigues rotation about unit axis e with (sin, cos)
+template <typename V> JB_HD Mat3<V> rodrigues(const Vec3<V>& e, const V& s, const V& c) {
+    V v = V(1) - c;
+    Mat3<V> R;
+    R.m[0] = c + e.x * e.x * v;       R.m[1] = e.x * e.y * v - e.z * s; R.m[2] = e.x * e.z * v + e.y * s;
+    R.m[3] = e.y * e.x * v + e.z * s; R.m[4] = c + e.y * e.y * v;       R.m[5] = e.y * e.z * v - e.x * s;
+    R.m[6] = e.z * e.x * v - e.y * s; R.m[7] = e.z * e.y * v + e.x * s; R.m[8] = c + e.z * e.z * v;
+    return R;
+}
+template <typename V> JB_HD Mat3<V> quat2mat(const V& w, const V& x, const V& y, const V& z) {
+    Mat3<V> R;
+    R.m[0] = w * w + x * x - y * y - z * z; R.m[1] = V(2) * (x * y - w * z);         R.m[2] = V(2) * (x * z + w * y);
+    R.m[3] = V(2) * (x * y + w * z);         R.m[4] = w * w - x * x + y * y - z * z; R.m[5] = V(2) * (y * z - w * x);
+    R.m[6] = V(2) * (x * z - w * y);         R.m[7] = V(2) * (y * z + w * x);         R.m[8] = w * w - x * x - y * y + z * z;
+    return R;
+}
+
+// ----------------------------------------------------------------------------- lane state
+template <typename V> struct LaneState {
+    // replicated in the 4 lanes of a quad
+    V px, py, pz, qw, qx, qy, qz;        // root pose (world)
+    V vx, vy, vz;                        // root linear velocity (world)
+    V wx, wy, wz;                        // root angular velocity (body frame)
+    V phi, phid, turns;                  // motor angle wrapped to [-pi, pi), rate, whole turns
+    // lane private: own leg
+    V th1, th2, thd1, thd2;
+    // warm start of the contact solve: last acceleration [alpha(3), world linear(3)], own leg (2), motor
+    V wa[3], wl[3], wj[2], wm;
+    V fail;                              // >0: the Newton iteration hit its cap in some substep
+};
+
+// The joint-space system in star form.  A: 6x6 symmetric, lower triangle packed row-wise
+// (index i*(i+1)/2+j, j<=i), dof order [ang(3), lin(3)]; B: 6x2 own-leg coupling; C: own-leg 2x2;
+// Bm, Cm: motor coupling / diagonal.
+template <typename V> struct StarSys {
+    V A[21];
+    V B[6][2];
+    V C11, C12, C22;
+    V Bm[6];
+    V Cm;
+};
+JB_HD constexpr int tri(int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
+
+// Solve  [A B Bm; B^T C 0; Bm^T 0 Cm] y = [rr; rl; rm].
+//   A      : replicated part (identical in the 4 lanes), added ONCE
+//   Aloc   : lane-private additive part of A (contact terms), summed over the quad
+//   B, C   : lane-private leg branch.  Bm/Cm: motor branch, replicated (+ Bmloc/Cmloc lane-private parts if XTRA)
+// rr is given as replicated part rr plus lane-private part rrloc.
+template <typename V, bool XTRA>
+JB_HD void star_solve(const V (&A)[21], const V (&Aloc)[21], const V (&B)[6][2], const V& C11, const V& C12, const V& C22,
+                      const V (&Bm)[6], const V& Cm, const V (&Bmloc)[6], const V& Cmloc,
+                      const V (&rr)[6], const V (&rrloc)[6], const V (&rl)[2], const V& rm, const V& rmloc,
+                      V (&yr)[6], V (&yl)[2], V& ym) {
+    // eliminate own leg
+    V det = C11 * C22 - C12 * C12;
+    V idet = V(1) / det;
+    V i11 = C22 * idet, i12 = -C12 * idet, i22 = C11 * idet;
+    V G[6][2];
+#pragma unroll
+    for (int i = 0; i < 6; i++) { G[i][0] = B[i][0] * i11 + B[i][1] * i12; G[i][1] = B[i][0] * i12 + B[i][1] * i22; }
+    V S[21], r[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+#pragma unroll
+        for (int j = 0; j <= i; j++) S[tri(i, j)] = quad_sum(Aloc[tri(i, j)] - (G[i][0] * B[j][0] + G[i][1] * B[j][1])) + A[tri(i, j)];
+        r[i] = quad_sum(rrloc[i] - (G[i][0] * rl[0] + G[i][1] * rl[1])) + rr[i];
+    }
+    // motor branch
+    V bm[6], cm = Cm, rmt = rm;
+#pragma unroll
+    for (int i = 0; i < 6; i++) bm[i] = Bm[i];
+    if (XTRA) {
+#pragma unroll
+        for (int i = 0; i < 6; i++) bm[i] = bm[i] + quad_sum(Bmloc[i]);
+        cm = cm + quad_sum(Cmloc);
+        rmt = rmt + quad_sum(rmloc);
+    }
+    V icm = V(1) / cm;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        V g = bm[i] * icm;
+#pragma unroll
+        for (int j = 0; j <= i; j++) S[tri(i, j)] = S[tri(i, j)] - g * bm[j];
+        r[i] = r[i] - g * rmt;
+    }
+    // Cholesky S = L L^T (in place), forward/back substitution
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        V s = S[tri(j, j)];
+#pragma unroll
+        for (int k = 0; k < j; k++) s = s - S[tri(j, k)] * S[tri(j, k)];
+        V d = vsqrt(s);
+        V id = V(1) / d;
+        S[tri(j, j)] = id;                      // store the reciprocal of the pivot
+#pragma unroll
+        for (int i = j + 1; i < 6; i++) {
+            V t = S[tri(i, j)];
+#pragma unroll
+            for (int k = 0; k < j; k++) t = t - S[tri(i, k)] * S[tri(j, k)];
+            S[tri(i, j)] = t * id;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        V s = r[i];
+#pragma unroll
+        for (int k = 0; k < i; k++) s = s - S[tri(i, k)] * yr[k];
+        yr[i] = s * S[tri(i, i)];
+    }
+#pragma unroll
+    for (int i = 5; i >= 0; i--) {
+        V s = yr[i];
+#pragma unroll
+        for (int k = i + 1; k < 6; k++) s = s - S[tri(k, i)] * yr[k];
+        yr[i] = s * S[tri(i, i)];
+    }
+    // back-substitute the branches
+    V t0 = rl[0], t1 = rl[1], tm = rmt;
+#pragma unroll
+    for (int i = 0; i < 6; i++) { t0 = t0 - B[i][0] * yr[i]; t1 = t1 - B[i][1] * yr[i]; tm = tm - bm[i] * yr[i]; }
+    yl[0] = i11 * t0 + i12 * t1;
+    yl[1] = i12 * t0 + i22 * t1;
+    ym = tm * icm;
+}
+
+// ----------------------------------------------------------------------------- contacts
+// MuJoCo solimp impedance d(r) (5-parameter form)
+template <typename V> JB_HD V impedance(const LaneModel<V>& m, const V& dist) {
+    V x = vmin(vabs(dist) * m.c[LM_IMP_IW], V(1));
+    V mid = m.c[LM_IMP_MID];
+    // power = 2 (MuJoCo default); other powers are rejected by the host when the table is built
+    V ya = x * x / mid;
+    V omx = V(1) - x;
+    V yb = V(1) - omx * omx / (V(1) - mid);
+    V y = sel(lt(x, mid), ya, yb);
+    return m.c[LM_IMP_D0] + y * (m.c[LM_IMP_DW] - m.c[LM_IMP_D0]);
+}
+
+// Per-substep direction data shared by all contacts of the lane: for the three contact-frame
+// directions d in {n, t1, t2} (root coordinates) the joint rows are affine in the contact point x:
+//   J_sh(x,d) = (d x e1).(x - a1),  J_kn(x,d) = (d x e2).(x - a2),  J_m(x,d) = (d x em).(x - am)
+template <typename V> struct DirData {
+    Vec3<V> d[3];
+    Vec3<V> wS[3], wK[3], wM[3];
+    V oS[3], oK[3], oM[3];
+    V du[3];                 // d . u  (root linear velocity in root coords)
+};
+
+// Accumulator of the Newton system for the lane
+template <typename V> struct NewtonAcc {
+    V A[21];                 // lane-private additive part of the root block
+    V B[6][2];               // leg coupling (starts from M's)
+    V C11, C12, C22;
+    V Bm[6], Cm;             // lane-private additive part of the motor branch
+    V rr[6], rl[2], rm;      // lane-private additive rhs parts (rl starts from tau)
+    typename lane_traits<V>::uint bw[5];   // active-set record: 5 bits (valid + 4 pyramid edges) per contact slot, 6 slots per word
+};
+
+// level: 0 root body, 1 upper leg (shoulder only), 2 lower leg (shoulder+knee), 3 motor body.
+// MODE 0: accumulate H and rhs for the active set at y;  MODE 1: accumulate the constraint force  -B^T W rho  into rr/rl/rm.
+template <typename V, int LEVEL, int MODE, int SLOT>
+JB_HD void contact_accumulate(const LaneModel<V>& m, const DirData<V>& dd, const Vec3<V>& x, const V& dist, const typename lane_traits<V>::mask& valid,
+                              const V& tran, const Vec3<V>& w, const V& thd1, const V& thd2, const V& phid,
+                              const V (&yr)[6], const V (&yl)[2], const V& ym, NewtonAcc<V>& acc) {
+    using U = typename lane_traits<V>::uint;
+    V imp = impedance(m, dist);
+    V R0 = (V(1) - imp) / imp * tran * (V(1) + m.c[LM_FR2]);
+    V mu = m.c[LM_MU];
+    V D = sel(valid, V(1) / (V(2) * mu * mu * R0), V(0));
+    // rows of B for the three directions: [x cross d (3), d (3), J_sh, J_kn | J_m]
+    V Bj[3][8], rho[3], ahat[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        Vec3<V> ang = cross(x, dd.d[k]);
+        Bj[k][0] = ang.x; Bj[k][1] = ang.y; Bj[k][2] = ang.z;
+        Bj[k][3] = dd.d[k].x; Bj[k][4] = dd.d[k].y; Bj[k][5] = dd.d[k].z;
+        V vel = dot(ang, w) + dd.du[k];
+        V acc_ = ang.x * yr[0] + ang.y * yr[1] + ang.z * yr[2] + dd.d[k].x * yr[3] + dd.d[k].y * yr[4] + dd.d[k].z * yr[5];
+        if (LEVEL == 1 || LEVEL == 2) {
+            Bj[k][6] = dot(dd.wS[k], x) - dd.oS[k];
+            vel = vel + Bj[k][6] * thd1; acc_ = acc_ + Bj[k][6] * yl[0];
+        } else Bj[k][6] = V(0);
+        if (LEVEL == 2) {
+            Bj[k][7] = dot(dd.wK[k], x) - dd.oK[k];
+            vel = vel + Bj[k][7] * thd2; acc_ = acc_ + Bj[k][7] * yl[1];
+        } else if (LEVEL == 3) {
+            Bj[k][7] = dot(dd.wM[k], x) - dd.oM[k];
+            vel = vel + Bj[k][7] * phid; acc_ = acc_ + Bj[k][7] * ym;
+        } else Bj[k][7] = V(0);
+        ahat[k] = -m.c[LM_BB] * vel;
+        if (k == 0) ahat[k] = ahat[k] - m.c[LM_KK] * imp * dist;
+        rho[k] = acc_ - ahat[k];
+    }
+    // pyramid edges  r = rho_n +- mu rho_t
+    V mr1 = mu * rho[1], mr2 = mu * rho[2];
+    auto a1 = lt(rho[0] + mr1, V(0)), a2 = lt(rho[0] - mr1, V(0)), a3 = lt(rho[0] + mr2, V(0)), a4 = lt(rho[0] - mr2, V(0));
+    V f1 = sel(a1, V(1), V(0)), f2 = sel(a2, V(1), V(0)), f3 = sel(a3, V(1), V(0)), f4 = sel(a4, V(1), V(0));
+    V Wnn = D * (f1 + f2 + f3 + f4), Wn1 = D * mu * (f1 - f2), Wn2 = D * mu * (f3 - f4), W11 = D * mu * mu * (f1 + f2), W22 = D * mu * mu * (f3 + f4);
+#ifdef JB_DEBUG_PRINT
+    for (int l = 0; l < 4; l++) if (valid.v[l]) fprintf(stderr, "  [lane %d lvl %d mode %d] dist %.6g rho %.5f %.5f %.5f ahat %.5f %.5f %.5f D %.6g act %d%d%d%d x %.5f %.5f %.5f\n", l, LEVEL, MODE, (double)dist.v[l],
+        (double)rho[0].v[l], (double)rho[1].v[l], (double)rho[2].v[l], (double)ahat[0].v[l], (double)ahat[1].v[l], (double)ahat[2].v[l], (double)D.v[l], a1.v[l], a2.v[l], a3.v[l], a4.v[l], (double)x.x.v[l], (double)x.y.v[l], (double)x.z.v[l]);
+#endif
+    if (MODE == 0) {
+        U bits = (mbit(a1) + mbit(a2) * 2u + mbit(a3) * 4u + mbit(a4) * 8u + 16u);
+        acc.bw[SLOT / 6] = acc.bw[SLOT / 6] + selu(valid, bits, zero_u<V>()) * (1u << (5 * (SLOT % 6)));
+        V wa0 = Wnn * ahat[0] + Wn1 * ahat[1] + Wn2 * ahat[2];
+        V wa1 = Wn1 * ahat[0] + W11 * ahat[1];
+        V wa2 = Wn2 * ahat[0] + W22 * ahat[2];
+        V WB[3][8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            WB[0][i] = Wnn * Bj[0][i] + Wn1 * Bj[1][i] + Wn2 * Bj[2][i];
+            WB[1][i] = Wn1 * Bj[0][i] + W11 * Bj[1][i];
+            WB[2][i] = Wn2 * Bj[0][i] + W22 * Bj[2][i];
+        }
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+#pragma unroll
+            for (int j = 0; j <= i; j++) acc.A[tri(i, j)] = acc.A[tri(i, j)] + (Bj[0][i] * WB[0][j] + Bj[1][i] * WB[1][j] + Bj[2][i] * WB[2][j]);
+            acc.rr[i] = acc.rr[i] + (Bj[0][i] * wa0 + Bj[1][i] * wa1 + Bj[2][i] * wa2);
+        }
+        if (LEVEL == 1 || LEVEL == 2) {
+#pragma unroll
+            for (int i = 0; i < 6; i++) acc.B[i][0] = acc.B[i][0] + (Bj[0][6] * WB[0][i] + Bj[1][6] * WB[1][i] + Bj[2][6] * WB[2][i]);
+            acc.C11 = acc.C11 + (Bj[0][6] * WB[0][6] + Bj[1][6] * WB[1][6] + Bj[2][6] * WB[2][6]);
+            acc.rl[0] = acc.rl[0] + (Bj[0][6] * wa0 + Bj[1][6] * wa1 + Bj[2][6] * wa2);
+        }
+        if (LEVEL == 2) {
+#pragma unroll
+            for (int i = 0; i < 6; i++) acc.B[i][1] = acc.B[i][1] + (Bj[0][7] * WB[0][i] + Bj[1][7] * WB[1][i] + Bj[2][7] * WB[2][i]);
+            acc.C12 = acc.C12 + (Bj[0][6] * WB[0][7] + Bj[1][6] * WB[1][7] + Bj[2][6] * WB[2][7]);
+            acc.C22 = acc.C22 + (Bj[0][7] * WB[0][7] + Bj[1][7] * WB[1][7] + Bj[2][7] * WB[2][7]);
+            acc.rl[1] = acc.rl[1] + (Bj[0][7] * wa0 + Bj[1][7] * wa1 + Bj[2][7] * wa2);
+        }
+        if (LEVEL == 3) {
+#pragma unroll
+            for (int i = 0; i < 6; i++) acc.Bm[i] = acc.Bm[i] + (Bj[0][7] * WB[0][i] + Bj[1][7] * WB[1][i] + Bj[2][7] * WB[2][i]);
+            acc.Cm = acc.Cm + (Bj[0][7] * WB[0][7] + Bj[1][7] * WB[1][7] + Bj[2][7] * WB[2][7]);
+            acc.rm = acc.rm + (Bj[0][7] * wa0 + Bj[1][7] * wa1 + Bj[2][7] * wa2);
+        }
+    } else {
+        // constraint force  qfrc = B^T (-W rho)
+        V g0 = -(Wnn * rho[0] + Wn1 * rho[1] + Wn2 * rho[2]);
+        V g1 = -(Wn1 * rho[0] + W11 * rho[1]);
+        V g2 = -(Wn2 * rho[0] + W22 * rho[2]);
+#pragma unroll
+        for (int i = 0; i < 6; i++) acc.rr[i] = acc.rr[i] + (Bj[0][i] * g0 + Bj[1][i] * g1 + Bj[2][i] * g2);
+        if (LEVEL == 1 || LEVEL == 2) acc.rl[0] = acc.rl[0] + (Bj[0][6] * g0 + Bj[1][6] * g1 + Bj[2][6] * g2);
+        if (LEVEL == 2) acc.rl[1] = acc.rl[1] + (Bj[0][7] * g0 + Bj[1][7] * g1 + Bj[2][7] * g2);
+        if (LEVEL == 3) acc.rm = acc.rm + (Bj[0][7] * g0 + Bj[1][7] * g1 + Bj[2][7] * g2);
+    }
+}
+
+// Cylinder vs floor, restating MuJoCo's plane-cylinder routine: up to 4 points.  c: centre, ax: unit axis,
+// xa: geom x axis (degenerate case), all in root coordinates relative to the root origin; nb: floor normal in
+// root coordinates; pz: world height of the root origin.  Outputs positions (relative to the root origin) and
+// distances; a point is a contact when its mask is set.
+template <typename V> struct CylContacts {
+    Vec3<V> x[4];
+    V dist[4];
+    typename lane_traits<V>::mask on[4];
+};
+template <typename V>
+JB_HD void cylinder_floor(const Vec3<V>& c, const Vec3<V>& ax_in, const Vec3<V>& xa, const V& rad, const V& half, const Vec3<V>& nb, const V& pz,
+                          const typename lane_traits<V>::mask& enabled, CylContacts<V>& out) {
+    V prj = dot(ax_in, nb);
+    auto flip = gt(prj, V(0));
+    Vec3<V> ax = v3<V>(sel(flip, -ax_in.x, ax_in.x), sel(flip, -ax_in.y, ax_in.y), sel(flip, -ax_in.z, ax_in.z));
+    prj = sel(flip, -prj, prj);
+    V dist0 = pz + dot(c, nb);
+    Vec3<V> vec = ax * prj - nb;
+    V len2 = dot(vec, vec);
+    auto degenerate = lt(len2, V(1e-20));
+    V scl = rad / vsqrt(vmax(len2, V(1e-30)));
+    vec = v3<V>(sel(degenerate, xa.x * rad, vec.x * scl), sel(degenerate, xa.y * rad, vec.y * scl), sel(degenerate, xa.z * rad, vec.z * scl));
+    V prjvec = dot(vec, nb);
+    Vec3<V> axh = ax * half;
+    V prjaxis = prj * half;
+    V d1 = dist0 + prjaxis + prjvec;
+    auto on1 = mand(enabled, lt(d1, V(0)));
+    out.dist[0] = d1; out.on[0] = on1;
+    out.x[0] = c + vec + axh - nb * (d1 * V(0.5));
+    V d2 = dist0 - prjaxis + prjvec;
+    out.dist[1] = d2; out.on[1] = mand(on1, lt(d2, V(0)));
+    out.x[1] = c + vec - axh - nb * (d2 * V(0.5));
+    V d3 = dist0 + prjaxis - V(0.5) * prjvec;
+    auto on3 = mand(on1, lt(d3, V(0)));
+    Vec3<V> v1 = cross(vec, axh);
+    V l1 = vsqrt(vmax(dot(v1, v1), V(1e-30)));
+    v1 = v1 * (rad * V(0.8660254037844386) / l1);
+    Vec3<V> base = c + axh - vec * V(0.5) - nb * (d3 * V(0.5));
+    out.dist[2] = d3; out.on[2] = on3; out.x[2] = base + v1;
+    out.dist[3] = d3; out.on[3] = on3; out.x[3] = base - v1;
+}
+
+// ----------------------------------------------------------------------------- options
+struct SimOpts {
+    int contacts;        // 0: contacts disabled (MuJoCo disableflags=contact)
+    int max_newton;      // cap on Newton iterations per substep
+    int implicit_damp;   // 1: MuJoCo Euler implicit joint damping
+};
+
+// small-angle sin/cos for the leg hinges (|th| < 1: truncation < 1e-9), exact libm otherwise
+template <typename V> JB_HD void sincos_small(const V& x, V& s, V& c) {
+    V x2 = x * x;
+    s = x * (V(1) + x2 * (V(-1.0 / 6) + x2 * (V(1.0 / 120) + x2 * (V(-1.0 / 5040) + x2 * (V(1.0 / 362880) + x2 * V(-1.0 / 39916800))))));
+    c = V(1) + x2 * (V(-0.5) + x2 * (V(1.0 / 24) + x2 * (V(-1.0 / 720) + x2 * (V(1.0 / 40320) + x2 * (V(-1.0 / 3628800) + x2 * V(1.0 / 479001600))))));
+}
+
+// ----------------------------------------------------------------------------- the substep
+template <typename V>
+JB_HD void substep(const LaneModel<V>& m, LaneState<V>& s, const V& ctrl, const SimOpts& o) {
+    using MK = typename lane_traits<V>::mask;
+    using U = typename lane_traits<V>::uint;
+    const V h = m.c[LM_H];
+
+    // ---- root frame
+    V qn = V(1) / vsqrt(s.qw * s.qw + s.qx * s.qx + s.qy * s.qy + s.qz * s.qz);
+    s.qw = s.qw * qn; s.qx = s.qx * qn; s.qy = s.qy * qn; s.qz = s.qz * qn;
+    Mat3<V> R = quat2mat(s.qw, s.qx, s.qy, s.qz);
+    Vec3<V> nb = v3<V>(R.m[6], R.m[7], R.m[8]);                 // R^T ez
+    Vec3<V> w = v3<V>(s.wx, s.wy, s.wz);
+    Vec3<V> u = mulT(R, v3<V>(s.vx, s.vy, s.vz));
+    Vec3<V> AO = -mulT(R, ldv3(m, LM_GRAV));                    // fictitious root acceleration = -g (root coords)
+
+    // ---- own leg kinematics
+    Vec3<V> a1 = ldv3(m, LM_A1), e1 = ldv3(m, LM_E1);
+    V s1, c1, s2, c2;
+    sincos_small(s.th1, s1, c1);
+    sincos_small(s.th2, s2, c2);
+    if (any_lane(mor(gt(vabs(s.th1), V(0.9)), gt(vabs(s.th2), V(0.9))))) { s1 = vsin(s.th1); c1 = vcos(s.th1); s2 = vsin(s.th2); c2 = vcos(s.th2); }
+    Mat3<V> R1 = rodrigues(e1, s1, c1);
+    Mat3<V> R12 = mul(R1, rodrigues(ldv3(m, LM_E2), s2, c2));
+    Vec3<V> a2 = a1 + mul(R1, ldv3(m, LM_DA2));
+    Vec3<V> e2 = mul(R1, ldv3(m, LM_E2));
+    Vec3<V> cc1 = a1 + mul(R1, ldv3(m, LM_DC1));
+    Vec3<V> cc2 = a2 + mul(R12, ldv3(m, LM_DC2));
+    Sym3<V> I1 = rotate(R1, ldsym(m, LM_I1));
+    Sym3<V> I2 = rotate(R12, ldsym(m, LM_I2));
+    const V m1 = m.c[LM_M1], m2 = m.c[LM_M2];
+
+    // ---- motor body kinematics (replicated)
+    Vec3<V> am = ldv3(m, LM_AM), em = ldv3(m, LM_EM);
+    V sp = vsin(s.phi), cp = vcos(s.phi);
+    Mat3<V> Rm = rodrigues(em, sp, cp);
+    Vec3<V> cm = am + mul(Rm, ldv3(m, LM_DCM));
+    Sym3<V> Im = rotate(Rm, ldsym(m, LM_IM));
+    const V mm = m.c[LM_MM], m0 = m.c[LM_M0];
+    Vec3<V> c0 = ldv3(m, LM_C0);
+    Sym3<V> I0 = ldsym(m, LM_I0);
+
+    // ---- composite rigid bodies -> star system of M
+    StarSys<V> M;
+    Vec3<V> h2 = cc2 * m2, h1 = cc1 * m1;
+    Sym3<V> J2 = about_origin(I2, m2, cc2);
+    Sym3<V> J12 = about_origin(I1, m1, cc1) + J2;
+    Vec3<V> h12 = h1 + h2;
+    V m12 = m1 + m2;
+    Vec3<V> sK = cross(a2, e2), sS = cross(a1, e1), sM = cross(am, em);          // linear part of the joint motion vectors
+    Vec3<V> fK = sK * m2 + cross(e2, h2), nK = mul(J2, e2) + cross(h2, sK);
+    Vec3<V> fS = sS * m12 + cross(e1, h12), nS = mul(J12, e1) + cross(h12, sS);
+    M.B[0][0] = nS.x; M.B[1][0] = nS.y; M.B[2][0] = nS.z; M.B[3][0] = fS.x; M.B[4][0] = fS.y; M.B[5][0] = fS.z;
+    M.B[0][1] = nK.x; M.B[1][1] = nK.y; M.B[2][1] = nK.z; M.B[3][1] = fK.x; M.B[4][1] = fK.y; M.B[5][1] = fK.z;
+    M.C11 = dot(e1, nS) + dot(sS, fS);
+    M.C12 = dot(e1, nK) + dot(sS, fK);
+    M.C22 = dot(e2, nK) + dot(sK, fK);
+    Vec3<V> hm = cm * mm;
+    Sym3<V> Jm = about_origin(Im, mm, cm);
+    Vec3<V> fM = sM * mm + cross(em, hm), nM = mul(Jm, em) + cross(hm, sM);
+    M.Bm[0] = nM.x; M.Bm[1] = nM.y; M.Bm[2] = nM.z; M.Bm[3] = fM.x; M.Bm[4] = fM.y; M.Bm[5] = fM.z;
+    M.Cm = dot(em, nM) + dot(sM, fM);
+    {
+        Vec3<V> ht = c0 * m0 + hm + qsum(h12);
+        Sym3<V> Jt = about_origin(I0, m0, c0) + Jm + qsum(J12);
+        V mt = m.c[LM_MTOT];
+        V Z = V(0);
+        // [[J, [h]x], [[h]x^T, m 1]] with [h]x = [[0,-hz,hy],[hz,0,-hx],[-hy,hx,0]]
+        M.A[tri(0, 0)] = Jt.xx; M.A[tri(1, 0)] = Jt.xy; M.A[tri(1, 1)] = Jt.yy; M.A[tri(2, 0)] = Jt.xz; M.A[tri(2, 1)] = Jt.yz; M.A[tri(2, 2)] = Jt.zz;
+        M.A[tri(3, 0)] = Z;     M.A[tri(3, 1)] = ht.z;  M.A[tri(3, 2)] = -ht.y;
+        M.A[tri(4, 0)] = -ht.z; M.A[tri(4, 1)] = Z;     M.A[tri(4, 2)] = ht.x;
+        M.A[tri(5, 0)] = ht.y;  M.A[tri(5, 1)] = -ht.x; M.A[tri(5, 2)] = Z;
+        M.A[tri(3, 3)] = mt; M.A[tri(4, 3)] = Z; M.A[tri(4, 4)] = mt; M.A[tri(5, 3)] = Z; M.A[tri(5, 4)] = Z; M.A[tri(5, 5)] = mt;
+    }
+
+    // ---- bias forces (Newton-Euler with qacc = 0 in MuJoCo coordinates) and applied forces
+    V tr[6], tl[2], tm;      // tau: root (replicated), own leg, motor
+    {
+        auto accel_at = [&](const Vec3<V>& x) { return AO + cross(w, cross(w, x)); };
+        Vec3<V> F0 = accel_at(c0) * m0;
+        Vec3<V> N0 = cross(w, mul(I0, w));
+        // own leg
+        Vec3<V> Aa1 = accel_at(a1);
+        Vec3<V> w1 = w + e1 * s.thd1;
+        Vec3<V> al1 = cross(w, e1) * s.thd1;
+        Vec3<V> r1 = cc1 - a1;
+        Vec3<V> F1 = (Aa1 + cross(al1, r1) + cross(w1, cross(w1, r1))) * m1;
+        Vec3<V> N1 = mul(I1, al1) + cross(w1, mul(I1, w1));
+        Vec3<V> r12 = a2 - a1;
+        Vec3<V> Aa2 = Aa1 + cross(al1, r12) + cross(w1, cross(w1, r12));
+        Vec3<V> w2 = w1 + e2 * s.thd2;
+        Vec3<V> al2 = al1 + cross(w1, e2) * s.thd2;
+        Vec3<V> r2 = cc2 - a2;
+        Vec3<V> F2 = (Aa2 + cross(al2, r2) + cross(w2, cross(w2, r2))) * m2;
+        Vec3<V> N2 = mul(I2, al2) + cross(w2, mul(I2, w2));
+        V cK = dot(e2, N2 + cross(r2, F2));
+        V cS = dot(e1, N1 + cross(r1, F1) + N2 + cross(cc2 - a1, F2));
+        Vec3<V> legF = F1 + F2;
+        Vec3<V> legN = N1 + cross(cc1, F1) + N2 + cross(cc2, F2);
+        // motor body
+        Vec3<V> wm = w + em * s.phid;
+        Vec3<V> alm = cross(w, em) * s.phid;
+        Vec3<V> rm = cm - am;
+        Vec3<V> Fm = (accel_at(am) + cross(alm, rm) + cross(wm, cross(wm, rm))) * mm;
+        Vec3<V> Nm = mul(Im, alm) + cross(wm, mul(Im, wm));
+        V cM = dot(em, Nm + cross(rm, Fm));
+        Vec3<V> bl = F0 + Fm + qsum(legF);
+        Vec3<V> ba = N0 + cross(c0, F0) + Nm + cross(cm, Fm) + qsum(legN);
+        tr[0] = -ba.x; tr[1] = -ba.y; tr[2] = -ba.z; tr[3] = -bl.x; tr[4] = -bl.y; tr[5] = -bl.z;
+        tl[0] = -cS - m.c[LM_K1] * s.th1 - m.c[LM_B1] * s.thd1;
+        tl[1] = -cK - m.c[LM_K2] * s.th2 - m.c[LM_B2] * s.thd2;
+        V uc = vmin(vmax(ctrl, m.c[LM_CTRL_LO]), m.c[LM_CTRL_HI]);
+        V gear = m.c[LM_GEAR];
+        V len = gear * (s.phi + s.turns * V(6.283185307179586));
+        V force = m.c[LM_GAIN] * uc + m.c[LM_BIAS] + m.c[LM_BIAS + 1] * len + m.c[LM_BIAS + 2] * gear * s.phid;
+        tm = -cM + gear * force;
+    }
+
+    // ---- contacts: candidate geometry (root coords, relative to the root origin)
+    V qfr[6], qfl[2], qfm;            // constraint force (root part lane-private until summed in the final solve)
+#pragma unroll
+    for (int i = 0; i < 6; i++) qfr[i] = V(0);
+    qfl[0] = qfl[1] = V(0); qfm = V(0);
+    bool xtra = false;
+    if (o.contacts) {
+        // foot sphere and lower-leg cylinder: always evaluated
+        Vec3<V> foot = a2 + mul(R12, ldv3(m, LM_DFOOT));
+        V fdist = s.pz + dot(foot, nb) - m.c[LM_FOOT_R];
+        MK fon = lt(fdist, V(0));
+        Vec3<V> fx = foot - nb * (m.c[LM_FOOT_R] + fdist * V(0.5));
+        CylContacts<V> lc;
+        MK all_on = lt(V(0), V(1));
+        cylinder_floor(a2 + mul(R12, ldv3(m, LM_LC_D)), mul(R12, ldv3(m, LM_LC_AX)), mul(R12, ldv3(m, LM_LC_XA)), m.c[LM_LC_R], m.c[LM_LC_H], nb, s.pz, all_on, lc);
+        MK any_con = mor(fon, lc.on[0]);
+        // broadphase for the rarely touching geoms: upper cylinder + knee tip (bounding sphere about the
+        // shoulder anchor) and the lane's root/motor-body geoms
+        MK near_leg = lt(s.pz + dot(a1, nb), m.c[LM_BOUND_LEG]);
+        Vec3<V> xref = sel_v3(gt(m.c[LM_X_ONM], V(0.5)), am, v3<V>(V(0), V(0), V(0)));
+        MK near_x = lt(s.pz + dot(xref, nb), m.c[LM_BOUND_X]);
+        xtra = any_lane(mor(near_leg, near_x));
+        // rarely-touching candidates, evaluated only when some lane of the wave is near the floor
+        CylContacts<V> ucx, xcx;
+        Vec3<V> tipx, ellx, boxx[8];
+        V tipd = V(1), elld = V(1), boxd[8];
+        MK tipon = lt(V(1), V(0)), ellon = tipon, boxon[8];
+        MK x_onm = gt(m.c[LM_X_ONM], V(0.5));
+        if (xtra) {
+            cylinder_floor(a1 + mul(R1, ldv3(m, LM_UC_D)), mul(R1, ldv3(m, LM_UC_AX)), mul(R1, ldv3(m, LM_UC_XA)), m.c[LM_UC_R], m.c[LM_UC_H], nb, s.pz, all_on, ucx);
+            Vec3<V> tip = a1 + mul(R1, ldv3(m, LM_DTIP));
+            tipd = s.pz + dot(tip, nb) - m.c[LM_TIP_R];
+            tipon = lt(tipd, V(0));
+            tipx = tip - nb * (m.c[LM_TIP_R] + tipd * V(0.5));
+            // lane cylinder (root body: lane 2 screw1; motor body: lane 3 threadMass)
+            Vec3<V> xc_c = ldv3(m, LM_XC_C), xc_ax = ldv3(m, LM_XC_AX), xc_xa = ldv3(m, LM_XC_XA);
+            Vec3<V> xc_cm = am + mul(Rm, xc_c - am);
+            cylinder_floor(sel_v3(x_onm, xc_cm, xc_c), sel_v3(x_onm, mul(Rm, xc_ax), xc_ax), sel_v3(x_onm, mul(Rm, xc_xa), xc_xa),
+                           m.c[LM_XC_R], m.c[LM_XC_H], nb, s.pz, gt(m.c[LM_XC_EN], V(0.5)), xcx);
+            // lane ellipsoid: support point in direction -n
+            {
+                Mat3<V> Re; Mat3<V> Re0;
+#pragma unroll
+                for (int i = 0; i < 9; i++) Re0.m[i] = m.c[LM_XE_R + i];
+                Mat3<V> Rem = mul(Rm, Re0);
+#pragma unroll
+                for (int i = 0; i < 9; i++) Re.m[i] = sel(x_onm, Rem.m[i], Re0.m[i]);
+                Vec3<V> ec0 = ldv3(m, LM_XE_C);
+                Vec3<V> ec = sel_v3(x_onm, am + mul(Rm, ec0 - am), ec0);
+                Vec3<V> dl = mulT(Re, -nb);
+                Vec3<V> sz = ldv3(m, LM_XE_S);
+                V den = vsqrt(sz.x * sz.x * dl.x * dl.x + sz.y * sz.y * dl.y * dl.y + sz.z * sz.z * dl.z * dl.z);
+                Vec3<V> sup = ec + mul(Re, v3<V>(sz.x * sz.x * dl.x / den, sz.y * sz.y * dl.y / den, sz.z * sz.z * dl.z / den));
+                elld = s.pz + dot(sup, nb);
+                ellon = mand(gt(m.c[LM_XE_EN], V(0.5)), lt(elld, V(0)));
+                ellx = sup - nb * (elld * V(0.5));
+            }
+            // lane box (root body): first 4 penetrating vertices in vertex order
+            {
+                Mat3<V> Rb;
+#pragma unroll
+                for (int i = 0; i < 9; i++) Rb.m[i] = m.c[LM_XB_R + i];
+                Vec3<V> bc = ldv3(m, LM_XB_C), bs = ldv3(m, LM_XB_S);
+                MK ben = gt(m.c[LM_XB_EN], V(0.5));
+                V cnt = V(0);
+#pragma unroll
+                for (int vtx = 0; vtx < 8; vtx++) {
+                    Vec3<V> l = v3<V>((vtx & 1) ? bs.x : -bs.x, (vtx & 2) ? bs.y : -bs.y, (vtx & 4) ? bs.z : -bs.z);
+                    Vec3<V> p = bc + mul(Rb, l);
+                    V d = s.pz + dot(p, nb);
+                    MK on = mand(mand(ben, lt(d, V(0))), lt(cnt, V(3.5)));
+                    cnt = cnt + sel(on, V(1), V(0));
+                    boxd[vtx] = d; boxon[vtx] = on; boxx[vtx] = p - nb * (d * V(0.5));
+                    any_con = mor(any_con, on);
+                }
+            }
+            any_con = mor(any_con, mor(mor(ucx.on[0], tipon), mor(xcx.on[0], ellon)));
+        }
+
+        if (any_lane(any_con)) {
+            // direction data for the contact frame (n, t1, t2) = R^T (ez, ey, -ex)
+            DirData<V> dd;
+            dd.d[0] = nb;
+            dd.d[1] = v3<V>(R.m[3], R.m[4], R.m[5]);
+            dd.d[2] = v3<V>(-R.m[0], -R.m[1], -R.m[2]);
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                dd.wS[k] = cross(dd.d[k], e1); dd.oS[k] = dot(dd.wS[k], a1);
+                dd.wK[k] = cross(dd.d[k], e2); dd.oK[k] = dot(dd.wK[k], a2);
+                dd.wM[k] = cross(dd.d[k], em); dd.oM[k] = dot(dd.wM[k], am);
+                dd.du[k] = dot(dd.d[k], u);
+            }
+            const V tran0 = m.c[LM_TRAN0], tran1 = m.c[LM_TRAN1], tran2 = m.c[LM_TRAN2], tranm = m.c[LM_TRANM];
+            // warm start (world linear part rotated into the root frame)
+            V yr[6], yl[2], ym;
+            {
+                Vec3<V> lw = mulT(R, v3<V>(s.wl[0], s.wl[1], s.wl[2]));
+                yr[0] = s.wa[0]; yr[1] = s.wa[1]; yr[2] = s.wa[2]; yr[3] = lw.x; yr[4] = lw.y; yr[5] = lw.z;
+                yl[0] = s.wj[0]; yl[1] = s.wj[1]; ym = s.wm;
+            }
+            auto sweep = [&](auto mode_tag, NewtonAcc<V>& acc) {
+                constexpr int MODE = decltype(mode_tag)::value;
+                contact_accumulate<V, 2, MODE, 0>(m, dd, fx, fdist, fon, tran2, w, s.thd1, s.thd2, s.phid, yr, yl, ym, acc);
+#define JB_CA(LV, SL, X, DIST, ON, TRAN) contact_accumulate<V, LV, MODE, SL>(m, dd, X, DIST, ON, TRAN, w, s.thd1, s.thd2, s.phid, yr, yl, ym, acc)
+                JB_CA(2, 1, lc.x[0], lc.dist[0], lc.on[0], tran2); JB_CA(2, 2, lc.x[1], lc.dist[1], lc.on[1], tran2);
+                JB_CA(2, 3, lc.x[2], lc.dist[2], lc.on[2], tran2); JB_CA(2, 4, lc.x[3], lc.dist[3], lc.on[3], tran2);
+                if (xtra) {
+                    JB_CA(1, 5, ucx.x[0], ucx.dist[0], ucx.on[0], tran1); JB_CA(1, 6, ucx.x[1], ucx.dist[1], ucx.on[1], tran1);
+                    JB_CA(1, 7, ucx.x[2], ucx.dist[2], ucx.on[2], tran1); JB_CA(1, 8, ucx.x[3], ucx.dist[3], ucx.on[3], tran1);
+                    JB_CA(1, 9, tipx, tipd, tipon, tran1);
+                    JB_CA(0, 10, xcx.x[0], xcx.dist[0], mand(xcx.on[0], mnot(x_onm)), tran0); JB_CA(0, 11, xcx.x[1], xcx.dist[1], mand(xcx.on[1], mnot(x_onm)), tran0);
+                    JB_CA(0, 12, xcx.x[2], xcx.dist[2], mand(xcx.on[2], mnot(x_onm)), tran0); JB_CA(0, 13, xcx.x[3], xcx.dist[3], mand(xcx.on[3], mnot(x_onm)), tran0);
+                    JB_CA(3, 14, xcx.x[0], xcx.dist[0], mand(xcx.on[0], x_onm), tranm); JB_CA(3, 15, xcx.x[1], xcx.dist[1], mand(xcx.on[1], x_onm), tranm);
+                    JB_CA(3, 16, xcx.x[2], xcx.dist[2], mand(xcx.on[2], x_onm), tranm); JB_CA(3, 17, xcx.x[3], xcx.dist[3], mand(xcx.on[3], x_onm), tranm);
+                    JB_CA(0, 18, ellx, elld, mand(ellon, mnot(x_onm)), tran0);
+                    JB_CA(3, 19, ellx, elld, mand(ellon, x_onm), tranm);
+                    JB_CA(0, 20, boxx[0], boxd[0], boxon[0], tran0); JB_CA(0, 21, boxx[1], boxd[1], boxon[1], tran0);
+                    JB_CA(0, 22, boxx[2], boxd[2], boxon[2], tran0); JB_CA(0, 23, boxx[3], boxd[3], boxon[3], tran0);
+                    JB_CA(0, 24, boxx[4], boxd[4], boxon[4], tran0); JB_CA(0, 25, boxx[5], boxd[5], boxon[5], tran0);
+                    JB_CA(0, 26, boxx[6], boxd[6], boxon[6], tran0); JB_CA(0, 27, boxx[7], boxd[7], boxon[7], tran0);
+                }
+#undef JB_CA
+            };
+            using Mode0 = std::integral_constant<int, 0>;
+            using Mode1 = std::integral_constant<int, 1>;
+            auto init_acc = [&](NewtonAcc<V>& acc) {
+#pragma unroll
+                for (int i = 0; i < 21; i++) acc.A[i] = V(0);
+#pragma unroll
+                for (int i = 0; i < 6; i++) { acc.B[i][0] = M.B[i][0]; acc.B[i][1] = M.B[i][1]; acc.Bm[i] = V(0); acc.rr[i] = V(0); }
+                acc.C11 = M.C11; acc.C12 = M.C12; acc.C22 = M.C22; acc.Cm = V(0);
+                acc.rl[0] = tl[0]; acc.rl[1] = tl[1]; acc.rm = V(0);
+#pragma unroll
+                for (int i = 0; i < 5; i++) acc.bw[i] = zero_u<V>();
+            };
+            U prev_bw[5];
+#pragma unroll
+            for (int i = 0; i < 5; i++) prev_bw[i] = zero_u<V>();
+            MK unconverged = lt(V(0), V(1));
+            for (int it = 0; it < o.max_newton; it++) {
+                NewtonAcc<V> acc;
+                init_acc(acc);
+                sweep(Mode0{}, acc);
+                // the active set of the ENV changed if any lane of the quad saw a different bit record
+                MK changed = neq_u(acc.bw[0], prev_bw[0]);
+#pragma unroll
+                for (int i = 1; i < 5; i++) changed = mor(changed, neq_u(acc.bw[i], prev_bw[i]));
+#pragma unroll
+                for (int i = 0; i < 5; i++) prev_bw[i] = acc.bw[i];
+                unconverged = (it == 0) ? lt(V(0), V(1)) : neq_u(quad_sum_u(mbit(changed)), zero_u<V>());
+#ifdef JB_DEBUG_PRINT
+                fprintf(stderr, "it %d bw0 %u unconv %d%d%d%d\n", it, acc.bw[0].v[0], unconverged.v[0], unconverged.v[1], unconverged.v[2], unconverged.v[3]);
+#endif
+                if (!any_lane(unconverged)) break;
+                V nyr[6], nyl[2], nym;
+                if (xtra) star_solve<V, true>(M.A, acc.A, acc.B, acc.C11, acc.C12, acc.C22, M.Bm, M.Cm, acc.Bm, acc.Cm, tr, acc.rr, acc.rl, tm, acc.rm, nyr, nyl, nym);
+                else star_solve<V, false>(M.A, acc.A, acc.B, acc.C11, acc.C12, acc.C22, M.Bm, M.Cm, acc.Bm, acc.Cm, tr, acc.rr, acc.rl, tm, acc.rm, nyr, nyl, nym);
+                // envs whose active set already repeated keep their (exact) solution
+#pragma unroll
+                for (int i = 0; i < 6; i++) yr[i] = sel(unconverged, nyr[i], yr[i]);
+                yl[0] = sel(unconverged, nyl[0], yl[0]); yl[1] = sel(unconverged, nyl[1], yl[1]); ym = sel(unconverged, nym, ym);
+            }
+            s.fail = s.fail + sel(unconverged, V(1), V(0));
+            // constraint force at the solution
+            NewtonAcc<V> fa;
+            init_acc(fa);
+            fa.rl[0] = V(0); fa.rl[1] = V(0);
+            sweep(Mode1{}, fa);
+#pragma unroll
+            for (int i = 0; i < 6; i++) qfr[i] = fa.rr[i];
+            qfl[0] = fa.rl[0]; qfl[1] = fa.rl[1]; qfm = fa.rm;
+        }
+    }
+
+    // ---- final acceleration: (M + h diag(b)) qacc = tau + qfrc_constraint   (MuJoCo Euler, implicit joint damping)
+    V yr[6], yl[2], ym;
+    {
+        V zero21[21], zero6[6];
+#pragma unroll
+        for (int i = 0; i < 21; i++) zero21[i] = V(0);
+#pragma unroll
+        for (int i = 0; i < 6; i++) zero6[i] = V(0);
+        V hb1 = o.implicit_damp ? h * m.c[LM_B1] : V(0), hb2 = o.implicit_damp ? h * m.c[LM_B2] : V(0);
+        V rl[2] = {tl[0] + qfl[0], tl[1] + qfl[1]};
+        if (xtra) star_solve<V, true>(M.A, zero21, M.B, M.C11 + hb1, M.C12, M.C22 + hb2, M.Bm, M.Cm, zero6, V(0), tr, qfr, rl, tm, qfm, yr, yl, ym);
+        else star_solve<V, false>(M.A, zero21, M.B, M.C11 + hb1, M.C12, M.C22 + hb2, M.Bm, M.Cm, zero6, V(0), tr, qfr, rl, tm, qfm, yr, yl, ym);
+    }
+
+    // ---- integrate (mj_advance): velocities, then positions with the new velocities
+    Vec3<V> lin = mul(R, v3<V>(yr[3], yr[4], yr[5]));
+    s.wa[0] = yr[0]; s.wa[1] = yr[1]; s.wa[2] = yr[2]; s.wl[0] = lin.x; s.wl[1] = lin.y; s.wl[2] = lin.z; s.wj[0] = yl[0]; s.wj[1] = yl[1]; s.wm = ym;
+    s.wx = s.wx + h * yr[0]; s.wy = s.wy + h * yr[1]; s.wz = s.wz + h * yr[2];
+    s.vx = s.vx + h * lin.x; s.vy = s.vy + h * lin.y; s.vz = s.vz + h * lin.z;
+    s.thd1 = s.thd1 + h * yl[0]; s.thd2 = s.thd2 + h * yl[1]; s.phid = s.phid + h * ym;
+    s.px = s.px + h * s.vx; s.py = s.py + h * s.vy; s.pz = s.pz + h * s.vz;
+    {   // q <- q * exp(h w / 2)
+        V wn2 = s.wx * s.wx + s.wy * s.wy + s.wz * s.wz;
+        V half = V(0.5) * h;
+        // sin(a)/|w| and cos(a) with a = h|w|/2 (tiny): series in a^2
+        V a2_ = half * half * wn2;
+        V sc = half * (V(1) + a2_ * (V(-1.0 / 6) + a2_ * (V(1.0 / 120) + a2_ * V(-1.0 / 5040))));
+        V cc = V(1) + a2_ * (V(-0.5) + a2_ * (V(1.0 / 24) + a2_ * V(-1.0 / 720)));
+        V dx = s.wx * sc, dy = s.wy * sc, dz = s.wz * sc;
+        V r0 = s.qw * cc - s.qx * dx - s.qy * dy - s.qz * dz;
+        V r1 = s.qw * dx + s.qx * cc + s.qy * dz - s.qz * dy;
+        V r2 = s.qw * dy - s.qx * dz + s.qy * cc + s.qz * dx;
+        V r3 = s.qw * dz + s.qx * dy - s.qy * dx + s.qz * cc;
+        V n = V(1) / vsqrt(r0 * r0 + r1 * r1 + r2 * r2 + r3 * r3);
+        s.qw = r0 * n; s.qx = r1 * n; s.qy = r2 * n; s.qz = r3 * n;
+    }
+    s.th1 = s.th1 + h * s.thd1; s.th2 = s.th2 + h * s.thd2;
+    {
+        V p = s.phi + h * s.phid;
+        V k = vfloor((p + V(3.141592653589793)) * V(0.15915494309189535));
+        s.phi = p - k * V(6.283185307179586);
+        s.turns = s.turns + k;
+    }
+}
+
+}  // namespace jb

@@ -532,6 +532,8 @@ static void substep(const double* P, double* qpos, double* qvel, double ctrl, co
                     icpt += sgn * Di * r[i] * sj[i];
                 }
                 if (!found) alpha = 1.0;
+                if (o->solver == 2) alpha = 1.0;        /* experiment: semismooth Newton with full steps */
+                if (st && fabs(alpha - 1.0) > 1e-9) st->overflow += 2;   /* counts non-unit line-search steps (diagnostic) */
                 double maxstep = 0;
                 for (int d = 0; d < NV; d++) { double dx = alpha * p[d]; x[d] += dx; double sc = fabs(dx) * M[d * NV + d]; if (sc > maxstep) maxstep = sc; }
                 sweeps++;

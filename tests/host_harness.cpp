@@ -1,0 +1,50 @@
+// host_harness.cpp — TEST INFRASTRUCTURE.  Compiles the simulator source the HIP kernel runs
+// (jitterbug_amd/csrc/jb_sim.hpp) for the host, with the 4 lanes of a quad emulated by jb::Quad<T>,
+// so tests/ can check that math in fp64 and fp32 against the oracle without a GPU.
+// It is never linked into, or loaded by, the product library.
+#include <cstring>
+
+#include "../jitterbug_amd/csrc/jb_model_build.hpp"
+
+using namespace jb;
+
+template <typename T>
+static int run(const double* P, double* qpos, double* qvel, double ctrl, int nsub, int contacts, int max_newton, int implicit_damp, double* fail) {
+    using V = Quad<T>;
+    LaneModel<V> m;
+    T tab[4][LM_COUNT];
+    for (int l = 0; l < 4; l++) { int rc = build_lane_model<T>(P, l, tab[l]); if (rc) return rc; }
+    for (int i = 0; i < LM_COUNT; i++) m.c[i] = V(tab[0][i], tab[1][i], tab[2][i], tab[3][i]);
+    LaneState<V> s;
+    s.px = V(T(qpos[0])); s.py = V(T(qpos[1])); s.pz = V(T(qpos[2]));
+    s.qw = V(T(qpos[3])); s.qx = V(T(qpos[4])); s.qy = V(T(qpos[5])); s.qz = V(T(qpos[6]));
+    s.vx = V(T(qvel[0])); s.vy = V(T(qvel[1])); s.vz = V(T(qvel[2]));
+    s.wx = V(T(qvel[3])); s.wy = V(T(qvel[4])); s.wz = V(T(qvel[5]));
+    double ph = qpos[15], k = std::floor((ph + M_PI) / (2 * M_PI));
+    s.phi = V(T(ph - k * 2 * M_PI)); s.turns = V(T(k)); s.phid = V(T(qvel[14]));
+    s.th1 = V(T(qpos[7]), T(qpos[9]), T(qpos[11]), T(qpos[13]));
+    s.th2 = V(T(qpos[8]), T(qpos[10]), T(qpos[12]), T(qpos[14]));
+    s.thd1 = V(T(qvel[6]), T(qvel[8]), T(qvel[10]), T(qvel[12]));
+    s.thd2 = V(T(qvel[7]), T(qvel[9]), T(qvel[11]), T(qvel[13]));
+    for (int i = 0; i < 3; i++) { s.wa[i] = V(T(0)); s.wl[i] = V(T(0)); }
+    s.wj[0] = s.wj[1] = V(T(0)); s.wm = V(T(0)); s.fail = V(T(0));
+    SimOpts o; o.contacts = contacts; o.max_newton = max_newton; o.implicit_damp = implicit_damp;
+    for (int i = 0; i < nsub; i++) substep<V>(m, s, V(T(ctrl)), o);
+    // replicated quantities must agree across the quad
+    for (int l = 1; l < 4; l++) if (s.px.v[l] != s.px.v[0] || s.qw.v[l] != s.qw.v[0] || s.wz.v[l] != s.wz.v[0] || s.phid.v[l] != s.phid.v[0]) return -100;
+    T n = std::sqrt(s.qw.v[0] * s.qw.v[0] + s.qx.v[0] * s.qx.v[0] + s.qy.v[0] * s.qy.v[0] + s.qz.v[0] * s.qz.v[0]);
+    qpos[0] = s.px.v[0]; qpos[1] = s.py.v[0]; qpos[2] = s.pz.v[0];
+    qpos[3] = s.qw.v[0] / n; qpos[4] = s.qx.v[0] / n; qpos[5] = s.qy.v[0] / n; qpos[6] = s.qz.v[0] / n;
+    qvel[0] = s.vx.v[0]; qvel[1] = s.vy.v[0]; qvel[2] = s.vz.v[0]; qvel[3] = s.wx.v[0]; qvel[4] = s.wy.v[0]; qvel[5] = s.wz.v[0];
+    for (int l = 0; l < 4; l++) { qpos[7 + 2 * l] = s.th1.v[l]; qpos[8 + 2 * l] = s.th2.v[l]; qvel[6 + 2 * l] = s.thd1.v[l]; qvel[7 + 2 * l] = s.thd2.v[l]; }
+    qpos[15] = (double)s.phi.v[0] + 2 * M_PI * (double)s.turns.v[0]; qvel[14] = s.phid.v[0];
+    if (fail) *fail = s.fail.v[0];
+    return 0;
+}
+
+extern "C" int jbh_step(const double* P, double* qpos, double* qvel, double ctrl, int nsub, int contacts, int max_newton, int implicit_damp,
+                        int use_float, double* fail) {
+    return use_float ? run<float>(P, qpos, qvel, ctrl, nsub, contacts, max_newton, implicit_damp, fail)
+                     : run<double>(P, qpos, qvel, ctrl, nsub, contacts, max_newton, implicit_damp, fail);
+}
+extern "C" int jbh_lm_count(void) { return LM_COUNT; }
