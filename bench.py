@@ -1,0 +1,176 @@
+#!/usr/bin/env python
+"""bench.py — env steps/s of the MI355X-native Jitterbug stepper (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+A "step" is one control step (50 physics substeps + reward + observation, in-kernel auto-reset) of every
+environment of the batch.  Workload at N=1: BASELINE.json configs[2] — move_from_origin, 4096 envs, full
+contact solve (configs[1], contacts off, is reported alongside in "also").  For N>1 (launched by
+torch.distributed.run, one rank per GPU) each rank steps its own 4096 envs (weak scaling; env indices are
+global so results do not depend on the split) and rank 0 gathers [N_local, D+2] obs/reward/done rows over
+RCCL every step, inside the timed region.
+
+Inputs (actions) are resident in HBM before the timed region; the timed region is K launches bracketed by
+barrier + torch.cuda.synchronize(); rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+ALGO_BYTES_PER_ENV_STEP = 317       # read qpos 64 + qvel 60 + ctrl 4; write qpos 64 + qvel 60 + obs 60 + reward 4 + done 1
+HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: 8.0 TB/s spec
+N_ENVS_PER_GPU = 4096
+TASK = "move_from_origin"
+
+
+def cpu_baseline(n_cores, budget_s=12.0):
+    """The CPU fp64 oracle (a port/restatement, NOT MuJoCo) on the host cores, on a bounded sample of the same workload."""
+    import numpy as np
+    from jitterbug_amd import model
+    from oracle import oracle as O
+    P = model.default_params()
+    n = 64 * n_cores
+    env = O.OracleEnv(n, TASK, P, seed=0)
+    env.reset()
+    rng = np.random.default_rng(0)
+    t0 = time.perf_counter()
+    env.step(rng.uniform(-1, 1, size=n), nthreads=n_cores)
+    dt = time.perf_counter() - t0
+    steps = int(max(3, min(200, budget_s / max(dt, 1e-3))))
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        env.step(rng.uniform(-1, 1, size=n), nthreads=n_cores)
+    dt = time.perf_counter() - t0
+    return {"value": n * steps / dt, "unit": "env steps/s", "cores": n_cores, "kind": "port",
+            "sample": "%d envs x %d control steps of %s, fp64 oracle (oracle/jb_oracle.c: Newton contact solve), OpenMP over envs" % (n, steps, TASK)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--envs-per-gpu", type=int, default=N_ENVS_PER_GPU)
+    ap.add_argument("--contacts", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    from jitterbug_amd import model
+    from jitterbug_amd.vec_env import JitterbugVecEnv
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks (WORLD_SIZE=%d)" % (args.gpus, args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    n = args.envs_per_gpu
+    D = model.OBS_DIM[TASK]
+    K, W = args.steps, args.warmup
+
+    def make_env(contacts):
+        # the handle launches on torch's current stream so torch.cuda.Event brackets exactly these kernels
+        return JitterbugVecEnv(n, TASK, seed=0, device_id=local_rank, contacts=bool(contacts), env_offset=rank * n,
+                               stream=torch.cuda.current_stream(dev).cuda_stream)
+
+    def run(contacts, steps, warmup, gather):
+        env = make_env(contacts)
+        g = torch.Generator(device=dev)
+        g.manual_seed(1234 + rank)
+        actions = torch.rand((steps + warmup, n), generator=g, device=dev, dtype=torch.float32) * 2 - 1
+        out = torch.empty((n, D + 2), device=dev, dtype=torch.float32)       # packed row: obs | reward | done
+        obs = torch.empty((n, D), device=dev, dtype=torch.float32)
+        rew = torch.empty((n,), device=dev, dtype=torch.float32)
+        done = torch.empty((n,), device=dev, dtype=torch.uint8)
+        gathered = [torch.empty_like(out) for _ in range(world)] if (gather and rank == 0) else None
+        env.reset_device(None, obs.data_ptr())
+
+        def one(i):
+            env.step_device(actions[i].data_ptr(), obs.data_ptr(), rew.data_ptr(), done.data_ptr())
+            if gather:
+                out[:, :D] = obs
+                out[:, D] = rew
+                out[:, D + 1] = done
+                dist.gather(out, gathered, dst=0)
+
+        for i in range(warmup):
+            one(i)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record()
+        for i in range(warmup, warmup + steps):
+            one(i)
+        ev1.record()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        wall = time.perf_counter() - t0
+        dev_ms = ev0.elapsed_time(ev1)
+        sc, ep, cap = env.counters()
+        finite = bool(torch.isfinite(obs).all().item())
+        env.close()
+        return wall, dev_ms, float(cap.sum()), finite
+
+    wall, dev_ms, cap_hits, finite = run(args.contacts, K, W, gather=(world > 1))
+    t = torch.tensor([wall], device=dev, dtype=torch.float64)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    wall_max = float(t.item())
+    total_envs = n * world
+    value = total_envs * K / wall_max
+
+    also = None
+    if not args.no_also and world == 1:
+        w2, d2, _, _ = run(1 - args.contacts, max(50, K // 5), 20, gather=False)
+        also = {"workload": "%s N_envs=%d contacts %s (BASELINE configs[%d])" % (TASK, n, "off" if args.contacts else "on", 1 if args.contacts else 2),
+                "value": n * max(50, K // 5) / w2, "unit": "env steps/s"}
+
+    if rank == 0:
+        launch_s = dev_ms * 1e-3 / K                 # average duration of one jb_step_kernel launch, from HIP events on its stream
+        achieved = ALGO_BYTES_PER_ENV_STEP * n / launch_s / 1e9
+        res = {
+            "metric": "env steps/s at N_envs=4096, move_from_origin",
+            "value": value, "unit": "env steps/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": wall_max * 1e3 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s, N_envs=%d per GPU, %s, 50 substeps/step, in-kernel auto-reset (BASELINE configs[%d])"
+                                   % (TASK, n, "full Newton contact solve" if args.contacts else "contacts off", 2 if args.contacts else 1),
+                       "global_envs": total_envs, "parallelism": "env-sharded x%d%s" % (world, ", RCCL gather of [N,D+2] to rank 0 per step" if world > 1 else "")},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None,
+                         "kernel": "jb_step_kernel", "launch_ms": launch_s * 1e3, "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * n,
+                         "note": "path is fp32-VALU/latency bound, not HBM bound (SURVEY.md §8d): 317 B per env step vs ~1e5-1e6 dependent flops"},
+            "solver_cap_hits": cap_hits, "finite": finite,
+        }
+        if also:
+            res["also"] = also
+        if world == 1 and not args.no_cpu_baseline:
+            cores = len(os.sched_getaffinity(0))
+            res["cpu_baseline"] = cpu_baseline(cores)
+        print(json.dumps(res))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,112 @@
+/* jitterbug_hip.h — C ABI of libjitterbug_hip.so, the MI355X-native Jitterbug stepper.
+ *
+ * Drop-in boundary for the reference's hot path.  The reference has no FFI of
+ * its own (it is pure Python over dm_control/MuJoCo); the entry points below are
+ * what a binding for that path would bind, one per reference interface:
+ *
+ *   jb_create / jb_destroy   suite.load('jitterbug', task, task_kwargs, environment_kwargs)
+ *                            -> task factories, reference jitterbug_dmc/jitterbug.py:72-174
+ *                            (Physics.from_xml_string + Jitterbug task + control.Environment
+ *                            with time_limit=10, control_timestep=0.01: :84-90)
+ *   jb_reset                 control.Environment.reset() -> Jitterbug.initialize_episode,
+ *                            reference jitterbug.py:601-666, then get_observation :673-763
+ *   jb_step                  control.Environment.step(action): 50 x Physics.step() on
+ *                            jitterbug.xml, then Jitterbug.get_reward (jitterbug.py:891-925)
+ *                            and get_observation (:673-763); call sites
+ *                            benchmarks/evaluate_policy.py:29-33, gym_wrapper.py:59
+ *   jb_get_state/jb_set_state  physics.named.data.qpos / qvel  (jitterbug.py:180-243) and the
+ *                            target pose written at :621-648
+ *   jb_set_model_params      per-environment model constants, the intent of
+ *                            augmented_jitterbug.py:95-267 (domain randomisation)
+ *   jb_obs_dim               observation widths 15/16/19/18/19, jitterbug.py:700-753
+ *
+ * Conventions
+ *   - N environments advance in lockstep.  Arrays are C-contiguous, row major:
+ *     action[N], obs[N, D], reward[N], done[N] (uint8), qpos[N,16], qvel[N,15],
+ *     target[N,3] = (x, y, yaw).  qpos/qvel use MuJoCo's layout for this model
+ *     (SURVEY.md §8a): qpos = [x y z | qw qx qy qz | 8 leg hinges | motor],
+ *     qvel = [v_world(3) | omega_body(3) | 8 leg rates | motor rate].
+ *   - The caller owns every buffer it passes; the handle owns device memory,
+ *     its stream and the RNG counters.  "_device" entry points take device
+ *     pointers and are asynchronous on the handle's stream; the others take
+ *     host pointers and return with the results valid.
+ *   - Every function returns 0 on success or a negative JB_E_* code; the
+ *     message is available from jb_last_error() (thread local).  No C++
+ *     exception crosses this boundary.  There is no CPU fallback: without a
+ *     usable HIP device jb_create fails with JB_E_NODEVICE.
+ *   - A handle is not thread safe; distinct handles (one per GPU / rank) are
+ *     independent.
+ */
+#ifndef JITTERBUG_HIP_H
+#define JITTERBUG_HIP_H
+
+#include <stdint.h>
+
+#include "jitterbug_model.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define JB_ABI_VERSION 1
+
+#define JB_OK            0
+#define JB_E_INVALID    -1   /* bad argument */
+#define JB_E_NODEVICE   -2   /* no usable HIP device */
+#define JB_E_HIP        -3   /* a HIP runtime call failed */
+#define JB_E_MODEL      -4   /* parameter table asks for something the kernel does not implement */
+
+typedef struct jb_handle jb_handle;
+
+typedef struct jb_config {
+    int32_t  n_envs;        /* N >= 1 */
+    int32_t  task_id;       /* JB_TASK_* */
+    int32_t  device_id;     /* HIP device ordinal */
+    int32_t  random_pose;   /* reference jitterbug.py:378 (default 1) */
+    int32_t  contacts;      /* 1: floor contacts on; 0: MuJoCo disableflags=contact */
+    int32_t  substeps;      /* physics substeps per control step (reference: 0.01/0.0002 = 50) */
+    int32_t  step_limit;    /* control steps per episode (reference: 10/(0.0002*50) = 1000) */
+    int32_t  auto_reset;    /* 1: VecEnv semantics - an env that reports done is reset inside the
+                                  same call and its returned observation is the new episode's first */
+    int32_t  max_newton;    /* cap on contact-solver iterations per substep (0 -> default 12) */
+    int32_t  use_caller_stream; /* 1: launch on `stream` below even when it is NULL (the legacy default stream) */
+    uint64_t seed;          /* RNG key */
+    uint64_t env_offset;    /* global index of env 0 (sharding: results do not depend on the split) */
+    void*    stream;        /* hipStream_t to run on when use_caller_stream=1; otherwise the handle owns a stream */
+} jb_config;
+
+/* fills cfg with the reference defaults for `task_id` and `n_envs` */
+int jb_default_config(jb_config* cfg, int32_t n_envs, int32_t task_id);
+
+int jb_create(const jb_config* cfg, jb_handle** out);
+int jb_destroy(jb_handle* h);
+
+/* host-buffer entry points (synchronous) */
+int jb_reset(jb_handle* h, const uint8_t* mask /*[N] nullable = all*/, float* obs_out /*[N,D] nullable*/);
+int jb_step(jb_handle* h, const float* action /*[N]*/, float* obs_out /*[N,D]*/, float* reward_out /*[N]*/, uint8_t* done_out /*[N]*/);
+int jb_observe(jb_handle* h, float* obs_out /*[N,D]*/, float* reward_out /*[N] nullable*/);
+int jb_get_state(jb_handle* h, double* qpos /*[N,16]*/, double* qvel /*[N,15]*/, double* target /*[N,3]*/);
+int jb_set_state(jb_handle* h, const double* qpos, const double* qvel, const double* target);   /* any may be NULL = keep */
+int jb_get_counters(jb_handle* h, int32_t* step_count /*[N]*/, uint32_t* episode /*[N]*/, float* solver_cap_hits /*[N]*/);
+/* n_tables is 1 (shared) or N (one table per env); each table is JB_NPARAM doubles (jitterbug_model.h) */
+int jb_set_model_params(jb_handle* h, const double* params, int32_t n_tables);
+
+/* device-buffer entry points (asynchronous on the handle's stream) */
+int jb_reset_device(jb_handle* h, const uint8_t* d_mask /*nullable*/, float* d_obs_out /*nullable*/);
+int jb_step_device(jb_handle* h, const float* d_action, float* d_obs_out, float* d_reward_out, uint8_t* d_done_out);
+int jb_observe_device(jb_handle* h, float* d_obs_out, float* d_reward_out /*nullable*/);
+int jb_synchronize(jb_handle* h);
+void* jb_stream(jb_handle* h);                 /* the hipStream_t the handle launches on */
+
+/* queries */
+int jb_obs_dim(int32_t task_id);               /* 15/16/19/18/19, or JB_E_INVALID */
+int jb_num_envs(jb_handle* h);
+int jb_device_count(void);
+int jb_abi_version(void);
+const double* jb_default_model_params(void);   /* the compiled nominal model, JB_NPARAM doubles */
+const char* jb_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

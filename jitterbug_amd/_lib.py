@@ -1,0 +1,83 @@
+"""ctypes binding of libjitterbug_hip.so (C ABI: include/jitterbug_hip.h).
+
+There is no CPU fallback: if the library is missing or no HIP device is usable the
+import of the library / creation of a handle raises."""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libjitterbug_hip.so")
+
+JB_OK = 0
+ERR_NAMES = {-1: "JB_E_INVALID", -2: "JB_E_NODEVICE", -3: "JB_E_HIP", -4: "JB_E_MODEL"}
+
+EXPORTS = ["jb_default_config", "jb_create", "jb_destroy", "jb_reset", "jb_step", "jb_observe", "jb_get_state", "jb_set_state",
+           "jb_get_counters", "jb_set_model_params", "jb_reset_device", "jb_step_device", "jb_observe_device", "jb_synchronize",
+           "jb_stream", "jb_obs_dim", "jb_num_envs", "jb_device_count", "jb_abi_version", "jb_default_model_params", "jb_last_error"]
+
+
+class JitterbugHipError(RuntimeError):
+    pass
+
+
+class Config(C.Structure):
+    _fields_ = [("n_envs", C.c_int32), ("task_id", C.c_int32), ("device_id", C.c_int32), ("random_pose", C.c_int32),
+                ("contacts", C.c_int32), ("substeps", C.c_int32), ("step_limit", C.c_int32), ("auto_reset", C.c_int32),
+                ("max_newton", C.c_int32), ("use_caller_stream", C.c_int32), ("seed", C.c_uint64), ("env_offset", C.c_uint64),
+                ("stream", C.c_void_p)]
+
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once). Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise JitterbugHipError(
+            "libjitterbug_hip.so is not built (%s). Build it with `python -m jitterbug_amd.build` "
+            "(needs hipcc); there is no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, fp, dp, u8p = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p
+    L.jb_default_config.argtypes = [C.POINTER(Config), C.c_int32, C.c_int32]
+    L.jb_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
+    L.jb_destroy.argtypes = [vp]
+    L.jb_reset.argtypes = [vp, u8p, fp]
+    L.jb_step.argtypes = [vp, fp, fp, fp, u8p]
+    L.jb_observe.argtypes = [vp, fp, fp]
+    L.jb_get_state.argtypes = [vp, dp, dp, dp]
+    L.jb_set_state.argtypes = [vp, dp, dp, dp]
+    L.jb_get_counters.argtypes = [vp, vp, vp, vp]
+    L.jb_set_model_params.argtypes = [vp, dp, C.c_int32]
+    L.jb_reset_device.argtypes = [vp, u8p, fp]
+    L.jb_step_device.argtypes = [vp, fp, fp, fp, u8p]
+    L.jb_observe_device.argtypes = [vp, fp, fp]
+    L.jb_synchronize.argtypes = [vp]
+    L.jb_stream.argtypes = [vp]
+    L.jb_stream.restype = vp
+    L.jb_obs_dim.argtypes = [C.c_int32]
+    L.jb_num_envs.argtypes = [vp]
+    L.jb_default_model_params.restype = C.POINTER(C.c_double)
+    L.jb_last_error.restype = C.c_char_p
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != JB_OK:
+        msg = load().jb_last_error().decode("utf-8", "replace")
+        raise JitterbugHipError("%s: %s" % (ERR_NAMES.get(rc, str(rc)), msg))
+
+
+def ptr(a):
+    return None if a is None else a.ctypes.data
+
+
+def default_model_params():
+    from . import model
+    p = load().jb_default_model_params()
+    return np.ctypeslib.as_array(p, shape=(model.NPARAM,)).copy()

@@ -1,0 +1,447 @@
+// jb_api.hip — kernels and host side of the C ABI declared in include/jitterbug_hip.h.
+//
+// Layout in HBM (all fp32 unless noted), N environments, 4 lanes per environment:
+//   root [ROOT_F][N]      root pose/velocity, motor angle/rate/turns, warm-start accelerations, target
+//   leg  [LEG_F][4N]      per-leg hinge angles/rates and warm-start accelerations (lane-private, fully coalesced)
+//   lane_model [T][LM_COUNT][4]   per-lane constant tables (T = 1 shared, or N per-env)
+//   step_count[N] (i32), episode[N] (u32)
+// One launch of jb_step_kernel advances every env by one control step (cfg.substeps physics substeps),
+// then computes reward, done, optional in-kernel episode reset, and the observation row.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/jitterbug_hip.h"
+#include "jb_default_params.h"
+#include "jb_model_build.hpp"
+#include "jb_sim.hpp"
+#include "jb_task.hpp"
+
+using namespace jb;
+
+namespace {
+
+enum RootF : int { RF_P = 0, RF_Q = 3, RF_V = 7, RF_W = 10, RF_PHI = 13, RF_PHID = 14, RF_TURNS = 15, RF_WA = 16, RF_WL = 19, RF_WM = 22, RF_FAIL = 23, RF_TGT = 24, ROOT_F = 27 };
+enum LegF : int { LF_TH1 = 0, LF_TH2 = 1, LF_THD1 = 2, LF_THD2 = 3, LF_WJ0 = 4, LF_WJ1 = 5, LEG_F = 6 };
+
+struct KArgs {
+    int n, task, substeps, step_limit, auto_reset, contacts, max_newton, random_pose, per_env_model;
+    unsigned long long seed, env_offset;
+    float* root; float* leg; const float* lane_model;
+    int* step_count; unsigned* episode;
+};
+
+__device__ __forceinline__ void load_model(const KArgs& a, int env, int leg, LaneModel<float>& m) {
+    const float* tab = a.lane_model + (a.per_env_model ? (size_t)env * LM_COUNT * 4 : 0);
+#pragma unroll
+    for (int f = 0; f < LM_HOT; f++) m.c[f] = tab[f * 4 + leg];
+    m.cold = tab + leg;
+}
+__device__ __forceinline__ void load_state(const KArgs& a, int env, int lane, LaneState<float>& s) {
+    const float* r = a.root + env;
+    const int N = a.n;
+    s.px = r[(RF_P + 0) * N]; s.py = r[(RF_P + 1) * N]; s.pz = r[(RF_P + 2) * N];
+    s.qw = r[(RF_Q + 0) * N]; s.qx = r[(RF_Q + 1) * N]; s.qy = r[(RF_Q + 2) * N]; s.qz = r[(RF_Q + 3) * N];
+    s.vx = r[(RF_V + 0) * N]; s.vy = r[(RF_V + 1) * N]; s.vz = r[(RF_V + 2) * N];
+    s.wx = r[(RF_W + 0) * N]; s.wy = r[(RF_W + 1) * N]; s.wz = r[(RF_W + 2) * N];
+    s.phi = r[RF_PHI * N]; s.phid = r[RF_PHID * N]; s.turns = r[RF_TURNS * N];
+#pragma unroll
+    for (int i = 0; i < 3; i++) { s.wa[i] = r[(RF_WA + i) * N]; s.wl[i] = r[(RF_WL + i) * N]; }
+    s.wm = r[RF_WM * N]; s.fail = r[RF_FAIL * N];
+    const float* l = a.leg + lane;
+    const int L = 4 * N;
+    s.th1 = l[LF_TH1 * L]; s.th2 = l[LF_TH2 * L]; s.thd1 = l[LF_THD1 * L]; s.thd2 = l[LF_THD2 * L]; s.wj[0] = l[LF_WJ0 * L]; s.wj[1] = l[LF_WJ1 * L];
+}
+__device__ __forceinline__ void store_state(const KArgs& a, int env, int lane, int leg, const LaneState<float>& s) {
+    const int N = a.n, L = 4 * N;
+    float* l = a.leg + lane;
+    l[LF_TH1 * L] = s.th1; l[LF_TH2 * L] = s.th2; l[LF_THD1 * L] = s.thd1; l[LF_THD2 * L] = s.thd2; l[LF_WJ0 * L] = s.wj[0]; l[LF_WJ1 * L] = s.wj[1];
+    // the replicated root block: each of the 4 lanes writes a quarter of the fields
+    float* r = a.root + env;
+    const float vals[24] = {s.px, s.py, s.pz, s.qw, s.qx, s.qy, s.qz, s.vx, s.vy, s.vz, s.wx, s.wy, s.wz, s.phi, s.phid, s.turns,
+                            s.wa[0], s.wa[1], s.wa[2], s.wl[0], s.wl[1], s.wl[2], s.wm, s.fail};
+#pragma unroll
+    for (int f = 0; f < 24; f++) if ((f & 3) == leg) r[f * N] = vals[f];
+}
+__device__ __forceinline__ void core_from_state(const KArgs& a, int env, const LaneState<float>& s, EnvCore<float>& e) {
+    e.px = s.px; e.py = s.py; e.pz = s.pz; e.qw = s.qw; e.qx = s.qx; e.qy = s.qy; e.qz = s.qz;
+    e.vx = s.vx; e.vy = s.vy; e.vz = s.vz; e.wx = s.wx; e.wy = s.wy; e.wz = s.wz; e.phi = s.phi; e.phid = s.phid;
+    e.tx = a.root[(RF_TGT + 0) * a.n + env]; e.ty = a.root[(RF_TGT + 1) * a.n + env]; e.tpsi = a.root[(RF_TGT + 2) * a.n + env];
+}
+__device__ __forceinline__ void state_from_reset(const EnvCore<float>& e, LaneState<float>& s) {
+    s.px = e.px; s.py = e.py; s.pz = e.pz; s.qw = e.qw; s.qx = e.qx; s.qy = e.qy; s.qz = e.qz;
+    s.vx = s.vy = s.vz = s.wx = s.wy = s.wz = 0.f; s.phi = 0.f; s.phid = 0.f; s.turns = 0.f;
+    s.th1 = s.th2 = s.thd1 = s.thd2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; i++) { s.wa[i] = 0.f; s.wl[i] = 0.f; }
+    s.wj[0] = s.wj[1] = 0.f; s.wm = 0.f;
+}
+__device__ __forceinline__ void write_obs(const KArgs& a, int env, int leg, const EnvCore<float>& e, float target_z, float* obs_out) {
+    if (!obs_out) return;
+    float obs[19];
+    observe<float>(a.task, e, target_z, obs, 1);
+    const int D = obs_dim(a.task);
+    float* row = obs_out + (size_t)env * D;
+#pragma unroll
+    for (int j = 0; j < 19; j++) if ((j & 3) == leg && j < D) row[j] = obs[j];
+}
+__device__ __forceinline__ void store_target(const KArgs& a, int env, const EnvCore<float>& e) {
+    a.root[(RF_TGT + 0) * a.n + env] = e.tx; a.root[(RF_TGT + 1) * a.n + env] = e.ty; a.root[(RF_TGT + 2) * a.n + env] = e.tpsi;
+}
+
+// ---------------------------------------------------------------------------------------------- step
+__global__ __launch_bounds__(64) void jb_step_kernel(KArgs a, const float* __restrict__ action, float* __restrict__ obs_out,
+                                                     float* __restrict__ reward_out, unsigned char* __restrict__ done_out) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    int env = t >> 2, leg = t & 3;
+    const bool live = env < a.n;
+    if (!live) env = a.n - 1;                    // tail lanes shadow the last env so wave-level ops stay uniform; they store nothing
+    const int lane = env * 4 + leg;
+    LaneModel<float> m;
+    load_model(a, env, leg, m);
+    LaneState<float> s;
+    load_state(a, env, lane, s);
+    const float ctrl = action[env];
+    SimOpts o; o.contacts = a.contacts; o.max_newton = a.max_newton; o.implicit_damp = 1;
+#pragma unroll 1
+    for (int k = 0; k < a.substeps; k++) substep<float>(m, s, ctrl, o);
+    {   // trailing mj_step1: derived quantities use the normalised quaternion
+        float n = 1.0f / sqrtf(s.qw * s.qw + s.qx * s.qx + s.qy * s.qy + s.qz * s.qz);
+        s.qw *= n; s.qx *= n; s.qy *= n; s.qz *= n;
+    }
+    int sc = a.step_count[env] + 1;
+    EnvCore<float> e;
+    core_from_state(a, env, s, e);
+    const float target_z = m.c[LM_TARGET_Z];
+    const float rew = reward<float>(a.task, e, target_z);
+    const bool done = sc >= a.step_limit;
+    if (done && a.auto_reset) {
+        unsigned ep = a.episode[env];
+        episode_reset<float>(a.task, a.random_pose, a.seed, a.env_offset + (unsigned long long)env, ep, m.c[LM_ROOT_Z0], e);
+        state_from_reset(e, s);
+        sc = 0;
+        if (live && leg == 0) { a.episode[env] = ep + 1; store_target(a, env, e); }
+    }
+    if (!live) return;
+    write_obs(a, env, leg, e, target_z, obs_out);
+    store_state(a, env, lane, leg, s);
+    if (leg == 0) {
+        a.step_count[env] = sc;
+        if (reward_out) reward_out[env] = rew;
+        if (done_out) done_out[env] = done ? 1 : 0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- reset / observe
+__global__ __launch_bounds__(64) void jb_reset_kernel(KArgs a, const unsigned char* __restrict__ mask, float* __restrict__ obs_out) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    int env = t >> 2, leg = t & 3;
+    if (env >= a.n) return;
+    const int lane = env * 4 + leg;
+    const float* tab = a.lane_model + (a.per_env_model ? (size_t)env * LM_COUNT * 4 : 0);
+    const float target_z = tab[LM_TARGET_Z * 4 + leg], root_z0 = tab[LM_ROOT_Z0 * 4 + leg];
+    LaneState<float> s;
+    EnvCore<float> e;
+    if (!mask || mask[env]) {
+        unsigned ep = a.episode[env];
+        episode_reset<float>(a.task, a.random_pose, a.seed, a.env_offset + (unsigned long long)env, ep, root_z0, e);
+        state_from_reset(e, s);
+        s.fail = a.root[RF_FAIL * a.n + env];
+        store_state(a, env, lane, leg, s);
+        if (leg == 0) { a.episode[env] = ep + 1; a.step_count[env] = 0; store_target(a, env, e); }
+    } else {
+        load_state(a, env, lane, s);
+        core_from_state(a, env, s, e);
+    }
+    write_obs(a, env, leg, e, target_z, obs_out);
+}
+
+__global__ __launch_bounds__(64) void jb_observe_kernel(KArgs a, float* __restrict__ obs_out, float* __restrict__ reward_out) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    int env = t >> 2, leg = t & 3;
+    if (env >= a.n) return;
+    const float* tab = a.lane_model + (a.per_env_model ? (size_t)env * LM_COUNT * 4 : 0);
+    const float target_z = tab[LM_TARGET_Z * 4 + leg];
+    LaneState<float> s;
+    load_state(a, env, env * 4 + leg, s);
+    EnvCore<float> e;
+    core_from_state(a, env, s, e);
+    write_obs(a, env, leg, e, target_z, obs_out);
+    if (leg == 0 && reward_out) reward_out[env] = reward<float>(a.task, e, target_z);
+}
+
+// ---------------------------------------------------------------------------------------------- state import / export (fp64 MuJoCo layout)
+__global__ void jb_export_kernel(KArgs a, double* __restrict__ qpos, double* __restrict__ qvel, double* __restrict__ target) {
+    int env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= a.n) return;
+    const int N = a.n, L = 4 * N;
+    const float* r = a.root + env;
+    if (qpos) {
+        double* q = qpos + (size_t)env * 16;
+        for (int i = 0; i < 7; i++) q[i] = r[i * N];
+        for (int l = 0; l < 4; l++) { q[7 + 2 * l] = a.leg[LF_TH1 * L + env * 4 + l]; q[8 + 2 * l] = a.leg[LF_TH2 * L + env * 4 + l]; }
+        q[15] = (double)r[RF_PHI * N] + 6.283185307179586 * (double)r[RF_TURNS * N];
+    }
+    if (qvel) {
+        double* v = qvel + (size_t)env * 15;
+        for (int i = 0; i < 6; i++) v[i] = r[(RF_V + i) * N];
+        for (int l = 0; l < 4; l++) { v[6 + 2 * l] = a.leg[LF_THD1 * L + env * 4 + l]; v[7 + 2 * l] = a.leg[LF_THD2 * L + env * 4 + l]; }
+        v[14] = r[RF_PHID * N];
+    }
+    if (target) for (int i = 0; i < 3; i++) target[(size_t)env * 3 + i] = r[(RF_TGT + i) * N];
+}
+__global__ void jb_import_kernel(KArgs a, const double* __restrict__ qpos, const double* __restrict__ qvel, const double* __restrict__ target) {
+    int env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= a.n) return;
+    const int N = a.n, L = 4 * N;
+    float* r = a.root + env;
+    if (qpos) {
+        const double* q = qpos + (size_t)env * 16;
+        for (int i = 0; i < 7; i++) r[i * N] = (float)q[i];
+        for (int l = 0; l < 4; l++) { a.leg[LF_TH1 * L + env * 4 + l] = (float)q[7 + 2 * l]; a.leg[LF_TH2 * L + env * 4 + l] = (float)q[8 + 2 * l]; }
+        double k = floor((q[15] + 3.141592653589793) / 6.283185307179586);
+        r[RF_PHI * N] = (float)(q[15] - k * 6.283185307179586); r[RF_TURNS * N] = (float)k;
+    }
+    if (qvel) {
+        const double* v = qvel + (size_t)env * 15;
+        for (int i = 0; i < 6; i++) r[(RF_V + i) * N] = (float)v[i];
+        for (int l = 0; l < 4; l++) { a.leg[LF_THD1 * L + env * 4 + l] = (float)v[6 + 2 * l]; a.leg[LF_THD2 * L + env * 4 + l] = (float)v[7 + 2 * l]; }
+        r[RF_PHID * N] = (float)v[14];
+    }
+    if (target) for (int i = 0; i < 3; i++) r[(RF_TGT + i) * N] = (float)target[(size_t)env * 3 + i];
+    // a teacher-forced state has no history: clear the contact-solver warm start
+    for (int i = 0; i < 7; i++) r[(RF_WA + i) * N] = 0.f;
+    for (int l = 0; l < 4; l++) { a.leg[LF_WJ0 * L + env * 4 + l] = 0.f; a.leg[LF_WJ1 * L + env * 4 + l] = 0.f; }
+}
+
+thread_local std::string g_err;
+int fail(int code, const std::string& msg) { g_err = msg; return code; }
+#define JB_HIP(call)                                                                                     \
+    do {                                                                                                 \
+        hipError_t _e = (call);                                                                          \
+        if (_e != hipSuccess) return fail(JB_E_HIP, std::string(#call) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+}  // namespace
+
+struct jb_handle {
+    jb_config cfg;
+    KArgs ka;
+    int D;
+    hipStream_t stream;
+    bool own_stream;
+    float *d_root, *d_leg, *d_model;
+    int* d_step; unsigned* d_episode;
+    // staging for the host-buffer entry points
+    float *d_action, *d_obs, *d_reward; unsigned char *d_done, *d_mask;
+    double *d_qpos, *d_qvel, *d_target;
+    size_t model_tables;
+};
+
+static dim3 grid_lanes(int n) { return dim3((unsigned)(((size_t)n * 4 + 63) / 64)); }
+
+static int upload_model(jb_handle* h, const double* params, int n_tables) {
+    std::vector<float> host((size_t)n_tables * LM_COUNT * 4);
+    float tmp[LM_COUNT];
+    for (int t = 0; t < n_tables; t++)
+        for (int leg = 0; leg < 4; leg++) {
+            int rc = build_lane_model<float>(params + (size_t)t * JB_NPARAM, leg, tmp);
+            if (rc) return fail(JB_E_MODEL, "parameter table " + std::to_string(t) + " not supported by the kernel (code " + std::to_string(rc) + ")");
+            for (int f = 0; f < LM_COUNT; f++) host[((size_t)t * LM_COUNT + f) * 4 + leg] = tmp[f];
+        }
+    if ((size_t)n_tables != h->model_tables) {
+        if (h->d_model) JB_HIP(hipFree(h->d_model));
+        h->d_model = nullptr;
+        JB_HIP(hipMalloc(&h->d_model, host.size() * sizeof(float)));
+        h->model_tables = n_tables;
+    }
+    JB_HIP(hipMemcpyAsync(h->d_model, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    JB_HIP(hipStreamSynchronize(h->stream));
+    h->ka.lane_model = h->d_model;
+    h->ka.per_env_model = n_tables > 1 ? 1 : 0;
+    return JB_OK;
+}
+
+extern "C" {
+
+const char* jb_last_error(void) { return g_err.c_str(); }
+int jb_abi_version(void) { return JB_ABI_VERSION; }
+const double* jb_default_model_params(void) { return JB_DEFAULT_PARAMS; }
+int jb_obs_dim(int32_t task_id) { return (task_id >= 0 && task_id < JB_NTASK) ? obs_dim(task_id) : JB_E_INVALID; }
+int jb_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+int jb_default_config(jb_config* cfg, int32_t n_envs, int32_t task_id) {
+    if (!cfg) return fail(JB_E_INVALID, "cfg is NULL");
+    std::memset(cfg, 0, sizeof *cfg);
+    cfg->n_envs = n_envs; cfg->task_id = task_id; cfg->device_id = 0; cfg->random_pose = 1; cfg->contacts = 1;
+    cfg->substeps = 50; cfg->step_limit = 1000; cfg->auto_reset = 1; cfg->max_newton = 12; cfg->seed = 0; cfg->env_offset = 0; cfg->stream = nullptr;
+    return JB_OK;
+}
+
+int jb_create(const jb_config* cfg, jb_handle** out) {
+    if (!cfg || !out) return fail(JB_E_INVALID, "cfg/out is NULL");
+    *out = nullptr;
+    if (cfg->n_envs < 1) return fail(JB_E_INVALID, "n_envs must be >= 1");
+    if (cfg->task_id < 0 || cfg->task_id >= JB_NTASK) return fail(JB_E_INVALID, "unknown task_id");
+    if (cfg->substeps < 1 || cfg->step_limit < 1) return fail(JB_E_INVALID, "substeps and step_limit must be >= 1");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(JB_E_NODEVICE, "no HIP device available (there is no CPU fallback)");
+    if (cfg->device_id < 0 || cfg->device_id >= ndev) return fail(JB_E_INVALID, "device_id out of range");
+    JB_HIP(hipSetDevice(cfg->device_id));
+    jb_handle* h = new (std::nothrow) jb_handle();
+    if (!h) return fail(JB_E_INVALID, "out of host memory");
+    std::memset(h, 0, sizeof *h);
+    h->cfg = *cfg;
+    if (h->cfg.max_newton <= 0) h->cfg.max_newton = 12;
+    h->D = obs_dim(cfg->task_id);
+    const size_t N = (size_t)cfg->n_envs;
+    if (cfg->use_caller_stream) { h->stream = (hipStream_t)cfg->stream; h->own_stream = false; }
+    else { JB_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)); h->own_stream = true; }
+    JB_HIP(hipMalloc(&h->d_root, sizeof(float) * ROOT_F * N));
+    JB_HIP(hipMalloc(&h->d_leg, sizeof(float) * LEG_F * 4 * N));
+    JB_HIP(hipMalloc(&h->d_step, sizeof(int) * N));
+    JB_HIP(hipMalloc(&h->d_episode, sizeof(unsigned) * N));
+    JB_HIP(hipMalloc(&h->d_action, sizeof(float) * N));
+    JB_HIP(hipMalloc(&h->d_obs, sizeof(float) * N * h->D));
+    JB_HIP(hipMalloc(&h->d_reward, sizeof(float) * N));
+    JB_HIP(hipMalloc(&h->d_done, N));
+    JB_HIP(hipMalloc(&h->d_mask, N));
+    JB_HIP(hipMalloc(&h->d_qpos, sizeof(double) * 16 * N));
+    JB_HIP(hipMalloc(&h->d_qvel, sizeof(double) * 15 * N));
+    JB_HIP(hipMalloc(&h->d_target, sizeof(double) * 3 * N));
+    JB_HIP(hipMemsetAsync(h->d_root, 0, sizeof(float) * ROOT_F * N, h->stream));
+    JB_HIP(hipMemsetAsync(h->d_leg, 0, sizeof(float) * LEG_F * 4 * N, h->stream));
+    JB_HIP(hipMemsetAsync(h->d_step, 0, sizeof(int) * N, h->stream));
+    JB_HIP(hipMemsetAsync(h->d_episode, 0, sizeof(unsigned) * N, h->stream));
+    KArgs& k = h->ka;
+    k.n = cfg->n_envs; k.task = cfg->task_id; k.substeps = cfg->substeps; k.step_limit = cfg->step_limit; k.auto_reset = cfg->auto_reset;
+    k.contacts = cfg->contacts; k.max_newton = h->cfg.max_newton; k.random_pose = cfg->random_pose; k.per_env_model = 0;
+    k.seed = cfg->seed; k.env_offset = cfg->env_offset;
+    k.root = h->d_root; k.leg = h->d_leg; k.step_count = h->d_step; k.episode = h->d_episode;
+    int rc = upload_model(h, JB_DEFAULT_PARAMS, 1);
+    if (rc) { jb_destroy(h); return rc; }
+    rc = jb_reset_device(h, nullptr, nullptr);     // every env starts in a valid episode-0 state
+    if (rc) { jb_destroy(h); return rc; }
+    JB_HIP(hipStreamSynchronize(h->stream));
+    *out = h;
+    return JB_OK;
+}
+
+int jb_destroy(jb_handle* h) {
+    if (!h) return JB_OK;
+    hipStreamSynchronize(h->stream);
+    void* bufs[] = {h->d_root, h->d_leg, h->d_model, h->d_step, h->d_episode, h->d_action, h->d_obs, h->d_reward, h->d_done, h->d_mask, h->d_qpos, h->d_qvel, h->d_target};
+    for (void* b : bufs) if (b) hipFree(b);
+    if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
+    delete h;
+    return JB_OK;
+}
+
+int jb_num_envs(jb_handle* h) { return h ? h->cfg.n_envs : JB_E_INVALID; }
+void* jb_stream(jb_handle* h) { return h ? (void*)h->stream : nullptr; }
+int jb_synchronize(jb_handle* h) {
+    if (!h) return fail(JB_E_INVALID, "handle is NULL");
+    JB_HIP(hipStreamSynchronize(h->stream));
+    return JB_OK;
+}
+
+int jb_reset_device(jb_handle* h, const uint8_t* d_mask, float* d_obs_out) {
+    if (!h) return fail(JB_E_INVALID, "handle is NULL");
+    hipLaunchKernelGGL(jb_reset_kernel, grid_lanes(h->cfg.n_envs), dim3(64), 0, h->stream, h->ka, d_mask, d_obs_out);
+    JB_HIP(hipGetLastError());
+    return JB_OK;
+}
+int jb_step_device(jb_handle* h, const float* d_action, float* d_obs_out, float* d_reward_out, uint8_t* d_done_out) {
+    if (!h || !d_action) return fail(JB_E_INVALID, "handle/action is NULL");
+    hipLaunchKernelGGL(jb_step_kernel, grid_lanes(h->cfg.n_envs), dim3(64), 0, h->stream, h->ka, d_action, d_obs_out, d_reward_out, d_done_out);
+    JB_HIP(hipGetLastError());
+    return JB_OK;
+}
+int jb_observe_device(jb_handle* h, float* d_obs_out, float* d_reward_out) {
+    if (!h) return fail(JB_E_INVALID, "handle is NULL");
+    hipLaunchKernelGGL(jb_observe_kernel, grid_lanes(h->cfg.n_envs), dim3(64), 0, h->stream, h->ka, d_obs_out, d_reward_out);
+    JB_HIP(hipGetLastError());
+    return JB_OK;
+}
+
+int jb_reset(jb_handle* h, const uint8_t* mask, float* obs_out) {
+    if (!h) return fail(JB_E_INVALID, "handle is NULL");
+    const size_t N = (size_t)h->cfg.n_envs;
+    if (mask) JB_HIP(hipMemcpyAsync(h->d_mask, mask, N, hipMemcpyHostToDevice, h->stream));
+    int rc = jb_reset_device(h, mask ? h->d_mask : nullptr, obs_out ? h->d_obs : nullptr);
+    if (rc) return rc;
+    if (obs_out) JB_HIP(hipMemcpyAsync(obs_out, h->d_obs, sizeof(float) * N * h->D, hipMemcpyDeviceToHost, h->stream));
+    JB_HIP(hipStreamSynchronize(h->stream));
+    return JB_OK;
+}
+int jb_step(jb_handle* h, const float* action, float* obs_out, float* reward_out, uint8_t* done_out) {
+    if (!h || !action) return fail(JB_E_INVALID, "handle/action is NULL");
+    const size_t N = (size_t)h->cfg.n_envs;
+    JB_HIP(hipMemcpyAsync(h->d_action, action, sizeof(float) * N, hipMemcpyHostToDevice, h->stream));
+    int rc = jb_step_device(h, h->d_action, h->d_obs, h->d_reward, h->d_done);
+    if (rc) return rc;
+    if (obs_out) JB_HIP(hipMemcpyAsync(obs_out, h->d_obs, sizeof(float) * N * h->D, hipMemcpyDeviceToHost, h->stream));
+    if (reward_out) JB_HIP(hipMemcpyAsync(reward_out, h->d_reward, sizeof(float) * N, hipMemcpyDeviceToHost, h->stream));
+    if (done_out) JB_HIP(hipMemcpyAsync(done_out, h->d_done, N, hipMemcpyDeviceToHost, h->stream));
+    JB_HIP(hipStreamSynchronize(h->stream));
+    return JB_OK;
+}
+int jb_observe(jb_handle* h, float* obs_out, float* reward_out) {
+    if (!h || !obs_out) return fail(JB_E_INVALID, "handle/obs_out is NULL");
+    const size_t N = (size_t)h->cfg.n_envs;
+    int rc = jb_observe_device(h, h->d_obs, reward_out ? h->d_reward : nullptr);
+    if (rc) return rc;
+    JB_HIP(hipMemcpyAsync(obs_out, h->d_obs, sizeof(float) * N * h->D, hipMemcpyDeviceToHost, h->stream));
+    if (reward_out) JB_HIP(hipMemcpyAsync(reward_out, h->d_reward, sizeof(float) * N, hipMemcpyDeviceToHost, h->stream));
+    JB_HIP(hipStreamSynchronize(h->stream));
+    return JB_OK;
+}
+int jb_get_state(jb_handle* h, double* qpos, double* qvel, double* target) {
+    if (!h) return fail(JB_E_INVALID, "handle is NULL");
+    const size_t N = (size_t)h->cfg.n_envs;
+    hipLaunchKernelGGL(jb_export_kernel, dim3((unsigned)((N + 127) / 128)), dim3(128), 0, h->stream, h->ka, qpos ? h->d_qpos : nullptr, qvel ? h->d_qvel : nullptr,
+                       target ? h->d_target : nullptr);
+    JB_HIP(hipGetLastError());
+    if (qpos) JB_HIP(hipMemcpyAsync(qpos, h->d_qpos, sizeof(double) * 16 * N, hipMemcpyDeviceToHost, h->stream));
+    if (qvel) JB_HIP(hipMemcpyAsync(qvel, h->d_qvel, sizeof(double) * 15 * N, hipMemcpyDeviceToHost, h->stream));
+    if (target) JB_HIP(hipMemcpyAsync(target, h->d_target, sizeof(double) * 3 * N, hipMemcpyDeviceToHost, h->stream));
+    JB_HIP(hipStreamSynchronize(h->stream));
+    return JB_OK;
+}
+int jb_set_state(jb_handle* h, const double* qpos, const double* qvel, const double* target) {
+    if (!h) return fail(JB_E_INVALID, "handle is NULL");
+    const size_t N = (size_t)h->cfg.n_envs;
+    if (qpos) JB_HIP(hipMemcpyAsync(h->d_qpos, qpos, sizeof(double) * 16 * N, hipMemcpyHostToDevice, h->stream));
+    if (qvel) JB_HIP(hipMemcpyAsync(h->d_qvel, qvel, sizeof(double) * 15 * N, hipMemcpyHostToDevice, h->stream));
+    if (target) JB_HIP(hipMemcpyAsync(h->d_target, target, sizeof(double) * 3 * N, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(jb_import_kernel, dim3((unsigned)((N + 127) / 128)), dim3(128), 0, h->stream, h->ka, qpos ? h->d_qpos : nullptr, qvel ? h->d_qvel : nullptr,
+                       target ? h->d_target : nullptr);
+    JB_HIP(hipGetLastError());
+    JB_HIP(hipStreamSynchronize(h->stream));
+    return JB_OK;
+}
+int jb_get_counters(jb_handle* h, int32_t* step_count, uint32_t* episode, float* solver_cap_hits) {
+    if (!h) return fail(JB_E_INVALID, "handle is NULL");
+    const size_t N = (size_t)h->cfg.n_envs;
+    JB_HIP(hipStreamSynchronize(h->stream));
+    if (step_count) JB_HIP(hipMemcpy(step_count, h->d_step, sizeof(int) * N, hipMemcpyDeviceToHost));
+    if (episode) JB_HIP(hipMemcpy(episode, h->d_episode, sizeof(unsigned) * N, hipMemcpyDeviceToHost));
+    if (solver_cap_hits) JB_HIP(hipMemcpy(solver_cap_hits, h->d_root + RF_FAIL * N, sizeof(float) * N, hipMemcpyDeviceToHost));
+    return JB_OK;
+}
+int jb_set_model_params(jb_handle* h, const double* params, int32_t n_tables) {
+    if (!h || !params) return fail(JB_E_INVALID, "handle/params is NULL");
+    if (n_tables != 1 && n_tables != h->cfg.n_envs) return fail(JB_E_INVALID, "n_tables must be 1 or n_envs");
+    JB_HIP(hipStreamSynchronize(h->stream));
+    return upload_model(h, params, n_tables);
+}
+
+}  // extern "C"

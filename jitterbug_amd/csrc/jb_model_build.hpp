@@ -74,28 +74,33 @@ template <typename T> inline int build_lane_model(const double* P, int leg, T* o
     put_cyl(LM_LC_D, LM_LC_AX, LM_LC_XA, LM_LC_R, LM_LC_H, gl, a2);
     put_cyl(LM_UC_D, LM_UC_AX, LM_UC_XA, LM_UC_R, LM_UC_H, gu, a1);
     put3d(LM_DTIP, gt + JB_G_CENTER, a1); out[LM_TIP_R] = T(gt[JB_G_SIZE]);
-    double bleg = norm3d(gu + JB_G_CENTER, a1) + std::sqrt(gu[JB_G_SIZE] * gu[JB_G_SIZE] + gu[JB_G_SIZE + 1] * gu[JB_G_SIZE + 1]);
-    double btip = norm3d(gt + JB_G_CENTER, a1) + gt[JB_G_SIZE];
-    out[LM_BOUND_LEG] = T((bleg > btip ? bleg : btip) + 1e-4);
-
+    // broadphase sphere of the upper leg: centre = upper cylinder centre; the knee tip sits at the cylinder's far end
+    put3(LM_BS_LEG_C, gu + JB_G_CENTER);
+    {
+        double rc = std::sqrt(gu[JB_G_SIZE] * gu[JB_G_SIZE] + gu[JB_G_SIZE + 1] * gu[JB_G_SIZE + 1]);
+        double rt = norm3d(gt + JB_G_CENTER, gu + JB_G_CENTER) + gt[JB_G_SIZE];
+        double slack = 0.3 * norm3d(gu + JB_G_CENTER, a1) + 1e-3;      // the centre moves with the shoulder angle (|th1| <= 0.3 here)
+        out[LM_BS_LEG_R] = T((rc > rt ? rc : rt) + slack);
+    }
     // lane-assigned root / motor-body geoms; disabled slots get finite, harmless geometry
     out[LM_XB_EN] = T(0); out[LM_XC_EN] = T(0); out[LM_XE_EN] = T(0); out[LM_X_ONM] = T(0);
     for (int i = 0; i < 9; i++) { out[LM_XB_R + i] = T(i % 4 == 0); out[LM_XE_R + i] = T(i % 4 == 0); }
     out[LM_XC_AX + 2] = T(1); out[LM_XC_XA] = T(1);
     out[LM_XE_S] = out[LM_XE_S + 1] = out[LM_XE_S + 2] = T(1);
-    double bound = 0;
+    double xs_c[2][3], xs_r[2]; int xs_n = 0;
     auto put_box = [&](const double* g) {
         out[LM_XB_EN] = T(1); put3(LM_XB_C, g + JB_G_CENTER);
         for (int i = 0; i < 9; i++) out[LM_XB_R + i] = T(g[JB_G_ROT + i]);
         put3(LM_XB_S, g + JB_G_SIZE);
-        double b = norm3d(g + JB_G_CENTER, zero3) + norm3d(g + JB_G_SIZE, zero3);
-        if (b > bound) bound = b;
+        for (int i = 0; i < 3; i++) xs_c[xs_n][i] = g[JB_G_CENTER + i];
+        xs_r[xs_n++] = norm3d(g + JB_G_SIZE, zero3);
     };
     auto put_xcyl = [&](const double* g, const double* ref) {
         out[LM_XC_EN] = T(1);
         put_cyl(LM_XC_C, LM_XC_AX, LM_XC_XA, LM_XC_R, LM_XC_H, g, zero3);
-        double b = norm3d(g + JB_G_CENTER, ref) + std::sqrt(g[JB_G_SIZE] * g[JB_G_SIZE] + g[JB_G_SIZE + 1] * g[JB_G_SIZE + 1]);
-        if (b > bound) bound = b;
+        (void)ref;
+        for (int i = 0; i < 3; i++) xs_c[xs_n][i] = g[JB_G_CENTER + i];
+        xs_r[xs_n++] = std::sqrt(g[JB_G_SIZE] * g[JB_G_SIZE] + g[JB_G_SIZE + 1] * g[JB_G_SIZE + 1]);
     };
     auto put_ell = [&](const double* g, const double* ref) {
         out[LM_XE_EN] = T(1); put3(LM_XE_C, g + JB_G_CENTER);
@@ -103,8 +108,9 @@ template <typename T> inline int build_lane_model(const double* P, int leg, T* o
         put3(LM_XE_S, g + JB_G_SIZE);
         double mx = g[JB_G_SIZE];
         for (int i = 1; i < 3; i++) if (g[JB_G_SIZE + i] > mx) mx = g[JB_G_SIZE + i];
-        double b = norm3d(g + JB_G_CENTER, ref) + mx;
-        if (b > bound) bound = b;
+        (void)ref;
+        for (int i = 0; i < 3; i++) xs_c[xs_n][i] = g[JB_G_CENTER + i];
+        xs_r[xs_n++] = mx;
     };
     if (leg == 0) { if ((int)geom(0)[JB_G_TYPE] != JB_GEOM_BOX) return -5; put_box(geom(0)); }
     if (leg == 1) { if ((int)geom(1)[JB_G_TYPE] != JB_GEOM_BOX) return -5; put_box(geom(1)); }
@@ -117,7 +123,20 @@ template <typename T> inline int build_lane_model(const double* P, int leg, T* o
         put_xcyl(geom(20), am); put_ell(geom(21), am);
         out[LM_X_ONM] = T(1);
     }
-    out[LM_BOUND_X] = T(bound + 1e-4);
+    {   // one sphere around the lane's geoms; for motor-body geoms its centre is projected onto the motor axis
+        double c[3] = {0, 0, 0};
+        for (int k = 0; k < xs_n; k++) for (int i = 0; i < 3; i++) c[i] += xs_c[k][i] / xs_n;
+        if (leg == 3) {
+            const double* em = hinge(8) + JB_H_AXIS;
+            double t = 0;
+            for (int i = 0; i < 3; i++) t += (c[i] - am[i]) * em[i];
+            for (int i = 0; i < 3; i++) c[i] = am[i] + t * em[i];
+        }
+        double r = 0;
+        for (int k = 0; k < xs_n; k++) { double d = norm3d(xs_c[k], c) + xs_r[k]; if (d > r) r = d; }
+        put3(LM_BS_X_C, c);
+        out[LM_BS_X_R] = T(r + 1e-3);
+    }
     return 0;
 }
 

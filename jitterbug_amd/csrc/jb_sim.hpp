@@ -40,6 +40,7 @@ namespace jb {
 // Index map of the per-lane constant table.  Filled by jb_build_lane_model()
 // (host) from the compiled parameter table of include/jitterbug_model.h.
 enum LM : int {
+    // ---------------- hot part: kept in registers for the whole control step
     LM_H = 0, LM_GRAV = 1 /*3*/, LM_KK = 4, LM_BB = 5, LM_IMP_D0 = 6, LM_IMP_DW = 7, LM_IMP_IW /*1/width*/ = 8, LM_IMP_MID = 9, LM_IMP_POW = 10,
     LM_MU = 11, LM_FR2 = 12, LM_GEAR = 13, LM_GAIN = 14, LM_BIAS = 15 /*3*/, LM_CTRL_LO = 18, LM_CTRL_HI = 19, LM_MTOT = 20,
     // root body
@@ -51,24 +52,42 @@ enum LM : int {
     LM_DC2 = 71 /*3: com2 - knee anchor*/, LM_I2 = 74 /*6*/, LM_M2 = 80, LM_K1 = 81, LM_B1 = 82, LM_K2 = 83, LM_B2 = 84, LM_TRAN1 = 85, LM_TRAN2 = 86,
     LM_DFOOT = 87 /*3*/, LM_FOOT_R = 90,
     LM_LC_D = 91 /*3: lower cylinder centre - knee anchor*/, LM_LC_AX = 94 /*3*/, LM_LC_XA = 97 /*3*/, LM_LC_R = 100, LM_LC_H = 101,
-    LM_UC_D = 102 /*3: upper cylinder centre - a1*/, LM_UC_AX = 105 /*3*/, LM_UC_XA = 108 /*3*/, LM_UC_R = 111, LM_UC_H = 112,
-    LM_DTIP = 113 /*3*/, LM_TIP_R = 116,
+    LM_TARGET_Z = 102, LM_ROOT_Z0 = 103, LM_LANE = 104 /* 0..3: which leg this lane owns */,
+    // broadphase spheres (root reference coordinates) for the rarely touching geoms of this lane:
+    //   LEG: upper cylinder + knee tip (centre = cylinder centre);  X: the lane's root / motor-body geoms
+    //   (for motor-body geoms the centre lies on the motor axis, so it does not move with the motor angle)
+    LM_BS_LEG_C = 105 /*3*/, LM_BS_LEG_R = 108, LM_BS_X_C = 109 /*3*/, LM_BS_X_R = 112,
+    LM_HOT = 113,
+    // ---------------- cold part: read from the table only on the rare path
+    LM_UC_D = 113 /*3: upper cylinder centre - a1*/, LM_UC_AX = 116 /*3*/, LM_UC_XA = 119 /*3*/, LM_UC_R = 122, LM_UC_H = 123,
+    LM_DTIP = 124 /*3*/, LM_TIP_R = 127,
     // lane-assigned geoms of the root / motor body (lane 0: coreBody1 box, lane 1: coreBody2 box,
     // lane 2: screw1 cylinder + screw2 ellipsoid, lane 3: threadMass cylinder + mass ellipsoid on the motor body)
-    LM_XB_EN = 117, LM_XB_C = 118 /*3*/, LM_XB_R = 121 /*9*/, LM_XB_S = 130 /*3*/,
-    LM_XC_EN = 133, LM_XC_C = 134 /*3*/, LM_XC_AX = 137 /*3*/, LM_XC_XA = 140 /*3*/, LM_XC_R = 143, LM_XC_H = 144,
-    LM_XE_EN = 145, LM_XE_C = 146 /*3*/, LM_XE_R = 149 /*9*/, LM_XE_S = 158 /*3*/,
-    LM_X_ONM = 161 /*1: the lane's cylinder+ellipsoid sit on the motor body*/,
-    LM_BOUND_LEG = 162 /* bounding radius of upper cylinder + tip about a1 */, LM_BOUND_X = 163 /* bounding radius of lane geoms about their reference point */,
-    LM_TARGET_Z = 164, LM_ROOT_Z0 = 165, LM_LANE = 166 /* 0..3: which leg this lane owns */,
-    LM_COUNT = 168
+    LM_XB_EN = 128, LM_XB_C = 129 /*3*/, LM_XB_R = 132 /*9*/, LM_XB_S = 141 /*3*/,
+    LM_XC_EN = 144, LM_XC_C = 145 /*3*/, LM_XC_AX = 148 /*3*/, LM_XC_XA = 151 /*3*/, LM_XC_R = 154, LM_XC_H = 155,
+    LM_XE_EN = 156, LM_XE_C = 157 /*3*/, LM_XE_R = 160 /*9*/, LM_XE_S = 169 /*3*/,
+    LM_X_ONM = 172 /*1: the lane's cylinder+ellipsoid sit on the motor body*/,
+    LM_COUNT = 176
 };
 
-template <typename V> struct LaneModel { V c[LM_COUNT]; };
+// The constant table is stored [LM_COUNT][4] (4 = lane of the quad).  `c` holds the hot prefix in registers;
+// `cold` addresses the table for on-demand reads (device: already offset by the lane; host Quad: the row base).
+template <typename V> struct LaneModel {
+    V c[LM_HOT];
+    const typename lane_traits<V>::real* cold;
+};
+JB_HD float lane_from4(const float* p, float*) { return p[0]; }
+JB_HD double lane_from4(const double* p, double*) { return p[0]; }
+#if !defined(__HIPCC__)
+template <typename T> inline Quad<T> lane_from4(const T* p, Quad<T>*) { return Quad<T>(p[0], p[1], p[2], p[3]); }
+#endif
+template <typename V> JB_HD V ldc(const LaneModel<V>& m, int i) { return lane_from4(m.cold + 4 * i, (V*)nullptr); }
+
 
 template <typename V> struct Vec3 { V x, y, z; };
 template <typename V> JB_HD Vec3<V> v3(const V& x, const V& y, const V& z) { Vec3<V> r; r.x = x; r.y = y; r.z = z; return r; }
 template <typename V> JB_HD Vec3<V> ldv3(const LaneModel<V>& m, int i) { return v3(m.c[i], m.c[i + 1], m.c[i + 2]); }
+template <typename V> JB_HD Vec3<V> ldc3(const LaneModel<V>& m, int i) { return v3(ldc(m, i), ldc(m, i + 1), ldc(m, i + 2)); }
 template <typename V> JB_HD Vec3<V> operator+(const Vec3<V>& a, const Vec3<V>& b) { return v3<V>(a.x + b.x, a.y + b.y, a.z + b.z); }
 template <typename V> JB_HD Vec3<V> operator-(const Vec3<V>& a, const Vec3<V>& b) { return v3<V>(a.x - b.x, a.y - b.y, a.z - b.z); }
 template <typename V> JB_HD Vec3<V> operator-(const Vec3<V>& a) { return v3<V>(-a.x, -a.y, -a.z); }
@@ -279,7 +298,7 @@ template <typename V> JB_HD V impedance(const LaneModel<V>& m, const V& dist) {
 //   J_sh(x,d) = (d x e1).(x - a1),  J_kn(x,d) = (d x e2).(x - a2),  J_m(x,d) = (d x em).(x - am)
 template <typename V> struct DirData {
     Vec3<V> d[3];
-    Vec3<V> wS[3], wK[3], wM[3];
+    Vec3<V> wS[3], wK[3], wM[3];   // wM/oM are filled only on the rare path
     V oS[3], oK[3], oM[3];
     V du[3];                 // d . u  (root linear velocity in root coords)
 };
@@ -446,8 +465,8 @@ template <typename V> JB_HD void sincos_small(const V& x, V& s, V& c) {
 }
 
 // ----------------------------------------------------------------------------- the substep
-template <typename V>
-JB_HD void substep(const LaneModel<V>& m, LaneState<V>& s, const V& ctrl, const SimOpts& o) {
+template <typename V, bool XTRA>
+JB_HD void substep_impl(const LaneModel<V>& m, LaneState<V>& s, const V& ctrl, const SimOpts& o) {
     using MK = typename lane_traits<V>::mask;
     using U = typename lane_traits<V>::uint;
     const V h = m.c[LM_H];
@@ -568,7 +587,7 @@ JB_HD void substep(const LaneModel<V>& m, LaneState<V>& s, const V& ctrl, const 
 #pragma unroll
     for (int i = 0; i < 6; i++) qfr[i] = V(0);
     qfl[0] = qfl[1] = V(0); qfm = V(0);
-    bool xtra = false;
+    constexpr bool xtra = XTRA;
     if (o.contacts) {
         // foot sphere and lower-leg cylinder: always evaluated
         Vec3<V> foot = a2 + mul(R12, ldv3(m, LM_DFOOT));
@@ -579,54 +598,49 @@ JB_HD void substep(const LaneModel<V>& m, LaneState<V>& s, const V& ctrl, const 
         MK all_on = lt(V(0), V(1));
         cylinder_floor(a2 + mul(R12, ldv3(m, LM_LC_D)), mul(R12, ldv3(m, LM_LC_AX)), mul(R12, ldv3(m, LM_LC_XA)), m.c[LM_LC_R], m.c[LM_LC_H], nb, s.pz, all_on, lc);
         MK any_con = mor(fon, lc.on[0]);
-        // broadphase for the rarely touching geoms: upper cylinder + knee tip (bounding sphere about the
-        // shoulder anchor) and the lane's root/motor-body geoms
-        MK near_leg = lt(s.pz + dot(a1, nb), m.c[LM_BOUND_LEG]);
-        Vec3<V> xref = sel_v3(gt(m.c[LM_X_ONM], V(0.5)), am, v3<V>(V(0), V(0), V(0)));
-        MK near_x = lt(s.pz + dot(xref, nb), m.c[LM_BOUND_X]);
-        xtra = any_lane(mor(near_leg, near_x));
         // rarely-touching candidates, evaluated only when some lane of the wave is near the floor
         CylContacts<V> ucx, xcx;
         Vec3<V> tipx, ellx, boxx[8];
         V tipd = V(1), elld = V(1), boxd[8];
         MK tipon = lt(V(1), V(0)), ellon = tipon, boxon[8];
-        MK x_onm = gt(m.c[LM_X_ONM], V(0.5));
+        MK x_onm = lt(V(1), V(0));
         if (xtra) {
-            cylinder_floor(a1 + mul(R1, ldv3(m, LM_UC_D)), mul(R1, ldv3(m, LM_UC_AX)), mul(R1, ldv3(m, LM_UC_XA)), m.c[LM_UC_R], m.c[LM_UC_H], nb, s.pz, all_on, ucx);
-            Vec3<V> tip = a1 + mul(R1, ldv3(m, LM_DTIP));
-            tipd = s.pz + dot(tip, nb) - m.c[LM_TIP_R];
+            x_onm = gt(ldc(m, LM_X_ONM), V(0.5));
+            cylinder_floor(a1 + mul(R1, ldc3(m, LM_UC_D)), mul(R1, ldc3(m, LM_UC_AX)), mul(R1, ldc3(m, LM_UC_XA)), ldc(m, LM_UC_R), ldc(m, LM_UC_H), nb, s.pz, all_on, ucx);
+            Vec3<V> tip = a1 + mul(R1, ldc3(m, LM_DTIP));
+            tipd = s.pz + dot(tip, nb) - ldc(m, LM_TIP_R);
             tipon = lt(tipd, V(0));
-            tipx = tip - nb * (m.c[LM_TIP_R] + tipd * V(0.5));
+            tipx = tip - nb * (ldc(m, LM_TIP_R) + tipd * V(0.5));
             // lane cylinder (root body: lane 2 screw1; motor body: lane 3 threadMass)
-            Vec3<V> xc_c = ldv3(m, LM_XC_C), xc_ax = ldv3(m, LM_XC_AX), xc_xa = ldv3(m, LM_XC_XA);
+            Vec3<V> xc_c = ldc3(m, LM_XC_C), xc_ax = ldc3(m, LM_XC_AX), xc_xa = ldc3(m, LM_XC_XA);
             Vec3<V> xc_cm = am + mul(Rm, xc_c - am);
             cylinder_floor(sel_v3(x_onm, xc_cm, xc_c), sel_v3(x_onm, mul(Rm, xc_ax), xc_ax), sel_v3(x_onm, mul(Rm, xc_xa), xc_xa),
-                           m.c[LM_XC_R], m.c[LM_XC_H], nb, s.pz, gt(m.c[LM_XC_EN], V(0.5)), xcx);
+                           ldc(m, LM_XC_R), ldc(m, LM_XC_H), nb, s.pz, gt(ldc(m, LM_XC_EN), V(0.5)), xcx);
             // lane ellipsoid: support point in direction -n
             {
                 Mat3<V> Re; Mat3<V> Re0;
 #pragma unroll
-                for (int i = 0; i < 9; i++) Re0.m[i] = m.c[LM_XE_R + i];
+                for (int i = 0; i < 9; i++) Re0.m[i] = ldc(m, LM_XE_R + i);
                 Mat3<V> Rem = mul(Rm, Re0);
 #pragma unroll
                 for (int i = 0; i < 9; i++) Re.m[i] = sel(x_onm, Rem.m[i], Re0.m[i]);
-                Vec3<V> ec0 = ldv3(m, LM_XE_C);
+                Vec3<V> ec0 = ldc3(m, LM_XE_C);
                 Vec3<V> ec = sel_v3(x_onm, am + mul(Rm, ec0 - am), ec0);
                 Vec3<V> dl = mulT(Re, -nb);
-                Vec3<V> sz = ldv3(m, LM_XE_S);
+                Vec3<V> sz = ldc3(m, LM_XE_S);
                 V den = vsqrt(sz.x * sz.x * dl.x * dl.x + sz.y * sz.y * dl.y * dl.y + sz.z * sz.z * dl.z * dl.z);
                 Vec3<V> sup = ec + mul(Re, v3<V>(sz.x * sz.x * dl.x / den, sz.y * sz.y * dl.y / den, sz.z * sz.z * dl.z / den));
                 elld = s.pz + dot(sup, nb);
-                ellon = mand(gt(m.c[LM_XE_EN], V(0.5)), lt(elld, V(0)));
+                ellon = mand(gt(ldc(m, LM_XE_EN), V(0.5)), lt(elld, V(0)));
                 ellx = sup - nb * (elld * V(0.5));
             }
             // lane box (root body): first 4 penetrating vertices in vertex order
             {
                 Mat3<V> Rb;
 #pragma unroll
-                for (int i = 0; i < 9; i++) Rb.m[i] = m.c[LM_XB_R + i];
-                Vec3<V> bc = ldv3(m, LM_XB_C), bs = ldv3(m, LM_XB_S);
-                MK ben = gt(m.c[LM_XB_EN], V(0.5));
+                for (int i = 0; i < 9; i++) Rb.m[i] = ldc(m, LM_XB_R + i);
+                Vec3<V> bc = ldc3(m, LM_XB_C), bs = ldc3(m, LM_XB_S);
+                MK ben = gt(ldc(m, LM_XB_EN), V(0.5));
                 V cnt = V(0);
 #pragma unroll
                 for (int vtx = 0; vtx < 8; vtx++) {
@@ -652,7 +666,7 @@ JB_HD void substep(const LaneModel<V>& m, LaneState<V>& s, const V& ctrl, const 
             for (int k = 0; k < 3; k++) {
                 dd.wS[k] = cross(dd.d[k], e1); dd.oS[k] = dot(dd.wS[k], a1);
                 dd.wK[k] = cross(dd.d[k], e2); dd.oK[k] = dot(dd.wK[k], a2);
-                dd.wM[k] = cross(dd.d[k], em); dd.oM[k] = dot(dd.wM[k], am);
+                if (xtra) { dd.wM[k] = cross(dd.d[k], em); dd.oM[k] = dot(dd.wM[k], am); }
                 dd.du[k] = dot(dd.d[k], u);
             }
             const V tran0 = m.c[LM_TRAN0], tran1 = m.c[LM_TRAN1], tran2 = m.c[LM_TRAN2], tranm = m.c[LM_TRANM];
@@ -780,6 +794,29 @@ JB_HD void substep(const LaneModel<V>& m, LaneState<V>& s, const V& ctrl, const 
         s.phi = p - k * V(6.283185307179586);
         s.turns = s.turns + k;
     }
+}
+
+
+// One physics substep.  A wave-uniform broadphase decides between the lean variant (foot sphere + lower-leg
+// cylinder contacts only) and the complete one (every geom of the model against the floor).
+template <typename V>
+JB_HD void substep(const LaneModel<V>& m, LaneState<V>& s, const V& ctrl, const SimOpts& o) {
+    bool xtra = false;
+    if (o.contacts) {
+        V qn2 = s.qw * s.qw + s.qx * s.qx + s.qy * s.qy + s.qz * s.qz;
+        // third row of the rotation matrix of the (not yet normalised) quaternion, scaled by 1/|q|^2
+        V iq = V(1) / qn2;
+        Vec3<V> nb = v3<V>(V(2) * (s.qx * s.qz - s.qw * s.qy) * iq, V(2) * (s.qy * s.qz + s.qw * s.qx) * iq,
+                           (s.qw * s.qw - s.qx * s.qx - s.qy * s.qy + s.qz * s.qz) * iq);
+        auto near_leg = mor(lt(s.pz + dot(ldv3(m, LM_BS_LEG_C), nb), m.c[LM_BS_LEG_R]), gt(vabs(s.th1), V(0.3)));
+        auto near_x = lt(s.pz + dot(ldv3(m, LM_BS_X_C), nb), m.c[LM_BS_X_R]);
+        xtra = any_lane(mor(near_leg, near_x));
+    }
+#ifdef JB_NO_XTRA
+    xtra = false;
+#endif
+    if (xtra) substep_impl<V, true>(m, s, ctrl, o);
+    else substep_impl<V, false>(m, s, ctrl, o);
 }
 
 }  // namespace jb

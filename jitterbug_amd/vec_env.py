@@ -1,0 +1,148 @@
+"""Batched Jitterbug environment on one MI355X.
+
+Host mirror of the reference's vectorised use of the env (stable-baselines VecEnv in
+reference benchmarks/benchmark.py:146-185: reset() -> obs[N,D], step(actions) ->
+(obs, reward, done, infos), auto-reset on done), backed by libjitterbug_hip.so.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib, model
+
+TASKS = model.TASKS
+DEFAULT_TIME_LIMIT = 10          # reference jitterbug.py:56
+DEFAULT_CONTROL_TIMESTEP = 0.01  # reference jitterbug.py:57
+PHYSICS_TIMESTEP = 0.0002        # reference jitterbug.xml:18
+
+
+def compute_n_substeps(control_timestep, physics_timestep=PHYSICS_TIMESTEP, tol=1e-8):
+    """dm_control.rl.control.compute_n_steps: control step must be an integer multiple of the physics step."""
+    if control_timestep < physics_timestep:
+        raise ValueError("Control timestep ({}) cannot be smaller than physics timestep ({}).".format(control_timestep, physics_timestep))
+    n = control_timestep / physics_timestep
+    if abs(n - round(n)) > tol:
+        raise ValueError("Control timestep ({}) must be an integer multiple of physics timestep ({})".format(control_timestep, physics_timestep))
+    return int(round(n))
+
+
+class JitterbugVecEnv:
+    """N lockstep Jitterbug environments on one GPU."""
+
+    def __init__(self, n_envs, task="move_from_origin", seed=0, device_id=0, random_pose=True, contacts=True,
+                 time_limit=DEFAULT_TIME_LIMIT, control_timestep=DEFAULT_CONTROL_TIMESTEP, auto_reset=True,
+                 env_offset=0, max_newton=12, stream=None, params=None):
+        if task not in TASKS:
+            raise AssertionError("Invalid task {}, options are {}".format(task, list(TASKS)))   # reference jitterbug.py:425
+        self._L = _lib.load()
+        self.task = task
+        self.task_id = TASKS.index(task)
+        self.num_envs = int(n_envs)
+        self.obs_dim = model.OBS_DIM[task]
+        self.substeps = compute_n_substeps(control_timestep)
+        self.control_timestep = float(control_timestep)
+        if time_limit == float("inf"):
+            self.step_limit = 2 ** 31 - 1
+        else:
+            self.step_limit = int(np.ceil(time_limit / (PHYSICS_TIMESTEP * self.substeps) - 1e-9))
+        cfg = _lib.Config()
+        _lib.check(self._L.jb_default_config(C.byref(cfg), self.num_envs, self.task_id))
+        cfg.device_id = int(device_id)
+        cfg.random_pose = int(bool(random_pose))
+        cfg.contacts = int(bool(contacts))
+        cfg.substeps = self.substeps
+        cfg.step_limit = self.step_limit
+        cfg.auto_reset = int(bool(auto_reset))
+        cfg.max_newton = int(max_newton)
+        cfg.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        cfg.env_offset = int(env_offset)
+        cfg.use_caller_stream = 0 if stream is None else 1
+        cfg.stream = None if stream is None else int(stream)
+        self.cfg = cfg
+        h = C.c_void_p()
+        _lib.check(self._L.jb_create(C.byref(cfg), C.byref(h)))
+        self._h = h
+        self._obs = np.zeros((self.num_envs, self.obs_dim), dtype=np.float32)
+        self._rew = np.zeros(self.num_envs, dtype=np.float32)
+        self._done = np.zeros(self.num_envs, dtype=np.uint8)
+        self._pending = None
+        if params is not None:
+            self.set_model_params(params)
+
+    # ------------------------------------------------------------------ lifetime
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.jb_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ host-buffer API
+    def reset(self, mask=None):
+        m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        _lib.check(self._L.jb_reset(self._h, _lib.ptr(m), _lib.ptr(self._obs)))
+        return self._obs.copy()
+
+    def step(self, actions):
+        a = np.ascontiguousarray(np.broadcast_to(np.asarray(actions, dtype=np.float32).reshape(-1), (self.num_envs,)))
+        _lib.check(self._L.jb_step(self._h, _lib.ptr(a), _lib.ptr(self._obs), _lib.ptr(self._rew), _lib.ptr(self._done)))
+        return self._obs.copy(), self._rew.copy(), self._done.astype(bool), [{} for _ in range(self.num_envs)] if self.num_envs <= 64 else None
+
+    def step_async(self, actions):
+        self._pending = actions
+
+    def step_wait(self):
+        out = self.step(self._pending)
+        self._pending = None
+        return out
+
+    def observe(self):
+        _lib.check(self._L.jb_observe(self._h, _lib.ptr(self._obs), _lib.ptr(self._rew)))
+        return self._obs.copy(), self._rew.copy()
+
+    def get_state(self):
+        q = np.zeros((self.num_envs, model.NQ))
+        v = np.zeros((self.num_envs, model.NV))
+        t = np.zeros((self.num_envs, 3))
+        _lib.check(self._L.jb_get_state(self._h, _lib.ptr(q), _lib.ptr(v), _lib.ptr(t)))
+        return q, v, t
+
+    def set_state(self, qpos=None, qvel=None, target=None):
+        def prep(a, w):
+            return None if a is None else np.ascontiguousarray(np.asarray(a, dtype=np.float64).reshape(self.num_envs, w))
+        q, v, t = prep(qpos, model.NQ), prep(qvel, model.NV), prep(target, 3)
+        _lib.check(self._L.jb_set_state(self._h, _lib.ptr(q), _lib.ptr(v), _lib.ptr(t)))
+
+    def counters(self):
+        sc = np.zeros(self.num_envs, dtype=np.int32)
+        ep = np.zeros(self.num_envs, dtype=np.uint32)
+        cap = np.zeros(self.num_envs, dtype=np.float32)
+        _lib.check(self._L.jb_get_counters(self._h, _lib.ptr(sc), _lib.ptr(ep), _lib.ptr(cap)))
+        return sc, ep, cap
+
+    def set_model_params(self, params):
+        p = np.ascontiguousarray(params, dtype=np.float64)
+        n_tables = 1 if p.ndim == 1 else p.shape[0]
+        assert p.size == n_tables * model.NPARAM
+        _lib.check(self._L.jb_set_model_params(self._h, _lib.ptr(p), n_tables))
+
+    # ------------------------------------------------------------------ device-buffer API (raw pointers; torch tensors via .data_ptr())
+    def step_device(self, action_ptr, obs_ptr, reward_ptr, done_ptr):
+        _lib.check(self._L.jb_step_device(self._h, action_ptr, obs_ptr, reward_ptr, done_ptr))
+
+    def reset_device(self, mask_ptr=None, obs_ptr=None):
+        _lib.check(self._L.jb_reset_device(self._h, mask_ptr, obs_ptr))
+
+    def observe_device(self, obs_ptr, reward_ptr=None):
+        _lib.check(self._L.jb_observe_device(self._h, obs_ptr, reward_ptr))
+
+    def synchronize(self):
+        _lib.check(self._L.jb_synchronize(self._h))
+
+    @property
+    def stream(self):
+        return self._L.jb_stream(self._h)

@@ -533,7 +533,6 @@ static void substep(const double* P, double* qpos, double* qvel, double ctrl, co
                 }
                 if (!found) alpha = 1.0;
                 if (o->solver == 2) alpha = 1.0;        /* experiment: semismooth Newton with full steps */
-                if (st && fabs(alpha - 1.0) > 1e-9) st->overflow += 2;   /* counts non-unit line-search steps (diagnostic) */
                 double maxstep = 0;
                 for (int d = 0; d < NV; d++) { double dx = alpha * p[d]; x[d] += dx; double sc = fabs(dx) * M[d * NV + d]; if (sc > maxstep) maxstep = sc; }
                 sweeps++;
@@ -824,6 +823,8 @@ jbo_env* jbo_env_create(int n, int task, int random_pose, int nsub, int step_lim
     e->qpos = calloc((size_t)n * NQ, sizeof(double)); e->qvel = calloc((size_t)n * NV, sizeof(double));
     e->target = calloc((size_t)n * 3, sizeof(double)); e->warm = calloc((size_t)n * WARM_SIZE, sizeof(double));
     e->step_count = calloc(n, sizeof(int)); e->episode = calloc(n, sizeof(uint32_t));
+    /* like jb_create: a created env is already in a valid state (reset #0); the first explicit reset is #1 */
+    for (int i = 0; i < n; i++) { jbo_reset(envP(e, i), e->task, e->random_pose, e->seed, e->env_offset + (uint64_t)i, 0, e->qpos + (size_t)i * NQ, e->qvel + (size_t)i * NV, e->target + (size_t)i * 3); e->episode[i] = 1; }
     return e;
 }
 void jbo_env_destroy(jbo_env* e) {

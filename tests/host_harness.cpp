@@ -14,7 +14,10 @@ static int run(const double* P, double* qpos, double* qvel, double ctrl, int nsu
     LaneModel<V> m;
     T tab[4][LM_COUNT];
     for (int l = 0; l < 4; l++) { int rc = build_lane_model<T>(P, l, tab[l]); if (rc) return rc; }
-    for (int i = 0; i < LM_COUNT; i++) m.c[i] = V(tab[0][i], tab[1][i], tab[2][i], tab[3][i]);
+    T tabT[LM_COUNT][4];
+    for (int i = 0; i < LM_COUNT; i++) for (int l = 0; l < 4; l++) tabT[i][l] = tab[l][i];
+    for (int i = 0; i < LM_HOT; i++) m.c[i] = V(tab[0][i], tab[1][i], tab[2][i], tab[3][i]);
+    m.cold = &tabT[0][0];
     LaneState<V> s;
     s.px = V(T(qpos[0])); s.py = V(T(qpos[1])); s.pz = V(T(qpos[2]));
     s.qw = V(T(qpos[3])); s.qx = V(T(qpos[4])); s.qy = V(T(qpos[5])); s.qz = V(T(qpos[6]));

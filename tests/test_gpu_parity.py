@@ -1,0 +1,223 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU fp64 oracle on identical inputs.
+
+Tolerance (north_star: fp64 -> fp32, 1e-4 relative): an observation / reward entry PASSES when
+    |gpu - oracle| <= 1e-4 * |oracle| + 1e-6.
+Teacher-forced comparison: every control step the oracle's (qpos, qvel, target) is copied into
+the GPU env, both advance one control step (50 substeps) with the same action.  Contact activation is
+discontinuous, so an env whose foot crosses the floor within fp32 resolution of a substep boundary can differ
+by one substep's contact impulse; the tests therefore require >= 99.5 % of entries inside the tolerance and
+bound the rest by 5e-3 absolute (measured on the fp32 host build of the same source: 99.97 % / 2e-4)."""
+import numpy as np
+import pytest
+
+from jitterbug_amd import model
+
+pytestmark = pytest.mark.gpu
+
+
+def _envs(n, task, seed=0, **kw):
+    from jitterbug_amd.vec_env import JitterbugVecEnv
+    from oracle import oracle as O
+    P = model.default_params()
+    g = JitterbugVecEnv(n, task, seed=seed, **kw)
+    okw = {}
+    if "contacts" in kw:
+        okw["opts"] = O.default_opts(contacts=int(kw["contacts"]))
+    o = O.OracleEnv(n, task, P, seed=seed, random_pose=kw.get("random_pose", True), **okw)
+    return g, o
+
+
+def _within(a, b):
+    return np.abs(a - b) <= 1e-4 * np.abs(b) + 1e-6
+
+
+@pytest.mark.parametrize("task", model.TASKS)
+def test_reset_matches_oracle(task):
+    g, o = _envs(257, task, seed=11)
+    og, oo = g.reset(), o.reset()
+    assert og.shape == (257, model.OBS_DIM[task]) and og.dtype == np.float32
+    np.testing.assert_allclose(og, oo, rtol=2e-6, atol=2e-6)
+    qg, vg, tg = g.get_state()
+    qo, vo, to = o.get_state()
+    np.testing.assert_allclose(qg, qo, atol=2e-7)
+    np.testing.assert_allclose(tg, to, atol=1e-6)
+    assert np.all(vg == 0)
+    sc, ep, _ = g.counters()
+    assert np.all(sc == 0) and np.all(ep == 2)         # jb_create performs reset #0, this call reset #1
+    g.close()
+
+
+def test_free_fall_known_answer():
+    from jitterbug_amd.vec_env import JitterbugVecEnv
+    g = JitterbugVecEnv(8, "move_from_origin", random_pose=False, contacts=False)
+    g.reset()
+    g.step(np.zeros(8))
+    q, v, _ = g.get_state()
+    np.testing.assert_allclose(v[:, 2], -0.0981, rtol=2e-6)
+    np.testing.assert_allclose(q[:, 2], 0.035 - 9.81 * 0.0002 ** 2 * (50 * 51 / 2), rtol=1e-6)
+    assert np.abs(q[:, 7:]).max() < 1e-6
+    g.close()
+
+
+def test_state_roundtrip():
+    g, o = _envs(33, "move_to_pose", seed=2)
+    rng = np.random.default_rng(0)
+    q = np.tile(model.qpos0(), (33, 1))
+    q[:, :3] += rng.normal(size=(33, 3)) * 0.01
+    quat = rng.normal(size=(33, 4))
+    q[:, 3:7] = quat / np.linalg.norm(quat, axis=1, keepdims=True)
+    q[:, 7:15] = rng.normal(size=(33, 8)) * 0.05
+    q[:, 15] = rng.uniform(-50, 50, size=33)
+    v = rng.normal(size=(33, 15))
+    t = rng.normal(size=(33, 3))
+    g.set_state(q, v, t)
+    q2, v2, t2 = g.get_state()
+    np.testing.assert_allclose(q2[:, :15], q[:, :15], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(q2[:, 15], q[:, 15], atol=5e-6)          # motor angle: wrapped fp32 + whole turns
+    np.testing.assert_allclose(v2, v, rtol=1e-6)
+    np.testing.assert_allclose(t2, t, rtol=1e-6)
+    # observation of an injected state vs the oracle's
+    o.set_state(q, v, t)
+    from oracle import oracle as O
+    P = model.default_params()
+    og, rg = g.observe()
+    for i in range(33):
+        np.testing.assert_allclose(og[i], O.observation(P, "move_to_pose", q[i], v[i], t[i]), rtol=1e-5, atol=2e-6)
+        assert abs(rg[i] - O.reward(P, "move_to_pose", q[i], v[i], t[i])) < 1e-5
+    g.close()
+
+
+def _teacher_forced(task, n, steps, seed, contacts=True):
+    g, o = _envs(n, task, seed=seed, auto_reset=False, contacts=contacts)
+    g.reset(), o.reset()
+    rng = np.random.default_rng(seed)
+    ok = tot = 0
+    worst = 0.0
+    okr = 0
+    for t in range(steps):
+        a = rng.uniform(-1, 1, size=n)
+        g.set_state(*o.get_state())
+        og, rg, dg, _ = g.step(a)
+        oo, ro, do = o.step(a, auto_reset=False)
+        w = _within(og.astype(np.float64), oo)
+        ok += w.sum(); tot += w.size
+        okr += _within(rg.astype(np.float64), ro).sum()
+        worst = max(worst, np.abs(og - oo).max())
+        assert np.array_equal(dg, do.astype(bool))
+    sc, ep, cap = g.counters()
+    g.close()
+    return ok / tot, worst, okr / (n * steps), cap.sum()
+
+
+@pytest.mark.parametrize("task", ["move_from_origin", "move_to_pose", "move_in_direction"])
+def test_step_teacher_forced_contacts(task):
+    frac, worst, frac_r, cap = _teacher_forced(task, 64, 120, seed=3)
+    print("teacher-forced", task, "frac within 1e-4 rel:", frac, "worst abs:", worst, "reward frac:", frac_r, "solver cap hits:", cap)
+    assert frac >= 0.995 and frac_r >= 0.995
+    assert worst <= 5e-3
+    assert cap == 0
+
+
+def test_step_teacher_forced_contacts_off():
+    frac, worst, frac_r, cap = _teacher_forced("move_from_origin", 64, 40, seed=4, contacts=False)
+    print("teacher-forced contacts off: frac", frac, "worst", worst)
+    assert frac >= 0.9999 and worst <= 2e-5
+
+
+def test_all_geoms_contact_parity():
+    """Random orientations pushed into the floor: exercises every geom type (upper legs, knee tips, boxes,
+    cylinders, ellipsoids, motor-body geoms) through the complete-collision variant of the kernel."""
+    from oracle import oracle as O
+    from jitterbug_amd.vec_env import JitterbugVecEnv
+    P = model.default_params()
+    n = 256
+    rng = np.random.default_rng(5)
+    q = np.tile(model.qpos0(), (n, 1))
+    quat = rng.normal(size=(n, 4))
+    q[:, 3:7] = quat / np.linalg.norm(quat, axis=1, keepdims=True)
+    q[:, 7:15] = rng.normal(size=(n, 8)) * 0.03
+    q[:, 15] = rng.uniform(-3, 3, size=n)
+    v = rng.normal(size=(n, 15)) * np.array([.05] * 3 + [1] * 3 + [1] * 8 + [20])
+    seen = set()
+    for i in range(n):
+        lo, hi = -0.1, 0.2
+        for _ in range(30):
+            mid = 0.5 * (lo + hi)
+            q[i, 2] = mid
+            if O.forward_debug(P, q[i], v[i], 0.0)["ncon"] > 0:
+                lo = mid
+            else:
+                hi = mid
+        q[i, 2] = lo - rng.uniform(0.0002, 0.002) - (0.03 if i % 2 else 0.0)
+        seen |= set(O.forward_debug(P, q[i], v[i], 0.0)["con_geom"].tolist())
+    assert seen == set(range(22))
+    g = JitterbugVecEnv(n, "move_from_origin", auto_reset=False, control_timestep=0.0004, time_limit=1000)   # 2 substeps
+    o = O.OracleEnv(n, "move_from_origin", P, nsub=2, step_limit=10 ** 9)
+    u = rng.uniform(-1, 1, size=n)
+    g.set_state(q, v, np.zeros((n, 3)))
+    o.set_state(q, v, np.zeros((n, 3)))
+    g.step(u)
+    o.step(u, auto_reset=False)
+    qg, vg, _ = g.get_state()
+    qo, vo, _ = o.get_state()
+    # deep penetrations give huge forces: compare the velocity change relative to its own size
+    dv_o, dv_g = vo - v, vg - v
+    rel = np.abs(dv_g[:, :6] - dv_o[:, :6]) / (np.abs(dv_o[:, :6]).max(axis=1, keepdims=True) + 1e-3)
+    print("all-geom contact parity: median rel err", np.median(rel), "max", rel.max())
+    assert np.quantile(rel, 0.99) < 1e-3 and rel.max() < 5e-2
+    _, _, cap = g.counters()
+    assert cap.sum() == 0
+    g.close()
+
+
+def test_auto_reset_and_episode_streams():
+    g, o = _envs(50, "move_to_position", seed=9, time_limit=0.05)      # 5 control steps per episode
+    o2 = None
+    from oracle import oracle as O
+    o = O.OracleEnv(50, "move_to_position", model.default_params(), seed=9, step_limit=5)
+    g.reset(), o.reset()
+    rng = np.random.default_rng(1)
+    for t in range(12):
+        a = rng.uniform(-1, 1, size=50)
+        g.set_state(*o.get_state())
+        og, rg, dg, _ = g.step(a)
+        oo, ro, do = o.step(a, auto_reset=True)
+        assert np.array_equal(dg, do.astype(bool)) and dg.all() == ((t + 1) % 5 == 0)
+        if dg.all():          # VecEnv semantics: the returned observation belongs to the NEW episode (same Philox stream)
+            np.testing.assert_allclose(og, oo, rtol=1e-5, atol=2e-6)
+        scg, epg, _ = g.counters()
+        sco, epo = o.counters()
+        assert np.array_equal(scg, sco) and np.array_equal(epg, epo)
+    g.close()
+
+
+def test_sharding_invariance_and_determinism_full_size():
+    """BASELINE size (N=4096): results are bit-identical run to run, and do not depend on how the batch is
+    split into shards (env_offset), which is what makes the multi-GPU path a pure partition."""
+    from jitterbug_amd.vec_env import JitterbugVecEnv
+    n = 4096
+    rng = np.random.default_rng(0)
+    acts = rng.uniform(-1, 1, size=(6, n)).astype(np.float32)
+
+    def run(parts):
+        outs = []
+        for lo, hi in parts:
+            e = JitterbugVecEnv(hi - lo, "move_from_origin", seed=5, env_offset=lo)
+            ob = [e.reset()]
+            for a in acts:
+                o_, r_, d_, _ = e.step(a[lo:hi])
+                ob.append(o_)
+            outs.append(np.stack(ob))
+            e.close()
+        return np.concatenate(outs, axis=1)
+
+    whole = run([(0, n)])
+    again = run([(0, n)])
+    split = run([(0, 1000), (1000, 2048), (2048, n)])
+    assert np.array_equal(whole, again)
+    assert np.array_equal(whole, split)
+    assert np.isfinite(whole).all()
+    # physical sanity at full size: quaternion stays unit, robot stays near the floor
+    assert np.abs(np.linalg.norm(whole[-1][:, 3:7], axis=1) - 1).max() < 1e-5
+    z = (whole[-1][:, 2] + 1) / 20
+    assert z.min() > 0.02 and z.max() < 0.06

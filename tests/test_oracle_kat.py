@@ -262,9 +262,9 @@ def test_episode_counters_and_auto_reset(params):
     ob, r, d = env.step(np.zeros(3))          # 4th step: done, VecEnv semantics -> obs of the new episode
     assert d.all()
     sc, ep = env.counters()
-    assert np.all(sc == 0) and np.all(ep == 2)
+    assert np.all(sc == 0) and np.all(ep == 3)      # create = reset #0, reset() = #1, auto-reset = #2
     q, v, t = env.get_state()
     for i in range(3):
-        qe, ve, te = O.reset(params, "move_from_origin", True, 1, i, 1)
+        qe, ve, te = O.reset(params, "move_from_origin", True, 1, i, 2)
         np.testing.assert_array_equal(q[i], qe)
         np.testing.assert_allclose(ob[i], O.observation(params, "move_from_origin", qe, ve, te))
