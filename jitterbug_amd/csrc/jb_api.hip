@@ -36,11 +36,25 @@ struct KArgs {
     int* step_count; unsigned* episode;
 };
 
-__device__ __forceinline__ void load_model(const KArgs& a, int env, int leg, LaneModel<float>& m) {
-    const float* tab = a.lane_model + (a.per_env_model ? (size_t)env * LM_COUNT * 4 : 0);
-#pragma unroll
-    for (int f = 0; f < LM_HOT; f++) m.c[f] = tab[f * 4 + leg];
-    m.cold = tab + leg;
+// Stage the lane constant table(s) of this workgroup (64 threads = 16 envs) into LDS: one [LM_COUNT][4] copy for
+// a shared model, 16 copies for per-env models.
+#define JB_ENVS_PER_BLOCK 16
+__device__ __forceinline__ void stage_model(const KArgs& a, float* lds, int env, int leg, LaneModel<float>& m) {
+    const int tsz = LM_COUNT * 4;
+    if (a.per_env_model) {
+        const int env0 = (int)(blockIdx.x * JB_ENVS_PER_BLOCK);
+        for (int i = threadIdx.x; i < tsz * JB_ENVS_PER_BLOCK; i += blockDim.x) {
+            int e = env0 + i / tsz;
+            if (e >= a.n) e = a.n - 1;
+            lds[i] = a.lane_model[(size_t)e * tsz + (i % tsz)];
+        }
+        __syncthreads();
+        m.c.tab = lds + (threadIdx.x >> 2) * tsz + leg;
+    } else {
+        for (int i = threadIdx.x; i < tsz; i += blockDim.x) lds[i] = a.lane_model[i];
+        __syncthreads();
+        m.c.tab = lds + leg;
+    }
 }
 __device__ __forceinline__ void load_state(const KArgs& a, int env, int lane, LaneState<float>& s) {
     const float* r = a.root + env;
@@ -102,14 +116,17 @@ __global__ __launch_bounds__(64) void jb_step_kernel(KArgs a, const float* __res
     const bool live = env < a.n;
     if (!live) env = a.n - 1;                    // tail lanes shadow the last env so wave-level ops stay uniform; they store nothing
     const int lane = env * 4 + leg;
+    extern __shared__ float lds[];           // [SC_COUNT][64] per-lane scratch, then the lane constant table(s)
+    LaneScratch<float> scr;
+    scr.p = lds + threadIdx.x;
     LaneModel<float> m;
-    load_model(a, env, leg, m);
+    stage_model(a, lds + SC_COUNT * 64, env, leg, m);
     LaneState<float> s;
     load_state(a, env, lane, s);
     const float ctrl = action[env];
     SimOpts o; o.contacts = a.contacts; o.max_newton = a.max_newton; o.implicit_damp = 1;
 #pragma unroll 1
-    for (int k = 0; k < a.substeps; k++) substep<float>(m, s, ctrl, o);
+    for (int k = 0; k < a.substeps; k++) substep<float>(m, scr, s, ctrl, o);
     {   // trailing mj_step1: derived quantities use the normalised quaternion
         float n = 1.0f / sqrtf(s.qw * s.qw + s.qx * s.qx + s.qy * s.qy + s.qz * s.qz);
         s.qw *= n; s.qx *= n; s.qy *= n; s.qz *= n;
@@ -361,7 +378,7 @@ int jb_reset_device(jb_handle* h, const uint8_t* d_mask, float* d_obs_out) {
 }
 int jb_step_device(jb_handle* h, const float* d_action, float* d_obs_out, float* d_reward_out, uint8_t* d_done_out) {
     if (!h || !d_action) return fail(JB_E_INVALID, "handle/action is NULL");
-    hipLaunchKernelGGL(jb_step_kernel, grid_lanes(h->cfg.n_envs), dim3(64), 0, h->stream, h->ka, d_action, d_obs_out, d_reward_out, d_done_out);
+    hipLaunchKernelGGL(jb_step_kernel, grid_lanes(h->cfg.n_envs), dim3(64), ((size_t)SC_COUNT * 64 + (size_t)LM_COUNT * 4 * (h->ka.per_env_model ? JB_ENVS_PER_BLOCK : 1)) * sizeof(float), h->stream, h->ka, d_action, d_obs_out, d_reward_out, d_done_out);
     JB_HIP(hipGetLastError());
     return JB_OK;
 }

@@ -34,6 +34,16 @@
 
 #include "jb_lane.hpp"
 
+#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+#define JB_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+// hide the provenance of the constant-table pointer once per substep so the compiler re-reads constants from LDS
+// where they are used instead of hoisting ~110 loads out of the substep loop and pinning them in registers
+#define JB_LAUNDER(p) asm volatile("" : "+v"(p))
+#else
+#define JB_SCHED_FENCE() ((void)0)
+#define JB_LAUNDER(p) ((void)0)
+#endif
+
 namespace jb {
 
 // ----------------------------------------------------------------------------- lane model table
@@ -70,18 +80,21 @@ enum LM : int {
     LM_COUNT = 176
 };
 
-// The constant table is stored [LM_COUNT][4] (4 = lane of the quad).  `c` holds the hot prefix in registers;
-// `cold` addresses the table for on-demand reads (device: already offset by the lane; host Quad: the row base).
-template <typename V> struct LaneModel {
-    V c[LM_HOT];
-    const typename lane_traits<V>::real* cold;
-};
+// The constant table is stored [LM_COUNT][4] (4 = lane of the quad) — on the device in LDS, one copy per
+// workgroup (shared model) or per env (per-env models).  Constants are read where they are used instead of
+// being pinned in registers for the whole control step: `m.c[LM_X]` is one ds_read_b32 with an immediate offset.
+// tab: device = table base already offset by the lane's leg; host Quad = the row base.
 JB_HD float lane_from4(const float* p, float*) { return p[0]; }
 JB_HD double lane_from4(const double* p, double*) { return p[0]; }
 #if !defined(__HIPCC__)
 template <typename T> inline Quad<T> lane_from4(const T* p, Quad<T>*) { return Quad<T>(p[0], p[1], p[2], p[3]); }
 #endif
-template <typename V> JB_HD V ldc(const LaneModel<V>& m, int i) { return lane_from4(m.cold + 4 * i, (V*)nullptr); }
+template <typename V> struct LaneConsts {
+    const typename lane_traits<V>::real* tab;
+    JB_HD V operator[](int i) const { return lane_from4(tab + 4 * i, (V*)nullptr); }
+};
+template <typename V> struct LaneModel { LaneConsts<V> c; };
+template <typename V> JB_HD V ldc(const LaneModel<V>& m, int i) { return m.c[i]; }
 
 
 template <typename V> struct Vec3 { V x, y, z; };
@@ -186,51 +199,87 @@ template <typename V> struct LaneState {
     V fail;                              // >0: the Newton iteration hit its cap in some substep
 };
 
-// The joint-space system in star form.  A: 6x6 symmetric, lower triangle packed row-wise
-// (index i*(i+1)/2+j, j<=i), dof order [ang(3), lin(3)]; B: 6x2 own-leg coupling; C: own-leg 2x2;
-// Bm, Cm: motor coupling / diagonal.
-template <typename V> struct StarSys {
-    V A[21];
-    V B[6][2];
-    V C11, C12, C22;
-    V Bm[6];
-    V Cm;
+// ----------------------------------------------------------------------------- per-lane scratch
+// Values that are produced once per substep and consumed by several later phases (joint-space system, applied
+// forces, contact-frame direction data, contact candidates) live in a per-lane scratch instead of registers:
+// on the device this is LDS with element i of lane L at lds[i*64 + L] (conflict free); on the host a plain array.
+// This keeps the register-resident working set of each phase small enough that nothing spills to scratch memory.
+enum SC : int {
+    SC_MA = 0 /*21: root block of M, packed lower triangle, dof order [ang, lin]*/, SC_MB = 21 /*12: leg coupling [i*2+j]*/,
+    SC_MC = 33 /*3: C11 C12 C22*/, SC_MBM = 36 /*6: motor coupling*/, SC_MCM = 42,
+    SC_TR = 43 /*6: applied+bias force on the root dofs (replicated)*/, SC_TL = 49 /*2: own leg*/, SC_TM = 51 /*motor*/,
+    SC_DD = 52 /*3 directions x 12: d(3) wS(3) wK(3) oS oK du*/,
+    SC_CAND = 88 /*28 contact candidates x 4: position (3, root coords rel. root origin) and effective distance
+                   (the real distance when the candidate is a contact, +1 otherwise).  Slots: 0 foot, 1-4 lower-leg
+                   cylinder | 5-8 upper cylinder, 9 knee tip | root body: 10-13 lane cylinder, 14 lane ellipsoid,
+                   15-22 lane box vertices | motor body: 23-26 lane cylinder, 27 lane ellipsoid*/,
+    SC_R = 200 /*9: root rotation matrix*/,
+    SC_COUNT = 212
+};
+template <typename V> struct scratch_stride { static constexpr int value = 1; };
+template <> struct scratch_stride<float> { static constexpr int value = 64; };
+template <typename V> struct LaneScratch {
+    V* p;
+    JB_HD V ld(int i) const { return p[i * scratch_stride<V>::value]; }
+    JB_HD void st(int i, const V& v) const { p[i * scratch_stride<V>::value] = v; }
+    JB_HD Vec3<V> ld3(int i) const { return v3<V>(ld(i), ld(i + 1), ld(i + 2)); }
+    JB_HD void st3(int i, const Vec3<V>& v) const { st(i, v.x); st(i + 1, v.y); st(i + 2, v.z); }
 };
 JB_HD constexpr int tri(int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
 
-// Solve  [A B Bm; B^T C 0; Bm^T 0 Cm] y = [rr; rl; rm].
-//   A      : replicated part (identical in the 4 lanes), added ONCE
-//   Aloc   : lane-private additive part of A (contact terms), summed over the quad
-//   B, C   : lane-private leg branch.  Bm/Cm: motor branch, replicated (+ Bmloc/Cmloc lane-private parts if XTRA)
-// rr is given as replicated part rr plus lane-private part rrloc.
-template <typename V, bool XTRA>
-JB_HD void star_solve(const V (&A)[21], const V (&Aloc)[21], const V (&B)[6][2], const V& C11, const V& C12, const V& C22,
-                      const V (&Bm)[6], const V& Cm, const V (&Bmloc)[6], const V& Cmloc,
-                      const V (&rr)[6], const V (&rrloc)[6], const V (&rl)[2], const V& rm, const V& rmloc,
-                      V (&yr)[6], V (&yl)[2], V& ym) {
-    // eliminate own leg
-    V det = C11 * C22 - C12 * C12;
-    V idet = V(1) / det;
-    V i11 = C22 * idet, i12 = -C12 * idet, i22 = C11 * idet;
-    V G[6][2];
+// Accumulator of the contact terms of the Newton system for the lane (everything here is ADDED to M / tau,
+// which stay in the scratch)
+template <typename V> struct NewtonAcc {
+    V A[21];                 // lane-private additive part of the root block
+    V B[6][2];               // additive part of the leg coupling
+    V C11, C12, C22;
+    V Bm[6], Cm;             // lane-private additive part of the motor branch
+    V rr[6], rl[2], rm;      // additive rhs parts
+    typename lane_traits<V>::uint bw0;     // active-set record of the always-evaluated slots 0..4: 5 bits (valid + 4 pyramid edges) each, exact
+    typename lane_traits<V>::uint xh;      // polynomial hash of the records of the rarely-evaluated slots (lane-private, never summed across lanes)
+};
+template <typename V> JB_HD void acc_clear(NewtonAcc<V>& acc) {
 #pragma unroll
-    for (int i = 0; i < 6; i++) { G[i][0] = B[i][0] * i11 + B[i][1] * i12; G[i][1] = B[i][0] * i12 + B[i][1] * i22; }
+    for (int i = 0; i < 21; i++) acc.A[i] = V(0);
+#pragma unroll
+    for (int i = 0; i < 6; i++) { acc.B[i][0] = V(0); acc.B[i][1] = V(0); acc.Bm[i] = V(0); acc.rr[i] = V(0); }
+    acc.C11 = V(0); acc.C12 = V(0); acc.C22 = V(0); acc.Cm = V(0);
+    acc.rl[0] = V(0); acc.rl[1] = V(0); acc.rm = V(0);
+    acc.bw0 = zero_u<V>(); acc.xh = zero_u<V>();
+}
+
+// Solve  [A B Bm; B^T C 0; Bm^T 0 Cm] y = rhs  where the matrix is M (scratch) + the contact terms in `acc`
+// (+ hb1/hb2 on the leg diagonal: implicit joint damping) and rhs = tau (scratch) + acc.r*.
+//   A, tau_root, Bm, Cm : replicated in the 4 lanes, added ONCE;  acc.A, acc.rr (and acc.Bm/Cm/rm if XTRA): lane-private
+//   parts that are summed over the quad;  B, C, tau_leg: lane-private leg branch.
+// The own leg (2x2) and the motor (1x1) are eliminated onto the 6 root dofs; the 6x6 Schur complement is
+// Cholesky-factored redundantly by the 4 lanes.
+template <typename V, bool XTRA>
+JB_HD void star_solve(const LaneScratch<V>& sc, const NewtonAcc<V>& acc, const V& hb1, const V& hb2, V (&yr)[6], V (&yl)[2], V& ym) {
+    V B[6][2];
+#pragma unroll
+    for (int i = 0; i < 6; i++) { B[i][0] = sc.ld(SC_MB + 2 * i) + acc.B[i][0]; B[i][1] = sc.ld(SC_MB + 2 * i + 1) + acc.B[i][1]; }
+    V C11 = sc.ld(SC_MC) + acc.C11 + hb1, C12 = sc.ld(SC_MC + 1) + acc.C12, C22 = sc.ld(SC_MC + 2) + acc.C22 + hb2;
+    V rl0 = sc.ld(SC_TL) + acc.rl[0], rl1 = sc.ld(SC_TL + 1) + acc.rl[1];
+    V idet = V(1) / (C11 * C22 - C12 * C12);
+    V i11 = C22 * idet, i12 = -C12 * idet, i22 = C11 * idet;
     V S[21], r[6];
 #pragma unroll
     for (int i = 0; i < 6; i++) {
+        V g0 = B[i][0] * i11 + B[i][1] * i12, g1 = B[i][0] * i12 + B[i][1] * i22;
 #pragma unroll
-        for (int j = 0; j <= i; j++) S[tri(i, j)] = quad_sum(Aloc[tri(i, j)] - (G[i][0] * B[j][0] + G[i][1] * B[j][1])) + A[tri(i, j)];
-        r[i] = quad_sum(rrloc[i] - (G[i][0] * rl[0] + G[i][1] * rl[1])) + rr[i];
+        for (int j = 0; j <= i; j++) S[tri(i, j)] = quad_sum(acc.A[tri(i, j)] - (g0 * B[j][0] + g1 * B[j][1])) + sc.ld(SC_MA + tri(i, j));
+        r[i] = quad_sum(acc.rr[i] - (g0 * rl0 + g1 * rl1)) + sc.ld(SC_TR + i);
     }
     // motor branch
-    V bm[6], cm = Cm, rmt = rm;
+    V bm[6], cm = sc.ld(SC_MCM), rmt = sc.ld(SC_TM);
 #pragma unroll
-    for (int i = 0; i < 6; i++) bm[i] = Bm[i];
+    for (int i = 0; i < 6; i++) bm[i] = sc.ld(SC_MBM + i);
     if (XTRA) {
 #pragma unroll
-        for (int i = 0; i < 6; i++) bm[i] = bm[i] + quad_sum(Bmloc[i]);
-        cm = cm + quad_sum(Cmloc);
-        rmt = rmt + quad_sum(rmloc);
+        for (int i = 0; i < 6; i++) bm[i] = bm[i] + quad_sum(acc.Bm[i]);
+        cm = cm + quad_sum(acc.Cm);
+        rmt = rmt + quad_sum(acc.rm);
     }
     V icm = V(1) / cm;
 #pragma unroll
@@ -240,44 +289,43 @@ JB_HD void star_solve(const V (&A)[21], const V (&Aloc)[21], const V (&B)[6][2],
         for (int j = 0; j <= i; j++) S[tri(i, j)] = S[tri(i, j)] - g * bm[j];
         r[i] = r[i] - g * rmt;
     }
-    // Cholesky S = L L^T (in place), forward/back substitution
+    // Cholesky S = L L^T (in place, reciprocal pivots on the diagonal), forward/back substitution
 #pragma unroll
     for (int j = 0; j < 6; j++) {
-        V s = S[tri(j, j)];
+        V t = S[tri(j, j)];
 #pragma unroll
-        for (int k = 0; k < j; k++) s = s - S[tri(j, k)] * S[tri(j, k)];
-        V d = vsqrt(s);
-        V id = V(1) / d;
-        S[tri(j, j)] = id;                      // store the reciprocal of the pivot
+        for (int k = 0; k < j; k++) t = t - S[tri(j, k)] * S[tri(j, k)];
+        V id = V(1) / vsqrt(t);
+        S[tri(j, j)] = id;
 #pragma unroll
         for (int i = j + 1; i < 6; i++) {
-            V t = S[tri(i, j)];
+            V u = S[tri(i, j)];
 #pragma unroll
-            for (int k = 0; k < j; k++) t = t - S[tri(i, k)] * S[tri(j, k)];
-            S[tri(i, j)] = t * id;
+            for (int k = 0; k < j; k++) u = u - S[tri(i, k)] * S[tri(j, k)];
+            S[tri(i, j)] = u * id;
         }
     }
 #pragma unroll
     for (int i = 0; i < 6; i++) {
-        V s = r[i];
+        V t = r[i];
 #pragma unroll
-        for (int k = 0; k < i; k++) s = s - S[tri(i, k)] * yr[k];
-        yr[i] = s * S[tri(i, i)];
+        for (int k = 0; k < i; k++) t = t - S[tri(i, k)] * yr[k];
+        yr[i] = t * S[tri(i, i)];
     }
 #pragma unroll
     for (int i = 5; i >= 0; i--) {
-        V s = yr[i];
+        V t = yr[i];
 #pragma unroll
-        for (int k = i + 1; k < 6; k++) s = s - S[tri(k, i)] * yr[k];
-        yr[i] = s * S[tri(i, i)];
+        for (int k = i + 1; k < 6; k++) t = t - S[tri(k, i)] * yr[k];
+        yr[i] = t * S[tri(i, i)];
     }
     // back-substitute the branches
-    V t0 = rl[0], t1 = rl[1], tm = rmt;
+    V t0 = rl0, t1 = rl1, tmm = rmt;
 #pragma unroll
-    for (int i = 0; i < 6; i++) { t0 = t0 - B[i][0] * yr[i]; t1 = t1 - B[i][1] * yr[i]; tm = tm - bm[i] * yr[i]; }
+    for (int i = 0; i < 6; i++) { t0 = t0 - B[i][0] * yr[i]; t1 = t1 - B[i][1] * yr[i]; tmm = tmm - bm[i] * yr[i]; }
     yl[0] = i11 * t0 + i12 * t1;
     yl[1] = i12 * t0 + i22 * t1;
-    ym = tm * icm;
+    ym = tmm * icm;
 }
 
 // ----------------------------------------------------------------------------- contacts
@@ -293,33 +341,22 @@ template <typename V> JB_HD V impedance(const LaneModel<V>& m, const V& dist) {
     return m.c[LM_IMP_D0] + y * (m.c[LM_IMP_DW] - m.c[LM_IMP_D0]);
 }
 
-// Per-substep direction data shared by all contacts of the lane: for the three contact-frame
-// directions d in {n, t1, t2} (root coordinates) the joint rows are affine in the contact point x:
-//   J_sh(x,d) = (d x e1).(x - a1),  J_kn(x,d) = (d x e2).(x - a2),  J_m(x,d) = (d x em).(x - am)
-template <typename V> struct DirData {
-    Vec3<V> d[3];
-    Vec3<V> wS[3], wK[3], wM[3];   // wM/oM are filled only on the rare path
-    V oS[3], oK[3], oM[3];
-    V du[3];                 // d . u  (root linear velocity in root coords)
-};
 
-// Accumulator of the Newton system for the lane
-template <typename V> struct NewtonAcc {
-    V A[21];                 // lane-private additive part of the root block
-    V B[6][2];               // leg coupling (starts from M's)
-    V C11, C12, C22;
-    V Bm[6], Cm;             // lane-private additive part of the motor branch
-    V rr[6], rl[2], rm;      // lane-private additive rhs parts (rl starts from tau)
-    typename lane_traits<V>::uint bw[5];   // active-set record: 5 bits (valid + 4 pyramid edges) per contact slot, 6 slots per word
-};
-
+// One contact candidate (a slot of the scratch table: compile-time CSLOT >= 0, or run-time `slot` when CSLOT < 0)
+// against the current iterate y.
 // level: 0 root body, 1 upper leg (shoulder only), 2 lower leg (shoulder+knee), 3 motor body.
-// MODE 0: accumulate H and rhs for the active set at y;  MODE 1: accumulate the constraint force  -B^T W rho  into rr/rl/rm.
-template <typename V, int LEVEL, int MODE, int SLOT>
-JB_HD void contact_accumulate(const LaneModel<V>& m, const DirData<V>& dd, const Vec3<V>& x, const V& dist, const typename lane_traits<V>::mask& valid,
-                              const V& tran, const Vec3<V>& w, const V& thd1, const V& thd2, const V& phid,
-                              const V (&yr)[6], const V (&yl)[2], const V& ym, NewtonAcc<V>& acc) {
+// MODE 0: accumulate the Newton matrix / rhs terms for the active set at y;  MODE 1: accumulate the constraint
+// force  -B^T W rho  into rr/rl/rm.
+// Direction data in the scratch (SC_DD + 12k, k = n, t1, t2): the contact rows are affine in the contact point x:
+//   J_sh(x,d) = (d x e1).(x - a1) = wS.x - oS,   J_kn(x,d) = wK.x - oK,   J_m(x,d) = (d x em).(x - am)
+template <typename V, int LEVEL, int MODE, int CSLOT>
+JB_HD void contact_accumulate(const LaneModel<V>& m, const LaneScratch<V>& sc, int slot, const V& tran, const Vec3<V>& w, const V& thd1, const V& thd2,
+                              const V& phid, const V (&yr)[6], const V (&yl)[2], const V& ym, NewtonAcc<V>& acc) {
     using U = typename lane_traits<V>::uint;
+    if (CSLOT >= 0) slot = CSLOT;
+    const Vec3<V> x = sc.ld3(SC_CAND + 4 * slot);
+    const V dist = sc.ld(SC_CAND + 4 * slot + 3);
+    const auto valid = lt(dist, V(0));
     V imp = impedance(m, dist);
     V R0 = (V(1) - imp) / imp * tran * (V(1) + m.c[LM_FR2]);
     V mu = m.c[LM_MU];
@@ -328,20 +365,22 @@ JB_HD void contact_accumulate(const LaneModel<V>& m, const DirData<V>& dd, const
     V Bj[3][8], rho[3], ahat[3];
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-        Vec3<V> ang = cross(x, dd.d[k]);
+        const Vec3<V> d = sc.ld3(SC_DD + 12 * k);
+        Vec3<V> ang = cross(x, d);
         Bj[k][0] = ang.x; Bj[k][1] = ang.y; Bj[k][2] = ang.z;
-        Bj[k][3] = dd.d[k].x; Bj[k][4] = dd.d[k].y; Bj[k][5] = dd.d[k].z;
-        V vel = dot(ang, w) + dd.du[k];
-        V acc_ = ang.x * yr[0] + ang.y * yr[1] + ang.z * yr[2] + dd.d[k].x * yr[3] + dd.d[k].y * yr[4] + dd.d[k].z * yr[5];
+        Bj[k][3] = d.x; Bj[k][4] = d.y; Bj[k][5] = d.z;
+        V vel = dot(ang, w) + sc.ld(SC_DD + 12 * k + 11);
+        V acc_ = ang.x * yr[0] + ang.y * yr[1] + ang.z * yr[2] + d.x * yr[3] + d.y * yr[4] + d.z * yr[5];
         if (LEVEL == 1 || LEVEL == 2) {
-            Bj[k][6] = dot(dd.wS[k], x) - dd.oS[k];
+            Bj[k][6] = dot(sc.ld3(SC_DD + 12 * k + 3), x) - sc.ld(SC_DD + 12 * k + 9);
             vel = vel + Bj[k][6] * thd1; acc_ = acc_ + Bj[k][6] * yl[0];
         } else Bj[k][6] = V(0);
         if (LEVEL == 2) {
-            Bj[k][7] = dot(dd.wK[k], x) - dd.oK[k];
+            Bj[k][7] = dot(sc.ld3(SC_DD + 12 * k + 6), x) - sc.ld(SC_DD + 12 * k + 10);
             vel = vel + Bj[k][7] * thd2; acc_ = acc_ + Bj[k][7] * yl[1];
         } else if (LEVEL == 3) {
-            Bj[k][7] = dot(dd.wM[k], x) - dd.oM[k];
+            Vec3<V> wM = cross(d, ldv3(m, LM_EM));
+            Bj[k][7] = dot(wM, x) - dot(wM, ldv3(m, LM_AM));
             vel = vel + Bj[k][7] * phid; acc_ = acc_ + Bj[k][7] * ym;
         } else Bj[k][7] = V(0);
         ahat[k] = -m.c[LM_BB] * vel;
@@ -353,13 +392,10 @@ JB_HD void contact_accumulate(const LaneModel<V>& m, const DirData<V>& dd, const
     auto a1 = lt(rho[0] + mr1, V(0)), a2 = lt(rho[0] - mr1, V(0)), a3 = lt(rho[0] + mr2, V(0)), a4 = lt(rho[0] - mr2, V(0));
     V f1 = sel(a1, V(1), V(0)), f2 = sel(a2, V(1), V(0)), f3 = sel(a3, V(1), V(0)), f4 = sel(a4, V(1), V(0));
     V Wnn = D * (f1 + f2 + f3 + f4), Wn1 = D * mu * (f1 - f2), Wn2 = D * mu * (f3 - f4), W11 = D * mu * mu * (f1 + f2), W22 = D * mu * mu * (f3 + f4);
-#ifdef JB_DEBUG_PRINT
-    for (int l = 0; l < 4; l++) if (valid.v[l]) fprintf(stderr, "  [lane %d lvl %d mode %d] dist %.6g rho %.5f %.5f %.5f ahat %.5f %.5f %.5f D %.6g act %d%d%d%d x %.5f %.5f %.5f\n", l, LEVEL, MODE, (double)dist.v[l],
-        (double)rho[0].v[l], (double)rho[1].v[l], (double)rho[2].v[l], (double)ahat[0].v[l], (double)ahat[1].v[l], (double)ahat[2].v[l], (double)D.v[l], a1.v[l], a2.v[l], a3.v[l], a4.v[l], (double)x.x.v[l], (double)x.y.v[l], (double)x.z.v[l]);
-#endif
     if (MODE == 0) {
         U bits = (mbit(a1) + mbit(a2) * 2u + mbit(a3) * 4u + mbit(a4) * 8u + 16u);
-        acc.bw[SLOT / 6] = acc.bw[SLOT / 6] + selu(valid, bits, zero_u<V>()) * (1u << (5 * (SLOT % 6)));
+        if (CSLOT >= 0) acc.bw0 = acc.bw0 + selu(valid, bits, zero_u<V>()) * (1u << (5 * (CSLOT >= 0 ? CSLOT : 0)));
+        else acc.xh = acc.xh * 0x9E3779B1u + selu(valid, bits, zero_u<V>() + 7u);
         V wa0 = Wnn * ahat[0] + Wn1 * ahat[1] + Wn2 * ahat[2];
         V wa1 = Wn1 * ahat[0] + W11 * ahat[1];
         V wa2 = Wn2 * ahat[0] + W22 * ahat[2];
@@ -406,6 +442,7 @@ JB_HD void contact_accumulate(const LaneModel<V>& m, const DirData<V>& dd, const
         if (LEVEL == 2) acc.rl[1] = acc.rl[1] + (Bj[0][7] * g0 + Bj[1][7] * g1 + Bj[2][7] * g2);
         if (LEVEL == 3) acc.rm = acc.rm + (Bj[0][7] * g0 + Bj[1][7] * g1 + Bj[2][7] * g2);
     }
+    JB_SCHED_FENCE();
 }
 
 // Cylinder vs floor, restating MuJoCo's plane-cylinder routine: up to 4 points.  c: centre, ax: unit axis,
@@ -450,6 +487,19 @@ JB_HD void cylinder_floor(const Vec3<V>& c, const Vec3<V>& ax_in, const Vec3<V>&
     out.dist[3] = d3; out.on[3] = on3; out.x[3] = base - v1;
 }
 
+
+// store a candidate: position and effective distance (+1 when it is not a contact)
+template <typename V, typename MKT>
+JB_HD void cand_store(const LaneScratch<V>& sc, int slot, const Vec3<V>& x, const V& dist, const MKT& on) {
+    sc.st3(SC_CAND + 4 * slot, x);
+    sc.st(SC_CAND + 4 * slot + 3, sel(on, dist, V(1)));
+}
+template <typename V, typename MKT>
+JB_HD void cand_store_cyl(const LaneScratch<V>& sc, int slot0, const CylContacts<V>& c, const MKT& gate) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) cand_store(sc, slot0 + k, c.x[k], c.dist[k], mand(c.on[k], gate));
+}
+
 // ----------------------------------------------------------------------------- options
 struct SimOpts {
     int contacts;        // 0: contacts disabled (MuJoCo disableflags=contact)
@@ -466,308 +516,287 @@ template <typename V> JB_HD void sincos_small(const V& x, V& s, V& c) {
 
 // ----------------------------------------------------------------------------- the substep
 template <typename V, bool XTRA>
-JB_HD void substep_impl(const LaneModel<V>& m, LaneState<V>& s, const V& ctrl, const SimOpts& o) {
+JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneState<V>& s, const V& ctrl, const SimOpts& o) {
     using MK = typename lane_traits<V>::mask;
     using U = typename lane_traits<V>::uint;
     const V h = m.c[LM_H];
+    const Vec3<V> w = v3<V>(s.wx, s.wy, s.wz);
+    bool any_contact = false;
 
-    // ---- root frame
-    V qn = V(1) / vsqrt(s.qw * s.qw + s.qx * s.qx + s.qy * s.qy + s.qz * s.qz);
-    s.qw = s.qw * qn; s.qx = s.qx * qn; s.qy = s.qy * qn; s.qz = s.qz * qn;
-    Mat3<V> R = quat2mat(s.qw, s.qx, s.qy, s.qz);
-    Vec3<V> nb = v3<V>(R.m[6], R.m[7], R.m[8]);                 // R^T ez
-    Vec3<V> w = v3<V>(s.wx, s.wy, s.wz);
-    Vec3<V> u = mulT(R, v3<V>(s.vx, s.vy, s.vz));
-    Vec3<V> AO = -mulT(R, ldv3(m, LM_GRAV));                    // fictitious root acceleration = -g (root coords)
-
-    // ---- own leg kinematics
-    Vec3<V> a1 = ldv3(m, LM_A1), e1 = ldv3(m, LM_E1);
-    V s1, c1, s2, c2;
-    sincos_small(s.th1, s1, c1);
-    sincos_small(s.th2, s2, c2);
-    if (any_lane(mor(gt(vabs(s.th1), V(0.9)), gt(vabs(s.th2), V(0.9))))) { s1 = vsin(s.th1); c1 = vcos(s.th1); s2 = vsin(s.th2); c2 = vcos(s.th2); }
-    Mat3<V> R1 = rodrigues(e1, s1, c1);
-    Mat3<V> R12 = mul(R1, rodrigues(ldv3(m, LM_E2), s2, c2));
-    Vec3<V> a2 = a1 + mul(R1, ldv3(m, LM_DA2));
-    Vec3<V> e2 = mul(R1, ldv3(m, LM_E2));
-    Vec3<V> cc1 = a1 + mul(R1, ldv3(m, LM_DC1));
-    Vec3<V> cc2 = a2 + mul(R12, ldv3(m, LM_DC2));
-    Sym3<V> I1 = rotate(R1, ldsym(m, LM_I1));
-    Sym3<V> I2 = rotate(R12, ldsym(m, LM_I2));
-    const V m1 = m.c[LM_M1], m2 = m.c[LM_M2];
-
-    // ---- motor body kinematics (replicated)
-    Vec3<V> am = ldv3(m, LM_AM), em = ldv3(m, LM_EM);
-    V sp = vsin(s.phi), cp = vcos(s.phi);
-    Mat3<V> Rm = rodrigues(em, sp, cp);
-    Vec3<V> cm = am + mul(Rm, ldv3(m, LM_DCM));
-    Sym3<V> Im = rotate(Rm, ldsym(m, LM_IM));
-    const V mm = m.c[LM_MM], m0 = m.c[LM_M0];
-    Vec3<V> c0 = ldv3(m, LM_C0);
-    Sym3<V> I0 = ldsym(m, LM_I0);
-
-    // ---- composite rigid bodies -> star system of M
-    StarSys<V> M;
-    Vec3<V> h2 = cc2 * m2, h1 = cc1 * m1;
-    Sym3<V> J2 = about_origin(I2, m2, cc2);
-    Sym3<V> J12 = about_origin(I1, m1, cc1) + J2;
-    Vec3<V> h12 = h1 + h2;
-    V m12 = m1 + m2;
-    Vec3<V> sK = cross(a2, e2), sS = cross(a1, e1), sM = cross(am, em);          // linear part of the joint motion vectors
-    Vec3<V> fK = sK * m2 + cross(e2, h2), nK = mul(J2, e2) + cross(h2, sK);
-    Vec3<V> fS = sS * m12 + cross(e1, h12), nS = mul(J12, e1) + cross(h12, sS);
-    M.B[0][0] = nS.x; M.B[1][0] = nS.y; M.B[2][0] = nS.z; M.B[3][0] = fS.x; M.B[4][0] = fS.y; M.B[5][0] = fS.z;
-    M.B[0][1] = nK.x; M.B[1][1] = nK.y; M.B[2][1] = nK.z; M.B[3][1] = fK.x; M.B[4][1] = fK.y; M.B[5][1] = fK.z;
-    M.C11 = dot(e1, nS) + dot(sS, fS);
-    M.C12 = dot(e1, nK) + dot(sS, fK);
-    M.C22 = dot(e2, nK) + dot(sK, fK);
-    Vec3<V> hm = cm * mm;
-    Sym3<V> Jm = about_origin(Im, mm, cm);
-    Vec3<V> fM = sM * mm + cross(em, hm), nM = mul(Jm, em) + cross(hm, sM);
-    M.Bm[0] = nM.x; M.Bm[1] = nM.y; M.Bm[2] = nM.z; M.Bm[3] = fM.x; M.Bm[4] = fM.y; M.Bm[5] = fM.z;
-    M.Cm = dot(em, nM) + dot(sM, fM);
-    {
-        Vec3<V> ht = c0 * m0 + hm + qsum(h12);
-        Sym3<V> Jt = about_origin(I0, m0, c0) + Jm + qsum(J12);
-        V mt = m.c[LM_MTOT];
-        V Z = V(0);
-        // [[J, [h]x], [[h]x^T, m 1]] with [h]x = [[0,-hz,hy],[hz,0,-hx],[-hy,hx,0]]
-        M.A[tri(0, 0)] = Jt.xx; M.A[tri(1, 0)] = Jt.xy; M.A[tri(1, 1)] = Jt.yy; M.A[tri(2, 0)] = Jt.xz; M.A[tri(2, 1)] = Jt.yz; M.A[tri(2, 2)] = Jt.zz;
-        M.A[tri(3, 0)] = Z;     M.A[tri(3, 1)] = ht.z;  M.A[tri(3, 2)] = -ht.y;
-        M.A[tri(4, 0)] = -ht.z; M.A[tri(4, 1)] = Z;     M.A[tri(4, 2)] = ht.x;
-        M.A[tri(5, 0)] = ht.y;  M.A[tri(5, 1)] = -ht.x; M.A[tri(5, 2)] = Z;
-        M.A[tri(3, 3)] = mt; M.A[tri(4, 3)] = Z; M.A[tri(4, 4)] = mt; M.A[tri(5, 3)] = Z; M.A[tri(5, 4)] = Z; M.A[tri(5, 5)] = mt;
-    }
-
-    // ---- bias forces (Newton-Euler with qacc = 0 in MuJoCo coordinates) and applied forces
-    V tr[6], tl[2], tm;      // tau: root (replicated), own leg, motor
-    {
-        auto accel_at = [&](const Vec3<V>& x) { return AO + cross(w, cross(w, x)); };
-        Vec3<V> F0 = accel_at(c0) * m0;
-        Vec3<V> N0 = cross(w, mul(I0, w));
-        // own leg
-        Vec3<V> Aa1 = accel_at(a1);
-        Vec3<V> w1 = w + e1 * s.thd1;
-        Vec3<V> al1 = cross(w, e1) * s.thd1;
-        Vec3<V> r1 = cc1 - a1;
-        Vec3<V> F1 = (Aa1 + cross(al1, r1) + cross(w1, cross(w1, r1))) * m1;
-        Vec3<V> N1 = mul(I1, al1) + cross(w1, mul(I1, w1));
-        Vec3<V> r12 = a2 - a1;
-        Vec3<V> Aa2 = Aa1 + cross(al1, r12) + cross(w1, cross(w1, r12));
-        Vec3<V> w2 = w1 + e2 * s.thd2;
-        Vec3<V> al2 = al1 + cross(w1, e2) * s.thd2;
-        Vec3<V> r2 = cc2 - a2;
-        Vec3<V> F2 = (Aa2 + cross(al2, r2) + cross(w2, cross(w2, r2))) * m2;
-        Vec3<V> N2 = mul(I2, al2) + cross(w2, mul(I2, w2));
-        V cK = dot(e2, N2 + cross(r2, F2));
-        V cS = dot(e1, N1 + cross(r1, F1) + N2 + cross(cc2 - a1, F2));
-        Vec3<V> legF = F1 + F2;
-        Vec3<V> legN = N1 + cross(cc1, F1) + N2 + cross(cc2, F2);
-        // motor body
-        Vec3<V> wm = w + em * s.phid;
-        Vec3<V> alm = cross(w, em) * s.phid;
-        Vec3<V> rm = cm - am;
-        Vec3<V> Fm = (accel_at(am) + cross(alm, rm) + cross(wm, cross(wm, rm))) * mm;
-        Vec3<V> Nm = mul(Im, alm) + cross(wm, mul(Im, wm));
-        V cM = dot(em, Nm + cross(rm, Fm));
-        Vec3<V> bl = F0 + Fm + qsum(legF);
-        Vec3<V> ba = N0 + cross(c0, F0) + Nm + cross(cm, Fm) + qsum(legN);
-        tr[0] = -ba.x; tr[1] = -ba.y; tr[2] = -ba.z; tr[3] = -bl.x; tr[4] = -bl.y; tr[5] = -bl.z;
-        tl[0] = -cS - m.c[LM_K1] * s.th1 - m.c[LM_B1] * s.thd1;
-        tl[1] = -cK - m.c[LM_K2] * s.th2 - m.c[LM_B2] * s.thd2;
-        V uc = vmin(vmax(ctrl, m.c[LM_CTRL_LO]), m.c[LM_CTRL_HI]);
-        V gear = m.c[LM_GEAR];
-        V len = gear * (s.phi + s.turns * V(6.283185307179586));
-        V force = m.c[LM_GAIN] * uc + m.c[LM_BIAS] + m.c[LM_BIAS + 1] * len + m.c[LM_BIAS + 2] * gear * s.phid;
-        tm = -cM + gear * force;
-    }
-
-    // ---- contacts: candidate geometry (root coords, relative to the root origin)
-    V qfr[6], qfl[2], qfm;            // constraint force (root part lane-private until summed in the final solve)
+    {   // ================= phase A: kinematics, composite inertia, bias forces, contact candidates -> scratch
+        V qn = V(1) / vsqrt(s.qw * s.qw + s.qx * s.qx + s.qy * s.qy + s.qz * s.qz);
+        s.qw = s.qw * qn; s.qx = s.qx * qn; s.qy = s.qy * qn; s.qz = s.qz * qn;
+        Mat3<V> R = quat2mat(s.qw, s.qx, s.qy, s.qz);
 #pragma unroll
-    for (int i = 0; i < 6; i++) qfr[i] = V(0);
-    qfl[0] = qfl[1] = V(0); qfm = V(0);
-    constexpr bool xtra = XTRA;
-    if (o.contacts) {
-        // foot sphere and lower-leg cylinder: always evaluated
-        Vec3<V> foot = a2 + mul(R12, ldv3(m, LM_DFOOT));
-        V fdist = s.pz + dot(foot, nb) - m.c[LM_FOOT_R];
-        MK fon = lt(fdist, V(0));
-        Vec3<V> fx = foot - nb * (m.c[LM_FOOT_R] + fdist * V(0.5));
-        CylContacts<V> lc;
-        MK all_on = lt(V(0), V(1));
-        cylinder_floor(a2 + mul(R12, ldv3(m, LM_LC_D)), mul(R12, ldv3(m, LM_LC_AX)), mul(R12, ldv3(m, LM_LC_XA)), m.c[LM_LC_R], m.c[LM_LC_H], nb, s.pz, all_on, lc);
-        MK any_con = mor(fon, lc.on[0]);
-        // rarely-touching candidates, evaluated only when some lane of the wave is near the floor
-        CylContacts<V> ucx, xcx;
-        Vec3<V> tipx, ellx, boxx[8];
-        V tipd = V(1), elld = V(1), boxd[8];
-        MK tipon = lt(V(1), V(0)), ellon = tipon, boxon[8];
-        MK x_onm = lt(V(1), V(0));
-        if (xtra) {
-            x_onm = gt(ldc(m, LM_X_ONM), V(0.5));
-            cylinder_floor(a1 + mul(R1, ldc3(m, LM_UC_D)), mul(R1, ldc3(m, LM_UC_AX)), mul(R1, ldc3(m, LM_UC_XA)), ldc(m, LM_UC_R), ldc(m, LM_UC_H), nb, s.pz, all_on, ucx);
-            Vec3<V> tip = a1 + mul(R1, ldc3(m, LM_DTIP));
-            tipd = s.pz + dot(tip, nb) - ldc(m, LM_TIP_R);
-            tipon = lt(tipd, V(0));
-            tipx = tip - nb * (ldc(m, LM_TIP_R) + tipd * V(0.5));
-            // lane cylinder (root body: lane 2 screw1; motor body: lane 3 threadMass)
-            Vec3<V> xc_c = ldc3(m, LM_XC_C), xc_ax = ldc3(m, LM_XC_AX), xc_xa = ldc3(m, LM_XC_XA);
-            Vec3<V> xc_cm = am + mul(Rm, xc_c - am);
-            cylinder_floor(sel_v3(x_onm, xc_cm, xc_c), sel_v3(x_onm, mul(Rm, xc_ax), xc_ax), sel_v3(x_onm, mul(Rm, xc_xa), xc_xa),
-                           ldc(m, LM_XC_R), ldc(m, LM_XC_H), nb, s.pz, gt(ldc(m, LM_XC_EN), V(0.5)), xcx);
-            // lane ellipsoid: support point in direction -n
-            {
-                Mat3<V> Re; Mat3<V> Re0;
+        for (int i = 0; i < 9; i++) sc.st(SC_R + i, R.m[i]);
+        Vec3<V> nb = v3<V>(R.m[6], R.m[7], R.m[8]);                 // R^T ez
+        Vec3<V> u = mulT(R, v3<V>(s.vx, s.vy, s.vz));
+        Vec3<V> AO = -mulT(R, ldv3(m, LM_GRAV));                    // fictitious root acceleration = -g (root coords)
+
+        // ---- own leg kinematics
+        Vec3<V> a1 = ldv3(m, LM_A1), e1 = ldv3(m, LM_E1);
+        V s1, c1, s2, c2;
+        sincos_small(s.th1, s1, c1);
+        sincos_small(s.th2, s2, c2);
+        if (any_lane(mor(gt(vabs(s.th1), V(0.9)), gt(vabs(s.th2), V(0.9))))) { s1 = vsin(s.th1); c1 = vcos(s.th1); s2 = vsin(s.th2); c2 = vcos(s.th2); }
+        Mat3<V> R1 = rodrigues(e1, s1, c1);
+        Mat3<V> R12 = mul(R1, rodrigues(ldv3(m, LM_E2), s2, c2));
+        Vec3<V> a2 = a1 + mul(R1, ldv3(m, LM_DA2));
+        Vec3<V> e2 = mul(R1, ldv3(m, LM_E2));
+        Vec3<V> cc1 = a1 + mul(R1, ldv3(m, LM_DC1));
+        Vec3<V> cc2 = a2 + mul(R12, ldv3(m, LM_DC2));
+        Sym3<V> I1 = rotate(R1, ldsym(m, LM_I1));
+        Sym3<V> I2 = rotate(R12, ldsym(m, LM_I2));
+        const V m1 = m.c[LM_M1], m2 = m.c[LM_M2];
+
+        // ---- motor body kinematics (replicated)
+        Vec3<V> am = ldv3(m, LM_AM), em = ldv3(m, LM_EM);
+        V sp = vsin(s.phi), cp = vcos(s.phi);
+        Mat3<V> Rm = rodrigues(em, sp, cp);
+        Vec3<V> cm = am + mul(Rm, ldv3(m, LM_DCM));
+        Sym3<V> Im = rotate(Rm, ldsym(m, LM_IM));
+        const V mm = m.c[LM_MM], m0 = m.c[LM_M0];
+        Vec3<V> c0 = ldv3(m, LM_C0);
+        Sym3<V> I0 = ldsym(m, LM_I0);
+
+        // ---- contact candidates and contact-frame direction data (before the heavy dynamics, while the
+        //      kinematic quantities are still live)
+        if (o.contacts) {
+            Vec3<V> foot = a2 + mul(R12, ldv3(m, LM_DFOOT));
+            V fdist = s.pz + dot(foot, nb) - m.c[LM_FOOT_R];
+            MK fon = lt(fdist, V(0));
+            cand_store(sc, 0, foot - nb * (m.c[LM_FOOT_R] + fdist * V(0.5)), fdist, fon);
+            CylContacts<V> lc;
+            MK all_on = lt(V(0), V(1));
+            cylinder_floor(a2 + mul(R12, ldv3(m, LM_LC_D)), mul(R12, ldv3(m, LM_LC_AX)), mul(R12, ldv3(m, LM_LC_XA)), m.c[LM_LC_R], m.c[LM_LC_H], nb, s.pz, all_on, lc);
+            cand_store_cyl(sc, 1, lc, all_on);
+            MK any_con = mor(fon, lc.on[0]);
+            if (XTRA) {
+                // every remaining geom of the model against the floor
+                CylContacts<V> cy;
+                cylinder_floor(a1 + mul(R1, ldc3(m, LM_UC_D)), mul(R1, ldc3(m, LM_UC_AX)), mul(R1, ldc3(m, LM_UC_XA)), ldc(m, LM_UC_R), ldc(m, LM_UC_H), nb, s.pz, all_on, cy);
+                cand_store_cyl(sc, 5, cy, all_on);
+                any_con = mor(any_con, cy.on[0]);
+                Vec3<V> tip = a1 + mul(R1, ldc3(m, LM_DTIP));
+                V tipd = s.pz + dot(tip, nb) - ldc(m, LM_TIP_R);
+                cand_store(sc, 9, tip - nb * (ldc(m, LM_TIP_R) + tipd * V(0.5)), tipd, lt(tipd, V(0)));
+                any_con = mor(any_con, lt(tipd, V(0)));
+                // lane cylinder (root body: lane 2 screw1; motor body: lane 3 threadMass)
+                MK x_onm = gt(ldc(m, LM_X_ONM), V(0.5));
+                Vec3<V> xc_c = ldc3(m, LM_XC_C), xc_ax = ldc3(m, LM_XC_AX), xc_xa = ldc3(m, LM_XC_XA);
+                cylinder_floor(sel_v3(x_onm, am + mul(Rm, xc_c - am), xc_c), sel_v3(x_onm, mul(Rm, xc_ax), xc_ax), sel_v3(x_onm, mul(Rm, xc_xa), xc_xa),
+                               ldc(m, LM_XC_R), ldc(m, LM_XC_H), nb, s.pz, gt(ldc(m, LM_XC_EN), V(0.5)), cy);
+                cand_store_cyl(sc, 10, cy, mnot(x_onm));
+                cand_store_cyl(sc, 23, cy, x_onm);
+                any_con = mor(any_con, cy.on[0]);
+                {   // lane ellipsoid: support point in direction -n
+                    Mat3<V> Re0, Re;
 #pragma unroll
-                for (int i = 0; i < 9; i++) Re0.m[i] = ldc(m, LM_XE_R + i);
-                Mat3<V> Rem = mul(Rm, Re0);
+                    for (int i = 0; i < 9; i++) Re0.m[i] = ldc(m, LM_XE_R + i);
+                    Mat3<V> Rem = mul(Rm, Re0);
 #pragma unroll
-                for (int i = 0; i < 9; i++) Re.m[i] = sel(x_onm, Rem.m[i], Re0.m[i]);
-                Vec3<V> ec0 = ldc3(m, LM_XE_C);
-                Vec3<V> ec = sel_v3(x_onm, am + mul(Rm, ec0 - am), ec0);
-                Vec3<V> dl = mulT(Re, -nb);
-                Vec3<V> sz = ldc3(m, LM_XE_S);
-                V den = vsqrt(sz.x * sz.x * dl.x * dl.x + sz.y * sz.y * dl.y * dl.y + sz.z * sz.z * dl.z * dl.z);
-                Vec3<V> sup = ec + mul(Re, v3<V>(sz.x * sz.x * dl.x / den, sz.y * sz.y * dl.y / den, sz.z * sz.z * dl.z / den));
-                elld = s.pz + dot(sup, nb);
-                ellon = mand(gt(ldc(m, LM_XE_EN), V(0.5)), lt(elld, V(0)));
-                ellx = sup - nb * (elld * V(0.5));
-            }
-            // lane box (root body): first 4 penetrating vertices in vertex order
-            {
-                Mat3<V> Rb;
+                    for (int i = 0; i < 9; i++) Re.m[i] = sel(x_onm, Rem.m[i], Re0.m[i]);
+                    Vec3<V> ec0 = ldc3(m, LM_XE_C);
+                    Vec3<V> ec = sel_v3(x_onm, am + mul(Rm, ec0 - am), ec0);
+                    Vec3<V> dl = mulT(Re, -nb);
+                    Vec3<V> sz = ldc3(m, LM_XE_S);
+                    V den = vsqrt(sz.x * sz.x * dl.x * dl.x + sz.y * sz.y * dl.y * dl.y + sz.z * sz.z * dl.z * dl.z);
+                    Vec3<V> sup = ec + mul(Re, v3<V>(sz.x * sz.x * dl.x / den, sz.y * sz.y * dl.y / den, sz.z * sz.z * dl.z / den));
+                    V elld = s.pz + dot(sup, nb);
+                    MK ellon = mand(gt(ldc(m, LM_XE_EN), V(0.5)), lt(elld, V(0)));
+                    Vec3<V> ellx = sup - nb * (elld * V(0.5));
+                    cand_store(sc, 14, ellx, elld, mand(ellon, mnot(x_onm)));
+                    cand_store(sc, 27, ellx, elld, mand(ellon, x_onm));
+                    any_con = mor(any_con, ellon);
+                }
+                {   // lane box (root body): first 4 penetrating vertices in vertex order
+                    Mat3<V> Rb;
 #pragma unroll
-                for (int i = 0; i < 9; i++) Rb.m[i] = ldc(m, LM_XB_R + i);
-                Vec3<V> bc = ldc3(m, LM_XB_C), bs = ldc3(m, LM_XB_S);
-                MK ben = gt(ldc(m, LM_XB_EN), V(0.5));
-                V cnt = V(0);
+                    for (int i = 0; i < 9; i++) Rb.m[i] = ldc(m, LM_XB_R + i);
+                    Vec3<V> bc = ldc3(m, LM_XB_C), bs = ldc3(m, LM_XB_S);
+                    MK ben = gt(ldc(m, LM_XB_EN), V(0.5));
+                    V cnt = V(0);
 #pragma unroll
-                for (int vtx = 0; vtx < 8; vtx++) {
-                    Vec3<V> l = v3<V>((vtx & 1) ? bs.x : -bs.x, (vtx & 2) ? bs.y : -bs.y, (vtx & 4) ? bs.z : -bs.z);
-                    Vec3<V> p = bc + mul(Rb, l);
-                    V d = s.pz + dot(p, nb);
-                    MK on = mand(mand(ben, lt(d, V(0))), lt(cnt, V(3.5)));
-                    cnt = cnt + sel(on, V(1), V(0));
-                    boxd[vtx] = d; boxon[vtx] = on; boxx[vtx] = p - nb * (d * V(0.5));
-                    any_con = mor(any_con, on);
+                    for (int vtx = 0; vtx < 8; vtx++) {
+                        Vec3<V> l = v3<V>((vtx & 1) ? bs.x : -bs.x, (vtx & 2) ? bs.y : -bs.y, (vtx & 4) ? bs.z : -bs.z);
+                        Vec3<V> pnt = bc + mul(Rb, l);
+                        V d = s.pz + dot(pnt, nb);
+                        MK on = mand(mand(ben, lt(d, V(0))), lt(cnt, V(3.5)));
+                        cnt = cnt + sel(on, V(1), V(0));
+                        cand_store(sc, 15 + vtx, pnt - nb * (d * V(0.5)), d, on);
+                        any_con = mor(any_con, on);
+                    }
                 }
             }
-            any_con = mor(any_con, mor(mor(ucx.on[0], tipon), mor(xcx.on[0], ellon)));
+            any_contact = any_lane(any_con);
+            if (any_contact) {
+                // direction data for the contact frame (n, t1, t2) = R^T (ez, ey, -ex)
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    Vec3<V> d = (k == 0) ? nb : (k == 1) ? v3<V>(R.m[3], R.m[4], R.m[5]) : v3<V>(-R.m[0], -R.m[1], -R.m[2]);
+                    Vec3<V> wS = cross(d, e1), wK = cross(d, e2);
+                    sc.st3(SC_DD + 12 * k, d); sc.st3(SC_DD + 12 * k + 3, wS); sc.st3(SC_DD + 12 * k + 6, wK);
+                    sc.st(SC_DD + 12 * k + 9, dot(wS, a1)); sc.st(SC_DD + 12 * k + 10, dot(wK, a2)); sc.st(SC_DD + 12 * k + 11, dot(d, u));
+                }
+            }
         }
+        JB_SCHED_FENCE();
 
-        if (any_lane(any_con)) {
-            // direction data for the contact frame (n, t1, t2) = R^T (ez, ey, -ex)
-            DirData<V> dd;
-            dd.d[0] = nb;
-            dd.d[1] = v3<V>(R.m[3], R.m[4], R.m[5]);
-            dd.d[2] = v3<V>(-R.m[0], -R.m[1], -R.m[2]);
+        // ---- composite rigid bodies -> star system of M (into the scratch)
+        Vec3<V> h2 = cc2 * m2, h1 = cc1 * m1;
+        Sym3<V> J2 = about_origin(I2, m2, cc2);
+        Sym3<V> J12 = about_origin(I1, m1, cc1) + J2;
+        Vec3<V> h12 = h1 + h2;
+        V m12 = m1 + m2;
+        Vec3<V> sK = cross(a2, e2), sS = cross(a1, e1), sM = cross(am, em);          // linear part of the joint motion vectors
+        Vec3<V> fK = sK * m2 + cross(e2, h2), nK = mul(J2, e2) + cross(h2, sK);
+        Vec3<V> fS = sS * m12 + cross(e1, h12), nS = mul(J12, e1) + cross(h12, sS);
+        sc.st(SC_MB + 0, nS.x); sc.st(SC_MB + 2, nS.y); sc.st(SC_MB + 4, nS.z); sc.st(SC_MB + 6, fS.x); sc.st(SC_MB + 8, fS.y); sc.st(SC_MB + 10, fS.z);
+        sc.st(SC_MB + 1, nK.x); sc.st(SC_MB + 3, nK.y); sc.st(SC_MB + 5, nK.z); sc.st(SC_MB + 7, fK.x); sc.st(SC_MB + 9, fK.y); sc.st(SC_MB + 11, fK.z);
+        sc.st(SC_MC + 0, dot(e1, nS) + dot(sS, fS));
+        sc.st(SC_MC + 1, dot(e1, nK) + dot(sS, fK));
+        sc.st(SC_MC + 2, dot(e2, nK) + dot(sK, fK));
+        Vec3<V> hm = cm * mm;
+        Sym3<V> Jm = about_origin(Im, mm, cm);
+        Vec3<V> fM = sM * mm + cross(em, hm), nM = mul(Jm, em) + cross(hm, sM);
+        sc.st3(SC_MBM, nM); sc.st3(SC_MBM + 3, fM);
+        sc.st(SC_MCM, dot(em, nM) + dot(sM, fM));
+        {
+            Vec3<V> ht = c0 * m0 + hm + qsum(h12);
+            Sym3<V> Jt = about_origin(I0, m0, c0) + Jm + qsum(J12);
+            V mt = m.c[LM_MTOT];
+            V Z = V(0);
+            // [[J, [h]x], [[h]x^T, m 1]] with [h]x = [[0,-hz,hy],[hz,0,-hx],[-hy,hx,0]]
+            sc.st(SC_MA + tri(0, 0), Jt.xx); sc.st(SC_MA + tri(1, 0), Jt.xy); sc.st(SC_MA + tri(1, 1), Jt.yy);
+            sc.st(SC_MA + tri(2, 0), Jt.xz); sc.st(SC_MA + tri(2, 1), Jt.yz); sc.st(SC_MA + tri(2, 2), Jt.zz);
+            sc.st(SC_MA + tri(3, 0), Z);     sc.st(SC_MA + tri(3, 1), ht.z);  sc.st(SC_MA + tri(3, 2), -ht.y);
+            sc.st(SC_MA + tri(4, 0), -ht.z); sc.st(SC_MA + tri(4, 1), Z);     sc.st(SC_MA + tri(4, 2), ht.x);
+            sc.st(SC_MA + tri(5, 0), ht.y);  sc.st(SC_MA + tri(5, 1), -ht.x); sc.st(SC_MA + tri(5, 2), Z);
+            sc.st(SC_MA + tri(3, 3), mt); sc.st(SC_MA + tri(4, 3), Z); sc.st(SC_MA + tri(4, 4), mt);
+            sc.st(SC_MA + tri(5, 3), Z); sc.st(SC_MA + tri(5, 4), Z); sc.st(SC_MA + tri(5, 5), mt);
+        }
+        JB_SCHED_FENCE();
+
+        // ---- bias forces (Newton-Euler with qacc = 0 in MuJoCo coordinates) and applied forces
+        {
+            auto accel_at = [&](const Vec3<V>& x) { return AO + cross(w, cross(w, x)); };
+            Vec3<V> F0 = accel_at(c0) * m0;
+            Vec3<V> N0 = cross(w, mul(I0, w));
+            // own leg
+            Vec3<V> Aa1 = accel_at(a1);
+            Vec3<V> w1 = w + e1 * s.thd1;
+            Vec3<V> al1 = cross(w, e1) * s.thd1;
+            Vec3<V> r1 = cc1 - a1;
+            Vec3<V> F1 = (Aa1 + cross(al1, r1) + cross(w1, cross(w1, r1))) * m1;
+            Vec3<V> N1 = mul(I1, al1) + cross(w1, mul(I1, w1));
+            Vec3<V> r12 = a2 - a1;
+            Vec3<V> Aa2 = Aa1 + cross(al1, r12) + cross(w1, cross(w1, r12));
+            Vec3<V> w2 = w1 + e2 * s.thd2;
+            Vec3<V> al2 = al1 + cross(w1, e2) * s.thd2;
+            Vec3<V> r2 = cc2 - a2;
+            Vec3<V> F2 = (Aa2 + cross(al2, r2) + cross(w2, cross(w2, r2))) * m2;
+            Vec3<V> N2 = mul(I2, al2) + cross(w2, mul(I2, w2));
+            V cK = dot(e2, N2 + cross(r2, F2));
+            V cS = dot(e1, N1 + cross(r1, F1) + N2 + cross(cc2 - a1, F2));
+            Vec3<V> legF = F1 + F2;
+            Vec3<V> legN = N1 + cross(cc1, F1) + N2 + cross(cc2, F2);
+            // motor body
+            Vec3<V> wm = w + em * s.phid;
+            Vec3<V> alm = cross(w, em) * s.phid;
+            Vec3<V> rm = cm - am;
+            Vec3<V> Fm = (accel_at(am) + cross(alm, rm) + cross(wm, cross(wm, rm))) * mm;
+            Vec3<V> Nm = mul(Im, alm) + cross(wm, mul(Im, wm));
+            V cM = dot(em, Nm + cross(rm, Fm));
+            Vec3<V> bl = F0 + Fm + qsum(legF);
+            Vec3<V> ba = N0 + cross(c0, F0) + Nm + cross(cm, Fm) + qsum(legN);
+            sc.st3(SC_TR, -ba); sc.st3(SC_TR + 3, -bl);
+            sc.st(SC_TL + 0, -cS - m.c[LM_K1] * s.th1 - m.c[LM_B1] * s.thd1);
+            sc.st(SC_TL + 1, -cK - m.c[LM_K2] * s.th2 - m.c[LM_B2] * s.thd2);
+            V uc = vmin(vmax(ctrl, m.c[LM_CTRL_LO]), m.c[LM_CTRL_HI]);
+            V gear = m.c[LM_GEAR];
+            V len = gear * (s.phi + s.turns * V(6.283185307179586));
+            V force = m.c[LM_GAIN] * uc + m.c[LM_BIAS] + m.c[LM_BIAS + 1] * len + m.c[LM_BIAS + 2] * gear * s.phid;
+            sc.st(SC_TM, -cM + gear * force);
+        }
+    }
+    JB_SCHED_FENCE();
+
+    // ================= phase B: contact solve (primal Newton on the active set), result = constraint force in `fa`
+    NewtonAcc<V> fa;
+    acc_clear(fa);
+    if (any_contact) {
+        const V tran0 = m.c[LM_TRAN0], tran1 = m.c[LM_TRAN1], tran2 = m.c[LM_TRAN2], tranm = m.c[LM_TRANM];
+        // wave-uniform skips for the lower-leg cylinder slots
+        const bool lc0 = any_lane(lt(sc.ld(SC_CAND + 4 * 1 + 3), V(0))), lc1 = any_lane(lt(sc.ld(SC_CAND + 4 * 2 + 3), V(0))),
+                   lc2 = any_lane(lt(sc.ld(SC_CAND + 4 * 3 + 3), V(0)));
+        // warm start (world linear part rotated into the root frame)
+        V yr[6], yl[2], ym;
+        {
+            Mat3<V> R;
 #pragma unroll
-            for (int k = 0; k < 3; k++) {
-                dd.wS[k] = cross(dd.d[k], e1); dd.oS[k] = dot(dd.wS[k], a1);
-                dd.wK[k] = cross(dd.d[k], e2); dd.oK[k] = dot(dd.wK[k], a2);
-                if (xtra) { dd.wM[k] = cross(dd.d[k], em); dd.oM[k] = dot(dd.wM[k], am); }
-                dd.du[k] = dot(dd.d[k], u);
+            for (int i = 0; i < 9; i++) R.m[i] = sc.ld(SC_R + i);
+            Vec3<V> lw = mulT(R, v3<V>(s.wl[0], s.wl[1], s.wl[2]));
+            yr[0] = s.wa[0]; yr[1] = s.wa[1]; yr[2] = s.wa[2]; yr[3] = lw.x; yr[4] = lw.y; yr[5] = lw.z;
+            yl[0] = s.wj[0]; yl[1] = s.wj[1]; ym = s.wm;
+        }
+        auto sweep = [&](auto mode_tag, NewtonAcc<V>& acc) {
+            constexpr int MODE = decltype(mode_tag)::value;
+#define JB_CA(LV, SL, TRAN) contact_accumulate<V, LV, MODE, SL>(m, sc, SL, TRAN, w, s.thd1, s.thd2, s.phid, yr, yl, ym, acc)
+#define JB_CA_RT(LV, SL, TRAN) contact_accumulate<V, LV, MODE, -1>(m, sc, SL, TRAN, w, s.thd1, s.thd2, s.phid, yr, yl, ym, acc)
+            JB_CA(2, 0, tran2);
+            if (lc0) {
+                JB_CA(2, 1, tran2);
+                if (lc1) JB_CA(2, 2, tran2);
+                if (lc2) { JB_CA(2, 3, tran2); JB_CA(2, 4, tran2); }
             }
-            const V tran0 = m.c[LM_TRAN0], tran1 = m.c[LM_TRAN1], tran2 = m.c[LM_TRAN2], tranm = m.c[LM_TRANM];
-            // warm start (world linear part rotated into the root frame)
-            V yr[6], yl[2], ym;
-            {
-                Vec3<V> lw = mulT(R, v3<V>(s.wl[0], s.wl[1], s.wl[2]));
-                yr[0] = s.wa[0]; yr[1] = s.wa[1]; yr[2] = s.wa[2]; yr[3] = lw.x; yr[4] = lw.y; yr[5] = lw.z;
-                yl[0] = s.wj[0]; yl[1] = s.wj[1]; ym = s.wm;
+            if (XTRA) {       // rolled loops: this path is rare, keep its code and register footprint small
+#pragma unroll 1
+                for (int sl = 5; sl < 10; sl++) JB_CA_RT(1, sl, tran1);
+#pragma unroll 1
+                for (int sl = 10; sl < 23; sl++) JB_CA_RT(0, sl, tran0);
+#pragma unroll 1
+                for (int sl = 23; sl < 28; sl++) JB_CA_RT(3, sl, tranm);
             }
-            auto sweep = [&](auto mode_tag, NewtonAcc<V>& acc) {
-                constexpr int MODE = decltype(mode_tag)::value;
-                contact_accumulate<V, 2, MODE, 0>(m, dd, fx, fdist, fon, tran2, w, s.thd1, s.thd2, s.phid, yr, yl, ym, acc);
-#define JB_CA(LV, SL, X, DIST, ON, TRAN) contact_accumulate<V, LV, MODE, SL>(m, dd, X, DIST, ON, TRAN, w, s.thd1, s.thd2, s.phid, yr, yl, ym, acc)
-                JB_CA(2, 1, lc.x[0], lc.dist[0], lc.on[0], tran2); JB_CA(2, 2, lc.x[1], lc.dist[1], lc.on[1], tran2);
-                JB_CA(2, 3, lc.x[2], lc.dist[2], lc.on[2], tran2); JB_CA(2, 4, lc.x[3], lc.dist[3], lc.on[3], tran2);
-                if (xtra) {
-                    JB_CA(1, 5, ucx.x[0], ucx.dist[0], ucx.on[0], tran1); JB_CA(1, 6, ucx.x[1], ucx.dist[1], ucx.on[1], tran1);
-                    JB_CA(1, 7, ucx.x[2], ucx.dist[2], ucx.on[2], tran1); JB_CA(1, 8, ucx.x[3], ucx.dist[3], ucx.on[3], tran1);
-                    JB_CA(1, 9, tipx, tipd, tipon, tran1);
-                    JB_CA(0, 10, xcx.x[0], xcx.dist[0], mand(xcx.on[0], mnot(x_onm)), tran0); JB_CA(0, 11, xcx.x[1], xcx.dist[1], mand(xcx.on[1], mnot(x_onm)), tran0);
-                    JB_CA(0, 12, xcx.x[2], xcx.dist[2], mand(xcx.on[2], mnot(x_onm)), tran0); JB_CA(0, 13, xcx.x[3], xcx.dist[3], mand(xcx.on[3], mnot(x_onm)), tran0);
-                    JB_CA(3, 14, xcx.x[0], xcx.dist[0], mand(xcx.on[0], x_onm), tranm); JB_CA(3, 15, xcx.x[1], xcx.dist[1], mand(xcx.on[1], x_onm), tranm);
-                    JB_CA(3, 16, xcx.x[2], xcx.dist[2], mand(xcx.on[2], x_onm), tranm); JB_CA(3, 17, xcx.x[3], xcx.dist[3], mand(xcx.on[3], x_onm), tranm);
-                    JB_CA(0, 18, ellx, elld, mand(ellon, mnot(x_onm)), tran0);
-                    JB_CA(3, 19, ellx, elld, mand(ellon, x_onm), tranm);
-                    JB_CA(0, 20, boxx[0], boxd[0], boxon[0], tran0); JB_CA(0, 21, boxx[1], boxd[1], boxon[1], tran0);
-                    JB_CA(0, 22, boxx[2], boxd[2], boxon[2], tran0); JB_CA(0, 23, boxx[3], boxd[3], boxon[3], tran0);
-                    JB_CA(0, 24, boxx[4], boxd[4], boxon[4], tran0); JB_CA(0, 25, boxx[5], boxd[5], boxon[5], tran0);
-                    JB_CA(0, 26, boxx[6], boxd[6], boxon[6], tran0); JB_CA(0, 27, boxx[7], boxd[7], boxon[7], tran0);
-                }
+#undef JB_CA_RT
 #undef JB_CA
-            };
-            using Mode0 = std::integral_constant<int, 0>;
-            using Mode1 = std::integral_constant<int, 1>;
-            auto init_acc = [&](NewtonAcc<V>& acc) {
+        };
+        using Mode0 = std::integral_constant<int, 0>;
+        using Mode1 = std::integral_constant<int, 1>;
+        U prev_bw0 = zero_u<V>(), prev_xh = zero_u<V>();
+        MK unconverged = lt(V(0), V(1));
+        for (int it = 0; it < o.max_newton; it++) {
+            NewtonAcc<V> acc;
+            acc_clear(acc);
+            sweep(Mode0{}, acc);
+            // the active set of the ENV changed if any lane of the quad saw a different bit record
+            MK changed = mor(neq_u(acc.bw0, prev_bw0), neq_u(acc.xh, prev_xh));
+            prev_bw0 = acc.bw0; prev_xh = acc.xh;
+            unconverged = (it == 0) ? lt(V(0), V(1)) : neq_u(quad_sum_u(mbit(changed)), zero_u<V>());
+            if (!any_lane(unconverged)) break;
+            V nyr[6], nyl[2], nym;
+            star_solve<V, XTRA>(sc, acc, V(0), V(0), nyr, nyl, nym);
+            // envs whose active set already repeated keep their (exact) solution
 #pragma unroll
-                for (int i = 0; i < 21; i++) acc.A[i] = V(0);
-#pragma unroll
-                for (int i = 0; i < 6; i++) { acc.B[i][0] = M.B[i][0]; acc.B[i][1] = M.B[i][1]; acc.Bm[i] = V(0); acc.rr[i] = V(0); }
-                acc.C11 = M.C11; acc.C12 = M.C12; acc.C22 = M.C22; acc.Cm = V(0);
-                acc.rl[0] = tl[0]; acc.rl[1] = tl[1]; acc.rm = V(0);
-#pragma unroll
-                for (int i = 0; i < 5; i++) acc.bw[i] = zero_u<V>();
-            };
-            U prev_bw[5];
-#pragma unroll
-            for (int i = 0; i < 5; i++) prev_bw[i] = zero_u<V>();
-            MK unconverged = lt(V(0), V(1));
-            for (int it = 0; it < o.max_newton; it++) {
-                NewtonAcc<V> acc;
-                init_acc(acc);
-                sweep(Mode0{}, acc);
-                // the active set of the ENV changed if any lane of the quad saw a different bit record
-                MK changed = neq_u(acc.bw[0], prev_bw[0]);
-#pragma unroll
-                for (int i = 1; i < 5; i++) changed = mor(changed, neq_u(acc.bw[i], prev_bw[i]));
-#pragma unroll
-                for (int i = 0; i < 5; i++) prev_bw[i] = acc.bw[i];
-                unconverged = (it == 0) ? lt(V(0), V(1)) : neq_u(quad_sum_u(mbit(changed)), zero_u<V>());
-#ifdef JB_DEBUG_PRINT
-                fprintf(stderr, "it %d bw0 %u unconv %d%d%d%d\n", it, acc.bw[0].v[0], unconverged.v[0], unconverged.v[1], unconverged.v[2], unconverged.v[3]);
-#endif
-                if (!any_lane(unconverged)) break;
-                V nyr[6], nyl[2], nym;
-                if (xtra) star_solve<V, true>(M.A, acc.A, acc.B, acc.C11, acc.C12, acc.C22, M.Bm, M.Cm, acc.Bm, acc.Cm, tr, acc.rr, acc.rl, tm, acc.rm, nyr, nyl, nym);
-                else star_solve<V, false>(M.A, acc.A, acc.B, acc.C11, acc.C12, acc.C22, M.Bm, M.Cm, acc.Bm, acc.Cm, tr, acc.rr, acc.rl, tm, acc.rm, nyr, nyl, nym);
-                // envs whose active set already repeated keep their (exact) solution
-#pragma unroll
-                for (int i = 0; i < 6; i++) yr[i] = sel(unconverged, nyr[i], yr[i]);
-                yl[0] = sel(unconverged, nyl[0], yl[0]); yl[1] = sel(unconverged, nyl[1], yl[1]); ym = sel(unconverged, nym, ym);
-            }
-            s.fail = s.fail + sel(unconverged, V(1), V(0));
-            // constraint force at the solution
-            NewtonAcc<V> fa;
-            init_acc(fa);
-            fa.rl[0] = V(0); fa.rl[1] = V(0);
-            sweep(Mode1{}, fa);
-#pragma unroll
-            for (int i = 0; i < 6; i++) qfr[i] = fa.rr[i];
-            qfl[0] = fa.rl[0]; qfl[1] = fa.rl[1]; qfm = fa.rm;
+            for (int i = 0; i < 6; i++) yr[i] = sel(unconverged, nyr[i], yr[i]);
+            yl[0] = sel(unconverged, nyl[0], yl[0]); yl[1] = sel(unconverged, nyl[1], yl[1]); ym = sel(unconverged, nym, ym);
         }
+        s.fail = s.fail + sel(unconverged, V(1), V(0));
+        sweep(Mode1{}, fa);            // constraint force at the solution
     }
+    JB_SCHED_FENCE();
 
-    // ---- final acceleration: (M + h diag(b)) qacc = tau + qfrc_constraint   (MuJoCo Euler, implicit joint damping)
+    // ================= phase C: (M + h diag(b)) qacc = tau + qfrc_constraint  (MuJoCo Euler, implicit joint damping), integrate
     V yr[6], yl[2], ym;
     {
-        V zero21[21], zero6[6];
-#pragma unroll
-        for (int i = 0; i < 21; i++) zero21[i] = V(0);
-#pragma unroll
-        for (int i = 0; i < 6; i++) zero6[i] = V(0);
         V hb1 = o.implicit_damp ? h * m.c[LM_B1] : V(0), hb2 = o.implicit_damp ? h * m.c[LM_B2] : V(0);
-        V rl[2] = {tl[0] + qfl[0], tl[1] + qfl[1]};
-        if (xtra) star_solve<V, true>(M.A, zero21, M.B, M.C11 + hb1, M.C12, M.C22 + hb2, M.Bm, M.Cm, zero6, V(0), tr, qfr, rl, tm, qfm, yr, yl, ym);
-        else star_solve<V, false>(M.A, zero21, M.B, M.C11 + hb1, M.C12, M.C22 + hb2, M.Bm, M.Cm, zero6, V(0), tr, qfr, rl, tm, qfm, yr, yl, ym);
+        star_solve<V, XTRA>(sc, fa, hb1, hb2, yr, yl, ym);
     }
-
-    // ---- integrate (mj_advance): velocities, then positions with the new velocities
+    Mat3<V> R;
+#pragma unroll
+    for (int i = 0; i < 9; i++) R.m[i] = sc.ld(SC_R + i);
     Vec3<V> lin = mul(R, v3<V>(yr[3], yr[4], yr[5]));
     s.wa[0] = yr[0]; s.wa[1] = yr[1]; s.wa[2] = yr[2]; s.wl[0] = lin.x; s.wl[1] = lin.y; s.wl[2] = lin.z; s.wj[0] = yl[0]; s.wj[1] = yl[1]; s.wm = ym;
+    // mj_advance: velocities, then positions with the new velocities
     s.wx = s.wx + h * yr[0]; s.wy = s.wy + h * yr[1]; s.wz = s.wz + h * yr[2];
     s.vx = s.vx + h * lin.x; s.vy = s.vy + h * lin.y; s.vz = s.vz + h * lin.z;
     s.thd1 = s.thd1 + h * yl[0]; s.thd2 = s.thd2 + h * yl[1]; s.phid = s.phid + h * ym;
@@ -777,9 +806,9 @@ JB_HD void substep_impl(const LaneModel<V>& m, LaneState<V>& s, const V& ctrl, c
         V half = V(0.5) * h;
         // sin(a)/|w| and cos(a) with a = h|w|/2 (tiny): series in a^2
         V a2_ = half * half * wn2;
-        V sc = half * (V(1) + a2_ * (V(-1.0 / 6) + a2_ * (V(1.0 / 120) + a2_ * V(-1.0 / 5040))));
+        V sc_ = half * (V(1) + a2_ * (V(-1.0 / 6) + a2_ * (V(1.0 / 120) + a2_ * V(-1.0 / 5040))));
         V cc = V(1) + a2_ * (V(-0.5) + a2_ * (V(1.0 / 24) + a2_ * V(-1.0 / 720)));
-        V dx = s.wx * sc, dy = s.wy * sc, dz = s.wz * sc;
+        V dx = s.wx * sc_, dy = s.wy * sc_, dz = s.wz * sc_;
         V r0 = s.qw * cc - s.qx * dx - s.qy * dy - s.qz * dz;
         V r1 = s.qw * dx + s.qx * cc + s.qy * dz - s.qz * dy;
         V r2 = s.qw * dy - s.qx * dz + s.qy * cc + s.qz * dx;
@@ -789,18 +818,19 @@ JB_HD void substep_impl(const LaneModel<V>& m, LaneState<V>& s, const V& ctrl, c
     }
     s.th1 = s.th1 + h * s.thd1; s.th2 = s.th2 + h * s.thd2;
     {
-        V p = s.phi + h * s.phid;
-        V k = vfloor((p + V(3.141592653589793)) * V(0.15915494309189535));
-        s.phi = p - k * V(6.283185307179586);
+        V pp = s.phi + h * s.phid;
+        V k = vfloor((pp + V(3.141592653589793)) * V(0.15915494309189535));
+        s.phi = pp - k * V(6.283185307179586);
         s.turns = s.turns + k;
     }
 }
 
-
 // One physics substep.  A wave-uniform broadphase decides between the lean variant (foot sphere + lower-leg
 // cylinder contacts only) and the complete one (every geom of the model against the floor).
 template <typename V>
-JB_HD void substep(const LaneModel<V>& m, LaneState<V>& s, const V& ctrl, const SimOpts& o) {
+JB_HD void substep(const LaneModel<V>& m_in, const LaneScratch<V>& sc, LaneState<V>& s, const V& ctrl, const SimOpts& o) {
+    LaneModel<V> m = m_in;
+    JB_LAUNDER(m.c.tab);
     bool xtra = false;
     if (o.contacts) {
         V qn2 = s.qw * s.qw + s.qx * s.qx + s.qy * s.qy + s.qz * s.qz;
@@ -815,8 +845,8 @@ JB_HD void substep(const LaneModel<V>& m, LaneState<V>& s, const V& ctrl, const 
 #ifdef JB_NO_XTRA
     xtra = false;
 #endif
-    if (xtra) substep_impl<V, true>(m, s, ctrl, o);
-    else substep_impl<V, false>(m, s, ctrl, o);
+    if (xtra) substep_impl<V, true>(m, sc, s, ctrl, o);
+    else substep_impl<V, false>(m, sc, s, ctrl, o);
 }
 
 }  // namespace jb

@@ -16,8 +16,7 @@ static int run(const double* P, double* qpos, double* qvel, double ctrl, int nsu
     for (int l = 0; l < 4; l++) { int rc = build_lane_model<T>(P, l, tab[l]); if (rc) return rc; }
     T tabT[LM_COUNT][4];
     for (int i = 0; i < LM_COUNT; i++) for (int l = 0; l < 4; l++) tabT[i][l] = tab[l][i];
-    for (int i = 0; i < LM_HOT; i++) m.c[i] = V(tab[0][i], tab[1][i], tab[2][i], tab[3][i]);
-    m.cold = &tabT[0][0];
+    m.c.tab = &tabT[0][0];
     LaneState<V> s;
     s.px = V(T(qpos[0])); s.py = V(T(qpos[1])); s.pz = V(T(qpos[2]));
     s.qw = V(T(qpos[3])); s.qx = V(T(qpos[4])); s.qy = V(T(qpos[5])); s.qz = V(T(qpos[6]));
@@ -32,7 +31,9 @@ static int run(const double* P, double* qpos, double* qvel, double ctrl, int nsu
     for (int i = 0; i < 3; i++) { s.wa[i] = V(T(0)); s.wl[i] = V(T(0)); }
     s.wj[0] = s.wj[1] = V(T(0)); s.wm = V(T(0)); s.fail = V(T(0));
     SimOpts o; o.contacts = contacts; o.max_newton = max_newton; o.implicit_damp = implicit_damp;
-    for (int i = 0; i < nsub; i++) substep<V>(m, s, V(T(ctrl)), o);
+    V scratch[SC_COUNT];
+    LaneScratch<V> sc; sc.p = scratch;
+    for (int i = 0; i < nsub; i++) substep<V>(m, sc, s, V(T(ctrl)), o);
     // replicated quantities must agree across the quad
     for (int l = 1; l < 4; l++) if (s.px.v[l] != s.px.v[0] || s.qw.v[l] != s.qw.v[0] || s.wz.v[l] != s.wz.v[0] || s.phid.v[l] != s.phid.v[0]) return -100;
     T n = std::sqrt(s.qw.v[0] * s.qw.v[0] + s.qx.v[0] * s.qx.v[0] + s.qy.v[0] * s.qy.v[0] + s.qz.v[0] * s.qz.v[0]);
