@@ -60,6 +60,8 @@ def main():
     ap.add_argument("--contacts", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true")
+    ap.add_argument("--max-newton", type=int, default=12)
+    ap.add_argument("--envs-per-wave", type=int, default=0)
     args = ap.parse_args()
 
     import numpy as np
@@ -87,7 +89,7 @@ def main():
 
     def make_env(contacts):
         # the handle launches on torch's current stream so torch.cuda.Event brackets exactly these kernels
-        return JitterbugVecEnv(n, TASK, seed=0, device_id=local_rank, contacts=bool(contacts), env_offset=rank * n,
+        return JitterbugVecEnv(n, TASK, seed=0, device_id=local_rank, contacts=bool(contacts), env_offset=rank * n, max_newton=args.max_newton, envs_per_wave=args.envs_per_wave,
                                stream=torch.cuda.current_stream(dev).cuda_stream)
 
     def run(contacts, steps, warmup, gather):

@@ -31,25 +31,25 @@ enum LegF : int { LF_TH1 = 0, LF_TH2 = 1, LF_THD1 = 2, LF_THD2 = 3, LF_WJ0 = 4, 
 
 struct KArgs {
     int n, task, substeps, step_limit, auto_reset, contacts, max_newton, random_pose, per_env_model;
+    int epw;       // environments per wave (= per 64-thread workgroup) of the step kernel
     unsigned long long seed, env_offset;
     float* root; float* leg; const float* lane_model;
     int* step_count; unsigned* episode;
 };
 
-// Stage the lane constant table(s) of this workgroup (64 threads = 16 envs) into LDS: one [LM_COUNT][4] copy for
-// a shared model, 16 copies for per-env models.
-#define JB_ENVS_PER_BLOCK 16
-__device__ __forceinline__ void stage_model(const KArgs& a, float* lds, int env, int leg, LaneModel<float>& m) {
+// Stage the lane constant table(s) of this workgroup (one wave = a.epw envs) into LDS: one [LM_COUNT][4] copy for a
+// shared model, epw copies for per-env models.  Called by all 64 threads before the idle quads retire.
+__device__ __forceinline__ void stage_model(const KArgs& a, float* lds, int quad, int leg, LaneModel<float>& m) {
     const int tsz = LM_COUNT * 4;
     if (a.per_env_model) {
-        const int env0 = (int)(blockIdx.x * JB_ENVS_PER_BLOCK);
-        for (int i = threadIdx.x; i < tsz * JB_ENVS_PER_BLOCK; i += blockDim.x) {
+        const int env0 = (int)blockIdx.x * a.epw;
+        for (int i = threadIdx.x; i < tsz * a.epw; i += blockDim.x) {
             int e = env0 + i / tsz;
             if (e >= a.n) e = a.n - 1;
             lds[i] = a.lane_model[(size_t)e * tsz + (i % tsz)];
         }
         __syncthreads();
-        m.c.tab = lds + (threadIdx.x >> 2) * tsz + leg;
+        m.c.tab = lds + quad * tsz + leg;
     } else {
         for (int i = threadIdx.x; i < tsz; i += blockDim.x) lds[i] = a.lane_model[i];
         __syncthreads();
@@ -111,16 +111,20 @@ __device__ __forceinline__ void store_target(const KArgs& a, int env, const EnvC
 // ---------------------------------------------------------------------------------------------- step
 __global__ __launch_bounds__(64) void jb_step_kernel(KArgs a, const float* __restrict__ action, float* __restrict__ obs_out,
                                                      float* __restrict__ reward_out, unsigned char* __restrict__ done_out) {
-    int t = blockIdx.x * blockDim.x + threadIdx.x;
-    int env = t >> 2, leg = t & 3;
-    const bool live = env < a.n;
-    if (!live) env = a.n - 1;                    // tail lanes shadow the last env so wave-level ops stay uniform; they store nothing
+    // one wave per workgroup; quad q (4 lanes) of the wave owns env blockIdx*epw + q.  Quads beyond epw (a small batch is
+    // spread over all SIMDs with partially filled waves) and beyond the batch retire at once: DPP quad sums and the
+    // wave ballots only ever involve complete, active quads.
+    extern __shared__ float lds[];           // [SC_COUNT][4*epw] per-lane scratch, then the lane constant table(s)
+    const int quad = threadIdx.x >> 2, leg = threadIdx.x & 3;
+    const int env = (int)blockIdx.x * a.epw + quad;
+    LaneModel<float> m;
+    stage_model(a, lds + SC_COUNT * 4 * a.epw, quad, leg, m);
+    if (quad >= a.epw || env >= a.n) return;
+    const bool live = true;
     const int lane = env * 4 + leg;
-    extern __shared__ float lds[];           // [SC_COUNT][64] per-lane scratch, then the lane constant table(s)
     LaneScratch<float> scr;
     scr.p = lds + threadIdx.x;
-    LaneModel<float> m;
-    stage_model(a, lds + SC_COUNT * 64, env, leg, m);
+    scr.stride = 4 * a.epw;
     LaneState<float> s;
     load_state(a, env, lane, s);
     const float ctrl = action[env];
@@ -342,6 +346,21 @@ int jb_create(const jb_config* cfg, jb_handle** out) {
     k.n = cfg->n_envs; k.task = cfg->task_id; k.substeps = cfg->substeps; k.step_limit = cfg->step_limit; k.auto_reset = cfg->auto_reset;
     k.contacts = cfg->contacts; k.max_newton = h->cfg.max_newton; k.random_pose = cfg->random_pose; k.per_env_model = 0;
     k.seed = cfg->seed; k.env_offset = cfg->env_offset;
+    {   // envs per wave: fill every SIMD of the device before filling the lanes of a wave.  The kernel holds one wave
+        // per SIMD (register budget), so the device runs (CUs x 4) waves at a time; LDS (scratch is per active lane)
+        // allows 4 resident waves per CU up to 8 envs per wave.
+        int epw = cfg->envs_per_wave;
+        if (epw <= 0) {
+            hipDeviceProp_t prop;
+            JB_HIP(hipGetDeviceProperties(&prop, cfg->device_id));
+            const int simds = prop.multiProcessorCount * 4;
+            epw = (cfg->n_envs + simds - 1) / simds;
+            if (epw > 8) epw = 8;
+        }
+        if (epw < 1) epw = 1;
+        if (epw > 16) epw = 16;
+        k.epw = epw;
+    }
     k.root = h->d_root; k.leg = h->d_leg; k.step_count = h->d_step; k.episode = h->d_episode;
     int rc = upload_model(h, JB_DEFAULT_PARAMS, 1);
     if (rc) { jb_destroy(h); return rc; }
@@ -378,7 +397,8 @@ int jb_reset_device(jb_handle* h, const uint8_t* d_mask, float* d_obs_out) {
 }
 int jb_step_device(jb_handle* h, const float* d_action, float* d_obs_out, float* d_reward_out, uint8_t* d_done_out) {
     if (!h || !d_action) return fail(JB_E_INVALID, "handle/action is NULL");
-    hipLaunchKernelGGL(jb_step_kernel, grid_lanes(h->cfg.n_envs), dim3(64), ((size_t)SC_COUNT * 64 + (size_t)LM_COUNT * 4 * (h->ka.per_env_model ? JB_ENVS_PER_BLOCK : 1)) * sizeof(float), h->stream, h->ka, d_action, d_obs_out, d_reward_out, d_done_out);
+    hipLaunchKernelGGL(jb_step_kernel, dim3((unsigned)((h->cfg.n_envs + h->ka.epw - 1) / h->ka.epw)), dim3(64),
+                       ((size_t)SC_COUNT * 4 * h->ka.epw + (size_t)LM_COUNT * 4 * (h->ka.per_env_model ? h->ka.epw : 1)) * sizeof(float), h->stream, h->ka, d_action, d_obs_out, d_reward_out, d_done_out);
     JB_HIP(hipGetLastError());
     return JB_OK;
 }

@@ -123,19 +123,39 @@ template <typename T> inline int build_lane_model(const double* P, int leg, T* o
         put_xcyl(geom(20), am); put_ell(geom(21), am);
         out[LM_X_ONM] = T(1);
     }
-    {   // one sphere around the lane's geoms; for motor-body geoms its centre is projected onto the motor axis
-        double c[3] = {0, 0, 0};
-        for (int k = 0; k < xs_n; k++) for (int i = 0; i < 3; i++) c[i] += xs_c[k][i] / xs_n;
+    {   // broadphase boxes (LM_BX): oriented boxes around the lane's root-body geoms; motor-body geoms (lane 3) get one
+        // axis-aligned cube centred on the motor axis (invariant under the motor angle).  Unused boxes have negative sizes.
+        for (int k = 0; k < 2; k++) {
+            T* bx = out + LM_BX + 15 * k;
+            for (int i = 0; i < 15; i++) bx[i] = T(0);
+            bx[3] = bx[7] = bx[11] = T(1);
+            bx[12] = bx[13] = bx[14] = T(-1);
+        }
+        const double margin = 2e-4;
+        auto put_bx = [&](int k, const double* g, const double* hs) {
+            T* bx = out + LM_BX + 15 * k;
+            for (int i = 0; i < 3; i++) bx[i] = T(g[JB_G_CENTER + i]);
+            const double* Rg = g + JB_G_ROT;
+            for (int ax = 0; ax < 3; ax++) for (int i = 0; i < 3; i++) bx[3 + 3 * ax + i] = T(Rg[3 * i + ax]);
+            for (int i = 0; i < 3; i++) bx[12 + i] = T(hs[i] + margin);
+        };
+        auto cyl_hs = [&](const double* g, double* hs) { hs[0] = hs[1] = g[JB_G_SIZE]; hs[2] = g[JB_G_SIZE + 1]; };
+        double hs[3];
+        if (leg == 0) put_bx(0, geom(0), geom(0) + JB_G_SIZE);
+        if (leg == 1) put_bx(0, geom(1), geom(1) + JB_G_SIZE);
+        if (leg == 2) { cyl_hs(geom(2), hs); put_bx(0, geom(2), hs); put_bx(1, geom(3), geom(3) + JB_G_SIZE); }
         if (leg == 3) {
+            double c[3] = {0, 0, 0};
+            for (int k = 0; k < xs_n; k++) for (int i = 0; i < 3; i++) c[i] += xs_c[k][i] / xs_n;
             const double* em = hinge(8) + JB_H_AXIS;
             double t = 0;
             for (int i = 0; i < 3; i++) t += (c[i] - am[i]) * em[i];
             for (int i = 0; i < 3; i++) c[i] = am[i] + t * em[i];
+            double r = 0;
+            for (int k = 0; k < xs_n; k++) { double d = norm3d(xs_c[k], c) + xs_r[k]; if (d > r) r = d; }
+            T* bx = out + LM_BX;
+            for (int i = 0; i < 3; i++) { bx[i] = T(c[i]); bx[12 + i] = T(r + margin); }
         }
-        double r = 0;
-        for (int k = 0; k < xs_n; k++) { double d = norm3d(xs_c[k], c) + xs_r[k]; if (d > r) r = d; }
-        put3(LM_BS_X_C, c);
-        out[LM_BS_X_R] = T(r + 1e-3);
     }
     return 0;
 }

@@ -64,20 +64,21 @@ enum LM : int {
     LM_LC_D = 91 /*3: lower cylinder centre - knee anchor*/, LM_LC_AX = 94 /*3*/, LM_LC_XA = 97 /*3*/, LM_LC_R = 100, LM_LC_H = 101,
     LM_TARGET_Z = 102, LM_ROOT_Z0 = 103, LM_LANE = 104 /* 0..3: which leg this lane owns */,
     // broadphase spheres (root reference coordinates) for the rarely touching geoms of this lane:
-    //   LEG: upper cylinder + knee tip (centre = cylinder centre);  X: the lane's root / motor-body geoms
-    //   (for motor-body geoms the centre lies on the motor axis, so it does not move with the motor angle)
-    LM_BS_LEG_C = 105 /*3*/, LM_BS_LEG_R = 108, LM_BS_X_C = 109 /*3*/, LM_BS_X_R = 112,
-    LM_HOT = 113,
+    //   LEG: sphere around upper cylinder + knee tip;  BX: two oriented boxes around the lane's root-body geoms
+    //   (motor-body geoms: one axis-aligned cube centred on the motor axis, so it does not move with the motor angle)
+    LM_BS_LEG_C = 105 /*3*/, LM_BS_LEG_R = 108,
+    LM_BX = 109 /*2 x 15: centre(3), axes(3x3, unit), half sizes(3) + margin: boxes bounding the lane's root/motor-body geoms*/,
+    LM_HOT = 139,
     // ---------------- cold part: read from the table only on the rare path
-    LM_UC_D = 113 /*3: upper cylinder centre - a1*/, LM_UC_AX = 116 /*3*/, LM_UC_XA = 119 /*3*/, LM_UC_R = 122, LM_UC_H = 123,
-    LM_DTIP = 124 /*3*/, LM_TIP_R = 127,
+    LM_UC_D = 139 /*3: upper cylinder centre - a1*/, LM_UC_AX = 142 /*3*/, LM_UC_XA = 145 /*3*/, LM_UC_R = 148, LM_UC_H = 149,
+    LM_DTIP = 150 /*3*/, LM_TIP_R = 153,
     // lane-assigned geoms of the root / motor body (lane 0: coreBody1 box, lane 1: coreBody2 box,
     // lane 2: screw1 cylinder + screw2 ellipsoid, lane 3: threadMass cylinder + mass ellipsoid on the motor body)
-    LM_XB_EN = 128, LM_XB_C = 129 /*3*/, LM_XB_R = 132 /*9*/, LM_XB_S = 141 /*3*/,
-    LM_XC_EN = 144, LM_XC_C = 145 /*3*/, LM_XC_AX = 148 /*3*/, LM_XC_XA = 151 /*3*/, LM_XC_R = 154, LM_XC_H = 155,
-    LM_XE_EN = 156, LM_XE_C = 157 /*3*/, LM_XE_R = 160 /*9*/, LM_XE_S = 169 /*3*/,
-    LM_X_ONM = 172 /*1: the lane's cylinder+ellipsoid sit on the motor body*/,
-    LM_COUNT = 176
+    LM_XB_EN = 154, LM_XB_C = 155 /*3*/, LM_XB_R = 158 /*9*/, LM_XB_S = 167 /*3*/,
+    LM_XC_EN = 170, LM_XC_C = 171 /*3*/, LM_XC_AX = 174 /*3*/, LM_XC_XA = 177 /*3*/, LM_XC_R = 180, LM_XC_H = 181,
+    LM_XE_EN = 182, LM_XE_C = 183 /*3*/, LM_XE_R = 186 /*9*/, LM_XE_S = 195 /*3*/,
+    LM_X_ONM = 198 /*1: the lane's cylinder+ellipsoid sit on the motor body*/,
+    LM_COUNT = 202
 };
 
 // The constant table is stored [LM_COUNT][4] (4 = lane of the quad) — on the device in LDS, one copy per
@@ -216,12 +217,11 @@ enum SC : int {
     SC_R = 200 /*9: root rotation matrix*/,
     SC_COUNT = 212
 };
-template <typename V> struct scratch_stride { static constexpr int value = 1; };
-template <> struct scratch_stride<float> { static constexpr int value = 64; };
 template <typename V> struct LaneScratch {
     V* p;
-    JB_HD V ld(int i) const { return p[i * scratch_stride<V>::value]; }
-    JB_HD void st(int i, const V& v) const { p[i * scratch_stride<V>::value] = v; }
+    int stride;            // device: number of active lanes of the wave (4 x envs per wave); host: 1
+    JB_HD V ld(int i) const { return p[i * stride]; }
+    JB_HD void st(int i, const V& v) const { p[i * stride] = v; }
     JB_HD Vec3<V> ld3(int i) const { return v3<V>(ld(i), ld(i + 1), ld(i + 2)); }
     JB_HD void st3(int i, const Vec3<V>& v) const { st(i, v.x); st(i + 1, v.y); st(i + 2, v.z); }
 };
@@ -254,8 +254,8 @@ template <typename V> JB_HD void acc_clear(NewtonAcc<V>& acc) {
 //   parts that are summed over the quad;  B, C, tau_leg: lane-private leg branch.
 // The own leg (2x2) and the motor (1x1) are eliminated onto the 6 root dofs; the 6x6 Schur complement is
 // Cholesky-factored redundantly by the 4 lanes.
-template <typename V, bool XTRA>
-JB_HD void star_solve(const LaneScratch<V>& sc, const NewtonAcc<V>& acc, const V& hb1, const V& hb2, V (&yr)[6], V (&yl)[2], V& ym) {
+template <typename V>
+JB_HD void star_solve(const LaneScratch<V>& sc, const NewtonAcc<V>& acc, bool xtra, const V& hb1, const V& hb2, V (&yr)[6], V (&yl)[2], V& ym) {
     V B[6][2];
 #pragma unroll
     for (int i = 0; i < 6; i++) { B[i][0] = sc.ld(SC_MB + 2 * i) + acc.B[i][0]; B[i][1] = sc.ld(SC_MB + 2 * i + 1) + acc.B[i][1]; }
@@ -275,7 +275,7 @@ JB_HD void star_solve(const LaneScratch<V>& sc, const NewtonAcc<V>& acc, const V
     V bm[6], cm = sc.ld(SC_MCM), rmt = sc.ld(SC_TM);
 #pragma unroll
     for (int i = 0; i < 6; i++) bm[i] = sc.ld(SC_MBM + i);
-    if (XTRA) {
+    if (xtra) {
 #pragma unroll
         for (int i = 0; i < 6; i++) bm[i] = bm[i] + quad_sum(acc.Bm[i]);
         cm = cm + quad_sum(acc.Cm);
@@ -342,21 +342,25 @@ template <typename V> JB_HD V impedance(const LaneModel<V>& m, const V& dist) {
 }
 
 
-// One contact candidate (a slot of the scratch table: compile-time CSLOT >= 0, or run-time `slot` when CSLOT < 0)
-// against the current iterate y.
+// One contact candidate (slot `slot` of the scratch table) against the current iterate y.  ONE copy of this code
+// serves every slot, body level and mode (all three are wave-uniform run-time values) so that the solver loop
+// stays small enough for the instruction cache.
 // level: 0 root body, 1 upper leg (shoulder only), 2 lower leg (shoulder+knee), 3 motor body.
-// MODE 0: accumulate the Newton matrix / rhs terms for the active set at y;  MODE 1: accumulate the constraint
+// mode 0: accumulate the Newton matrix / rhs terms for the active set at y;  mode 1: accumulate the constraint
 // force  -B^T W rho  into rr/rl/rm.
 // Direction data in the scratch (SC_DD + 12k, k = n, t1, t2): the contact rows are affine in the contact point x:
 //   J_sh(x,d) = (d x e1).(x - a1) = wS.x - oS,   J_kn(x,d) = wK.x - oK,   J_m(x,d) = (d x em).(x - am)
-template <typename V, int LEVEL, int MODE, int CSLOT>
-JB_HD void contact_accumulate(const LaneModel<V>& m, const LaneScratch<V>& sc, int slot, const V& tran, const Vec3<V>& w, const V& thd1, const V& thd2,
+JB_HD constexpr int slot_level(int slot) { return slot < 5 ? 2 : slot < 10 ? 1 : slot < 23 ? 0 : 3; }
+template <typename V>
+JB_HD void contact_accumulate(const LaneModel<V>& m, const LaneScratch<V>& sc, int slot, int mode, const Vec3<V>& w, const V& thd1, const V& thd2,
                               const V& phid, const V (&yr)[6], const V (&yl)[2], const V& ym, NewtonAcc<V>& acc) {
     using U = typename lane_traits<V>::uint;
-    if (CSLOT >= 0) slot = CSLOT;
+    const int level = slot_level(slot);
+    const bool has_sh = (level == 1 || level == 2), has_kn = (level == 2), has_m = (level == 3);
     const Vec3<V> x = sc.ld3(SC_CAND + 4 * slot);
     const V dist = sc.ld(SC_CAND + 4 * slot + 3);
     const auto valid = lt(dist, V(0));
+    const V tran = m.c[level == 2 ? LM_TRAN2 : level == 1 ? LM_TRAN1 : level == 0 ? LM_TRAN0 : LM_TRANM];
     V imp = impedance(m, dist);
     V R0 = (V(1) - imp) / imp * tran * (V(1) + m.c[LM_FR2]);
     V mu = m.c[LM_MU];
@@ -371,18 +375,20 @@ JB_HD void contact_accumulate(const LaneModel<V>& m, const LaneScratch<V>& sc, i
         Bj[k][3] = d.x; Bj[k][4] = d.y; Bj[k][5] = d.z;
         V vel = dot(ang, w) + sc.ld(SC_DD + 12 * k + 11);
         V acc_ = ang.x * yr[0] + ang.y * yr[1] + ang.z * yr[2] + d.x * yr[3] + d.y * yr[4] + d.z * yr[5];
-        if (LEVEL == 1 || LEVEL == 2) {
+        Bj[k][6] = V(0); Bj[k][7] = V(0);
+        if (has_sh) {
             Bj[k][6] = dot(sc.ld3(SC_DD + 12 * k + 3), x) - sc.ld(SC_DD + 12 * k + 9);
             vel = vel + Bj[k][6] * thd1; acc_ = acc_ + Bj[k][6] * yl[0];
-        } else Bj[k][6] = V(0);
-        if (LEVEL == 2) {
+        }
+        if (has_kn) {
             Bj[k][7] = dot(sc.ld3(SC_DD + 12 * k + 6), x) - sc.ld(SC_DD + 12 * k + 10);
             vel = vel + Bj[k][7] * thd2; acc_ = acc_ + Bj[k][7] * yl[1];
-        } else if (LEVEL == 3) {
+        }
+        if (has_m) {
             Vec3<V> wM = cross(d, ldv3(m, LM_EM));
             Bj[k][7] = dot(wM, x) - dot(wM, ldv3(m, LM_AM));
             vel = vel + Bj[k][7] * phid; acc_ = acc_ + Bj[k][7] * ym;
-        } else Bj[k][7] = V(0);
+        }
         ahat[k] = -m.c[LM_BB] * vel;
         if (k == 0) ahat[k] = ahat[k] - m.c[LM_KK] * imp * dist;
         rho[k] = acc_ - ahat[k];
@@ -392,9 +398,10 @@ JB_HD void contact_accumulate(const LaneModel<V>& m, const LaneScratch<V>& sc, i
     auto a1 = lt(rho[0] + mr1, V(0)), a2 = lt(rho[0] - mr1, V(0)), a3 = lt(rho[0] + mr2, V(0)), a4 = lt(rho[0] - mr2, V(0));
     V f1 = sel(a1, V(1), V(0)), f2 = sel(a2, V(1), V(0)), f3 = sel(a3, V(1), V(0)), f4 = sel(a4, V(1), V(0));
     V Wnn = D * (f1 + f2 + f3 + f4), Wn1 = D * mu * (f1 - f2), Wn2 = D * mu * (f3 - f4), W11 = D * mu * mu * (f1 + f2), W22 = D * mu * mu * (f3 + f4);
-    if (MODE == 0) {
+    if (mode == 0) {
+        // active-set record: exact 5-bit fields for the always-evaluated slots 0..4, a lane-private hash for the rest
         U bits = (mbit(a1) + mbit(a2) * 2u + mbit(a3) * 4u + mbit(a4) * 8u + 16u);
-        if (CSLOT >= 0) acc.bw0 = acc.bw0 + selu(valid, bits, zero_u<V>()) * (1u << (5 * (CSLOT >= 0 ? CSLOT : 0)));
+        if (slot < 5) acc.bw0 = acc.bw0 + selu(valid, bits, zero_u<V>()) * (1u << (5 * slot));
         else acc.xh = acc.xh * 0x9E3779B1u + selu(valid, bits, zero_u<V>() + 7u);
         V wa0 = Wnn * ahat[0] + Wn1 * ahat[1] + Wn2 * ahat[2];
         V wa1 = Wn1 * ahat[0] + W11 * ahat[1];
@@ -412,20 +419,20 @@ JB_HD void contact_accumulate(const LaneModel<V>& m, const LaneScratch<V>& sc, i
             for (int j = 0; j <= i; j++) acc.A[tri(i, j)] = acc.A[tri(i, j)] + (Bj[0][i] * WB[0][j] + Bj[1][i] * WB[1][j] + Bj[2][i] * WB[2][j]);
             acc.rr[i] = acc.rr[i] + (Bj[0][i] * wa0 + Bj[1][i] * wa1 + Bj[2][i] * wa2);
         }
-        if (LEVEL == 1 || LEVEL == 2) {
+        if (has_sh) {
 #pragma unroll
             for (int i = 0; i < 6; i++) acc.B[i][0] = acc.B[i][0] + (Bj[0][6] * WB[0][i] + Bj[1][6] * WB[1][i] + Bj[2][6] * WB[2][i]);
             acc.C11 = acc.C11 + (Bj[0][6] * WB[0][6] + Bj[1][6] * WB[1][6] + Bj[2][6] * WB[2][6]);
             acc.rl[0] = acc.rl[0] + (Bj[0][6] * wa0 + Bj[1][6] * wa1 + Bj[2][6] * wa2);
         }
-        if (LEVEL == 2) {
+        if (has_kn) {
 #pragma unroll
             for (int i = 0; i < 6; i++) acc.B[i][1] = acc.B[i][1] + (Bj[0][7] * WB[0][i] + Bj[1][7] * WB[1][i] + Bj[2][7] * WB[2][i]);
             acc.C12 = acc.C12 + (Bj[0][6] * WB[0][7] + Bj[1][6] * WB[1][7] + Bj[2][6] * WB[2][7]);
             acc.C22 = acc.C22 + (Bj[0][7] * WB[0][7] + Bj[1][7] * WB[1][7] + Bj[2][7] * WB[2][7]);
             acc.rl[1] = acc.rl[1] + (Bj[0][7] * wa0 + Bj[1][7] * wa1 + Bj[2][7] * wa2);
         }
-        if (LEVEL == 3) {
+        if (has_m) {
 #pragma unroll
             for (int i = 0; i < 6; i++) acc.Bm[i] = acc.Bm[i] + (Bj[0][7] * WB[0][i] + Bj[1][7] * WB[1][i] + Bj[2][7] * WB[2][i]);
             acc.Cm = acc.Cm + (Bj[0][7] * WB[0][7] + Bj[1][7] * WB[1][7] + Bj[2][7] * WB[2][7]);
@@ -438,11 +445,23 @@ JB_HD void contact_accumulate(const LaneModel<V>& m, const LaneScratch<V>& sc, i
         V g2 = -(Wn2 * rho[0] + W22 * rho[2]);
 #pragma unroll
         for (int i = 0; i < 6; i++) acc.rr[i] = acc.rr[i] + (Bj[0][i] * g0 + Bj[1][i] * g1 + Bj[2][i] * g2);
-        if (LEVEL == 1 || LEVEL == 2) acc.rl[0] = acc.rl[0] + (Bj[0][6] * g0 + Bj[1][6] * g1 + Bj[2][6] * g2);
-        if (LEVEL == 2) acc.rl[1] = acc.rl[1] + (Bj[0][7] * g0 + Bj[1][7] * g1 + Bj[2][7] * g2);
-        if (LEVEL == 3) acc.rm = acc.rm + (Bj[0][7] * g0 + Bj[1][7] * g1 + Bj[2][7] * g2);
+        if (has_sh) acc.rl[0] = acc.rl[0] + (Bj[0][6] * g0 + Bj[1][6] * g1 + Bj[2][6] * g2);
+        if (has_kn) acc.rl[1] = acc.rl[1] + (Bj[0][7] * g0 + Bj[1][7] * g1 + Bj[2][7] * g2);
+        if (has_m) acc.rm = acc.rm + (Bj[0][7] * g0 + Bj[1][7] * g1 + Bj[2][7] * g2);
     }
-    JB_SCHED_FENCE();
+}
+
+// all candidate slots against y: slots 0..4 always (wave-uniform skip of slots nobody uses), 5..27 on the rare path
+template <typename V>
+JB_HD void contact_sweep(const LaneModel<V>& m, const LaneScratch<V>& sc, bool xtra, int mode, const Vec3<V>& w, const V& thd1, const V& thd2,
+                         const V& phid, const V (&yr)[6], const V (&yl)[2], const V& ym, NewtonAcc<V>& acc) {
+    acc_clear(acc);
+    const int nslot = xtra ? 28 : 5;
+#pragma unroll 1
+    for (int slot = 0; slot < nslot; slot++) {
+        if (!any_lane(lt(sc.ld(SC_CAND + 4 * slot + 3), V(0)))) continue;
+        contact_accumulate<V>(m, sc, slot, mode, w, thd1, thd2, phid, yr, yl, ym, acc);
+    }
 }
 
 // Cylinder vs floor, restating MuJoCo's plane-cylinder routine: up to 4 points.  c: centre, ax: unit axis,
@@ -515,8 +534,8 @@ template <typename V> JB_HD void sincos_small(const V& x, V& s, V& c) {
 }
 
 // ----------------------------------------------------------------------------- the substep
-template <typename V, bool XTRA>
-JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneState<V>& s, const V& ctrl, const SimOpts& o) {
+template <typename V>
+JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneState<V>& s, const V& ctrl, const SimOpts& o, const bool xtra) {
     using MK = typename lane_traits<V>::mask;
     using U = typename lane_traits<V>::uint;
     const V h = m.c[LM_H];
@@ -571,7 +590,7 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
             cylinder_floor(a2 + mul(R12, ldv3(m, LM_LC_D)), mul(R12, ldv3(m, LM_LC_AX)), mul(R12, ldv3(m, LM_LC_XA)), m.c[LM_LC_R], m.c[LM_LC_H], nb, s.pz, all_on, lc);
             cand_store_cyl(sc, 1, lc, all_on);
             MK any_con = mor(fon, lc.on[0]);
-            if (XTRA) {
+            if (xtra) {
                 // every remaining geom of the model against the floor
                 CylContacts<V> cy;
                 cylinder_floor(a1 + mul(R1, ldc3(m, LM_UC_D)), mul(R1, ldc3(m, LM_UC_AX)), mul(R1, ldc3(m, LM_UC_XA)), ldc(m, LM_UC_R), ldc(m, LM_UC_H), nb, s.pz, all_on, cy);
@@ -721,76 +740,57 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
     }
     JB_SCHED_FENCE();
 
-    // ================= phase B: contact solve (primal Newton on the active set), result = constraint force in `fa`
-    NewtonAcc<V> fa;
-    acc_clear(fa);
-    if (any_contact) {
-        const V tran0 = m.c[LM_TRAN0], tran1 = m.c[LM_TRAN1], tran2 = m.c[LM_TRAN2], tranm = m.c[LM_TRANM];
-        // wave-uniform skips for the lower-leg cylinder slots
-        const bool lc0 = any_lane(lt(sc.ld(SC_CAND + 4 * 1 + 3), V(0))), lc1 = any_lane(lt(sc.ld(SC_CAND + 4 * 2 + 3), V(0))),
-                   lc2 = any_lane(lt(sc.ld(SC_CAND + 4 * 3 + 3), V(0)));
-        // warm start (world linear part rotated into the root frame)
-        V yr[6], yl[2], ym;
-        {
+    // ================= phase B: contact solve (primal Newton on the active set) and final acceleration, ONE loop:
+    //   while the active set changes:  H(active set at y) y' = tau + contact rhs          (M without damping)
+    //   then:  (M + h diag(b)) qacc = tau + qfrc_constraint(y)                            (MuJoCo Euler, implicit joint damping)
+    V yr[6], yl[2], ym;
+    {
+        NewtonAcc<V> acc;
+        bool final_pass = !any_contact;
+        MK unconverged = lt(V(1), V(0));
+        U prev_bw0 = zero_u<V>(), prev_xh = zero_u<V>();
+        if (any_contact) {      // warm start (world linear part rotated into the root frame)
             Mat3<V> R;
 #pragma unroll
             for (int i = 0; i < 9; i++) R.m[i] = sc.ld(SC_R + i);
             Vec3<V> lw = mulT(R, v3<V>(s.wl[0], s.wl[1], s.wl[2]));
             yr[0] = s.wa[0]; yr[1] = s.wa[1]; yr[2] = s.wa[2]; yr[3] = lw.x; yr[4] = lw.y; yr[5] = lw.z;
             yl[0] = s.wj[0]; yl[1] = s.wj[1]; ym = s.wm;
-        }
-        auto sweep = [&](auto mode_tag, NewtonAcc<V>& acc) {
-            constexpr int MODE = decltype(mode_tag)::value;
-#define JB_CA(LV, SL, TRAN) contact_accumulate<V, LV, MODE, SL>(m, sc, SL, TRAN, w, s.thd1, s.thd2, s.phid, yr, yl, ym, acc)
-#define JB_CA_RT(LV, SL, TRAN) contact_accumulate<V, LV, MODE, -1>(m, sc, SL, TRAN, w, s.thd1, s.thd2, s.phid, yr, yl, ym, acc)
-            JB_CA(2, 0, tran2);
-            if (lc0) {
-                JB_CA(2, 1, tran2);
-                if (lc1) JB_CA(2, 2, tran2);
-                if (lc2) { JB_CA(2, 3, tran2); JB_CA(2, 4, tran2); }
-            }
-            if (XTRA) {       // rolled loops: this path is rare, keep its code and register footprint small
-#pragma unroll 1
-                for (int sl = 5; sl < 10; sl++) JB_CA_RT(1, sl, tran1);
-#pragma unroll 1
-                for (int sl = 10; sl < 23; sl++) JB_CA_RT(0, sl, tran0);
-#pragma unroll 1
-                for (int sl = 23; sl < 28; sl++) JB_CA_RT(3, sl, tranm);
-            }
-#undef JB_CA_RT
-#undef JB_CA
-        };
-        using Mode0 = std::integral_constant<int, 0>;
-        using Mode1 = std::integral_constant<int, 1>;
-        U prev_bw0 = zero_u<V>(), prev_xh = zero_u<V>();
-        MK unconverged = lt(V(0), V(1));
-        for (int it = 0; it < o.max_newton; it++) {
-            NewtonAcc<V> acc;
+        } else {
             acc_clear(acc);
-            sweep(Mode0{}, acc);
-            // the active set of the ENV changed if any lane of the quad saw a different bit record
-            MK changed = mor(neq_u(acc.bw0, prev_bw0), neq_u(acc.xh, prev_xh));
-            prev_bw0 = acc.bw0; prev_xh = acc.xh;
-            unconverged = (it == 0) ? lt(V(0), V(1)) : neq_u(quad_sum_u(mbit(changed)), zero_u<V>());
-            if (!any_lane(unconverged)) break;
+        }
+        const V hb1 = o.implicit_damp ? h * m.c[LM_B1] : V(0), hb2 = o.implicit_damp ? h * m.c[LM_B2] : V(0);
+#pragma unroll 1
+        for (int it = 0;; it++) {
+            if (!final_pass) {
+                contact_sweep<V>(m, sc, xtra, 0, w, s.thd1, s.thd2, s.phid, yr, yl, ym, acc);
+                // the active set of the ENV changed if any lane of the quad saw a different record
+                MK changed = mor(neq_u(acc.bw0, prev_bw0), neq_u(acc.xh, prev_xh));
+                prev_bw0 = acc.bw0; prev_xh = acc.xh;
+                unconverged = (it == 0) ? lt(V(0), V(1)) : neq_u(quad_sum_u(mbit(changed)), zero_u<V>());
+                if (!any_lane(unconverged) || it >= o.max_newton) {
+                    s.fail = s.fail + sel(unconverged, V(1), V(0));
+                    final_pass = true;
+                    contact_sweep<V>(m, sc, xtra, 1, w, s.thd1, s.thd2, s.phid, yr, yl, ym, acc);     // constraint force at the solution
+                }
+            }
             V nyr[6], nyl[2], nym;
-            star_solve<V, XTRA>(sc, acc, V(0), V(0), nyr, nyl, nym);
+            star_solve<V>(sc, acc, xtra, final_pass ? hb1 : V(0), final_pass ? hb2 : V(0), nyr, nyl, nym);
+            if (final_pass) {
+#pragma unroll
+                for (int i = 0; i < 6; i++) yr[i] = nyr[i];
+                yl[0] = nyl[0]; yl[1] = nyl[1]; ym = nym;
+                break;
+            }
             // envs whose active set already repeated keep their (exact) solution
 #pragma unroll
             for (int i = 0; i < 6; i++) yr[i] = sel(unconverged, nyr[i], yr[i]);
             yl[0] = sel(unconverged, nyl[0], yl[0]); yl[1] = sel(unconverged, nyl[1], yl[1]); ym = sel(unconverged, nym, ym);
         }
-        s.fail = s.fail + sel(unconverged, V(1), V(0));
-        sweep(Mode1{}, fa);            // constraint force at the solution
     }
     JB_SCHED_FENCE();
 
-    // ================= phase C: (M + h diag(b)) qacc = tau + qfrc_constraint  (MuJoCo Euler, implicit joint damping), integrate
-    V yr[6], yl[2], ym;
-    {
-        V hb1 = o.implicit_damp ? h * m.c[LM_B1] : V(0), hb2 = o.implicit_damp ? h * m.c[LM_B2] : V(0);
-        star_solve<V, XTRA>(sc, fa, hb1, hb2, yr, yl, ym);
-    }
+    // ================= phase C: integrate
     Mat3<V> R;
 #pragma unroll
     for (int i = 0; i < 9; i++) R.m[i] = sc.ld(SC_R + i);
@@ -825,28 +825,33 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
     }
 }
 
-// One physics substep.  A wave-uniform broadphase decides between the lean variant (foot sphere + lower-leg
-// cylinder contacts only) and the complete one (every geom of the model against the floor).
+// One physics substep.  A wave-uniform broadphase decides whether only the foot sphere + lower-leg cylinder can
+// touch the floor (common) or every geom of the model has to be tested (rare).
 template <typename V>
 JB_HD void substep(const LaneModel<V>& m_in, const LaneScratch<V>& sc, LaneState<V>& s, const V& ctrl, const SimOpts& o) {
     LaneModel<V> m = m_in;
-    JB_LAUNDER(m.c.tab);
     bool xtra = false;
     if (o.contacts) {
-        V qn2 = s.qw * s.qw + s.qx * s.qx + s.qy * s.qy + s.qz * s.qz;
-        // third row of the rotation matrix of the (not yet normalised) quaternion, scaled by 1/|q|^2
-        V iq = V(1) / qn2;
+        V iq = V(1) / (s.qw * s.qw + s.qx * s.qx + s.qy * s.qy + s.qz * s.qz);
+        // third row of the rotation matrix of the (not yet normalised) quaternion
         Vec3<V> nb = v3<V>(V(2) * (s.qx * s.qz - s.qw * s.qy) * iq, V(2) * (s.qy * s.qz + s.qw * s.qx) * iq,
                            (s.qw * s.qw - s.qx * s.qx - s.qy * s.qy + s.qz * s.qz) * iq);
-        auto near_leg = mor(lt(s.pz + dot(ldv3(m, LM_BS_LEG_C), nb), m.c[LM_BS_LEG_R]), gt(vabs(s.th1), V(0.3)));
-        auto near_x = lt(s.pz + dot(ldv3(m, LM_BS_X_C), nb), m.c[LM_BS_X_R]);
-        xtra = any_lane(mor(near_leg, near_x));
+        // upper leg: sphere around the upper cylinder (+ slack for the shoulder angle)
+        auto near = mor(lt(s.pz + dot(ldv3(m, LM_BS_LEG_C), nb), m.c[LM_BS_LEG_R]), gt(vabs(s.th1), V(0.3)));
+        // the lane's root / motor-body geoms: two oriented boxes (support function of a box along -n)
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int b = LM_BX + 15 * k;
+            Vec3<V> ax0 = ldv3(m, b + 3), ax1 = ldv3(m, b + 6), ax2 = ldv3(m, b + 9);
+            V sup = vabs(dot(ax0, nb)) * m.c[b + 12] + vabs(dot(ax1, nb)) * m.c[b + 13] + vabs(dot(ax2, nb)) * m.c[b + 14];
+            near = mor(near, lt(s.pz + dot(ldv3(m, b), nb), sup));
+        }
+        xtra = any_lane(near);
     }
 #ifdef JB_NO_XTRA
     xtra = false;
 #endif
-    if (xtra) substep_impl<V, true>(m, sc, s, ctrl, o);
-    else substep_impl<V, false>(m, sc, s, ctrl, o);
+    substep_impl<V>(m, sc, s, ctrl, o, xtra);
 }
 
 }  // namespace jb
