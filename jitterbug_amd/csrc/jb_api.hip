@@ -35,6 +35,7 @@ struct KArgs {
     unsigned long long seed, env_offset;
     float* root; float* leg; const float* lane_model;
     int* step_count; unsigned* episode;
+    unsigned long long* wave_stats;   // diagnostic builds (-DJB_WAVE_STATS): [n_waves][4] = cycles, rare-path substeps, Newton sweeps, contact substeps
 };
 
 // Stage the lane constant table(s) of this workgroup (one wave = a.epw envs) into LDS: one [LM_COUNT][4] copy for a
@@ -125,12 +126,24 @@ __global__ __launch_bounds__(64) void jb_step_kernel(KArgs a, const float* __res
     LaneScratch<float> scr;
     scr.p = lds + threadIdx.x;
     scr.stride = 4 * a.epw;
+#ifdef JB_WAVE_STATS
+    const unsigned long long t_start = __builtin_amdgcn_s_memtime();
+#endif
     LaneState<float> s;
     load_state(a, env, lane, s);
+#ifdef JB_WAVE_STATS
+    s.st_xtra = 0.f; s.st_sweeps = 0.f; s.st_contact = 0.f;
+#endif
     const float ctrl = action[env];
     SimOpts o; o.contacts = a.contacts; o.max_newton = a.max_newton; o.implicit_damp = 1;
 #pragma unroll 1
     for (int k = 0; k < a.substeps; k++) substep<float>(m, scr, s, ctrl, o);
+#ifdef JB_WAVE_STATS
+    if (threadIdx.x == 0 && a.wave_stats) {
+        unsigned long long* ws = a.wave_stats + (size_t)blockIdx.x * 4;
+        ws[0] = __builtin_amdgcn_s_memtime() - t_start; ws[1] = (unsigned long long)s.st_xtra; ws[2] = (unsigned long long)s.st_sweeps; ws[3] = (unsigned long long)s.st_contact;
+    }
+#endif
     {   // trailing mj_step1: derived quantities use the normalised quaternion
         float n = 1.0f / sqrtf(s.qw * s.qw + s.qx * s.qx + s.qy * s.qy + s.qz * s.qz);
         s.qw *= n; s.qx *= n; s.qy *= n; s.qz *= n;
@@ -261,6 +274,7 @@ struct jb_handle {
     // staging for the host-buffer entry points
     float *d_action, *d_obs, *d_reward; unsigned char *d_done, *d_mask;
     double *d_qpos, *d_qvel, *d_target;
+    unsigned long long* d_wave_stats;
     size_t model_tables;
 };
 
@@ -338,6 +352,10 @@ int jb_create(const jb_config* cfg, jb_handle** out) {
     JB_HIP(hipMalloc(&h->d_qpos, sizeof(double) * 16 * N));
     JB_HIP(hipMalloc(&h->d_qvel, sizeof(double) * 15 * N));
     JB_HIP(hipMalloc(&h->d_target, sizeof(double) * 3 * N));
+#ifdef JB_WAVE_STATS
+    JB_HIP(hipMalloc(&h->d_wave_stats, sizeof(unsigned long long) * 4 * N));
+    JB_HIP(hipMemset(h->d_wave_stats, 0, sizeof(unsigned long long) * 4 * N));
+#endif
     JB_HIP(hipMemsetAsync(h->d_root, 0, sizeof(float) * ROOT_F * N, h->stream));
     JB_HIP(hipMemsetAsync(h->d_leg, 0, sizeof(float) * LEG_F * 4 * N, h->stream));
     JB_HIP(hipMemsetAsync(h->d_step, 0, sizeof(int) * N, h->stream));
@@ -361,7 +379,7 @@ int jb_create(const jb_config* cfg, jb_handle** out) {
         if (epw > 16) epw = 16;
         k.epw = epw;
     }
-    k.root = h->d_root; k.leg = h->d_leg; k.step_count = h->d_step; k.episode = h->d_episode;
+    k.root = h->d_root; k.leg = h->d_leg; k.step_count = h->d_step; k.episode = h->d_episode; k.wave_stats = h->d_wave_stats;
     int rc = upload_model(h, JB_DEFAULT_PARAMS, 1);
     if (rc) { jb_destroy(h); return rc; }
     rc = jb_reset_device(h, nullptr, nullptr);     // every env starts in a valid episode-0 state
@@ -374,7 +392,7 @@ int jb_create(const jb_config* cfg, jb_handle** out) {
 int jb_destroy(jb_handle* h) {
     if (!h) return JB_OK;
     hipStreamSynchronize(h->stream);
-    void* bufs[] = {h->d_root, h->d_leg, h->d_model, h->d_step, h->d_episode, h->d_action, h->d_obs, h->d_reward, h->d_done, h->d_mask, h->d_qpos, h->d_qvel, h->d_target};
+    void* bufs[] = {h->d_root, h->d_leg, h->d_model, h->d_step, h->d_episode, h->d_action, h->d_obs, h->d_reward, h->d_done, h->d_mask, h->d_qpos, h->d_qvel, h->d_target, h->d_wave_stats};
     for (void* b : bufs) if (b) hipFree(b);
     if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
     delete h;
@@ -474,6 +492,15 @@ int jb_get_counters(jb_handle* h, int32_t* step_count, uint32_t* episode, float*
     if (solver_cap_hits) JB_HIP(hipMemcpy(solver_cap_hits, h->d_root + RF_FAIL * N, sizeof(float) * N, hipMemcpyDeviceToHost));
     return JB_OK;
 }
+#ifdef JB_WAVE_STATS
+// diagnostic builds only: per-wave [cycles, rare-path substeps, Newton sweeps, contact substeps] of the last step launch
+int jb_debug_wave_stats(jb_handle* h, unsigned long long* out, int32_t n_waves) {
+    if (!h || !out) return fail(JB_E_INVALID, "NULL");
+    JB_HIP(hipStreamSynchronize(h->stream));
+    JB_HIP(hipMemcpy(out, h->d_wave_stats, sizeof(unsigned long long) * 4 * n_waves, hipMemcpyDeviceToHost));
+    return h->ka.epw;
+}
+#endif
 int jb_set_model_params(jb_handle* h, const double* params, int32_t n_tables) {
     if (!h || !params) return fail(JB_E_INVALID, "handle/params is NULL");
     if (n_tables != 1 && n_tables != h->cfg.n_envs) return fail(JB_E_INVALID, "n_tables must be 1 or n_envs");

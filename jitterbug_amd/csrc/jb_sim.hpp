@@ -198,6 +198,9 @@ template <typename V> struct LaneState {
     // warm start of the contact solve: last acceleration [alpha(3), world linear(3)], own leg (2), motor
     V wa[3], wl[3], wj[2], wm;
     V fail;                              // >0: the Newton iteration hit its cap in some substep
+#ifdef JB_WAVE_STATS
+    V st_xtra, st_sweeps, st_contact;    // diagnostic build only: substeps on the rare path, Newton sweeps, substeps with contact
+#endif
 };
 
 // ----------------------------------------------------------------------------- per-lane scratch
@@ -760,10 +763,16 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
             acc_clear(acc);
         }
         const V hb1 = o.implicit_damp ? h * m.c[LM_B1] : V(0), hb2 = o.implicit_damp ? h * m.c[LM_B2] : V(0);
+#ifdef JB_WAVE_STATS
+        if (any_contact) s.st_contact = s.st_contact + V(1);
+#endif
 #pragma unroll 1
         for (int it = 0;; it++) {
             if (!final_pass) {
                 contact_sweep<V>(m, sc, xtra, 0, w, s.thd1, s.thd2, s.phid, yr, yl, ym, acc);
+#ifdef JB_WAVE_STATS
+                s.st_sweeps = s.st_sweeps + V(1);
+#endif
                 // the active set of the ENV changed if any lane of the quad saw a different record
                 MK changed = mor(neq_u(acc.bw0, prev_bw0), neq_u(acc.xh, prev_xh));
                 prev_bw0 = acc.bw0; prev_xh = acc.xh;
@@ -850,6 +859,9 @@ JB_HD void substep(const LaneModel<V>& m_in, const LaneScratch<V>& sc, LaneState
     }
 #ifdef JB_NO_XTRA
     xtra = false;
+#endif
+#ifdef JB_WAVE_STATS
+    if (xtra) s.st_xtra = s.st_xtra + V(1);
 #endif
     substep_impl<V>(m, sc, s, ctrl, o, xtra);
 }

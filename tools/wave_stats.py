@@ -1,0 +1,32 @@
+"""Diagnostic: per-wave cycle counts of jb_step_kernel (needs a -DJB_WAVE_STATS build)."""
+import ctypes as C, os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from jitterbug_amd.vec_env import JitterbugVecEnv
+from jitterbug_amd import _lib
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+epw = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+env = JitterbugVecEnv(n, "move_from_origin", seed=0, envs_per_wave=epw)
+env.reset()
+rng = np.random.default_rng(0)
+for t in range(150):
+    env.step(rng.uniform(-1, 1, size=n).astype(np.float32))
+L = _lib.load()
+buf = np.zeros((n, 4), dtype=np.uint64)
+L.jb_debug_wave_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+e = L.jb_debug_wave_stats(env._h, buf.ctypes.data, n)
+nw = (n + e - 1) // e
+b = buf[:nw].astype(np.float64)
+cyc = b[:, 0] / 100.0   # s_memtime ticks at 100 MHz -> microseconds
+print("epw", e, "waves", nw)
+print("wave time us: mean %.1f median %.1f p90 %.1f p99 %.1f max %.1f" % (cyc.mean(), np.median(cyc), np.quantile(cyc, .9), np.quantile(cyc, .99), cyc.max()))
+print("rare-path substeps/50: mean %.2f max %d  frac waves with any %.3f" % (b[:, 1].mean(), b[:, 1].max(), (b[:, 1] > 0).mean()))
+print("newton sweeps per step: mean %.1f max %d ; contact substeps mean %.1f" % (b[:, 2].mean(), b[:, 2].max(), b[:, 3].mean()))
+order = np.argsort(-cyc)[:8]
+print("slowest waves [us, xtra, sweeps, contact]:", [(round(cyc[i], 1), int(b[i, 1]), int(b[i, 2]), int(b[i, 3])) for i in order])
+c = np.corrcoef(cyc, b[:, 1])[0, 1]; c2 = np.corrcoef(cyc, b[:, 2])[0, 1]
+print("corr(time, xtra) %.3f corr(time, sweeps) %.3f" % (c, c2))
+# linear fit time ~ a + b*xtra + c*sweeps
+A = np.stack([np.ones(nw), b[:, 1], b[:, 2], b[:, 3]], 1)
+coef = np.linalg.lstsq(A, cyc, rcond=None)[0]
+print("fit us: base %.1f + %.2f/xtra-substep + %.2f/sweep + %.2f/contact-substep" % tuple(coef))
