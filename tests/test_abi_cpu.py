@@ -1,0 +1,72 @@
+"""No-GPU checks of the drop-in boundary: the C-ABI library loads, exports every symbol include/jitterbug_hip.h
+declares, answers the device-free queries, and refuses to create a handle without a device (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from jitterbug_amd import _lib, model
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from jitterbug_amd import build
+    build.build()
+    return _lib.load()
+
+
+def test_exports_every_declared_symbol(lib):
+    hdr = open(os.path.join(ROOT, "include", "jitterbug_hip.h")).read()
+    declared = set(re.findall(r"\b(jb_[a-z_]+)\s*\(", hdr))
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    for sym in declared:
+        assert getattr(lib, sym) is not None
+
+
+def test_device_free_queries(lib):
+    assert lib.jb_abi_version() == 1
+    assert [lib.jb_obs_dim(i) for i in range(5)] == [15, 16, 19, 18, 19]
+    assert lib.jb_obs_dim(5) == -1 and lib.jb_obs_dim(-1) == -1
+    np.testing.assert_array_equal(_lib.default_model_params(), model.default_params())
+    cfg = _lib.Config()
+    assert lib.jb_default_config(C.byref(cfg), 4096, 0) == 0
+    assert (cfg.n_envs, cfg.substeps, cfg.step_limit, cfg.contacts, cfg.random_pose, cfg.auto_reset) == (4096, 50, 1000, 1, 1, 1)
+
+
+def test_config_struct_matches_header():
+    hdr = open(os.path.join(ROOT, "include", "jitterbug_hip.h")).read()
+    body = hdr[hdr.index("typedef struct jb_config {"):hdr.index("} jb_config;")]
+    fields = re.findall(r"^\s*(?:int32_t|uint64_t|void\*)\s+(\w+);", body, flags=re.M)
+    assert fields == [f[0] for f in _lib.Config._fields_]
+
+
+def test_no_cpu_fallback(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from jitterbug_amd.vec_env import JitterbugVecEnv
+    with pytest.raises(_lib.JitterbugHipError, match="JB_E_NODEVICE"):
+        JitterbugVecEnv(4)
+    # argument validation happens before the device probe
+    cfg = _lib.Config()
+    lib.jb_default_config(C.byref(cfg), 0, 0)
+    h = C.c_void_p()
+    assert lib.jb_create(C.byref(cfg), C.byref(h)) == -1 and b"n_envs" in lib.jb_last_error()
+
+
+def test_task_factories_validate_like_the_reference():
+    from jitterbug_amd import jitterbug, suite
+    with pytest.raises(AssertionError, match="Invalid task"):
+        jitterbug.Jitterbug(task="fly")
+    with pytest.raises(ValueError):
+        suite.load("jitterbug", "fly")
+    with pytest.raises(ValueError):
+        suite.load("hopper", "stand")
+    from jitterbug_amd.vec_env import compute_n_substeps
+    assert compute_n_substeps(0.01) == 50
+    with pytest.raises(ValueError):
+        compute_n_substeps(0.00031)

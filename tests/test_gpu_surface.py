@@ -1,0 +1,90 @@
+"""GPU tests of the reference-shaped Python surface: suite.load / Environment / Physics accessors / JitterbugGymEnv."""
+import collections
+
+import numpy as np
+import pytest
+
+from jitterbug_amd import model
+
+pytestmark = pytest.mark.gpu
+
+
+def test_suite_load_reset_step_specs():
+    from jitterbug_amd import suite
+    from jitterbug_amd.specs import StepType
+    from oracle import oracle as O
+    P = model.default_params()
+    for task, D in model.OBS_DIM.items():
+        env = suite.load("jitterbug", task, task_kwargs=dict(random=3, norm_obs=True))
+        spec = env.action_spec()
+        assert spec.shape == (1,) and spec.minimum[0] == -1 and spec.maximum[0] == 1 and spec.dtype == np.float64
+        ospec = env.observation_spec()
+        assert isinstance(ospec, collections.OrderedDict) and sum(s.shape[0] for s in ospec.values()) == D
+        assert list(ospec)[:4] == ["position", "velocity", "motor_position", "motor_velocity"]
+        ts = env.reset()
+        assert ts.step_type == StepType.FIRST and ts.reward is None and ts.discount is None
+        assert ts.observation["motor_position"].shape == (1,) and ts.observation["position"].shape == (7,)
+        ts = env.step(0.8)
+        assert ts.step_type == StepType.MID and 0.0 <= ts.reward <= 1.0 and ts.discount == 1.0
+        # Physics accessors against the oracle's observation/reward on the same state
+        ph = env.physics
+        q, v = ph.qpos(), ph.qvel()
+        tgt = np.array([ph.target_position_xyz()[0], ph.target_position_xyz()[1], ph.target_direction_yaw() % (2 * np.pi)])
+        flat = np.concatenate(list(ts.observation.values()))
+        np.testing.assert_allclose(flat, O.observation(P, task, q, v, tgt), rtol=1e-5, atol=2e-6)
+        assert abs(ts.reward - O.reward(P, task, q, v, tgt)) < 1e-5
+        assert ph.jitterbug_position_xyz().shape == (3,) and ph.jitterbug_position_quat().shape == (4,)
+        assert ph.angle_jitterbug_to_target().shape == (1,) and -np.pi < ph.angle_jitterbug_to_target()[0] <= np.pi
+        assert -np.pi < ph.motor_position() <= np.pi
+        np.testing.assert_allclose(np.linalg.norm(ph.target_position_in_jitterbug_frame()),
+                                   np.linalg.norm(ph.target_position_xyz() - ph.jitterbug_position_xyz()), rtol=1e-9)
+        env.close()
+
+
+def test_episode_end_semantics_and_flat_observation():
+    from jitterbug_amd import suite
+    env = suite.load("jitterbug", "move_from_origin", task_kwargs=dict(random=0, time_limit=0.05),
+                     environment_kwargs=dict(flat_observation=True))
+    assert env._step_limit == pytest.approx(5.0) and env.control_timestep() == 0.01
+    ts = env.reset()
+    assert list(ts.observation) == ["observations"] and ts.observation["observations"].shape == (15,)
+    for t in range(4):
+        assert env.step([0.5]).mid()
+    ts = env.step(np.array([0.5]))
+    assert ts.last() and ts.discount == 1.0
+    ts = env.step(0.5)                       # a step after LAST is a reset
+    assert ts.first() and ts.reward is None
+    env.close()
+
+
+def test_gym_wrapper():
+    from jitterbug_amd import JitterbugGymEnv, suite
+    env = JitterbugGymEnv(suite.load("jitterbug", "move_to_pose", task_kwargs=dict(random=1),
+                                     environment_kwargs=dict(flat_observation=True)))
+    assert env.num_envs == 1
+    assert env.action_space.shape == (1,) and env.action_space.low[0] == -1 and env.action_space.dtype == np.float32
+    assert env.observation_space["observations"].shape == (19,)
+    obs = env.reset()
+    assert obs["observations"].shape == (19,)
+    total = 0.0
+    for t in range(20):
+        obs, r, done, info = env.step(env.action_space.sample())
+        total += r
+        assert not done and info == {}
+        env.render()
+    assert env.frame_count == 20 and np.isfinite(total)
+    env.close()
+
+
+def test_vec_env_shapes_and_done_flags():
+    from jitterbug_amd import JitterbugVecEnv
+    env = JitterbugVecEnv(100, "face_direction", seed=2, time_limit=0.03)
+    obs = env.reset()
+    assert obs.shape == (100, 16) and obs.dtype == np.float32
+    env.step_async(np.zeros(100))
+    obs, rew, done, infos = env.step_wait()
+    assert rew.shape == (100,) and done.dtype == bool and not done.any()
+    env.step(np.zeros(100))
+    _, _, done, _ = env.step(np.zeros(100))
+    assert done.all()
+    env.close()
