@@ -40,10 +40,10 @@ struct KArgs {
 
 // Stage the lane constant table(s) of this workgroup (one wave = a.epw envs) into LDS: one [LM_COUNT][4] copy for a
 // shared model, epw copies for per-env models.  Called by all 64 threads before the idle quads retire.
-__device__ __forceinline__ void stage_model(const KArgs& a, float* lds, int quad, int leg, LaneModel<float>& m) {
+__device__ __forceinline__ void stage_model(const KArgs& a, float* lds, int lblock, int quad, int leg, LaneModel<float>& m) {
     const int tsz = LM_COUNT * 4;
     if (a.per_env_model) {
-        const int env0 = (int)blockIdx.x * a.epw;
+        const int env0 = lblock * a.epw;
         for (int i = threadIdx.x; i < tsz * a.epw; i += blockDim.x) {
             int e = env0 + i / tsz;
             if (e >= a.n) e = a.n - 1;
@@ -117,9 +117,14 @@ __global__ __launch_bounds__(64) void jb_step_kernel(KArgs a, const float* __res
     // wave ballots only ever involve complete, active quads.
     extern __shared__ float lds[];           // [SC_COUNT][4*epw] per-lane scratch, then the lane constant table(s)
     const int quad = threadIdx.x >> 2, leg = threadIdx.x & 3;
-    const int env = (int)blockIdx.x * a.epw + quad;
+    // XCD-aware workgroup -> env-range map: hardware deals workgroups round-robin over the 8 XCDs (b and b+8 share one),
+    // so give XCD x one contiguous range of envs; then every 128-byte line of the SoA state arrays is touched by a single
+    // XCD's L2 instead of all eight (placement is a speed/traffic matter only, never correctness).
+    const int nb = (int)gridDim.x, b = (int)blockIdx.x, xcd = b & 7, per = nb >> 3, rem = nb & 7;
+    const int lblock = xcd * per + (xcd < rem ? xcd : rem) + (b >> 3);
+    const int env = lblock * a.epw + quad;
     LaneModel<float> m;
-    stage_model(a, lds + SC_COUNT * 4 * a.epw, quad, leg, m);
+    stage_model(a, lds + SC_COUNT * 4 * a.epw, lblock, quad, leg, m);
     if (quad >= a.epw || env >= a.n) return;
     const bool live = true;
     const int lane = env * 4 + leg;
@@ -135,12 +140,17 @@ __global__ __launch_bounds__(64) void jb_step_kernel(KArgs a, const float* __res
     s.st_xtra = 0.f; s.st_sweeps = 0.f; s.st_contact = 0.f;
 #endif
     const float ctrl = action[env];
-    SimOpts o; o.contacts = a.contacts; o.max_newton = a.max_newton; o.implicit_damp = 1;
+    SimOpts o; o.contacts = a.contacts; o.max_newton = a.max_newton; o.implicit_damp = 1; o.prof = nullptr;
+#ifdef JB_WAVE_STATS
+    const unsigned long long rt_start = __builtin_amdgcn_s_memrealtime();
+    if (a.wave_stats) { o.prof = a.wave_stats + (size_t)lblock * 16 + 4; if (threadIdx.x == 0) for (int i = 0; i < 12; i++) o.prof[i] = 0; }
+#endif
 #pragma unroll 1
     for (int k = 0; k < a.substeps; k++) substep<float>(m, scr, s, ctrl, o);
 #ifdef JB_WAVE_STATS
     if (threadIdx.x == 0 && a.wave_stats) {
-        unsigned long long* ws = a.wave_stats + (size_t)blockIdx.x * 4;
+        unsigned long long* ws = a.wave_stats + (size_t)lblock * 16;
+        ws[10] = __builtin_amdgcn_s_memrealtime() - rt_start;
         ws[0] = __builtin_amdgcn_s_memtime() - t_start; ws[1] = (unsigned long long)s.st_xtra; ws[2] = (unsigned long long)s.st_sweeps; ws[3] = (unsigned long long)s.st_contact;
     }
 #endif
@@ -353,8 +363,8 @@ int jb_create(const jb_config* cfg, jb_handle** out) {
     JB_HIP(hipMalloc(&h->d_qvel, sizeof(double) * 15 * N));
     JB_HIP(hipMalloc(&h->d_target, sizeof(double) * 3 * N));
 #ifdef JB_WAVE_STATS
-    JB_HIP(hipMalloc(&h->d_wave_stats, sizeof(unsigned long long) * 4 * N));
-    JB_HIP(hipMemset(h->d_wave_stats, 0, sizeof(unsigned long long) * 4 * N));
+    JB_HIP(hipMalloc(&h->d_wave_stats, sizeof(unsigned long long) * 16 * N));
+    JB_HIP(hipMemset(h->d_wave_stats, 0, sizeof(unsigned long long) * 16 * N));
 #endif
     JB_HIP(hipMemsetAsync(h->d_root, 0, sizeof(float) * ROOT_F * N, h->stream));
     JB_HIP(hipMemsetAsync(h->d_leg, 0, sizeof(float) * LEG_F * 4 * N, h->stream));
@@ -497,7 +507,7 @@ int jb_get_counters(jb_handle* h, int32_t* step_count, uint32_t* episode, float*
 int jb_debug_wave_stats(jb_handle* h, unsigned long long* out, int32_t n_waves) {
     if (!h || !out) return fail(JB_E_INVALID, "NULL");
     JB_HIP(hipStreamSynchronize(h->stream));
-    JB_HIP(hipMemcpy(out, h->d_wave_stats, sizeof(unsigned long long) * 4 * n_waves, hipMemcpyDeviceToHost));
+    JB_HIP(hipMemcpy(out, h->d_wave_stats, sizeof(unsigned long long) * 16 * n_waves, hipMemcpyDeviceToHost));
     return h->ka.epw;
 }
 #endif

@@ -40,8 +40,17 @@
 // where they are used instead of hoisting ~110 loads out of the substep loop and pinning them in registers
 #define JB_LAUNDER(p) asm volatile("" : "+v"(p))
 #else
+#define JB_NO_DEVICE_PROF 1
 #define JB_SCHED_FENCE() ((void)0)
 #define JB_LAUNDER(p) ((void)0)
+#endif
+
+#if defined(JB_WAVE_STATS) && !defined(JB_NO_DEVICE_PROF)
+#define JB_PROF_T0() unsigned long long _pt = __builtin_amdgcn_s_memtime()
+#define JB_PROF_ADD(o, i) do { unsigned long long _n = __builtin_amdgcn_s_memtime(); if ((o).prof) (o).prof[i] += _n - _pt; _pt = _n; } while (0)
+#else
+#define JB_PROF_T0() ((void)0)
+#define JB_PROF_ADD(o, i) ((void)0)
 #endif
 
 namespace jb {
@@ -109,6 +118,12 @@ template <typename V> JB_HD Vec3<V> operator*(const Vec3<V>& a, const V& s) { re
 template <typename V> JB_HD V dot(const Vec3<V>& a, const Vec3<V>& b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 template <typename V> JB_HD Vec3<V> cross(const Vec3<V>& a, const Vec3<V>& b) {
     return v3<V>(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+// acc + a0*b0 + a1*b1 + a2*b2 as a chain of three fused multiply-adds
+template <typename V> JB_HD V fma3(const V& acc, const V& a0, const V& b0, const V& a1, const V& b1, const V& a2, const V& b2) {
+    V t = acc + a0 * b0;
+    t = t + a1 * b1;
+    return t + a2 * b2;
 }
 template <typename V, typename MKT> JB_HD Vec3<V> sel_v3(const MKT& k, const Vec3<V>& a, const Vec3<V>& b) { return v3<V>(sel(k, a.x, b.x), sel(k, a.y, b.y), sel(k, a.z, b.z)); }
 template <typename V> JB_HD typename lane_traits<V>::uint zero_u() { return mbit(lt(V(1), V(0))); }
@@ -253,12 +268,12 @@ template <typename V> JB_HD void acc_clear(NewtonAcc<V>& acc) {
 
 // Solve  [A B Bm; B^T C 0; Bm^T 0 Cm] y = rhs  where the matrix is M (scratch) + the contact terms in `acc`
 // (+ hb1/hb2 on the leg diagonal: implicit joint damping) and rhs = tau (scratch) + acc.r*.
-//   A, tau_root, Bm, Cm : replicated in the 4 lanes, added ONCE;  acc.A, acc.rr (and acc.Bm/Cm/rm if XTRA): lane-private
+//   A, tau_root, Bm, Cm : replicated in the 4 lanes, added ONCE;  acc.A, acc.rr, acc.Bm/Cm/rm: lane-private
 //   parts that are summed over the quad;  B, C, tau_leg: lane-private leg branch.
 // The own leg (2x2) and the motor (1x1) are eliminated onto the 6 root dofs; the 6x6 Schur complement is
 // Cholesky-factored redundantly by the 4 lanes.
 template <typename V>
-JB_HD void star_solve(const LaneScratch<V>& sc, const NewtonAcc<V>& acc, bool xtra, const V& hb1, const V& hb2, V (&yr)[6], V (&yl)[2], V& ym) {
+JB_HD void star_solve(const LaneScratch<V>& sc, const NewtonAcc<V>& acc, const V& hb1, const V& hb2, V (&yr)[6], V (&yl)[2], V& ym) {
     V B[6][2];
 #pragma unroll
     for (int i = 0; i < 6; i++) { B[i][0] = sc.ld(SC_MB + 2 * i) + acc.B[i][0]; B[i][1] = sc.ld(SC_MB + 2 * i + 1) + acc.B[i][1]; }
@@ -278,12 +293,10 @@ JB_HD void star_solve(const LaneScratch<V>& sc, const NewtonAcc<V>& acc, bool xt
     V bm[6], cm = sc.ld(SC_MCM), rmt = sc.ld(SC_TM);
 #pragma unroll
     for (int i = 0; i < 6; i++) bm[i] = sc.ld(SC_MBM + i);
-    if (xtra) {
 #pragma unroll
-        for (int i = 0; i < 6; i++) bm[i] = bm[i] + quad_sum(acc.Bm[i]);
-        cm = cm + quad_sum(acc.Cm);
-        rmt = rmt + quad_sum(acc.rm);
-    }
+    for (int i = 0; i < 6; i++) bm[i] = bm[i] + quad_sum(acc.Bm[i]);
+    cm = cm + quad_sum(acc.Cm);
+    rmt = rmt + quad_sum(acc.rm);
     V icm = V(1) / cm;
 #pragma unroll
     for (int i = 0; i < 6; i++) {
@@ -349,63 +362,78 @@ template <typename V> JB_HD V impedance(const LaneModel<V>& m, const V& dist) {
 // serves every slot, body level and mode (all three are wave-uniform run-time values) so that the solver loop
 // stays small enough for the instruction cache.
 // level: 0 root body, 1 upper leg (shoulder only), 2 lower leg (shoulder+knee), 3 motor body.
-// mode 0: accumulate the Newton matrix / rhs terms for the active set at y;  mode 1: accumulate the constraint
-// force  -B^T W rho  into rr/rl/rm.
+// mode 0: accumulate the Newton matrix / rhs terms for the active set at y;  mode 2: only record the active set at y
+// (the cheap convergence check).
 // Direction data in the scratch (SC_DD + 12k, k = n, t1, t2): the contact rows are affine in the contact point x:
 //   J_sh(x,d) = (d x e1).(x - a1) = wS.x - oS,   J_kn(x,d) = wK.x - oK,   J_m(x,d) = (d x em).(x - am)
 JB_HD constexpr int slot_level(int slot) { return slot < 5 ? 2 : slot < 10 ? 1 : slot < 23 ? 0 : 3; }
+
+// contact-frame direction data of the lane, read from the scratch ONCE per sweep (one batch of LDS reads)
+template <typename V> struct DirRegs {
+    Vec3<V> d[3], wS[3], wK[3], wM[3];
+    V oS[3], oK[3], oM[3], du[3];
+    V mu, fr2, bb, kk;
+};
+template <typename V> JB_HD void load_dirs(const LaneModel<V>& m, const LaneScratch<V>& sc, bool xtra, DirRegs<V>& dr) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        dr.d[k] = sc.ld3(SC_DD + 12 * k); dr.wS[k] = sc.ld3(SC_DD + 12 * k + 3); dr.wK[k] = sc.ld3(SC_DD + 12 * k + 6);
+        dr.oS[k] = sc.ld(SC_DD + 12 * k + 9); dr.oK[k] = sc.ld(SC_DD + 12 * k + 10); dr.du[k] = sc.ld(SC_DD + 12 * k + 11);
+        dr.wM[k] = v3<V>(V(0), V(0), V(0)); dr.oM[k] = V(0);
+    }
+    dr.mu = m.c[LM_MU]; dr.fr2 = m.c[LM_FR2]; dr.bb = m.c[LM_BB]; dr.kk = m.c[LM_KK];
+    if (xtra) {
+        Vec3<V> em = ldv3(m, LM_EM), am = ldv3(m, LM_AM);
+#pragma unroll
+        for (int k = 0; k < 3; k++) { dr.wM[k] = cross(dr.d[k], em); dr.oM[k] = dot(dr.wM[k], am); }
+    }
+}
+
 template <typename V>
-JB_HD void contact_accumulate(const LaneModel<V>& m, const LaneScratch<V>& sc, int slot, int mode, const Vec3<V>& w, const V& thd1, const V& thd2,
-                              const V& phid, const V (&yr)[6], const V (&yl)[2], const V& ym, NewtonAcc<V>& acc) {
+JB_HD void contact_accumulate(const LaneModel<V>& m, const LaneScratch<V>& sc, const DirRegs<V>& dr, int slot, int mode, const Vec3<V>& w,
+                              const V& thd1, const V& thd2, const V& phid, const V (&yr)[6], const V (&yl)[2], const V& ym, NewtonAcc<V>& acc) {
     using U = typename lane_traits<V>::uint;
     const int level = slot_level(slot);
-    const bool has_sh = (level == 1 || level == 2), has_kn = (level == 2), has_m = (level == 3);
+    // wave-uniform level flags as 0/1 factors: the body below is branch free so its LDS reads issue as one batch
+    const V f_sh = V((level == 1 || level == 2) ? 1.0f : 0.0f), f_kn = V(level == 2 ? 1.0f : 0.0f), f_m = V(level == 3 ? 1.0f : 0.0f);
     const Vec3<V> x = sc.ld3(SC_CAND + 4 * slot);
     const V dist = sc.ld(SC_CAND + 4 * slot + 3);
-    const auto valid = lt(dist, V(0));
     const V tran = m.c[level == 2 ? LM_TRAN2 : level == 1 ? LM_TRAN1 : level == 0 ? LM_TRAN0 : LM_TRANM];
+    const auto valid = lt(dist, V(0));
     V imp = impedance(m, dist);
-    V R0 = (V(1) - imp) / imp * tran * (V(1) + m.c[LM_FR2]);
-    V mu = m.c[LM_MU];
+    V R0 = (V(1) - imp) / imp * tran * (V(1) + dr.fr2);
+    V mu = dr.mu;
     V D = sel(valid, V(1) / (V(2) * mu * mu * R0), V(0));
     // rows of B for the three directions: [x cross d (3), d (3), J_sh, J_kn | J_m]
     V Bj[3][8], rho[3], ahat[3];
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-        const Vec3<V> d = sc.ld3(SC_DD + 12 * k);
+        const Vec3<V> d = dr.d[k];
         Vec3<V> ang = cross(x, d);
         Bj[k][0] = ang.x; Bj[k][1] = ang.y; Bj[k][2] = ang.z;
         Bj[k][3] = d.x; Bj[k][4] = d.y; Bj[k][5] = d.z;
-        V vel = dot(ang, w) + sc.ld(SC_DD + 12 * k + 11);
-        V acc_ = ang.x * yr[0] + ang.y * yr[1] + ang.z * yr[2] + d.x * yr[3] + d.y * yr[4] + d.z * yr[5];
-        Bj[k][6] = V(0); Bj[k][7] = V(0);
-        if (has_sh) {
-            Bj[k][6] = dot(sc.ld3(SC_DD + 12 * k + 3), x) - sc.ld(SC_DD + 12 * k + 9);
-            vel = vel + Bj[k][6] * thd1; acc_ = acc_ + Bj[k][6] * yl[0];
-        }
-        if (has_kn) {
-            Bj[k][7] = dot(sc.ld3(SC_DD + 12 * k + 6), x) - sc.ld(SC_DD + 12 * k + 10);
-            vel = vel + Bj[k][7] * thd2; acc_ = acc_ + Bj[k][7] * yl[1];
-        }
-        if (has_m) {
-            Vec3<V> wM = cross(d, ldv3(m, LM_EM));
-            Bj[k][7] = dot(wM, x) - dot(wM, ldv3(m, LM_AM));
-            vel = vel + Bj[k][7] * phid; acc_ = acc_ + Bj[k][7] * ym;
-        }
-        ahat[k] = -m.c[LM_BB] * vel;
-        if (k == 0) ahat[k] = ahat[k] - m.c[LM_KK] * imp * dist;
+        Bj[k][6] = f_sh * (dot(dr.wS[k], x) - dr.oS[k]);
+        Bj[k][7] = f_kn * (dot(dr.wK[k], x) - dr.oK[k]) + f_m * (dot(dr.wM[k], x) - dr.oM[k]);
+        V jdot = f_kn * thd2 + f_m * phid, jacc = f_kn * yl[1] + f_m * ym;      // what column 7 multiplies
+        V vel = dot(ang, w) + dr.du[k] + Bj[k][6] * thd1 + Bj[k][7] * jdot;
+        V acc_ = ang.x * yr[0] + ang.y * yr[1] + ang.z * yr[2] + d.x * yr[3] + d.y * yr[4] + d.z * yr[5] + Bj[k][6] * yl[0] + Bj[k][7] * jacc;
+        ahat[k] = -dr.bb * vel;
+        if (k == 0) ahat[k] = ahat[k] - dr.kk * imp * dist;
         rho[k] = acc_ - ahat[k];
     }
+    const bool has_sh = (level == 1 || level == 2), has_kn = (level == 2), has_m = (level == 3);
     // pyramid edges  r = rho_n +- mu rho_t
     V mr1 = mu * rho[1], mr2 = mu * rho[2];
     auto a1 = lt(rho[0] + mr1, V(0)), a2 = lt(rho[0] - mr1, V(0)), a3 = lt(rho[0] + mr2, V(0)), a4 = lt(rho[0] - mr2, V(0));
-    V f1 = sel(a1, V(1), V(0)), f2 = sel(a2, V(1), V(0)), f3 = sel(a3, V(1), V(0)), f4 = sel(a4, V(1), V(0));
-    V Wnn = D * (f1 + f2 + f3 + f4), Wn1 = D * mu * (f1 - f2), Wn2 = D * mu * (f3 - f4), W11 = D * mu * mu * (f1 + f2), W22 = D * mu * mu * (f3 + f4);
-    if (mode == 0) {
-        // active-set record: exact 5-bit fields for the always-evaluated slots 0..4, a lane-private hash for the rest
+    {   // active-set record: exact 5-bit fields for the always-evaluated slots 0..4, a lane-private hash for the rest
         U bits = (mbit(a1) + mbit(a2) * 2u + mbit(a3) * 4u + mbit(a4) * 8u + 16u);
         if (slot < 5) acc.bw0 = acc.bw0 + selu(valid, bits, zero_u<V>()) * (1u << (5 * slot));
         else acc.xh = acc.xh * 0x9E3779B1u + selu(valid, bits, zero_u<V>() + 7u);
+    }
+    if (mode == 2) return;
+    V f1 = sel(a1, V(1), V(0)), f2 = sel(a2, V(1), V(0)), f3 = sel(a3, V(1), V(0)), f4 = sel(a4, V(1), V(0));
+    V Wnn = D * (f1 + f2 + f3 + f4), Wn1 = D * mu * (f1 - f2), Wn2 = D * mu * (f3 - f4), W11 = D * mu * mu * (f1 + f2), W22 = D * mu * mu * (f3 + f4);
+    {
         V wa0 = Wnn * ahat[0] + Wn1 * ahat[1] + Wn2 * ahat[2];
         V wa1 = Wn1 * ahat[0] + W11 * ahat[1];
         V wa2 = Wn2 * ahat[0] + W22 * ahat[2];
@@ -419,51 +447,42 @@ JB_HD void contact_accumulate(const LaneModel<V>& m, const LaneScratch<V>& sc, i
 #pragma unroll
         for (int i = 0; i < 6; i++) {
 #pragma unroll
-            for (int j = 0; j <= i; j++) acc.A[tri(i, j)] = acc.A[tri(i, j)] + (Bj[0][i] * WB[0][j] + Bj[1][i] * WB[1][j] + Bj[2][i] * WB[2][j]);
-            acc.rr[i] = acc.rr[i] + (Bj[0][i] * wa0 + Bj[1][i] * wa1 + Bj[2][i] * wa2);
+            for (int j = 0; j <= i; j++) acc.A[tri(i, j)] = fma3(acc.A[tri(i, j)], Bj[0][i], WB[0][j], Bj[1][i], WB[1][j], Bj[2][i], WB[2][j]);
+            acc.rr[i] = fma3(acc.rr[i], Bj[0][i], wa0, Bj[1][i], wa1, Bj[2][i], wa2);
         }
         if (has_sh) {
 #pragma unroll
-            for (int i = 0; i < 6; i++) acc.B[i][0] = acc.B[i][0] + (Bj[0][6] * WB[0][i] + Bj[1][6] * WB[1][i] + Bj[2][6] * WB[2][i]);
-            acc.C11 = acc.C11 + (Bj[0][6] * WB[0][6] + Bj[1][6] * WB[1][6] + Bj[2][6] * WB[2][6]);
-            acc.rl[0] = acc.rl[0] + (Bj[0][6] * wa0 + Bj[1][6] * wa1 + Bj[2][6] * wa2);
+            for (int i = 0; i < 6; i++) acc.B[i][0] = fma3(acc.B[i][0], Bj[0][6], WB[0][i], Bj[1][6], WB[1][i], Bj[2][6], WB[2][i]);
+            acc.C11 = fma3(acc.C11, Bj[0][6], WB[0][6], Bj[1][6], WB[1][6], Bj[2][6], WB[2][6]);
+            acc.rl[0] = fma3(acc.rl[0], Bj[0][6], wa0, Bj[1][6], wa1, Bj[2][6], wa2);
         }
         if (has_kn) {
 #pragma unroll
-            for (int i = 0; i < 6; i++) acc.B[i][1] = acc.B[i][1] + (Bj[0][7] * WB[0][i] + Bj[1][7] * WB[1][i] + Bj[2][7] * WB[2][i]);
-            acc.C12 = acc.C12 + (Bj[0][6] * WB[0][7] + Bj[1][6] * WB[1][7] + Bj[2][6] * WB[2][7]);
-            acc.C22 = acc.C22 + (Bj[0][7] * WB[0][7] + Bj[1][7] * WB[1][7] + Bj[2][7] * WB[2][7]);
-            acc.rl[1] = acc.rl[1] + (Bj[0][7] * wa0 + Bj[1][7] * wa1 + Bj[2][7] * wa2);
+            for (int i = 0; i < 6; i++) acc.B[i][1] = fma3(acc.B[i][1], Bj[0][7], WB[0][i], Bj[1][7], WB[1][i], Bj[2][7], WB[2][i]);
+            acc.C12 = fma3(acc.C12, Bj[0][6], WB[0][7], Bj[1][6], WB[1][7], Bj[2][6], WB[2][7]);
+            acc.C22 = fma3(acc.C22, Bj[0][7], WB[0][7], Bj[1][7], WB[1][7], Bj[2][7], WB[2][7]);
+            acc.rl[1] = fma3(acc.rl[1], Bj[0][7], wa0, Bj[1][7], wa1, Bj[2][7], wa2);
         }
         if (has_m) {
 #pragma unroll
-            for (int i = 0; i < 6; i++) acc.Bm[i] = acc.Bm[i] + (Bj[0][7] * WB[0][i] + Bj[1][7] * WB[1][i] + Bj[2][7] * WB[2][i]);
-            acc.Cm = acc.Cm + (Bj[0][7] * WB[0][7] + Bj[1][7] * WB[1][7] + Bj[2][7] * WB[2][7]);
-            acc.rm = acc.rm + (Bj[0][7] * wa0 + Bj[1][7] * wa1 + Bj[2][7] * wa2);
+            for (int i = 0; i < 6; i++) acc.Bm[i] = fma3(acc.Bm[i], Bj[0][7], WB[0][i], Bj[1][7], WB[1][i], Bj[2][7], WB[2][i]);
+            acc.Cm = fma3(acc.Cm, Bj[0][7], WB[0][7], Bj[1][7], WB[1][7], Bj[2][7], WB[2][7]);
+            acc.rm = fma3(acc.rm, Bj[0][7], wa0, Bj[1][7], wa1, Bj[2][7], wa2);
         }
-    } else {
-        // constraint force  qfrc = B^T (-W rho)
-        V g0 = -(Wnn * rho[0] + Wn1 * rho[1] + Wn2 * rho[2]);
-        V g1 = -(Wn1 * rho[0] + W11 * rho[1]);
-        V g2 = -(Wn2 * rho[0] + W22 * rho[2]);
-#pragma unroll
-        for (int i = 0; i < 6; i++) acc.rr[i] = acc.rr[i] + (Bj[0][i] * g0 + Bj[1][i] * g1 + Bj[2][i] * g2);
-        if (has_sh) acc.rl[0] = acc.rl[0] + (Bj[0][6] * g0 + Bj[1][6] * g1 + Bj[2][6] * g2);
-        if (has_kn) acc.rl[1] = acc.rl[1] + (Bj[0][7] * g0 + Bj[1][7] * g1 + Bj[2][7] * g2);
-        if (has_m) acc.rm = acc.rm + (Bj[0][7] * g0 + Bj[1][7] * g1 + Bj[2][7] * g2);
     }
 }
 
-// all candidate slots against y: slots 0..4 always (wave-uniform skip of slots nobody uses), 5..27 on the rare path
+// every live candidate slot (bit set in live_slots) against y
 template <typename V>
-JB_HD void contact_sweep(const LaneModel<V>& m, const LaneScratch<V>& sc, bool xtra, int mode, const Vec3<V>& w, const V& thd1, const V& thd2,
+JB_HD void contact_sweep(const LaneModel<V>& m, const LaneScratch<V>& sc, bool xtra, unsigned live_slots, int mode, const Vec3<V>& w, const V& thd1, const V& thd2,
                          const V& phid, const V (&yr)[6], const V (&yl)[2], const V& ym, NewtonAcc<V>& acc) {
     acc_clear(acc);
-    const int nslot = xtra ? 28 : 5;
+    DirRegs<V> dr;
+    load_dirs(m, sc, xtra, dr);
 #pragma unroll 1
-    for (int slot = 0; slot < nslot; slot++) {
-        if (!any_lane(lt(sc.ld(SC_CAND + 4 * slot + 3), V(0)))) continue;
-        contact_accumulate<V>(m, sc, slot, mode, w, thd1, thd2, phid, yr, yl, ym, acc);
+    for (unsigned rest = live_slots; rest != 0u; rest &= rest - 1u) {
+        const int slot = __builtin_ctz(rest);
+        contact_accumulate<V>(m, sc, dr, slot, mode, w, thd1, thd2, phid, yr, yl, ym, acc);
     }
 }
 
@@ -511,15 +530,20 @@ JB_HD void cylinder_floor(const Vec3<V>& c, const Vec3<V>& ax_in, const Vec3<V>&
 
 
 // store a candidate: position and effective distance (+1 when it is not a contact)
+// Returns the wave-uniform bit "some lane of the wave has a contact in this slot" (shifted to the slot's position):
+// the sweeps of the substep visit only slots whose bit is set.
 template <typename V, typename MKT>
-JB_HD void cand_store(const LaneScratch<V>& sc, int slot, const Vec3<V>& x, const V& dist, const MKT& on) {
+JB_HD unsigned cand_store(const LaneScratch<V>& sc, int slot, const Vec3<V>& x, const V& dist, const MKT& on) {
     sc.st3(SC_CAND + 4 * slot, x);
     sc.st(SC_CAND + 4 * slot + 3, sel(on, dist, V(1)));
+    return any_lane(on) ? (1u << slot) : 0u;
 }
 template <typename V, typename MKT>
-JB_HD void cand_store_cyl(const LaneScratch<V>& sc, int slot0, const CylContacts<V>& c, const MKT& gate) {
+JB_HD unsigned cand_store_cyl(const LaneScratch<V>& sc, int slot0, const CylContacts<V>& c, const MKT& gate) {
+    unsigned live = 0;
 #pragma unroll
-    for (int k = 0; k < 4; k++) cand_store(sc, slot0 + k, c.x[k], c.dist[k], mand(c.on[k], gate));
+    for (int k = 0; k < 4; k++) live |= cand_store(sc, slot0 + k, c.x[k], c.dist[k], mand(c.on[k], gate));
+    return live;
 }
 
 // ----------------------------------------------------------------------------- options
@@ -527,6 +551,7 @@ struct SimOpts {
     int contacts;        // 0: contacts disabled (MuJoCo disableflags=contact)
     int max_newton;      // cap on Newton iterations per substep
     int implicit_damp;   // 1: MuJoCo Euler implicit joint damping
+    unsigned long long* prof;   // diagnostic builds: per-wave cycle accumulators [phaseA, check sweeps, full sweeps, solves, integrate]
 };
 
 // small-angle sin/cos for the leg hinges (|th| < 1: truncation < 1e-9), exact libm otherwise
@@ -544,6 +569,9 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
     const V h = m.c[LM_H];
     const Vec3<V> w = v3<V>(s.wx, s.wy, s.wz);
     bool any_contact = false;
+    unsigned live_slots = 0;            // wave-uniform: slots in which some lane has a contact
+    MK env_con = lt(V(1), V(0));       // this env (quad) has at least one contact
+    JB_PROF_T0();
 
     {   // ================= phase A: kinematics, composite inertia, bias forces, contact candidates -> scratch
         V qn = V(1) / vsqrt(s.qw * s.qw + s.qx * s.qx + s.qy * s.qy + s.qz * s.qz);
@@ -587,29 +615,29 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
             Vec3<V> foot = a2 + mul(R12, ldv3(m, LM_DFOOT));
             V fdist = s.pz + dot(foot, nb) - m.c[LM_FOOT_R];
             MK fon = lt(fdist, V(0));
-            cand_store(sc, 0, foot - nb * (m.c[LM_FOOT_R] + fdist * V(0.5)), fdist, fon);
+            live_slots |= cand_store(sc, 0, foot - nb * (m.c[LM_FOOT_R] + fdist * V(0.5)), fdist, fon);
             CylContacts<V> lc;
             MK all_on = lt(V(0), V(1));
             cylinder_floor(a2 + mul(R12, ldv3(m, LM_LC_D)), mul(R12, ldv3(m, LM_LC_AX)), mul(R12, ldv3(m, LM_LC_XA)), m.c[LM_LC_R], m.c[LM_LC_H], nb, s.pz, all_on, lc);
-            cand_store_cyl(sc, 1, lc, all_on);
+            live_slots |= cand_store_cyl(sc, 1, lc, all_on);
             MK any_con = mor(fon, lc.on[0]);
             if (xtra) {
                 // every remaining geom of the model against the floor
                 CylContacts<V> cy;
                 cylinder_floor(a1 + mul(R1, ldc3(m, LM_UC_D)), mul(R1, ldc3(m, LM_UC_AX)), mul(R1, ldc3(m, LM_UC_XA)), ldc(m, LM_UC_R), ldc(m, LM_UC_H), nb, s.pz, all_on, cy);
-                cand_store_cyl(sc, 5, cy, all_on);
+                live_slots |= cand_store_cyl(sc, 5, cy, all_on);
                 any_con = mor(any_con, cy.on[0]);
                 Vec3<V> tip = a1 + mul(R1, ldc3(m, LM_DTIP));
                 V tipd = s.pz + dot(tip, nb) - ldc(m, LM_TIP_R);
-                cand_store(sc, 9, tip - nb * (ldc(m, LM_TIP_R) + tipd * V(0.5)), tipd, lt(tipd, V(0)));
+                live_slots |= cand_store(sc, 9, tip - nb * (ldc(m, LM_TIP_R) + tipd * V(0.5)), tipd, lt(tipd, V(0)));
                 any_con = mor(any_con, lt(tipd, V(0)));
                 // lane cylinder (root body: lane 2 screw1; motor body: lane 3 threadMass)
                 MK x_onm = gt(ldc(m, LM_X_ONM), V(0.5));
                 Vec3<V> xc_c = ldc3(m, LM_XC_C), xc_ax = ldc3(m, LM_XC_AX), xc_xa = ldc3(m, LM_XC_XA);
                 cylinder_floor(sel_v3(x_onm, am + mul(Rm, xc_c - am), xc_c), sel_v3(x_onm, mul(Rm, xc_ax), xc_ax), sel_v3(x_onm, mul(Rm, xc_xa), xc_xa),
                                ldc(m, LM_XC_R), ldc(m, LM_XC_H), nb, s.pz, gt(ldc(m, LM_XC_EN), V(0.5)), cy);
-                cand_store_cyl(sc, 10, cy, mnot(x_onm));
-                cand_store_cyl(sc, 23, cy, x_onm);
+                live_slots |= cand_store_cyl(sc, 10, cy, mnot(x_onm));
+                live_slots |= cand_store_cyl(sc, 23, cy, x_onm);
                 any_con = mor(any_con, cy.on[0]);
                 {   // lane ellipsoid: support point in direction -n
                     Mat3<V> Re0, Re;
@@ -627,8 +655,8 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
                     V elld = s.pz + dot(sup, nb);
                     MK ellon = mand(gt(ldc(m, LM_XE_EN), V(0.5)), lt(elld, V(0)));
                     Vec3<V> ellx = sup - nb * (elld * V(0.5));
-                    cand_store(sc, 14, ellx, elld, mand(ellon, mnot(x_onm)));
-                    cand_store(sc, 27, ellx, elld, mand(ellon, x_onm));
+                    live_slots |= cand_store(sc, 14, ellx, elld, mand(ellon, mnot(x_onm)));
+                    live_slots |= cand_store(sc, 27, ellx, elld, mand(ellon, x_onm));
                     any_con = mor(any_con, ellon);
                 }
                 {   // lane box (root body): first 4 penetrating vertices in vertex order
@@ -645,12 +673,13 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
                         V d = s.pz + dot(pnt, nb);
                         MK on = mand(mand(ben, lt(d, V(0))), lt(cnt, V(3.5)));
                         cnt = cnt + sel(on, V(1), V(0));
-                        cand_store(sc, 15 + vtx, pnt - nb * (d * V(0.5)), d, on);
+                        live_slots |= cand_store(sc, 15 + vtx, pnt - nb * (d * V(0.5)), d, on);
                         any_con = mor(any_con, on);
                     }
                 }
             }
             any_contact = any_lane(any_con);
+            env_con = neq_u(quad_sum_u(mbit(any_con)), zero_u<V>());
             if (any_contact) {
                 // direction data for the contact frame (n, t1, t2) = R^T (ez, ey, -ex)
 #pragma unroll
@@ -743,6 +772,7 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
     }
     JB_SCHED_FENCE();
 
+    JB_PROF_ADD(o, 0);
     // ================= phase B: contact solve (primal Newton on the active set) and final acceleration, ONE loop:
     //   while the active set changes:  H(active set at y) y' = tau + contact rhs          (M without damping)
     //   then:  (M + h diag(b)) qacc = tau + qfrc_constraint(y)                            (MuJoCo Euler, implicit joint damping)
@@ -750,7 +780,7 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
     {
         NewtonAcc<V> acc;
         bool final_pass = !any_contact;
-        MK unconverged = lt(V(1), V(0));
+        MK unconverged = lt(V(0), V(1));
         U prev_bw0 = zero_u<V>(), prev_xh = zero_u<V>();
         if (any_contact) {      // warm start (world linear part rotated into the root frame)
             Mat3<V> R;
@@ -769,22 +799,57 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
 #pragma unroll 1
         for (int it = 0;; it++) {
             if (!final_pass) {
-                contact_sweep<V>(m, sc, xtra, 0, w, s.thd1, s.thd2, s.phid, yr, yl, ym, acc);
+                if (it > 0) {
+                    // cheap pass: only the active set at the new iterate.  The ENV's set changed if any lane of the quad
+                    // saw a different record; when nobody's changed, every y is the exact minimiser
+                    contact_sweep<V>(m, sc, xtra, live_slots, 2, w, s.thd1, s.thd2, s.phid, yr, yl, ym, acc);
+                    JB_PROF_ADD(o, 1);
+                    MK changed = mor(neq_u(acc.bw0, prev_bw0), neq_u(acc.xh, prev_xh));
+                    unconverged = neq_u(quad_sum_u(mbit(changed)), zero_u<V>());
+                    if (!any_lane(unconverged) || it >= o.max_newton) {
+                        s.fail = s.fail + sel(unconverged, V(1), V(0));
+                        final_pass = true;
+                    }
+                }
+                if (!final_pass) {
+                    contact_sweep<V>(m, sc, xtra, live_slots, 0, w, s.thd1, s.thd2, s.phid, yr, yl, ym, acc);
+                    prev_bw0 = acc.bw0; prev_xh = acc.xh;
+                    JB_PROF_ADD(o, 2);
 #ifdef JB_WAVE_STATS
-                s.st_sweeps = s.st_sweeps + V(1);
+                    s.st_sweeps = s.st_sweeps + V(1);
 #endif
-                // the active set of the ENV changed if any lane of the quad saw a different record
-                MK changed = mor(neq_u(acc.bw0, prev_bw0), neq_u(acc.xh, prev_xh));
-                prev_bw0 = acc.bw0; prev_xh = acc.xh;
-                unconverged = (it == 0) ? lt(V(0), V(1)) : neq_u(quad_sum_u(mbit(changed)), zero_u<V>());
-                if (!any_lane(unconverged) || it >= o.max_newton) {
-                    s.fail = s.fail + sel(unconverged, V(1), V(0));
-                    final_pass = true;
-                    contact_sweep<V>(m, sc, xtra, 1, w, s.thd1, s.thd2, s.phid, yr, yl, ym, acc);     // constraint force at the solution
+                } else {
+                    // At the minimiser  H y = tau + sum B^T W ahat,  so the constraint force is  qfrc = M y - tau.  Load
+                    // acc so that the solve below sees  rhs = tau + qfrc = M y  (replicated parts enter the quad sums as 1/4).
+                    acc_clear(acc);
+                    V my[6];
+#pragma unroll
+                    for (int i = 0; i < 6; i++) {
+                        V t = sc.ld(SC_MBM + i) * ym - sc.ld(SC_TR + i);
+#pragma unroll
+                        for (int j = 0; j < 6; j++) t = t + sc.ld(SC_MA + tri(i, j)) * yr[j];
+                        my[i] = t;
+                    }
+                    V l0 = sc.ld(SC_MC) * yl[0] + sc.ld(SC_MC + 1) * yl[1] - sc.ld(SC_TL);
+                    V l1 = sc.ld(SC_MC + 1) * yl[0] + sc.ld(SC_MC + 2) * yl[1] - sc.ld(SC_TL + 1);
+                    V mm_ = sc.ld(SC_MCM) * ym - sc.ld(SC_TM);
+#pragma unroll
+                    for (int i = 0; i < 6; i++) {
+                        V b0 = sc.ld(SC_MB + 2 * i), b1 = sc.ld(SC_MB + 2 * i + 1);
+                        acc.rr[i] = V(0.25) * my[i] + b0 * yl[0] + b1 * yl[1];
+                        l0 = l0 + b0 * yr[i]; l1 = l1 + b1 * yr[i];
+                        mm_ = mm_ + sc.ld(SC_MBM + i) * yr[i];
+                    }
+                    acc.rl[0] = l0; acc.rl[1] = l1; acc.rm = V(0.25) * mm_;
+                    // an env without contacts has qfrc = 0 exactly, whatever the rest of its wave is doing
+#pragma unroll
+                    for (int i = 0; i < 6; i++) acc.rr[i] = sel(env_con, acc.rr[i], V(0));
+                    acc.rl[0] = sel(env_con, acc.rl[0], V(0)); acc.rl[1] = sel(env_con, acc.rl[1], V(0)); acc.rm = sel(env_con, acc.rm, V(0));
                 }
             }
             V nyr[6], nyl[2], nym;
-            star_solve<V>(sc, acc, xtra, final_pass ? hb1 : V(0), final_pass ? hb2 : V(0), nyr, nyl, nym);
+            star_solve<V>(sc, acc, final_pass ? hb1 : V(0), final_pass ? hb2 : V(0), nyr, nyl, nym);
+            JB_PROF_ADD(o, 3);
             if (final_pass) {
 #pragma unroll
                 for (int i = 0; i < 6; i++) yr[i] = nyr[i];
@@ -832,6 +897,7 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
         s.phi = pp - k * V(6.283185307179586);
         s.turns = s.turns + k;
     }
+    JB_PROF_ADD(o, 4);
 }
 
 // One physics substep.  A wave-uniform broadphase decides whether only the foot sphere + lower-leg cylinder can

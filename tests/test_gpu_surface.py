@@ -37,7 +37,7 @@ def test_suite_load_reset_step_specs():
         assert ph.angle_jitterbug_to_target().shape == (1,) and -np.pi < ph.angle_jitterbug_to_target()[0] <= np.pi
         assert -np.pi < ph.motor_position() <= np.pi
         np.testing.assert_allclose(np.linalg.norm(ph.target_position_in_jitterbug_frame()),
-                                   np.linalg.norm(ph.target_position_xyz() - ph.jitterbug_position_xyz()), rtol=1e-9)
+                                   np.linalg.norm(ph.target_position_xyz() - ph.jitterbug_position_xyz()), rtol=1e-5)   # fp32 quaternion: unit to ~1e-7
         env.close()
 
 

@@ -12,12 +12,16 @@ rng = np.random.default_rng(0)
 for t in range(150):
     env.step(rng.uniform(-1, 1, size=n).astype(np.float32))
 L = _lib.load()
-buf = np.zeros((n, 4), dtype=np.uint64)
+buf = np.zeros((n, 16), dtype=np.uint64)
 L.jb_debug_wave_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
 e = L.jb_debug_wave_stats(env._h, buf.ctypes.data, n)
 nw = (n + e - 1) // e
 b = buf[:nw].astype(np.float64)
-cyc = b[:, 0] / 100.0   # s_memtime ticks at 100 MHz -> microseconds
+cyc = b[:, 0] / 100.0   # shader cycles / 100
+rt = b[:, 10] / 100.0   # s_memrealtime ticks (100 MHz) -> microseconds
+print('real time us: mean %.1f max %.1f ; clock MHz %.0f' % (rt.mean(), rt.max(), (b[:,0].sum()/b[:,10].sum())*100))
+ph = b[:, 4:9]
+print('phase cycles per substep: A %.0f check %.0f full %.0f solve %.0f integrate %.0f ; sum/total %.2f' % (*(ph.mean(0)/50), ph.sum()/b[:,0].sum()))
 print("epw", e, "waves", nw)
 print("wave time us: mean %.1f median %.1f p90 %.1f p99 %.1f max %.1f" % (cyc.mean(), np.median(cyc), np.quantile(cyc, .9), np.quantile(cyc, .99), cyc.max()))
 print("rare-path substeps/50: mean %.2f max %d  frac waves with any %.3f" % (b[:, 1].mean(), b[:, 1].max(), (b[:, 1] > 0).mean()))
