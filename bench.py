@@ -148,6 +148,15 @@ def main():
                 "value": n * max(50, K // 5) / w2, "unit": "env steps/s"}
 
     if rank == 0:
+        # HBM traffic per launch from the rocprofv3 PMC passes of the same workload (FETCH_SIZE + WRITE_SIZE, separate runs;
+        # profiles/r01_pmc_summary.md).  It cannot be collected inside this process, so it is read from the committed summary.
+        traffic = None
+        try:
+            raw = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_raw.json")))
+            if n == N_ENVS_PER_GPU and args.contacts:
+                traffic = (raw["FETCH_SIZE_KB"] + raw["WRITE_SIZE_KB"]) * 1024.0
+        except Exception:
+            pass
         launch_s = dev_ms * 1e-3 / K                 # average duration of one jb_step_kernel launch, from HIP events on its stream
         achieved = ALGO_BYTES_PER_ENV_STEP * n / launch_s / 1e9
         res = {
@@ -159,7 +168,7 @@ def main():
                                    % (TASK, n, "full Newton contact solve" if args.contacts else "contacts off", 2 if args.contacts else 1),
                        "global_envs": total_envs, "parallelism": "env-sharded x%d%s" % (world, ", RCCL gather of [N,D+2] to rank 0 per step" if world > 1 else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None,
+                         "traffic": traffic,
                          "kernel": "jb_step_kernel", "launch_ms": launch_s * 1e3, "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * n,
                          "note": "path is fp32-VALU/latency bound, not HBM bound (SURVEY.md §8d): 317 B per env step vs ~1e5-1e6 dependent flops"},
             "solver_cap_hits": cap_hits, "finite": finite,
