@@ -1,9 +1,9 @@
 """``suite.load`` for the Jitterbug domains (dm_control.suite.load signature; reference README.md:54-58,
 benchmarks/benchmark.py:138-143).  When dm_control is importable the domains are ALSO registered into
 ``dm_control.suite`` the way the reference does (reference jitterbug_dmc/__init__.py:31-43)."""
-from . import jitterbug
+from . import augmented_jitterbug, jitterbug
 
-_DOMAINS = {"jitterbug": jitterbug}
+_DOMAINS = {"jitterbug": jitterbug, "augmented_jitterbug": augmented_jitterbug}
 
 
 def load(domain_name, task_name, task_kwargs=None, environment_kwargs=None, visualize_reward=False):

@@ -18,9 +18,10 @@ def hstep():
     lib = C.CDLL(bh.build())
     dp = C.POINTER(C.c_double)
     lib.jbh_step.argtypes = [dp, dp, dp, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, dp]
-    P = model.default_params()
+    P0 = model.default_params()
 
-    def step(q, v, u, nsub=50, contacts=1, maxn=20, f32=0):
+    def step(q, v, u, nsub=50, contacts=1, maxn=20, f32=0, P=None):
+        P = np.ascontiguousarray(P0 if P is None else P, dtype=np.float64)
         q, v, fail = q.copy(), v.copy(), np.zeros(1)
         rc = lib.jbh_step(P.ctypes.data_as(dp), q.ctypes.data_as(dp), v.ctypes.data_as(dp), float(u), nsub, contacts, maxn, 1, f32,
                           fail.ctypes.data_as(dp))
@@ -89,3 +90,22 @@ def test_every_geom_type_fp64_equals_oracle(hstep, params):
         assert cap == 0
         assert np.abs(qh - qo).max() < 1e-12 and (np.abs(vh - vo) / (1 + np.abs(vo))).max() < 1e-10
     assert seen == set(range(22))
+
+
+def test_randomised_models_fp64_equals_oracle(hstep):
+    """Perturbed geometry (shoulder and knee axes no longer parallel, shifted anchors, moved motor axis): the star-topology
+    scheme must still equal the oracle."""
+    from jitterbug_amd import augmented_jitterbug as aj
+    Ps = aj.augmented_params(6, seed=11)
+    rng = np.random.default_rng(2)
+    for P in Ps:
+        env = O.OracleEnv(1, "move_from_origin", P, seed=0)
+        env.reset()
+        for t in range(6):
+            a = rng.uniform(-1, 1, size=1)
+            q0, v0, _ = env.get_state()
+            env.step(a, auto_reset=False)
+            q1, v1, _ = env.get_state()
+            qh, vh, cap = hstep(q0[0], v0[0], a[0], P=P)
+            assert cap == 0
+            assert np.abs(qh - q1[0]).max() < 1e-11 and (np.abs(vh - v1[0]) / (1 + np.abs(v1[0]))).max() < 1e-10
