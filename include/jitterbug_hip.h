@@ -98,6 +98,10 @@ int jb_set_model_params(jb_handle* h, const double* params, int32_t n_tables);
 int jb_reset_device(jb_handle* h, const uint8_t* d_mask /*nullable*/, float* d_obs_out /*nullable*/);
 int jb_step_device(jb_handle* h, const float* d_action, float* d_obs_out, float* d_reward_out, uint8_t* d_done_out);
 int jb_observe_device(jb_handle* h, float* d_obs_out, float* d_reward_out /*nullable*/);
+/* heuristic bang-bang policies of the reference (heuristic_policies.py:6-136) for the handle's task, evaluated on
+ * observation rows [N,D] -> actions [N]; the device form lets a rollout chain observe -> act -> step without leaving HBM */
+int jb_policy_device(jb_handle* h, const float* d_obs, float* d_action);
+int jb_policy(jb_handle* h, const float* obs, float* action);
 int jb_synchronize(jb_handle* h);
 void* jb_stream(jb_handle* h);                 /* the hipStream_t the handle launches on */
 

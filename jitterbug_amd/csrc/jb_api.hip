@@ -219,6 +219,13 @@ __global__ __launch_bounds__(64) void jb_observe_kernel(KArgs a, float* __restri
     if (leg == 0 && reward_out) reward_out[env] = reward<float>(a.task, e, target_z);
 }
 
+// ---------------------------------------------------------------------------------------------- heuristic policies
+__global__ void jb_policy_kernel(int n, int task, const float* __restrict__ obs, float* __restrict__ action) {
+    int env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= n) return;
+    action[env] = heuristic_policy<float>(task, obs + (size_t)env * obs_dim(task), 1);
+}
+
 // ---------------------------------------------------------------------------------------------- state import / export (fp64 MuJoCo layout)
 __global__ void jb_export_kernel(KArgs a, double* __restrict__ qpos, double* __restrict__ qvel, double* __restrict__ target) {
     int env = blockIdx.x * blockDim.x + threadIdx.x;
@@ -466,6 +473,23 @@ int jb_observe(jb_handle* h, float* obs_out, float* reward_out) {
     if (rc) return rc;
     JB_HIP(hipMemcpyAsync(obs_out, h->d_obs, sizeof(float) * N * h->D, hipMemcpyDeviceToHost, h->stream));
     if (reward_out) JB_HIP(hipMemcpyAsync(reward_out, h->d_reward, sizeof(float) * N, hipMemcpyDeviceToHost, h->stream));
+    JB_HIP(hipStreamSynchronize(h->stream));
+    return JB_OK;
+}
+int jb_policy_device(jb_handle* h, const float* d_obs, float* d_action) {
+    if (!h || !d_obs || !d_action) return fail(JB_E_INVALID, "handle/obs/action is NULL");
+    const int N = h->cfg.n_envs;
+    hipLaunchKernelGGL(jb_policy_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, h->stream, N, h->cfg.task_id, d_obs, d_action);
+    JB_HIP(hipGetLastError());
+    return JB_OK;
+}
+int jb_policy(jb_handle* h, const float* obs, float* action) {
+    if (!h || !obs || !action) return fail(JB_E_INVALID, "handle/obs/action is NULL");
+    const size_t N = (size_t)h->cfg.n_envs;
+    JB_HIP(hipMemcpyAsync(h->d_obs, obs, sizeof(float) * N * h->D, hipMemcpyHostToDevice, h->stream));
+    int rc = jb_policy_device(h, h->d_obs, h->d_action);
+    if (rc) return rc;
+    JB_HIP(hipMemcpyAsync(action, h->d_action, sizeof(float) * N, hipMemcpyDeviceToHost, h->stream));
     JB_HIP(hipStreamSynchronize(h->stream));
     return JB_OK;
 }

@@ -162,4 +162,37 @@ template <typename T> JB_HD T reward(int task, const EnvCore<T>& e, T target_z) 
     return r * U;
 }
 
+
+// ---- heuristic bang-bang policies on a flat (normalised) observation row; reference heuristic_policies.py:6-136.
+// They read the normalised observation entries and compare them with thresholds in radians, exactly like the reference.
+template <typename T> JB_HD T policy_face(T angle) {                                  // :6-25
+    T v = T(3) * angle / T(3.141592653589793);
+    v = v > T(1) ? T(1) : (v < T(-1) ? T(-1) : v);
+    return T(0.9) * v;
+}
+template <typename T> JB_HD T policy_forward(T motor_angle, T motor_vel, T offset) {  // :28-56
+    const T kick = T(0.7853981633974483), speed = T(0.3);
+    if (motor_angle < offset - kick) return speed;
+    if (motor_angle > offset + kick) return -speed;
+    return motor_vel > T(0) ? speed : -speed;
+}
+template <typename T> JB_HD T heuristic_policy(int task, const T* obs, int stride) {
+    const T PI = T(3.141592653589793), Q = T(0.7853981633974483), H = T(1.5707963267948966), THR = T(0.3490658503988659);
+    const T ma = obs[13 * stride], mv = obs[14 * stride];
+    if (task == TASK_MOVE_FROM_ORIGIN) return policy_forward(ma, mv, T(0));           // :59-61
+    if (task == TASK_FACE_DIRECTION) return policy_face(obs[15 * stride]);
+    if (task == TASK_MOVE_IN_DIRECTION || task == TASK_MOVE_TO_POSITION) {            // :64-95, 120-136
+        T ang = (task == TASK_MOVE_IN_DIRECTION) ? obs[15 * stride] : vatan2(obs[15 * stride], -obs[16 * stride]);
+        T off = T(0);
+        if (ang > Q && ang <= PI) { off = H; ang = vabs(vabs(ang) - H); }
+        else if (ang >= -PI && ang < -Q) { off = -H; ang = -vabs(vabs(ang) - H); }
+        return vabs(ang) > THR ? policy_face(ang) : policy_forward(ma, mv, off);
+    }
+    T dx = obs[15 * stride], dy = obs[16 * stride];                                   // move_to_pose :98-118
+    T ang = vatan2(dx, -dy);
+    if (vabs(ang) > THR) return policy_face(ang);
+    if (vsqrt(dx * dx + dy * dy) > T(0.01)) return policy_forward(ma, mv, T(0));
+    return policy_face(obs[18 * stride]);
+}
+
 }  // namespace jb

@@ -141,6 +141,16 @@ class JitterbugVecEnv:
     def observe_device(self, obs_ptr, reward_ptr=None):
         _lib.check(self._L.jb_observe_device(self._h, obs_ptr, reward_ptr))
 
+    def policy(self, obs):
+        """The reference's heuristic policy for this task, evaluated on the GPU: obs [N,D] -> actions [N]."""
+        o = np.ascontiguousarray(obs, dtype=np.float32).reshape(self.num_envs, self.obs_dim)
+        a = np.zeros(self.num_envs, dtype=np.float32)
+        _lib.check(self._L.jb_policy(self._h, _lib.ptr(o), _lib.ptr(a)))
+        return a
+
+    def policy_device(self, obs_ptr, action_ptr):
+        _lib.check(self._L.jb_policy_device(self._h, obs_ptr, action_ptr))
+
     def synchronize(self):
         _lib.check(self._L.jb_synchronize(self._h))
 

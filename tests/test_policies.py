@@ -1,0 +1,60 @@
+"""Heuristic policies against golden (obs -> action) vectors produced by running the reference's heuristic_policies.py
+(tools/gen_golden_policies.py)."""
+import collections
+import json
+import os
+
+import numpy as np
+import pytest
+
+from jitterbug_amd import heuristic_policies as hp
+from jitterbug_amd import model
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "policy_golden.json")))["cases"]
+
+
+@pytest.mark.parametrize("task", model.TASKS)
+def test_python_policies_match_reference(task):
+    cases = [c for c in GOLD if c["task"] == task]
+    obs = np.array([c["obs"] for c in cases])
+    exp = np.array([c["action"] for c in cases])
+    np.testing.assert_allclose(hp.policy_batch(task, obs), exp, rtol=0, atol=1e-15)
+    assert len(set(np.round(exp, 6))) >= 2                        # the vectors exercise several branches (bang-bang: +-0.3 at least)
+    # TimeStep call convention of the reference
+    from jitterbug_amd.jitterbug import Jitterbug
+    from jitterbug_amd.specs import StepType, TimeStep
+    t = Jitterbug(task=task)
+    for c in cases[:10]:
+        ts = TimeStep(StepType.MID, 0.0, 1.0, t.split_observation(np.array(c["obs"])))
+        assert hp.POLICIES[task](ts) == pytest.approx(c["action"], abs=1e-15)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("task", model.TASKS)
+def test_device_policies_match_reference(task):
+    from jitterbug_amd.vec_env import JitterbugVecEnv
+    cases = [c for c in GOLD if c["task"] == task]
+    obs = np.array([c["obs"] for c in cases], dtype=np.float32)
+    exp = np.array([c["action"] for c in cases])
+    env = JitterbugVecEnv(len(cases), task)
+    act = env.policy(obs)
+    # fp32 observations: a branch may flip only if an observation sits within fp32 rounding of a threshold
+    exp32 = hp.policy_batch(task, obs.astype(np.float64))
+    np.testing.assert_allclose(act, exp32, rtol=0, atol=2e-6)
+    assert (np.abs(act - exp) < 2e-6).mean() > 0.99
+    env.close()
+
+
+@pytest.mark.gpu
+def test_policy_rollout_moves_the_robot():
+    """evaluate_policy.py's loop (reference benchmarks/evaluate_policy.py:29-33) with the device policy: the heuristic
+    drives move_from_origin to a positive return."""
+    from jitterbug_amd.vec_env import JitterbugVecEnv
+    env = JitterbugVecEnv(64, "move_from_origin", seed=0)
+    obs = env.reset()
+    total = np.zeros(64)
+    for t in range(300):
+        obs, r, d, _ = env.step(env.policy(obs))
+        total += r
+    assert total.mean() > 5.0
+    env.close()
