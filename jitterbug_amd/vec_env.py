@@ -157,3 +157,65 @@ class JitterbugVecEnv:
     @property
     def stream(self):
         return self._L.jb_stream(self._h)
+
+
+class MonitoredVecEnv:
+    """stable-baselines ``Monitor`` semantics for a whole batch (reference benchmarks/benchmark.py:162-169, 177-184 wraps every
+    env in ``bench.Monitor``): per-env episode return / length / wall time are accumulated on the host and reported in
+    ``infos[i]['episode'] = {'r', 'l', 't'}`` on the step an env finishes; optionally appended to a monitor CSV with the
+    same header convention (``#{json}`` line, then ``r,l,t`` rows)."""
+
+    def __init__(self, venv, filename=None):
+        import json
+        import time
+        self.venv = venv
+        self.num_envs = venv.num_envs
+        self._t0 = time.time()
+        self._ret = np.zeros(self.num_envs)
+        self._len = np.zeros(self.num_envs, dtype=np.int64)
+        self.episode_returns, self.episode_lengths, self.episode_times = [], [], []
+        self._fh = None
+        if filename is not None:
+            if not filename.endswith("monitor.csv"):
+                filename = filename + ".monitor.csv"
+            self._fh = open(filename, "wt")
+            self._fh.write("#%s\n" % json.dumps({"t_start": self._t0, "env_id": "jitterbug-%s" % venv.task}))
+            self._fh.write("r,l,t\n")
+
+    def reset(self, mask=None):
+        obs = self.venv.reset(mask)
+        sel = np.ones(self.num_envs, bool) if mask is None else np.asarray(mask, bool)
+        self._ret[sel] = 0
+        self._len[sel] = 0
+        return obs
+
+    def step(self, actions):
+        import time
+        obs, rew, done, _ = self.venv.step(actions)
+        self._ret += rew
+        self._len += 1
+        infos = [{} for _ in range(self.num_envs)]
+        if done.any():
+            t = round(time.time() - self._t0, 6)
+            for i in np.nonzero(done)[0]:
+                ep = {"r": round(float(self._ret[i]), 6), "l": int(self._len[i]), "t": t}
+                infos[i]["episode"] = ep
+                self.episode_returns.append(ep["r"]); self.episode_lengths.append(ep["l"]); self.episode_times.append(t)
+                if self._fh:
+                    self._fh.write("%s,%d,%s\n" % (ep["r"], ep["l"], ep["t"]))
+            self._ret[done] = 0
+            self._len[done] = 0
+            if self._fh:
+                self._fh.flush()
+        return obs, rew, done, infos
+
+    def step_async(self, actions):
+        self._pending = actions
+
+    def step_wait(self):
+        return self.step(self._pending)
+
+    def close(self):
+        if self._fh:
+            self._fh.close()
+        self.venv.close()

@@ -88,3 +88,21 @@ def test_vec_env_shapes_and_done_flags():
     _, _, done, _ = env.step(np.zeros(100))
     assert done.all()
     env.close()
+
+
+def test_monitored_vec_env(tmp_path):
+    from jitterbug_amd.vec_env import JitterbugVecEnv, MonitoredVecEnv
+    env = MonitoredVecEnv(JitterbugVecEnv(10, "move_from_origin", seed=1, time_limit=0.04), filename=str(tmp_path / "run"))
+    env.reset()
+    seen = 0
+    for t in range(9):
+        obs, rew, done, infos = env.step(np.full(10, 0.5))
+        if done.any():
+            assert done.all() and all(i["episode"]["l"] == 4 for i in infos)
+            seen += 1
+        else:
+            assert all(i == {} for i in infos)
+    assert seen == 2 and len(env.episode_returns) == 20
+    env.close()
+    lines = open(str(tmp_path / "run.monitor.csv")).read().splitlines()
+    assert lines[0].startswith("#{") and lines[1] == "r,l,t" and len(lines) == 22
