@@ -110,6 +110,9 @@ __device__ __forceinline__ void store_target(const KArgs& a, int env, const EnvC
 }
 
 // ---------------------------------------------------------------------------------------------- step
+// EPW (envs per wave) is a template parameter so that the scratch stride is a compile-time constant and every LDS access
+// of the substep uses an immediate offset instead of integer address arithmetic.
+template <int EPW>
 __global__ __launch_bounds__(64) void jb_step_kernel(KArgs a, const float* __restrict__ action, float* __restrict__ obs_out,
                                                      float* __restrict__ reward_out, unsigned char* __restrict__ done_out) {
     // one wave per workgroup; quad q (4 lanes) of the wave owns env blockIdx*epw + q.  Quads beyond epw (a small batch is
@@ -122,15 +125,15 @@ __global__ __launch_bounds__(64) void jb_step_kernel(KArgs a, const float* __res
     // XCD's L2 instead of all eight (placement is a speed/traffic matter only, never correctness).
     const int nb = (int)gridDim.x, b = (int)blockIdx.x, xcd = b & 7, per = nb >> 3, rem = nb & 7;
     const int lblock = xcd * per + (xcd < rem ? xcd : rem) + (b >> 3);
-    const int env = lblock * a.epw + quad;
+    const int env = lblock * EPW + quad;
     LaneModel<float> m;
-    stage_model(a, lds + SC_COUNT * 4 * a.epw, lblock, quad, leg, m);
-    if (quad >= a.epw || env >= a.n) return;
+    stage_model(a, lds + SC_COUNT * 4 * EPW, lblock, quad, leg, m);
+    if (quad >= EPW || env >= a.n) return;
     const bool live = true;
     const int lane = env * 4 + leg;
     LaneScratch<float> scr;
     scr.p = lds + threadIdx.x;
-    scr.stride = 4 * a.epw;
+    scr.stride = 4 * EPW;
 #ifdef JB_WAVE_STATS
     const unsigned long long t_start = __builtin_amdgcn_s_memtime();
 #endif
@@ -143,7 +146,8 @@ __global__ __launch_bounds__(64) void jb_step_kernel(KArgs a, const float* __res
     SimOpts o; o.contacts = a.contacts; o.max_newton = a.max_newton; o.implicit_damp = 1; o.prof = nullptr;
 #ifdef JB_WAVE_STATS
     const unsigned long long rt_start = __builtin_amdgcn_s_memrealtime();
-    if (a.wave_stats) { o.prof = a.wave_stats + (size_t)lblock * 16 + 4; if (threadIdx.x == 0) for (int i = 0; i < 12; i++) o.prof[i] = 0; }
+    unsigned long long prof_local[5] = {0, 0, 0, 0, 0};      // accumulated in registers, written once at the end
+    o.prof = prof_local;
 #endif
 #pragma unroll 1
     for (int k = 0; k < a.substeps; k++) substep<float>(m, scr, s, ctrl, o);
@@ -151,7 +155,8 @@ __global__ __launch_bounds__(64) void jb_step_kernel(KArgs a, const float* __res
     if (threadIdx.x == 0 && a.wave_stats) {
         unsigned long long* ws = a.wave_stats + (size_t)lblock * 16;
         ws[10] = __builtin_amdgcn_s_memrealtime() - rt_start;
-        ws[0] = __builtin_amdgcn_s_memtime() - t_start; ws[1] = (unsigned long long)s.st_xtra; ws[2] = (unsigned long long)s.st_sweeps; ws[3] = (unsigned long long)s.st_contact;
+        ws[0] = __builtin_amdgcn_s_memtime() - t_start;
+        for (int i = 0; i < 5; i++) ws[4 + i] = prof_local[i]; ws[1] = (unsigned long long)s.st_xtra; ws[2] = (unsigned long long)s.st_sweeps; ws[3] = (unsigned long long)s.st_contact;
     }
 #endif
     {   // trailing mj_step1: derived quantities use the normalised quaternion
@@ -390,10 +395,11 @@ int jb_create(const jb_config* cfg, jb_handle** out) {
             JB_HIP(hipGetDeviceProperties(&prop, cfg->device_id));
             const int simds = prop.multiProcessorCount * 4;
             epw = (cfg->n_envs + simds - 1) / simds;
-            if (epw > 8) epw = 8;
+            if (epw > 4) epw = 4;     // LDS: 4 resident waves per CU need <= 40 KB each
         }
         if (epw < 1) epw = 1;
         if (epw > 16) epw = 16;
+        while (epw & (epw - 1)) epw++;       // 1, 2, 4, 8 or 16 (the kernel is instantiated for these)
         k.epw = epw;
     }
     k.root = h->d_root; k.leg = h->d_leg; k.step_count = h->d_step; k.episode = h->d_episode; k.wave_stats = h->d_wave_stats;
@@ -432,8 +438,17 @@ int jb_reset_device(jb_handle* h, const uint8_t* d_mask, float* d_obs_out) {
 }
 int jb_step_device(jb_handle* h, const float* d_action, float* d_obs_out, float* d_reward_out, uint8_t* d_done_out) {
     if (!h || !d_action) return fail(JB_E_INVALID, "handle/action is NULL");
-    hipLaunchKernelGGL(jb_step_kernel, dim3((unsigned)((h->cfg.n_envs + h->ka.epw - 1) / h->ka.epw)), dim3(64),
-                       ((size_t)SC_COUNT * 4 * h->ka.epw + (size_t)LM_COUNT * 4 * (h->ka.per_env_model ? h->ka.epw : 1)) * sizeof(float), h->stream, h->ka, d_action, d_obs_out, d_reward_out, d_done_out);
+    const dim3 grid((unsigned)((h->cfg.n_envs + h->ka.epw - 1) / h->ka.epw));
+    const size_t lds_bytes = ((size_t)SC_COUNT * 4 * h->ka.epw + (size_t)LM_COUNT * 4 * (h->ka.per_env_model ? h->ka.epw : 1)) * sizeof(float);
+#define JB_LAUNCH_STEP(E) hipLaunchKernelGGL(jb_step_kernel<E>, grid, dim3(64), lds_bytes, h->stream, h->ka, d_action, d_obs_out, d_reward_out, d_done_out)
+    switch (h->ka.epw) {
+    case 1: JB_LAUNCH_STEP(1); break;
+    case 2: JB_LAUNCH_STEP(2); break;
+    case 4: JB_LAUNCH_STEP(4); break;
+    case 8: JB_LAUNCH_STEP(8); break;
+    default: JB_LAUNCH_STEP(16); break;
+    }
+#undef JB_LAUNCH_STEP
     JB_HIP(hipGetLastError());
     return JB_OK;
 }

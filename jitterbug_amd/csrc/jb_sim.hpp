@@ -233,7 +233,8 @@ enum SC : int {
                    cylinder | 5-8 upper cylinder, 9 knee tip | root body: 10-13 lane cylinder, 14 lane ellipsoid,
                    15-22 lane box vertices | motor body: 23-26 lane cylinder, 27 lane ellipsoid*/,
     SC_R = 200 /*9: root rotation matrix*/,
-    SC_COUNT = 212
+    SC_ROWS = 212 /*(ROW_K + 1) x ROW_F: y-independent contact rows of the live slots of this substep (13 x 19)*/,
+    SC_COUNT = 212 + 13 * 19
 };
 template <typename V> struct LaneScratch {
     V* p;
@@ -358,70 +359,77 @@ template <typename V> JB_HD V impedance(const LaneModel<V>& m, const V& dist) {
 }
 
 
-// One contact candidate (slot `slot` of the scratch table) against the current iterate y.  ONE copy of this code
-// serves every slot, body level and mode (all three are wave-uniform run-time values) so that the solver loop
-// stays small enough for the instruction cache.
-// level: 0 root body, 1 upper leg (shoulder only), 2 lower leg (shoulder+knee), 3 motor body.
-// mode 0: accumulate the Newton matrix / rhs terms for the active set at y;  mode 2: only record the active set at y
-// (the cheap convergence check).
-// Direction data in the scratch (SC_DD + 12k, k = n, t1, t2): the contact rows are affine in the contact point x:
+// ---- contact rows.  Everything about a contact that does not depend on the iterate y is computed ONCE per substep
+// and kept in the scratch row cache (19 floats per live slot): the three rows of B without their shared linear part
+// [x cross d_k (3), J_sh, J_7] for k = n, t1, t2, the reference accelerations ahat (3) and the weight D (0 for a
+// lane without this contact).  A Newton pass then costs one batch of LDS reads and ~30 FMAs per live slot to get the
+// residuals, plus the rank-3 update when it accumulates.
+// level: 0 root body, 1 upper leg (shoulder only), 2 lower leg (shoulder+knee), 3 motor body; column 7 of a row belongs
+// to the knee (level 2) or to the motor (level 3).
+// Direction data in the scratch (SC_DD + 12k): the rows are affine in the contact point x:
 //   J_sh(x,d) = (d x e1).(x - a1) = wS.x - oS,   J_kn(x,d) = wK.x - oK,   J_m(x,d) = (d x em).(x - am)
 JB_HD constexpr int slot_level(int slot) { return slot < 5 ? 2 : slot < 10 ? 1 : slot < 23 ? 0 : 3; }
-
-// contact-frame direction data of the lane, read from the scratch ONCE per sweep (one batch of LDS reads)
-template <typename V> struct DirRegs {
-    Vec3<V> d[3], wS[3], wK[3], wM[3];
-    V oS[3], oK[3], oM[3], du[3];
-    V mu, fr2, bb, kk;
-};
-template <typename V> JB_HD void load_dirs(const LaneModel<V>& m, const LaneScratch<V>& sc, bool xtra, DirRegs<V>& dr) {
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-        dr.d[k] = sc.ld3(SC_DD + 12 * k); dr.wS[k] = sc.ld3(SC_DD + 12 * k + 3); dr.wK[k] = sc.ld3(SC_DD + 12 * k + 6);
-        dr.oS[k] = sc.ld(SC_DD + 12 * k + 9); dr.oK[k] = sc.ld(SC_DD + 12 * k + 10); dr.du[k] = sc.ld(SC_DD + 12 * k + 11);
-        dr.wM[k] = v3<V>(V(0), V(0), V(0)); dr.oM[k] = V(0);
-    }
-    dr.mu = m.c[LM_MU]; dr.fr2 = m.c[LM_FR2]; dr.bb = m.c[LM_BB]; dr.kk = m.c[LM_KK];
-    if (xtra) {
-        Vec3<V> em = ldv3(m, LM_EM), am = ldv3(m, LM_AM);
-#pragma unroll
-        for (int k = 0; k < 3; k++) { dr.wM[k] = cross(dr.d[k], em); dr.oM[k] = dot(dr.wM[k], am); }
-    }
-}
+constexpr int ROW_F = 19;            // floats per cached contact: ang[3][3], jsh[3], j7[3], ahat[3], D
+constexpr int ROW_K = 12;            // cached live slots per substep; further ones share entry ROW_K and are rebuilt per pass
 
 template <typename V>
-JB_HD void contact_accumulate(const LaneModel<V>& m, const LaneScratch<V>& sc, const DirRegs<V>& dr, int slot, int mode, const Vec3<V>& w,
-                              const V& thd1, const V& thd2, const V& phid, const V (&yr)[6], const V (&yl)[2], const V& ym, NewtonAcc<V>& acc) {
-    using U = typename lane_traits<V>::uint;
+JB_HD void contact_rows_build(const LaneModel<V>& m, const LaneScratch<V>& sc, bool xtra, int slot, int entry, const Vec3<V>& w, const V& thd1,
+                              const V& thd2, const V& phid) {
     const int level = slot_level(slot);
-    // wave-uniform level flags as 0/1 factors: the body below is branch free so its LDS reads issue as one batch
     const V f_sh = V((level == 1 || level == 2) ? 1.0f : 0.0f), f_kn = V(level == 2 ? 1.0f : 0.0f), f_m = V(level == 3 ? 1.0f : 0.0f);
     const Vec3<V> x = sc.ld3(SC_CAND + 4 * slot);
     const V dist = sc.ld(SC_CAND + 4 * slot + 3);
     const V tran = m.c[level == 2 ? LM_TRAN2 : level == 1 ? LM_TRAN1 : level == 0 ? LM_TRAN0 : LM_TRANM];
+    const V mu = m.c[LM_MU];
     const auto valid = lt(dist, V(0));
     V imp = impedance(m, dist);
-    V R0 = (V(1) - imp) / imp * tran * (V(1) + dr.fr2);
-    V mu = dr.mu;
-    V D = sel(valid, V(1) / (V(2) * mu * mu * R0), V(0));
-    // rows of B for the three directions: [x cross d (3), d (3), J_sh, J_kn | J_m]
-    V Bj[3][8], rho[3], ahat[3];
+    V R0 = (V(1) - imp) / imp * tran * (V(1) + m.c[LM_FR2]);
+    const int e0 = SC_ROWS + ROW_F * entry;
+    sc.st(e0 + 18, sel(valid, V(1) / (V(2) * mu * mu * R0), V(0)));
+    const V jdot = f_kn * thd2 + f_m * phid;                    // the rate column 7 multiplies
+    Vec3<V> em = ldv3(m, LM_EM), am = ldv3(m, LM_AM);
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-        const Vec3<V> d = dr.d[k];
+        const Vec3<V> d = sc.ld3(SC_DD + 12 * k);
         Vec3<V> ang = cross(x, d);
-        Bj[k][0] = ang.x; Bj[k][1] = ang.y; Bj[k][2] = ang.z;
-        Bj[k][3] = d.x; Bj[k][4] = d.y; Bj[k][5] = d.z;
-        Bj[k][6] = f_sh * (dot(dr.wS[k], x) - dr.oS[k]);
-        Bj[k][7] = f_kn * (dot(dr.wK[k], x) - dr.oK[k]) + f_m * (dot(dr.wM[k], x) - dr.oM[k]);
-        V jdot = f_kn * thd2 + f_m * phid, jacc = f_kn * yl[1] + f_m * ym;      // what column 7 multiplies
-        V vel = dot(ang, w) + dr.du[k] + Bj[k][6] * thd1 + Bj[k][7] * jdot;
-        V acc_ = ang.x * yr[0] + ang.y * yr[1] + ang.z * yr[2] + d.x * yr[3] + d.y * yr[4] + d.z * yr[5] + Bj[k][6] * yl[0] + Bj[k][7] * jacc;
-        ahat[k] = -dr.bb * vel;
-        if (k == 0) ahat[k] = ahat[k] - dr.kk * imp * dist;
-        rho[k] = acc_ - ahat[k];
+        V jsh = f_sh * (dot(sc.ld3(SC_DD + 12 * k + 3), x) - sc.ld(SC_DD + 12 * k + 9));
+        V j7 = f_kn * (dot(sc.ld3(SC_DD + 12 * k + 6), x) - sc.ld(SC_DD + 12 * k + 10));
+        if (xtra) { Vec3<V> wM = cross(d, em); j7 = j7 + f_m * (dot(wM, x) - dot(wM, am)); }
+        V vel = dot(ang, w) + sc.ld(SC_DD + 12 * k + 11) + jsh * thd1 + j7 * jdot;
+        V ah = -m.c[LM_BB] * vel;
+        if (k == 0) ah = ah - m.c[LM_KK] * imp * dist;
+        sc.st3(e0 + 3 * k, ang);
+        sc.st(e0 + 9 + k, jsh); sc.st(e0 + 12 + k, j7); sc.st(e0 + 15 + k, ah);
     }
+}
+
+// One cached contact against the iterate y.  mode 0: accumulate the Newton matrix / rhs terms for the active set at y;
+// mode 2: only record the active set (the cheap convergence check).
+template <typename V>
+JB_HD void contact_apply(const LaneScratch<V>& sc, const Vec3<V> (&dk)[3], const V& mu, int slot, int entry, int mode,
+                         const V (&yr)[6], const V (&yl)[2], const V& ym, NewtonAcc<V>& acc) {
+    using U = typename lane_traits<V>::uint;
+    const int level = slot_level(slot);
     const bool has_sh = (level == 1 || level == 2), has_kn = (level == 2), has_m = (level == 3);
+    const int e0 = SC_ROWS + ROW_F * entry;
+    V Bj[3][8], rho[3], ahat[3];
+    const V D = sc.ld(e0 + 18);
+    const V y7 = has_kn ? yl[1] : ym;              // levels 0/1 have a zero column 7
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        Vec3<V> ang = sc.ld3(e0 + 3 * k);
+        Bj[k][0] = ang.x; Bj[k][1] = ang.y; Bj[k][2] = ang.z;
+        Bj[k][3] = dk[k].x; Bj[k][4] = dk[k].y; Bj[k][5] = dk[k].z;
+        Bj[k][6] = sc.ld(e0 + 9 + k); Bj[k][7] = sc.ld(e0 + 12 + k); ahat[k] = sc.ld(e0 + 15 + k);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        V t = Bj[k][0] * yr[0] - ahat[k];
+        t = t + Bj[k][1] * yr[1]; t = t + Bj[k][2] * yr[2]; t = t + Bj[k][3] * yr[3]; t = t + Bj[k][4] * yr[4]; t = t + Bj[k][5] * yr[5];
+        t = t + Bj[k][6] * yl[0];
+        rho[k] = t + Bj[k][7] * y7;
+    }
+    const auto valid = gt(D, V(0));
     // pyramid edges  r = rho_n +- mu rho_t
     V mr1 = mu * rho[1], mr2 = mu * rho[2];
     auto a1 = lt(rho[0] + mr1, V(0)), a2 = lt(rho[0] - mr1, V(0)), a3 = lt(rho[0] + mr2, V(0)), a4 = lt(rho[0] - mr2, V(0));
@@ -472,17 +480,32 @@ JB_HD void contact_accumulate(const LaneModel<V>& m, const LaneScratch<V>& sc, c
     }
 }
 
+// y-independent rows of the first ROW_K live slots, once per substep
+template <typename V>
+JB_HD void contact_rows_build_all(const LaneModel<V>& m, const LaneScratch<V>& sc, bool xtra, unsigned live_slots, const Vec3<V>& w,
+                                  const V& thd1, const V& thd2, const V& phid) {
+    int j = 0;
+#pragma unroll 1
+    for (unsigned rest = live_slots; rest != 0u && j < ROW_K; rest &= rest - 1u, j++)
+        contact_rows_build<V>(m, sc, xtra, __builtin_ctz(rest), j, w, thd1, thd2, phid);
+}
+
 // every live candidate slot (bit set in live_slots) against y
 template <typename V>
 JB_HD void contact_sweep(const LaneModel<V>& m, const LaneScratch<V>& sc, bool xtra, unsigned live_slots, int mode, const Vec3<V>& w, const V& thd1, const V& thd2,
                          const V& phid, const V (&yr)[6], const V (&yl)[2], const V& ym, NewtonAcc<V>& acc) {
     acc_clear(acc);
-    DirRegs<V> dr;
-    load_dirs(m, sc, xtra, dr);
+    Vec3<V> dk[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) dk[k] = sc.ld3(SC_DD + 12 * k);
+    const V mu = m.c[LM_MU];
+    int j = 0;
 #pragma unroll 1
-    for (unsigned rest = live_slots; rest != 0u; rest &= rest - 1u) {
+    for (unsigned rest = live_slots; rest != 0u; rest &= rest - 1u, j++) {
         const int slot = __builtin_ctz(rest);
-        contact_accumulate<V>(m, sc, dr, slot, mode, w, thd1, thd2, phid, yr, yl, ym, acc);
+        const int entry = j < ROW_K ? j : ROW_K;
+        if (j >= ROW_K) contact_rows_build<V>(m, sc, xtra, slot, ROW_K, w, thd1, thd2, phid);      // beyond the cache: rebuilt per pass
+        contact_apply<V>(sc, dk, mu, slot, entry, mode, yr, yl, ym, acc);
     }
 }
 
@@ -782,7 +805,9 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
         bool final_pass = !any_contact;
         MK unconverged = lt(V(0), V(1));
         U prev_bw0 = zero_u<V>(), prev_xh = zero_u<V>();
-        if (any_contact) {      // warm start (world linear part rotated into the root frame)
+        if (any_contact) {
+            contact_rows_build_all<V>(m, sc, xtra, live_slots, w, s.thd1, s.thd2, s.phid);
+            // warm start (world linear part rotated into the root frame)
             Mat3<V> R;
 #pragma unroll
             for (int i = 0; i < 9; i++) R.m[i] = sc.ld(SC_R + i);

@@ -34,3 +34,7 @@ print("corr(time, xtra) %.3f corr(time, sweeps) %.3f" % (c, c2))
 A = np.stack([np.ones(nw), b[:, 1], b[:, 2], b[:, 3]], 1)
 coef = np.linalg.lstsq(A, cyc, rcond=None)[0]
 print("fit us: base %.1f + %.2f/xtra-substep + %.2f/sweep + %.2f/contact-substep" % tuple(coef))
+print("phase cycles per substep by wave class (A, check, full, solve, integrate):")
+for name, sel in (("no rare path", b[:, 1] == 0), ("rare path all 50 substeps", b[:, 1] == 50)):
+    if sel.any():
+        print("  %-28s n=%4d  total %.0f :" % (name, sel.sum(), b[sel, 0].mean() / 50), np.round(b[sel, 4:9].mean(0) / 50))
