@@ -36,13 +36,9 @@
 
 #if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
 #define JB_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
-// hide the provenance of the constant-table pointer once per substep so the compiler re-reads constants from LDS
-// where they are used instead of hoisting ~110 loads out of the substep loop and pinning them in registers
-#define JB_LAUNDER(p) asm volatile("" : "+v"(p))
 #else
 #define JB_NO_DEVICE_PROF 1
 #define JB_SCHED_FENCE() ((void)0)
-#define JB_LAUNDER(p) ((void)0)
 #endif
 
 #if defined(JB_WAVE_STATS) && !defined(JB_NO_DEVICE_PROF)
@@ -59,7 +55,7 @@ namespace jb {
 // Index map of the per-lane constant table.  Filled by jb_build_lane_model()
 // (host) from the compiled parameter table of include/jitterbug_model.h.
 enum LM : int {
-    // ---------------- hot part: kept in registers for the whole control step
+    // ---------------- used every substep
     LM_H = 0, LM_GRAV = 1 /*3*/, LM_KK = 4, LM_BB = 5, LM_IMP_D0 = 6, LM_IMP_DW = 7, LM_IMP_IW /*1/width*/ = 8, LM_IMP_MID = 9, LM_IMP_POW = 10,
     LM_MU = 11, LM_FR2 = 12, LM_GEAR = 13, LM_GAIN = 14, LM_BIAS = 15 /*3*/, LM_CTRL_LO = 18, LM_CTRL_HI = 19, LM_MTOT = 20,
     // root body
@@ -78,7 +74,7 @@ enum LM : int {
     LM_BS_LEG_C = 105 /*3*/, LM_BS_LEG_R = 108,
     LM_BX = 109 /*2 x 15: centre(3), axes(3x3, unit), half sizes(3) + margin: boxes bounding the lane's root/motor-body geoms*/,
     LM_HOT = 139,
-    // ---------------- cold part: read from the table only on the rare path
+    // ---------------- read only on the rare (all-geom) path
     LM_UC_D = 139 /*3: upper cylinder centre - a1*/, LM_UC_AX = 142 /*3*/, LM_UC_XA = 145 /*3*/, LM_UC_R = 148, LM_UC_H = 149,
     LM_DTIP = 150 /*3*/, LM_TIP_R = 153,
     // lane-assigned geoms of the root / motor body (lane 0: coreBody1 box, lane 1: coreBody2 box,
@@ -928,8 +924,7 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
 // One physics substep.  A wave-uniform broadphase decides whether only the foot sphere + lower-leg cylinder can
 // touch the floor (common) or every geom of the model has to be tested (rare).
 template <typename V>
-JB_HD void substep(const LaneModel<V>& m_in, const LaneScratch<V>& sc, LaneState<V>& s, const V& ctrl, const SimOpts& o) {
-    LaneModel<V> m = m_in;
+JB_HD void substep(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneState<V>& s, const V& ctrl, const SimOpts& o) {
     bool xtra = false;
     if (o.contacts) {
         V iq = V(1) / (s.qw * s.qw + s.qx * s.qx + s.qy * s.qy + s.qz * s.qz);
