@@ -140,7 +140,7 @@ __global__ __launch_bounds__(64) void jb_step_kernel(KArgs a, const float* __res
     LaneState<float> s;
     load_state(a, env, lane, s);
 #ifdef JB_WAVE_STATS
-    s.st_xtra = 0.f; s.st_sweeps = 0.f; s.st_contact = 0.f;
+    s.st_xtra = 0.f; s.st_sweeps = 0.f; s.st_contact = 0.f; s.st_slots = 0.f;
 #endif
     const float ctrl = action[env];
     SimOpts o; o.contacts = a.contacts; o.max_newton = a.max_newton; o.implicit_damp = 1; o.prof = nullptr;
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(64) void jb_step_kernel(KArgs a, const float* __res
         unsigned long long* ws = a.wave_stats + (size_t)lblock * 16;
         ws[10] = __builtin_amdgcn_s_memrealtime() - rt_start;
         ws[0] = __builtin_amdgcn_s_memtime() - t_start;
-        for (int i = 0; i < 5; i++) ws[4 + i] = prof_local[i]; ws[1] = (unsigned long long)s.st_xtra; ws[2] = (unsigned long long)s.st_sweeps; ws[3] = (unsigned long long)s.st_contact;
+        for (int i = 0; i < 5; i++) ws[4 + i] = prof_local[i]; ws[1] = (unsigned long long)s.st_xtra; ws[2] = (unsigned long long)s.st_sweeps; ws[3] = (unsigned long long)s.st_contact; ws[11] = (unsigned long long)s.st_slots;
     }
 #endif
     {   // trailing mj_step1: derived quantities use the normalised quaternion
@@ -496,6 +496,20 @@ int jb_policy_device(jb_handle* h, const float* d_obs, float* d_action) {
     const int N = h->cfg.n_envs;
     hipLaunchKernelGGL(jb_policy_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, h->stream, N, h->cfg.task_id, d_obs, d_action);
     JB_HIP(hipGetLastError());
+    return JB_OK;
+}
+// K control steps of "heuristic policy -> step" chained on the stream with no host round trip (the loop of the reference's
+// benchmarks/evaluate_policy.py:29-33, for every env of the batch at once).  d_rewards (nullable): [K, N] per-step rewards.
+int jb_rollout_policy_device(jb_handle* h, int32_t n_steps, float* d_obs_inout /*[N,D]: current observations in, last out*/,
+                             float* d_rewards /*[K,N] nullable*/, uint8_t* d_done_last /*[N] nullable*/) {
+    if (!h || !d_obs_inout || n_steps < 0) return fail(JB_E_INVALID, "handle/obs is NULL or n_steps < 0");
+    const size_t N = (size_t)h->cfg.n_envs;
+    for (int k = 0; k < n_steps; k++) {
+        int rc = jb_policy_device(h, d_obs_inout, h->d_action);
+        if (rc) return rc;
+        rc = jb_step_device(h, h->d_action, d_obs_inout, d_rewards ? d_rewards + (size_t)k * N : h->d_reward, d_done_last ? d_done_last : h->d_done);
+        if (rc) return rc;
+    }
     return JB_OK;
 }
 int jb_policy(jb_handle* h, const float* obs, float* action) {

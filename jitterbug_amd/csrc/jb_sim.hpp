@@ -210,7 +210,7 @@ template <typename V> struct LaneState {
     V wa[3], wl[3], wj[2], wm;
     V fail;                              // >0: the Newton iteration hit its cap in some substep
 #ifdef JB_WAVE_STATS
-    V st_xtra, st_sweeps, st_contact;    // diagnostic build only: substeps on the rare path, Newton sweeps, substeps with contact
+    V st_xtra, st_sweeps, st_contact, st_slots;    // diagnostic build only: substeps on the rare path, Newton sweeps, substeps with contact, live slots summed over contact substeps
 #endif
 };
 
@@ -815,7 +815,7 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
         }
         const V hb1 = o.implicit_damp ? h * m.c[LM_B1] : V(0), hb2 = o.implicit_damp ? h * m.c[LM_B2] : V(0);
 #ifdef JB_WAVE_STATS
-        if (any_contact) s.st_contact = s.st_contact + V(1);
+        if (any_contact) { s.st_contact = s.st_contact + V(1); s.st_slots = s.st_slots + V((float)__builtin_popcount(live_slots)); }
 #endif
 #pragma unroll 1
         for (int it = 0;; it++) {

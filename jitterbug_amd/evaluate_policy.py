@@ -1,0 +1,38 @@
+"""Policy evaluation (reference: benchmarks/evaluate_policy.py:10-35).
+
+``evaluate_policy(env, policy, num_repeats=...)`` keeps the reference's signature and result: a
+``num_repeats x (env._step_limit - 1)`` array of per-step rewards from running ``policy(ts)`` on the single env.
+``evaluate_heuristic_batch`` is the MI355X way to get the same statistic: one repeat per env of a batch, the reference's
+heuristic policy evaluated on the device, and all ``_step_limit - 1`` steps chained on the GPU without host round trips."""
+import numpy as np
+
+
+def evaluate_policy(env, policy, *, num_repeats=20, verbose=False):
+    if verbose:
+        print("Evaluating {} on {}".format(policy, env.task.task))
+    n = int(env._step_limit - 1)
+    results = np.empty((num_repeats, n))
+    for repeat in range(num_repeats):
+        ts = env.reset()
+        for i in range(n):
+            ts = env.step(policy(ts))
+            results[repeat, i] = ts.reward
+    return results
+
+
+def evaluate_heuristic_batch(task, num_repeats=20, seed=0, time_limit=10, device_id=0):
+    """-> rewards [num_repeats, step_limit - 1] with the task's heuristic policy; needs torch for the device buffers."""
+    import torch
+    from .vec_env import JitterbugVecEnv
+    dev = torch.device("cuda", device_id)
+    env = JitterbugVecEnv(num_repeats, task, seed=seed, device_id=device_id, time_limit=time_limit, auto_reset=False,
+                          stream=torch.cuda.current_stream(dev).cuda_stream)
+    n = env.step_limit - 1
+    obs = torch.empty((num_repeats, env.obs_dim), dtype=torch.float32, device=dev)
+    rew = torch.empty((n, num_repeats), dtype=torch.float32, device=dev)
+    env.reset_device(None, obs.data_ptr())
+    env.rollout_policy_device(n, obs.data_ptr(), rew.data_ptr())
+    torch.cuda.synchronize(dev)
+    out = rew.T.cpu().numpy().astype(np.float64)
+    env.close()
+    return out

@@ -151,6 +151,10 @@ class JitterbugVecEnv:
     def policy_device(self, obs_ptr, action_ptr):
         _lib.check(self._L.jb_policy_device(self._h, obs_ptr, action_ptr))
 
+    def rollout_policy_device(self, n_steps, obs_ptr, rewards_ptr=None, done_ptr=None):
+        """n_steps of heuristic policy -> step, chained on the GPU (device pointers; asynchronous)."""
+        _lib.check(self._L.jb_rollout_policy_device(self._h, int(n_steps), obs_ptr, rewards_ptr, done_ptr))
+
     def synchronize(self):
         _lib.check(self._L.jb_synchronize(self._h))
 

@@ -58,3 +58,19 @@ def test_policy_rollout_moves_the_robot():
         total += r
     assert total.mean() > 5.0
     env.close()
+
+
+@pytest.mark.gpu
+def test_evaluate_policy_single_env_and_batch_agree():
+    """reference evaluate_policy loop on the dm_control-style env vs the chained device rollout of the same seeds."""
+    from jitterbug_amd import suite
+    from jitterbug_amd.evaluate_policy import evaluate_heuristic_batch, evaluate_policy
+    env = suite.load("jitterbug", "move_in_direction", task_kwargs=dict(random=7, time_limit=0.4))
+    single = evaluate_policy(env, hp.move_in_direction, num_repeats=1)
+    assert single.shape == (1, 39) and np.isfinite(single).all()
+    env.close()
+    batch = evaluate_heuristic_batch("move_in_direction", num_repeats=32, seed=7, time_limit=0.4)
+    assert batch.shape == (32, 39) and np.isfinite(batch).all() and (batch >= 0).all() and (batch <= 1).all()
+    # env 0 of the batch has the same seed/stream as the single env; the first episode of the single env is its reset #1,
+    # the batch rollout starts from reset #1 as well -> identical trajectories while fp32 policy decisions agree
+    np.testing.assert_allclose(batch[0, :10], single[0, :10], rtol=1e-4, atol=1e-5)

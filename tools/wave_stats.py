@@ -37,4 +37,5 @@ print("fit us: base %.1f + %.2f/xtra-substep + %.2f/sweep + %.2f/contact-substep
 print("phase cycles per substep by wave class (A, check, full, solve, integrate):")
 for name, sel in (("no rare path", b[:, 1] == 0), ("rare path all 50 substeps", b[:, 1] == 50)):
     if sel.any():
-        print("  %-28s n=%4d  total %.0f :" % (name, sel.sum(), b[sel, 0].mean() / 50), np.round(b[sel, 4:9].mean(0) / 50))
+        print("  %-28s n=%4d  total %.0f :" % (name, sel.sum(), b[sel, 0].mean() / 50), np.round(b[sel, 4:9].mean(0) / 50),
+              "live slots per contact substep %.2f, full sweeps per substep %.2f" % ((b[sel, 11] / np.maximum(b[sel, 3], 1)).mean(), b[sel, 2].mean() / 50))
