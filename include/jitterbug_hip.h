@@ -105,6 +105,8 @@ int jb_policy(jb_handle* h, const float* obs, float* action);
 /* n_steps of (policy -> step) chained on the stream, the loop of benchmarks/evaluate_policy.py:29-33 for the whole batch;
  * d_obs_inout [N,D] holds the current observations on entry and the last ones on return; d_rewards [n_steps,N] nullable */
 int jb_rollout_policy_device(jb_handle* h, int32_t n_steps, float* d_obs_inout, float* d_rewards, uint8_t* d_done_last);
+/* host-buffer form: starts from the handle's current state; rewards_out [n_steps,N] and obs_out [N,D] are nullable */
+int jb_rollout_policy(jb_handle* h, int32_t n_steps, float* rewards_out, float* obs_out);
 int jb_synchronize(jb_handle* h);
 void* jb_stream(jb_handle* h);                 /* the hipStream_t the handle launches on */
 

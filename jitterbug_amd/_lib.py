@@ -14,7 +14,7 @@ JB_OK = 0
 ERR_NAMES = {-1: "JB_E_INVALID", -2: "JB_E_NODEVICE", -3: "JB_E_HIP", -4: "JB_E_MODEL"}
 
 EXPORTS = ["jb_default_config", "jb_create", "jb_destroy", "jb_reset", "jb_step", "jb_observe", "jb_get_state", "jb_set_state",
-           "jb_get_counters", "jb_set_model_params", "jb_policy", "jb_policy_device", "jb_rollout_policy_device", "jb_reset_device", "jb_step_device", "jb_observe_device", "jb_synchronize",
+           "jb_get_counters", "jb_set_model_params", "jb_policy", "jb_policy_device", "jb_rollout_policy_device", "jb_rollout_policy", "jb_reset_device", "jb_step_device", "jb_observe_device", "jb_synchronize",
            "jb_stream", "jb_obs_dim", "jb_num_envs", "jb_device_count", "jb_abi_version", "jb_default_model_params", "jb_last_error"]
 
 
@@ -32,6 +32,22 @@ class Config(C.Structure):
 _lib = None
 
 
+def _preload_torch_hip_runtime():
+    """If PyTorch-ROCm is installed it ships its own libamdhip64; a process must end up with ONE HIP runtime whatever the
+    import order, so bind to torch's copy (the configuration bench.py and torch.distributed run in) before loading ours.
+    Does not import torch."""
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass
+
+
 def load():
     """Load the shared library (once). Raises if it has not been built."""
     global _lib
@@ -41,6 +57,7 @@ def load():
         raise JitterbugHipError(
             "libjitterbug_hip.so is not built (%s). Build it with `python -m jitterbug_amd.build` "
             "(needs hipcc); there is no CPU fallback." % LIB_PATH)
+    _preload_torch_hip_runtime()
     L = C.CDLL(LIB_PATH)
     vp, fp, dp, u8p = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p
     L.jb_default_config.argtypes = [C.POINTER(Config), C.c_int32, C.c_int32]
@@ -59,6 +76,7 @@ def load():
     L.jb_policy.argtypes = [vp, fp, fp]
     L.jb_policy_device.argtypes = [vp, fp, fp]
     L.jb_rollout_policy_device.argtypes = [vp, C.c_int32, fp, fp, u8p]
+    L.jb_rollout_policy.argtypes = [vp, C.c_int32, fp, fp]
     L.jb_synchronize.argtypes = [vp]
     L.jb_stream.argtypes = [vp]
     L.jb_stream.restype = vp

@@ -512,6 +512,20 @@ int jb_rollout_policy_device(jb_handle* h, int32_t n_steps, float* d_obs_inout /
     }
     return JB_OK;
 }
+int jb_rollout_policy(jb_handle* h, int32_t n_steps, float* rewards_out /*[K,N] host, nullable*/, float* obs_out /*[N,D] host, nullable*/) {
+    if (!h || n_steps < 0) return fail(JB_E_INVALID, "handle is NULL or n_steps < 0");
+    const size_t N = (size_t)h->cfg.n_envs;
+    float* d_rew = nullptr;
+    if (rewards_out && n_steps > 0) JB_HIP(hipMalloc(&d_rew, sizeof(float) * N * (size_t)n_steps));
+    int rc = jb_observe_device(h, h->d_obs, nullptr);
+    if (!rc) rc = jb_rollout_policy_device(h, n_steps, h->d_obs, d_rew, nullptr);
+    if (!rc && d_rew && hipMemcpyAsync(rewards_out, d_rew, sizeof(float) * N * (size_t)n_steps, hipMemcpyDeviceToHost, h->stream) != hipSuccess) rc = fail(JB_E_HIP, "copy of rewards failed");
+    if (!rc && obs_out && hipMemcpyAsync(obs_out, h->d_obs, sizeof(float) * N * h->D, hipMemcpyDeviceToHost, h->stream) != hipSuccess) rc = fail(JB_E_HIP, "copy of observations failed");
+    hipError_t e = hipStreamSynchronize(h->stream);
+    if (d_rew) hipFree(d_rew);
+    if (!rc && e != hipSuccess) rc = fail(JB_E_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(e));
+    return rc;
+}
 int jb_policy(jb_handle* h, const float* obs, float* action) {
     if (!h || !obs || !action) return fail(JB_E_INVALID, "handle/obs/action is NULL");
     const size_t N = (size_t)h->cfg.n_envs;

@@ -3,7 +3,10 @@
 ``evaluate_policy(env, policy, num_repeats=...)`` keeps the reference's signature and result: a
 ``num_repeats x (env._step_limit - 1)`` array of per-step rewards from running ``policy(ts)`` on the single env.
 ``evaluate_heuristic_batch`` is the MI355X way to get the same statistic: one repeat per env of a batch, the reference's
-heuristic policy evaluated on the device, and all ``_step_limit - 1`` steps chained on the GPU without host round trips."""
+heuristic policy evaluated on the device, and all ``_step_limit - 1`` steps chained on the GPU without host round trips.
+
+Note for callers that also use torch in the same process: import torch (and touch the GPU) BEFORE creating a handle, as
+bench.py does; two HIP runtimes initialised in the other order fail to see the device."""
 import numpy as np
 
 
@@ -21,18 +24,10 @@ def evaluate_policy(env, policy, *, num_repeats=20, verbose=False):
 
 
 def evaluate_heuristic_batch(task, num_repeats=20, seed=0, time_limit=10, device_id=0):
-    """-> rewards [num_repeats, step_limit - 1] with the task's heuristic policy; needs torch for the device buffers."""
-    import torch
+    """-> rewards [num_repeats, step_limit - 1] with the task's heuristic policy (one repeat per env of a batch)."""
     from .vec_env import JitterbugVecEnv
-    dev = torch.device("cuda", device_id)
-    env = JitterbugVecEnv(num_repeats, task, seed=seed, device_id=device_id, time_limit=time_limit, auto_reset=False,
-                          stream=torch.cuda.current_stream(dev).cuda_stream)
-    n = env.step_limit - 1
-    obs = torch.empty((num_repeats, env.obs_dim), dtype=torch.float32, device=dev)
-    rew = torch.empty((n, num_repeats), dtype=torch.float32, device=dev)
-    env.reset_device(None, obs.data_ptr())
-    env.rollout_policy_device(n, obs.data_ptr(), rew.data_ptr())
-    torch.cuda.synchronize(dev)
-    out = rew.T.cpu().numpy().astype(np.float64)
+    env = JitterbugVecEnv(num_repeats, task, seed=seed, device_id=device_id, time_limit=time_limit, auto_reset=False)
+    env.reset()
+    rew, _ = env.rollout_policy(env.step_limit - 1)
     env.close()
-    return out
+    return rew.T.astype(np.float64)

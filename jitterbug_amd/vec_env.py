@@ -151,6 +151,12 @@ class JitterbugVecEnv:
     def policy_device(self, obs_ptr, action_ptr):
         _lib.check(self._L.jb_policy_device(self._h, obs_ptr, action_ptr))
 
+    def rollout_policy(self, n_steps):
+        """n_steps of heuristic policy -> step chained on the GPU from the current state; returns (rewards [n_steps, N], last obs)."""
+        rew = np.zeros((int(n_steps), self.num_envs), dtype=np.float32)
+        _lib.check(self._L.jb_rollout_policy(self._h, int(n_steps), _lib.ptr(rew), _lib.ptr(self._obs)))
+        return rew, self._obs.copy()
+
     def rollout_policy_device(self, n_steps, obs_ptr, rewards_ptr=None, done_ptr=None):
         """n_steps of heuristic policy -> step, chained on the GPU (device pointers; asynchronous)."""
         _lib.check(self._L.jb_rollout_policy_device(self._h, int(n_steps), obs_ptr, rewards_ptr, done_ptr))
