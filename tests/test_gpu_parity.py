@@ -258,3 +258,68 @@ def test_per_env_randomised_models():
     assert ok / tot >= 0.995
     # and the shared-model path is unaffected by having used per-env tables on another handle
     g.close()
+
+
+def test_edge_cases_batch_sizes_and_layouts():
+    """Odd batch sizes (tail quads / partially filled waves), every envs-per-wave instantiation, masked reset, partial
+    set_state, other substep counts, infinite time limit, argument errors."""
+    from jitterbug_amd import _lib
+    from jitterbug_amd.vec_env import JitterbugVecEnv
+    from oracle import oracle as O
+    P = model.default_params()
+    rng = np.random.default_rng(0)
+    ref = {}
+    for n, epw in [(1, 0), (3, 0), (5, 16), (37, 1), (37, 2), (37, 4), (37, 8), (37, 16), (4097, 0)]:
+        g = JitterbugVecEnv(n, "move_to_position", seed=21, envs_per_wave=epw)
+        obs = g.reset()
+        a = np.linspace(-1, 1, n).astype(np.float32)
+        for _ in range(3):
+            obs, rew, done, _ = g.step(a)
+        assert obs.shape == (n, 18) and np.isfinite(obs).all() and not done.any()
+        if n == 37:                          # same batch, different wave packing -> bit-identical results
+            if "o37" in ref:
+                assert np.array_equal(ref["o37"], obs) and np.array_equal(ref["r37"], rew)
+            ref["o37"], ref["r37"] = obs, rew
+        g.close()
+    # masked reset: only the selected envs start a new episode
+    g = JitterbugVecEnv(6, "move_to_pose", seed=3)
+    g.reset()
+    for _ in range(2):
+        g.step(np.full(6, 0.3))
+    q0, v0, t0 = g.get_state()
+    g.reset(mask=np.array([1, 0, 0, 1, 0, 0], dtype=np.uint8))
+    q1, v1, t1 = g.get_state()
+    sc, ep, _ = g.counters()
+    assert np.array_equal(sc, [0, 2, 2, 0, 2, 2]) and np.array_equal(ep, [3, 2, 2, 3, 2, 2])
+    assert np.array_equal(q1[[1, 2, 4, 5]], q0[[1, 2, 4, 5]]) and np.all(v1[[0, 3]] == 0) and not np.array_equal(t1[0], t0[0])
+    # partial set_state keeps the rest
+    qn = q1.copy(); qn[:, 0] += 0.01
+    g.set_state(qpos=qn)
+    q2, v2, t2 = g.get_state()
+    np.testing.assert_allclose(q2[:, 0], qn[:, 0], rtol=1e-6)
+    assert np.array_equal(v2, v1) and np.array_equal(t2, t1)
+    g.close()
+    # 10 substeps per control step, no time limit; against the oracle
+    g = JitterbugVecEnv(9, "move_from_origin", seed=2, control_timestep=0.002, time_limit=float("inf"), auto_reset=False)
+    o = O.OracleEnv(9, "move_from_origin", P, seed=2, nsub=10, step_limit=2 ** 31 - 1)
+    g.reset(), o.reset()
+    for t in range(20):
+        a = rng.uniform(-1, 1, size=9)
+        g.set_state(*o.get_state())
+        og, rg, dg, _ = g.step(a)
+        oo, ro, do = o.step(a, auto_reset=False)
+        assert not dg.any()
+        np.testing.assert_allclose(og, oo, rtol=2e-4, atol=2e-5)
+    g.close()
+    # argument errors come back as exceptions with the library's message
+    with pytest.raises(_lib.JitterbugHipError, match="n_envs"):
+        JitterbugVecEnv(0)
+    with pytest.raises(AssertionError, match="Invalid task"):
+        JitterbugVecEnv(4, "fly")
+    g = JitterbugVecEnv(4)
+    with pytest.raises(_lib.JitterbugHipError, match="n_tables"):
+        g.set_model_params(np.tile(P, (3, 1)))
+    bad = P.copy(); bad[model.P_SOLIMP + 4] = 3.0            # solimp power != 2 is not implemented by the kernel
+    with pytest.raises(_lib.JitterbugHipError, match="JB_E_MODEL"):
+        g.set_model_params(bad)
+    g.close()
