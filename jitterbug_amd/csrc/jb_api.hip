@@ -118,8 +118,14 @@ __global__ __launch_bounds__(64) void jb_step_kernel(KArgs a, const float* __res
     // one wave per workgroup; quad q (4 lanes) of the wave owns env blockIdx*epw + q.  Quads beyond epw (a small batch is
     // spread over all SIMDs with partially filled waves) and beyond the batch retire at once: DPP quad sums and the
     // wave ballots only ever involve complete, active quads.
-    extern __shared__ float lds[];           // [SC_COUNT][4*epw] per-lane scratch, then the lane constant table(s)
-    const int quad = threadIdx.x >> 2, leg = threadIdx.x & 3;
+    extern __shared__ float lds[];           // [SC_COUNT][4*EPW] per-lane scratch, then the lane constant table(s)
+    // Lanes 0 .. 4*EPW-1 are the MAIN lanes (quad q = env q of this wave, lane = leg).  A wave with fewer than 16 envs uses
+    // its spare lanes as NGRP-1 helper groups: helper lane L + g*4*EPW mirrors main lane L (same env, leg, scratch and
+    // constant-table addresses) and takes a share of the live contact slots in every Newton pass (jb_sim.hpp, SlotPlan).
+    constexpr int MAIN = 4 * EPW;
+    constexpr int NGRP = EPW >= 16 ? 1 : (EPW == 8 ? 2 : 4);
+    const int lane_in_grp = threadIdx.x % MAIN, grp = threadIdx.x / MAIN;
+    const int quad = lane_in_grp >> 2, leg = threadIdx.x & 3;
     // XCD-aware workgroup -> env-range map: hardware deals workgroups round-robin over the 8 XCDs (b and b+8 share one),
     // so give XCD x one contiguous range of envs; then every 128-byte line of the SoA state arrays is touched by a single
     // XCD's L2 instead of all eight (placement is a speed/traffic matter only, never correctness).
@@ -128,17 +134,24 @@ __global__ __launch_bounds__(64) void jb_step_kernel(KArgs a, const float* __res
     const int env = lblock * EPW + quad;
     LaneModel<float> m;
     stage_model(a, lds + SC_COUNT * 4 * EPW, lblock, quad, leg, m);
-    if (quad >= EPW || env >= a.n) return;
+    if (grp >= NGRP || env >= a.n) return;       // whole quads (and their mirrors in every group) retire together
     const bool live = true;
     const int lane = env * 4 + leg;
     LaneScratch<float> scr;
-    scr.p = lds + threadIdx.x;
-    scr.stride = 4 * EPW;
+    scr.p = lds + lane_in_grp;
+    scr.stride = MAIN;
+    scr.grp = grp; scr.ngrp = NGRP; scr.gstride = MAIN;
 #ifdef JB_WAVE_STATS
     const unsigned long long t_start = __builtin_amdgcn_s_memtime();
 #endif
     LaneState<float> s;
-    load_state(a, env, lane, s);
+    if (grp == 0) load_state(a, env, lane, s);
+    else {
+        s.px = s.py = s.pz = 0.f; s.qw = 1.f; s.qx = s.qy = s.qz = 0.f; s.vx = s.vy = s.vz = s.wx = s.wy = s.wz = 0.f;
+        s.phi = s.phid = s.turns = 0.f; s.th1 = s.th2 = s.thd1 = s.thd2 = 0.f;
+        for (int i = 0; i < 3; i++) { s.wa[i] = 0.f; s.wl[i] = 0.f; }
+        s.wj[0] = s.wj[1] = 0.f; s.wm = 0.f; s.fail = 0.f;
+    }
 #ifdef JB_WAVE_STATS
     s.st_xtra = 0.f; s.st_sweeps = 0.f; s.st_contact = 0.f; s.st_slots = 0.f;
 #endif
@@ -151,6 +164,7 @@ __global__ __launch_bounds__(64) void jb_step_kernel(KArgs a, const float* __res
 #endif
 #pragma unroll 1
     for (int k = 0; k < a.substeps; k++) substep<float>(m, scr, s, ctrl, o);
+    if (grp != 0) return;                        // helper lanes only take part in the substeps
 #ifdef JB_WAVE_STATS
     if (threadIdx.x == 0 && a.wave_stats) {
         unsigned long long* ws = a.wave_stats + (size_t)lblock * 16;

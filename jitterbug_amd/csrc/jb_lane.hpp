@@ -46,6 +46,10 @@ JB_D unsigned quad_sum_u(unsigned x) {
     return x;
 }
 JB_D bool any_lane(bool m) { return __builtin_amdgcn_ballot_w64(m) != 0ull; }
+// helper groups: lanes L, L^off hold the same (env, leg) in different slot groups
+JB_D float xlane_xor(float x, int off) { return __shfl_xor(x, off, 64); }
+JB_D unsigned xlane_xor_u(unsigned x, int off) { return (unsigned)__shfl_xor((int)x, off, 64); }
+JB_D unsigned wave_bcast_u(unsigned x) { return (unsigned)__builtin_amdgcn_readfirstlane((int)x); }   // value of the first active lane
 #endif
 
 JB_HD float sel(bool m, float a, float b) { return m ? a : b; }
@@ -102,6 +106,9 @@ template <typename T> inline Quad<T> operator-(const Quad<T>& a) { Quad<T> r; fo
 template <typename T> inline Quad<T> quad_sum(const Quad<T>& x) { return Quad<T>((x.v[0] + x.v[1]) + (x.v[2] + x.v[3])); }
 inline UQuad quad_sum_u(const UQuad& x) { uint32_t s = (x.v[0] + x.v[1]) + (x.v[2] + x.v[3]); return UQuad{{s, s, s, s}}; }
 inline bool any_lane(const Mask4& m) { return m.v[0] || m.v[1] || m.v[2] || m.v[3]; }
+template <typename T> inline Quad<T> xlane_xor(const Quad<T>& x, int) { return x; }      // the host harness has one group
+inline UQuad xlane_xor_u(const UQuad& x, int) { return x; }
+inline unsigned wave_bcast_u(unsigned x) { return x; }
 inline bool any_lane(bool m) { return m; }
 inline float quad_sum(float x) { return x; }
 inline double quad_sum(double x) { return x; }

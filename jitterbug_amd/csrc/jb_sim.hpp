@@ -229,17 +229,32 @@ enum SC : int {
                    cylinder | 5-8 upper cylinder, 9 knee tip | root body: 10-13 lane cylinder, 14 lane ellipsoid,
                    15-22 lane box vertices | motor body: 23-26 lane cylinder, 27 lane ellipsoid*/,
     SC_R = 200 /*9: root rotation matrix*/,
-    SC_ROWS = 212 /*(ROW_K + 1) x ROW_F: y-independent contact rows of the live slots of this substep (13 x 19)*/,
-    SC_COUNT = 212 + 13 * 19
+    SC_ROWS = 212 /*(ROW_K + 4) x ROW_F: y-independent contact rows of the live slots of this substep (12 cached + one
+                    overflow entry per group, 19 floats each)*/,
+    SC_Y = 212 + 16 * 19 /*9: current Newton iterate [yr(6), yl(2), ym], shared with the helper groups*/,
+    SC_ST = SC_Y + 9 /*6: w(3), thd1, thd2, phid for the helper groups*/,
+    SC_COUNT = SC_ST + 6
 };
 template <typename V> struct LaneScratch {
     V* p;
-    int stride;            // device: number of active lanes of the wave (4 x envs per wave); host: 1
+    int stride;            // device: number of MAIN lanes of the wave (4 x envs per wave); host: 1
+    // Helper groups: when a wave holds fewer than 16 envs its spare lanes form ngrp-1 helper groups that mirror the main
+    // lanes (same env, same leg, same scratch addresses) and take a share of the live contact slots in every pass.
+    int grp, ngrp, gstride;   // group of this lane (0 = main), number of groups (1, 2 or 4), lane distance between groups
     JB_HD V ld(int i) const { return p[i * stride]; }
     JB_HD void st(int i, const V& v) const { p[i * stride] = v; }
     JB_HD Vec3<V> ld3(int i) const { return v3<V>(ld(i), ld(i + 1), ld(i + 2)); }
     JB_HD void st3(int i, const Vec3<V>& v) const { st(i, v.x); st(i + 1, v.y); st(i + 2, v.z); }
 };
+// sum over the helper groups (every group ends with the same total)
+template <typename V> JB_HD V group_sum(const LaneScratch<V>& sc, V x) {
+    for (int off = sc.gstride; off < sc.gstride * sc.ngrp; off <<= 1) x = x + xlane_xor(x, off);
+    return x;
+}
+template <typename V> JB_HD typename lane_traits<V>::uint group_sum_u(const LaneScratch<V>& sc, typename lane_traits<V>::uint x) {
+    for (int off = sc.gstride; off < sc.gstride * sc.ngrp; off <<= 1) x = x + xlane_xor_u(x, off);
+    return x;
+}
 JB_HD constexpr int tri(int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
 
 // Accumulator of the contact terms of the Newton system for the lane (everything here is ADDED to M / tau,
@@ -369,8 +384,9 @@ constexpr int ROW_F = 19;            // floats per cached contact: ang[3][3], js
 constexpr int ROW_K = 12;            // cached live slots per substep; further ones share entry ROW_K and are rebuilt per pass
 
 template <typename V>
-JB_HD void contact_rows_build(const LaneModel<V>& m, const LaneScratch<V>& sc, bool xtra, int slot, int entry, const Vec3<V>& w, const V& thd1,
-                              const V& thd2, const V& phid) {
+JB_HD void contact_rows_build(const LaneModel<V>& m, const LaneScratch<V>& sc, bool xtra, int slot, int entry) {
+    const Vec3<V> w = sc.ld3(SC_ST);
+    const V thd1 = sc.ld(SC_ST + 3), thd2 = sc.ld(SC_ST + 4), phid = sc.ld(SC_ST + 5);
     const int level = slot_level(slot);
     const V f_sh = V((level == 1 || level == 2) ? 1.0f : 0.0f), f_kn = V(level == 2 ? 1.0f : 0.0f), f_m = V(level == 3 ? 1.0f : 0.0f);
     const Vec3<V> x = sc.ld3(SC_CAND + 4 * slot);
@@ -402,14 +418,14 @@ JB_HD void contact_rows_build(const LaneModel<V>& m, const LaneScratch<V>& sc, b
 // One cached contact against the iterate y.  mode 0: accumulate the Newton matrix / rhs terms for the active set at y;
 // mode 2: only record the active set (the cheap convergence check).
 template <typename V>
-JB_HD void contact_apply(const LaneScratch<V>& sc, const Vec3<V> (&dk)[3], const V& mu, int slot, int entry, int mode,
+JB_HD void contact_apply(const LaneScratch<V>& sc, const Vec3<V> (&dk)[3], const V& mu, int slot, int entry, bool lane_on, int mode,
                          const V (&yr)[6], const V (&yl)[2], const V& ym, NewtonAcc<V>& acc) {
     using U = typename lane_traits<V>::uint;
     const int level = slot_level(slot);
     const bool has_sh = (level == 1 || level == 2), has_kn = (level == 2), has_m = (level == 3);
     const int e0 = SC_ROWS + ROW_F * entry;
     V Bj[3][8], rho[3], ahat[3];
-    const V D = sc.ld(e0 + 18);
+    const V D = lane_on ? sc.ld(e0 + 18) : V(0);     // a lane without a slot in this round contributes nothing
     const V y7 = has_kn ? yl[1] : ym;              // levels 0/1 have a zero column 7
 #pragma unroll
     for (int k = 0; k < 3; k++) {
@@ -476,32 +492,112 @@ JB_HD void contact_apply(const LaneScratch<V>& sc, const Vec3<V> (&dk)[3], const
     }
 }
 
-// y-independent rows of the first ROW_K live slots, once per substep
-template <typename V>
-JB_HD void contact_rows_build_all(const LaneModel<V>& m, const LaneScratch<V>& sc, bool xtra, unsigned live_slots, const Vec3<V>& w,
-                                  const V& thd1, const V& thd2, const V& phid) {
-    int j = 0;
-#pragma unroll 1
-    for (unsigned rest = live_slots; rest != 0u && j < ROW_K; rest &= rest - 1u, j++)
-        contact_rows_build<V>(m, sc, xtra, __builtin_ctz(rest), j, w, thd1, thd2, phid);
+// j-th set bit of a mask (j < popcount(mask))
+JB_HD int nth_set_bit(unsigned mask, int j) {
+    for (int k = 0; k < j; k++) mask &= mask - 1u;
+    return __builtin_ctz(mask);
 }
 
-// every live candidate slot (bit set in live_slots) against y
+// Static slot -> helper-group map.  It depends on the slot index ONLY, so the order in which an env's contact terms are
+// summed never depends on what the other envs of its wave are doing (results stay bit-identical for any batch split).
+// The common multi-contact case - foot + the three lower-leg cylinder points (slots 0,1,3,4) - lands on four groups.
+JB_HD constexpr int slot_group(int slot, int ngroups) {
+    return ngroups <= 1 ? 0 : (slot < 5 ? (ngroups == 4 ? (slot == 0 ? 0 : slot == 1 ? 1 : slot == 2 ? 0 : slot == 3 ? 2 : 3)
+                                                        : (slot == 1 || slot == 4 ? 1 : 0))
+                                        : ((slot - 5) & (ngroups - 1)));
+}
+template <int G, int NG> struct GroupMask {
+    static constexpr unsigned make() { unsigned mk = 0; for (int sl = 0; sl < 28; sl++) if (slot_group(sl, NG) == G) mk |= 1u << sl; return mk; }
+    static constexpr unsigned value = make();
+};
+// compile-time masks, selected by the (per-lane) group index
+JB_HD unsigned group_mask(int g, int ngroups) {
+    if (ngroups == 4) return g == 0 ? GroupMask<0, 4>::value : g == 1 ? GroupMask<1, 4>::value : g == 2 ? GroupMask<2, 4>::value : GroupMask<3, 4>::value;
+    if (ngroups == 2) return g == 0 ? GroupMask<0, 2>::value : GroupMask<1, 2>::value;
+    return 0x0FFFFFFFu;
+}
+
+// How the live slots of a substep are shared out: group g works through the live slots of ITS static subset, one per round.
+// With a single group (or fewer than two live slots) only the main lanes work and nothing has to be reduced.
+struct SlotPlan {
+    unsigned live;       // wave-uniform bitmask of live slots
+    unsigned mine;       // the live slots of this lane's group
+    bool grouped;        // helper groups take part
+    int ngroups, rounds;
+};
+template <typename V> JB_HD SlotPlan make_slot_plan(const LaneScratch<V>& sc, unsigned live_slots) {
+    SlotPlan p;
+    p.live = live_slots;
+    const int count = __builtin_popcount(live_slots);
+    p.grouped = sc.ngrp > 1 && count >= 2;
+    p.ngroups = p.grouped ? sc.ngrp : 1;
+    p.rounds = 0;
+    for (int g = 0; g < p.ngroups; g++) {
+        const int c = __builtin_popcount(live_slots & group_mask(g, p.ngroups));
+        p.rounds = c > p.rounds ? c : p.rounds;
+    }
+    p.mine = live_slots & group_mask(p.grouped ? sc.grp : 0, p.ngroups);
+    return p;
+}
+// the slot group g takes in round r (or -1), and the row-cache entry of a slot: its rank among the live slots
+JB_HD int plan_slot(const SlotPlan& p, int, int r) {
+    return r < __builtin_popcount(p.mine) ? nth_set_bit(p.mine, r) : -1;
+}
+JB_HD int plan_entry(const SlotPlan& p, int g, int slot) {
+    const int rank = __builtin_popcount(p.live & ((1u << slot) - 1u));
+    return rank < ROW_K ? rank : ROW_K + g;
+}
+
+// y-independent rows of the live slots, once per substep (slots beyond the cache use the group's overflow entry and are
+// rebuilt in every pass)
 template <typename V>
-JB_HD void contact_sweep(const LaneModel<V>& m, const LaneScratch<V>& sc, bool xtra, unsigned live_slots, int mode, const Vec3<V>& w, const V& thd1, const V& thd2,
-                         const V& phid, const V (&yr)[6], const V (&yl)[2], const V& ym, NewtonAcc<V>& acc) {
+JB_HD void contact_rows_build_all(const LaneModel<V>& m, const LaneScratch<V>& sc, bool xtra, const SlotPlan& plan) {
+    if (!plan.grouped && sc.grp != 0) return;
+    const int g = plan.grouped ? sc.grp : 0;
+#pragma unroll 1
+    for (int r = 0; r < plan.rounds; r++) {
+        const int slot = plan_slot(plan, g, r);
+        if (slot >= 0) {
+            const int entry = plan_entry(plan, g, slot);
+            if (entry < ROW_K) contact_rows_build<V>(m, sc, xtra, slot, entry);
+        }
+    }
+}
+
+// every live candidate slot against the iterate y kept in the scratch (SC_Y); with helper groups the partial sums of the
+// groups are combined by cross-lane exchanges so that every group ends with the complete accumulator
+template <typename V>
+JB_HD void contact_sweep(const LaneModel<V>& m, const LaneScratch<V>& sc, bool xtra, const SlotPlan& plan, int mode, NewtonAcc<V>& acc) {
+    if (!plan.grouped && sc.grp != 0) return;
     acc_clear(acc);
     Vec3<V> dk[3];
 #pragma unroll
     for (int k = 0; k < 3; k++) dk[k] = sc.ld3(SC_DD + 12 * k);
     const V mu = m.c[LM_MU];
-    int j = 0;
+    V yr[6], yl[2], ym;
+#pragma unroll
+    for (int i = 0; i < 6; i++) yr[i] = sc.ld(SC_Y + i);
+    yl[0] = sc.ld(SC_Y + 6); yl[1] = sc.ld(SC_Y + 7); ym = sc.ld(SC_Y + 8);
+    const int g = plan.grouped ? sc.grp : 0;
 #pragma unroll 1
-    for (unsigned rest = live_slots; rest != 0u; rest &= rest - 1u, j++) {
-        const int slot = __builtin_ctz(rest);
-        const int entry = j < ROW_K ? j : ROW_K;
-        if (j >= ROW_K) contact_rows_build<V>(m, sc, xtra, slot, ROW_K, w, thd1, thd2, phid);      // beyond the cache: rebuilt per pass
-        contact_apply<V>(sc, dk, mu, slot, entry, mode, yr, yl, ym, acc);
+    for (int r = 0; r < plan.rounds; r++) {
+        const int mine = plan_slot(plan, g, r);
+        const bool lane_on = mine >= 0;
+        const int slot = lane_on ? mine : __builtin_ctz(plan.live);       // idle lanes read some valid entry and contribute nothing
+        const int entry = plan_entry(plan, g, slot);
+        if (lane_on && entry >= ROW_K) contact_rows_build<V>(m, sc, xtra, slot, entry);      // beyond the cache: rebuilt per pass
+        contact_apply<V>(sc, dk, mu, slot, entry, lane_on, mode, yr, yl, ym, acc);
+    }
+    if (plan.grouped) {
+        acc.bw0 = group_sum_u<V>(sc, acc.bw0); acc.xh = group_sum_u<V>(sc, acc.xh);
+        if (mode == 0) {
+#pragma unroll
+            for (int i = 0; i < 21; i++) acc.A[i] = group_sum(sc, acc.A[i]);
+#pragma unroll
+            for (int i = 0; i < 6; i++) { acc.B[i][0] = group_sum(sc, acc.B[i][0]); acc.B[i][1] = group_sum(sc, acc.B[i][1]); acc.Bm[i] = group_sum(sc, acc.Bm[i]); acc.rr[i] = group_sum(sc, acc.rr[i]); }
+            acc.C11 = group_sum(sc, acc.C11); acc.C12 = group_sum(sc, acc.C12); acc.C22 = group_sum(sc, acc.C22); acc.Cm = group_sum(sc, acc.Cm);
+            acc.rl[0] = group_sum(sc, acc.rl[0]); acc.rl[1] = group_sum(sc, acc.rl[1]); acc.rm = group_sum(sc, acc.rm);
+        }
     }
 }
 
@@ -592,7 +688,9 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
     MK env_con = lt(V(1), V(0));       // this env (quad) has at least one contact
     JB_PROF_T0();
 
-    {   // ================= phase A: kinematics, composite inertia, bias forces, contact candidates -> scratch
+    const bool is_main = (sc.grp == 0);
+    if (is_main) {   // ================= phase A: kinematics, composite inertia, bias forces, contact candidates -> scratch
+        sc.st3(SC_ST, w); sc.st(SC_ST + 3, s.thd1); sc.st(SC_ST + 4, s.thd2); sc.st(SC_ST + 5, s.phid);      // for the helper groups
         V qn = V(1) / vsqrt(s.qw * s.qw + s.qx * s.qx + s.qy * s.qy + s.qz * s.qz);
         s.qw = s.qw * qn; s.qx = s.qx * qn; s.qy = s.qy * qn; s.qz = s.qz * qn;
         Mat3<V> R = quat2mat(s.qw, s.qx, s.qy, s.qz);
@@ -792,9 +890,16 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
     JB_SCHED_FENCE();
 
     JB_PROF_ADD(o, 0);
+    // the helper groups learn what phase A found (values of the first lane, a main lane)
+    any_contact = wave_bcast_u(any_contact ? 1u : 0u) != 0u;
+    live_slots = wave_bcast_u(live_slots);
+    const SlotPlan plan = make_slot_plan(sc, live_slots);
+
     // ================= phase B: contact solve (primal Newton on the active set) and final acceleration, ONE loop:
     //   while the active set changes:  H(active set at y) y' = tau + contact rhs          (M without damping)
     //   then:  (M + h diag(b)) qacc = tau + qfrc_constraint(y)                            (MuJoCo Euler, implicit joint damping)
+    // Main lanes own the iterate and the solves; every decision that steers the loop is broadcast so that the helper groups
+    // follow the same control flow.
     V yr[6], yl[2], ym;
     {
         NewtonAcc<V> acc;
@@ -802,20 +907,24 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
         MK unconverged = lt(V(0), V(1));
         U prev_bw0 = zero_u<V>(), prev_xh = zero_u<V>();
         if (any_contact) {
-            contact_rows_build_all<V>(m, sc, xtra, live_slots, w, s.thd1, s.thd2, s.phid);
-            // warm start (world linear part rotated into the root frame)
-            Mat3<V> R;
+            contact_rows_build_all<V>(m, sc, xtra, plan);
+            if (is_main) {      // warm start (world linear part rotated into the root frame)
+                Mat3<V> R;
 #pragma unroll
-            for (int i = 0; i < 9; i++) R.m[i] = sc.ld(SC_R + i);
-            Vec3<V> lw = mulT(R, v3<V>(s.wl[0], s.wl[1], s.wl[2]));
-            yr[0] = s.wa[0]; yr[1] = s.wa[1]; yr[2] = s.wa[2]; yr[3] = lw.x; yr[4] = lw.y; yr[5] = lw.z;
-            yl[0] = s.wj[0]; yl[1] = s.wj[1]; ym = s.wm;
+                for (int i = 0; i < 9; i++) R.m[i] = sc.ld(SC_R + i);
+                Vec3<V> lw = mulT(R, v3<V>(s.wl[0], s.wl[1], s.wl[2]));
+                yr[0] = s.wa[0]; yr[1] = s.wa[1]; yr[2] = s.wa[2]; yr[3] = lw.x; yr[4] = lw.y; yr[5] = lw.z;
+                yl[0] = s.wj[0]; yl[1] = s.wj[1]; ym = s.wm;
+#pragma unroll
+                for (int i = 0; i < 6; i++) sc.st(SC_Y + i, yr[i]);
+                sc.st(SC_Y + 6, yl[0]); sc.st(SC_Y + 7, yl[1]); sc.st(SC_Y + 8, ym);
+            }
         } else {
             acc_clear(acc);
         }
         const V hb1 = o.implicit_damp ? h * m.c[LM_B1] : V(0), hb2 = o.implicit_damp ? h * m.c[LM_B2] : V(0);
 #ifdef JB_WAVE_STATS
-        if (any_contact) { s.st_contact = s.st_contact + V(1); s.st_slots = s.st_slots + V((float)__builtin_popcount(live_slots)); }
+        if (is_main && any_contact) { s.st_contact = s.st_contact + V(1); s.st_slots = s.st_slots + V((float)__builtin_popcount(plan.live)); }
 #endif
 #pragma unroll 1
         for (int it = 0;; it++) {
@@ -823,23 +932,27 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
                 if (it > 0) {
                     // cheap pass: only the active set at the new iterate.  The ENV's set changed if any lane of the quad
                     // saw a different record; when nobody's changed, every y is the exact minimiser
-                    contact_sweep<V>(m, sc, xtra, live_slots, 2, w, s.thd1, s.thd2, s.phid, yr, yl, ym, acc);
+                    contact_sweep<V>(m, sc, xtra, plan, 2, acc);
                     JB_PROF_ADD(o, 1);
-                    MK changed = mor(neq_u(acc.bw0, prev_bw0), neq_u(acc.xh, prev_xh));
-                    unconverged = neq_u(quad_sum_u(mbit(changed)), zero_u<V>());
-                    if (!any_lane(unconverged) || it >= o.max_newton) {
-                        s.fail = s.fail + sel(unconverged, V(1), V(0));
-                        final_pass = true;
+                    unsigned fin = 0u;
+                    if (is_main) {
+                        MK changed = mor(neq_u(acc.bw0, prev_bw0), neq_u(acc.xh, prev_xh));
+                        unconverged = neq_u(quad_sum_u(mbit(changed)), zero_u<V>());
+                        if (!any_lane(unconverged) || it >= o.max_newton) {
+                            s.fail = s.fail + sel(unconverged, V(1), V(0));
+                            fin = 1u;
+                        }
                     }
+                    final_pass = wave_bcast_u(fin) != 0u;
                 }
                 if (!final_pass) {
-                    contact_sweep<V>(m, sc, xtra, live_slots, 0, w, s.thd1, s.thd2, s.phid, yr, yl, ym, acc);
+                    contact_sweep<V>(m, sc, xtra, plan, 0, acc);
                     prev_bw0 = acc.bw0; prev_xh = acc.xh;
                     JB_PROF_ADD(o, 2);
 #ifdef JB_WAVE_STATS
-                    s.st_sweeps = s.st_sweeps + V(1);
+                    if (is_main) s.st_sweeps = s.st_sweeps + V(1);
 #endif
-                } else {
+                } else if (is_main) {
                     // At the minimiser  H y = tau + sum B^T W ahat,  so the constraint force is  qfrc = M y - tau.  Load
                     // acc so that the solve below sees  rhs = tau + qfrc = M y  (replicated parts enter the quad sums as 1/4).
                     acc_clear(acc);
@@ -868,22 +981,29 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
                     acc.rl[0] = sel(env_con, acc.rl[0], V(0)); acc.rl[1] = sel(env_con, acc.rl[1], V(0)); acc.rm = sel(env_con, acc.rm, V(0));
                 }
             }
-            V nyr[6], nyl[2], nym;
-            star_solve<V>(sc, acc, final_pass ? hb1 : V(0), final_pass ? hb2 : V(0), nyr, nyl, nym);
-            JB_PROF_ADD(o, 3);
-            if (final_pass) {
+            if (is_main) {
+                V nyr[6], nyl[2], nym;
+                star_solve<V>(sc, acc, final_pass ? hb1 : V(0), final_pass ? hb2 : V(0), nyr, nyl, nym);
+                if (final_pass) {
 #pragma unroll
-                for (int i = 0; i < 6; i++) yr[i] = nyr[i];
-                yl[0] = nyl[0]; yl[1] = nyl[1]; ym = nym;
-                break;
+                    for (int i = 0; i < 6; i++) yr[i] = nyr[i];
+                    yl[0] = nyl[0]; yl[1] = nyl[1]; ym = nym;
+                } else {
+                    // envs whose active set already repeated keep their (exact) solution
+#pragma unroll
+                    for (int i = 0; i < 6; i++) yr[i] = sel(unconverged, nyr[i], yr[i]);
+                    yl[0] = sel(unconverged, nyl[0], yl[0]); yl[1] = sel(unconverged, nyl[1], yl[1]); ym = sel(unconverged, nym, ym);
+#pragma unroll
+                    for (int i = 0; i < 6; i++) sc.st(SC_Y + i, yr[i]);
+                    sc.st(SC_Y + 6, yl[0]); sc.st(SC_Y + 7, yl[1]); sc.st(SC_Y + 8, ym);
+                }
             }
-            // envs whose active set already repeated keep their (exact) solution
-#pragma unroll
-            for (int i = 0; i < 6; i++) yr[i] = sel(unconverged, nyr[i], yr[i]);
-            yl[0] = sel(unconverged, nyl[0], yl[0]); yl[1] = sel(unconverged, nyl[1], yl[1]); ym = sel(unconverged, nym, ym);
+            JB_PROF_ADD(o, 3);
+            if (final_pass) break;
         }
     }
     JB_SCHED_FENCE();
+    if (!is_main) return;
 
     // ================= phase C: integrate
     Mat3<V> R;
@@ -926,7 +1046,7 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
 template <typename V>
 JB_HD void substep(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneState<V>& s, const V& ctrl, const SimOpts& o) {
     bool xtra = false;
-    if (o.contacts) {
+    if (o.contacts && sc.grp == 0) {
         V iq = V(1) / (s.qw * s.qw + s.qx * s.qx + s.qy * s.qy + s.qz * s.qz);
         // third row of the rotation matrix of the (not yet normalised) quaternion
         Vec3<V> nb = v3<V>(V(2) * (s.qx * s.qz - s.qw * s.qy) * iq, V(2) * (s.qy * s.qz + s.qw * s.qx) * iq,
@@ -943,11 +1063,12 @@ JB_HD void substep(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneState<V>
         }
         xtra = any_lane(near);
     }
+    xtra = wave_bcast_u(xtra ? 1u : 0u) != 0u;      // helper groups follow the main lanes' decision
 #ifdef JB_NO_XTRA
     xtra = false;
 #endif
 #ifdef JB_WAVE_STATS
-    if (xtra) s.st_xtra = s.st_xtra + V(1);
+    if (xtra && sc.grp == 0) s.st_xtra = s.st_xtra + V(1);
 #endif
     substep_impl<V>(m, sc, s, ctrl, o, xtra);
 }

@@ -32,7 +32,7 @@ static int run(const double* P, double* qpos, double* qvel, double ctrl, int nsu
     s.wj[0] = s.wj[1] = V(T(0)); s.wm = V(T(0)); s.fail = V(T(0));
     SimOpts o; o.contacts = contacts; o.max_newton = max_newton; o.implicit_damp = implicit_damp; o.prof = nullptr;
     V scratch[SC_COUNT];
-    LaneScratch<V> sc; sc.p = scratch; sc.stride = 1;
+    LaneScratch<V> sc; sc.p = scratch; sc.stride = 1; sc.grp = 0; sc.ngrp = 1; sc.gstride = 4;
     for (int i = 0; i < nsub; i++) substep<V>(m, sc, s, V(T(ctrl)), o);
     // replicated quantities must agree across the quad
     for (int l = 1; l < 4; l++) if (s.px.v[l] != s.px.v[0] || s.qw.v[l] != s.qw.v[0] || s.wz.v[l] != s.wz.v[0] || s.phid.v[l] != s.phid.v[0]) return -100;

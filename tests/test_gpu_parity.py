@@ -276,10 +276,13 @@ def test_edge_cases_batch_sizes_and_layouts():
         for _ in range(3):
             obs, rew, done, _ = g.step(a)
         assert obs.shape == (n, 18) and np.isfinite(obs).all() and not done.any()
-        if n == 37:                          # same batch, different wave packing -> bit-identical results
-            if "o37" in ref:
-                assert np.array_equal(ref["o37"], obs) and np.array_equal(ref["r37"], rew)
-            ref["o37"], ref["r37"] = obs, rew
+        if n == 37:       # same batch, different wave packing: bit-identical while the number of helper groups is the same
+            key = "g4" if epw <= 4 else "g%d" % epw          # (1, 2, 4 envs/wave -> 4 groups; 8 -> 2; 16 -> 1)
+            if key in ref:
+                assert np.array_equal(ref[key][0], obs) and np.array_equal(ref[key][1], rew)
+            ref[key] = (obs, rew)
+            if "g4" in ref:                                  # other group counts only change the summation order
+                np.testing.assert_allclose(obs, ref["g4"][0], rtol=2e-3, atol=2e-4)
         g.close()
     # masked reset: only the selected envs start a new episode
     g = JitterbugVecEnv(6, "move_to_pose", seed=3)

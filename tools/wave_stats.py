@@ -39,3 +39,13 @@ for name, sel in (("no rare path", b[:, 1] == 0), ("rare path all 50 substeps", 
     if sel.any():
         print("  %-28s n=%4d  total %.0f :" % (name, sel.sum(), b[sel, 0].mean() / 50), np.round(b[sel, 4:9].mean(0) / 50),
               "live slots per contact substep %.2f, full sweeps per substep %.2f" % ((b[sel, 11] / np.maximum(b[sel, 3], 1)).mean(), b[sel, 2].mean() / 50))
+nx = b[:, 1] == 0
+idx = np.argsort(-cyc * nx)[:12]
+print("slowest waves without rare path [cycles/substep, full sweeps/substep, live slots/contact substep, phases A chk full solve int]:")
+for i in idx:
+    print("   %6.0f %5.2f %5.2f " % (b[i, 0] / 50, b[i, 2] / 50, b[i, 11] / max(b[i, 3], 1)), np.round(b[i, 4:9] / 50))
+qs = np.quantile(b[nx, 0] / 50, [0.1, 0.5, 0.9, 0.99, 1.0])
+print("cycles/substep quantiles (no rare path) p10 p50 p90 p99 max:", np.round(qs))
+A = np.stack([np.ones(nx.sum()), b[nx, 2] / 50, b[nx, 11] / np.maximum(b[nx, 3], 1)], 1)
+coef = np.linalg.lstsq(A, b[nx, 0] / 50, rcond=None)[0]
+print("fit cycles/substep = %.0f + %.0f * fulls + %.0f * live_slots" % tuple(coef))
