@@ -66,6 +66,17 @@ JB_HD unsigned mbit(bool a) { return a ? 1u : 0u; }
 JB_HD bool neq_u(unsigned a, unsigned b) { return a != b; }
 JB_HD float vsqrt(float x) { return sqrtf(x); }
 JB_HD double vsqrt(double x) { return sqrt(x); }
+// reciprocal / reciprocal square root: one hardware instruction on the device (v_rcp_f32 / v_rsq_f32, ~1 ulp) instead of the
+// ~10-instruction IEEE division and square root sequences; exact arithmetic in the fp64 host build
+#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+JB_HD float vrcp(float x) { return __builtin_amdgcn_rcpf(x); }
+JB_HD float vrsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
+#else
+JB_HD float vrcp(float x) { return 1.0f / x; }
+JB_HD float vrsqrt(float x) { return 1.0f / sqrtf(x); }
+#endif
+JB_HD double vrcp(double x) { return 1.0 / x; }
+JB_HD double vrsqrt(double x) { return 1.0 / sqrt(x); }
 JB_HD float vabs(float x) { return fabsf(x); }
 JB_HD double vabs(double x) { return fabs(x); }
 JB_HD float vsin(float x) { return sinf(x); }
@@ -125,7 +136,7 @@ inline UQuad operator*(const UQuad& a, uint32_t b) { UQuad r; for (int i = 0; i 
 inline UQuad operator+(const UQuad& a, const UQuad& b) { UQuad r; for (int i = 0; i < 4; i++) r.v[i] = a.v[i] + b.v[i]; return r; }
 inline UQuad operator+(const UQuad& a, uint32_t b) { UQuad r; for (int i = 0; i < 4; i++) r.v[i] = a.v[i] + b; return r; }
 #define JB_QUN(name, fn) template <typename T> inline Quad<T> name(const Quad<T>& a) { Quad<T> r; for (int i = 0; i < 4; i++) r.v[i] = fn(a.v[i]); return r; }
-JB_QUN(vsqrt, vsqrt) JB_QUN(vabs, vabs) JB_QUN(vsin, vsin) JB_QUN(vcos, vcos) JB_QUN(vfloor, vfloor)
+JB_QUN(vsqrt, vsqrt) JB_QUN(vrcp, vrcp) JB_QUN(vrsqrt, vrsqrt) JB_QUN(vabs, vabs) JB_QUN(vsin, vsin) JB_QUN(vcos, vcos) JB_QUN(vfloor, vfloor)
 #undef JB_QUN
 template <typename T> inline Quad<T> vmin(const Quad<T>& a, const Quad<T>& b) { Quad<T> r; for (int i = 0; i < 4; i++) r.v[i] = vmin(a.v[i], b.v[i]); return r; }
 template <typename T> inline Quad<T> vmax(const Quad<T>& a, const Quad<T>& b) { Quad<T> r; for (int i = 0; i < 4; i++) r.v[i] = vmax(a.v[i], b.v[i]); return r; }

@@ -291,7 +291,7 @@ JB_HD void star_solve(const LaneScratch<V>& sc, const NewtonAcc<V>& acc, const V
     for (int i = 0; i < 6; i++) { B[i][0] = sc.ld(SC_MB + 2 * i) + acc.B[i][0]; B[i][1] = sc.ld(SC_MB + 2 * i + 1) + acc.B[i][1]; }
     V C11 = sc.ld(SC_MC) + acc.C11 + hb1, C12 = sc.ld(SC_MC + 1) + acc.C12, C22 = sc.ld(SC_MC + 2) + acc.C22 + hb2;
     V rl0 = sc.ld(SC_TL) + acc.rl[0], rl1 = sc.ld(SC_TL + 1) + acc.rl[1];
-    V idet = V(1) / (C11 * C22 - C12 * C12);
+    V idet = vrcp(C11 * C22 - C12 * C12);
     V i11 = C22 * idet, i12 = -C12 * idet, i22 = C11 * idet;
     V S[21], r[6];
 #pragma unroll
@@ -309,7 +309,7 @@ JB_HD void star_solve(const LaneScratch<V>& sc, const NewtonAcc<V>& acc, const V
     for (int i = 0; i < 6; i++) bm[i] = bm[i] + quad_sum(acc.Bm[i]);
     cm = cm + quad_sum(acc.Cm);
     rmt = rmt + quad_sum(acc.rm);
-    V icm = V(1) / cm;
+    V icm = vrcp(cm);
 #pragma unroll
     for (int i = 0; i < 6; i++) {
         V g = bm[i] * icm;
@@ -323,7 +323,7 @@ JB_HD void star_solve(const LaneScratch<V>& sc, const NewtonAcc<V>& acc, const V
         V t = S[tri(j, j)];
 #pragma unroll
         for (int k = 0; k < j; k++) t = t - S[tri(j, k)] * S[tri(j, k)];
-        V id = V(1) / vsqrt(t);
+        V id = vrsqrt(t);
         S[tri(j, j)] = id;
 #pragma unroll
         for (int i = j + 1; i < 6; i++) {
@@ -362,9 +362,9 @@ template <typename V> JB_HD V impedance(const LaneModel<V>& m, const V& dist) {
     V x = vmin(vabs(dist) * m.c[LM_IMP_IW], V(1));
     V mid = m.c[LM_IMP_MID];
     // power = 2 (MuJoCo default); other powers are rejected by the host when the table is built
-    V ya = x * x / mid;
+    V ya = x * x * vrcp(mid);
     V omx = V(1) - x;
-    V yb = V(1) - omx * omx / (V(1) - mid);
+    V yb = V(1) - omx * omx * vrcp(V(1) - mid);
     V y = sel(lt(x, mid), ya, yb);
     return m.c[LM_IMP_D0] + y * (m.c[LM_IMP_DW] - m.c[LM_IMP_D0]);
 }
@@ -395,9 +395,9 @@ JB_HD void contact_rows_build(const LaneModel<V>& m, const LaneScratch<V>& sc, b
     const V mu = m.c[LM_MU];
     const auto valid = lt(dist, V(0));
     V imp = impedance(m, dist);
-    V R0 = (V(1) - imp) / imp * tran * (V(1) + m.c[LM_FR2]);
+    V R0 = (V(1) - imp) * vrcp(imp) * tran * (V(1) + m.c[LM_FR2]);
     const int e0 = SC_ROWS + ROW_F * entry;
-    sc.st(e0 + 18, sel(valid, V(1) / (V(2) * mu * mu * R0), V(0)));
+    sc.st(e0 + 18, sel(valid, vrcp(V(2) * mu * mu * R0), V(0)));
     const V jdot = f_kn * thd2 + f_m * phid;                    // the rate column 7 multiplies
     Vec3<V> em = ldv3(m, LM_EM), am = ldv3(m, LM_AM);
 #pragma unroll
@@ -621,7 +621,7 @@ JB_HD void cylinder_floor(const Vec3<V>& c, const Vec3<V>& ax_in, const Vec3<V>&
     Vec3<V> vec = ax * prj - nb;
     V len2 = dot(vec, vec);
     auto degenerate = lt(len2, V(1e-20));
-    V scl = rad / vsqrt(vmax(len2, V(1e-30)));
+    V scl = rad * vrsqrt(vmax(len2, V(1e-30)));
     vec = v3<V>(sel(degenerate, xa.x * rad, vec.x * scl), sel(degenerate, xa.y * rad, vec.y * scl), sel(degenerate, xa.z * rad, vec.z * scl));
     V prjvec = dot(vec, nb);
     Vec3<V> axh = ax * half;
@@ -636,8 +636,7 @@ JB_HD void cylinder_floor(const Vec3<V>& c, const Vec3<V>& ax_in, const Vec3<V>&
     V d3 = dist0 + prjaxis - V(0.5) * prjvec;
     auto on3 = mand(on1, lt(d3, V(0)));
     Vec3<V> v1 = cross(vec, axh);
-    V l1 = vsqrt(vmax(dot(v1, v1), V(1e-30)));
-    v1 = v1 * (rad * V(0.8660254037844386) / l1);
+    v1 = v1 * (rad * V(0.8660254037844386) * vrsqrt(vmax(dot(v1, v1), V(1e-30))));
     Vec3<V> base = c + axh - vec * V(0.5) - nb * (d3 * V(0.5));
     out.dist[2] = d3; out.on[2] = on3; out.x[2] = base + v1;
     out.dist[3] = d3; out.on[3] = on3; out.x[3] = base - v1;
@@ -691,7 +690,7 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
     const bool is_main = (sc.grp == 0);
     if (is_main) {   // ================= phase A: kinematics, composite inertia, bias forces, contact candidates -> scratch
         sc.st3(SC_ST, w); sc.st(SC_ST + 3, s.thd1); sc.st(SC_ST + 4, s.thd2); sc.st(SC_ST + 5, s.phid);      // for the helper groups
-        V qn = V(1) / vsqrt(s.qw * s.qw + s.qx * s.qx + s.qy * s.qy + s.qz * s.qz);
+        V qn = vrsqrt(s.qw * s.qw + s.qx * s.qx + s.qy * s.qy + s.qz * s.qz);
         s.qw = s.qw * qn; s.qx = s.qx * qn; s.qy = s.qy * qn; s.qz = s.qz * qn;
         Mat3<V> R = quat2mat(s.qw, s.qx, s.qy, s.qz);
 #pragma unroll
@@ -767,8 +766,8 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
                     Vec3<V> ec = sel_v3(x_onm, am + mul(Rm, ec0 - am), ec0);
                     Vec3<V> dl = mulT(Re, -nb);
                     Vec3<V> sz = ldc3(m, LM_XE_S);
-                    V den = vsqrt(sz.x * sz.x * dl.x * dl.x + sz.y * sz.y * dl.y * dl.y + sz.z * sz.z * dl.z * dl.z);
-                    Vec3<V> sup = ec + mul(Re, v3<V>(sz.x * sz.x * dl.x / den, sz.y * sz.y * dl.y / den, sz.z * sz.z * dl.z / den));
+                    V iden = vrsqrt(sz.x * sz.x * dl.x * dl.x + sz.y * sz.y * dl.y * dl.y + sz.z * sz.z * dl.z * dl.z);
+                    Vec3<V> sup = ec + mul(Re, v3<V>(sz.x * sz.x * dl.x * iden, sz.y * sz.y * dl.y * iden, sz.z * sz.z * dl.z * iden));
                     V elld = s.pz + dot(sup, nb);
                     MK ellon = mand(gt(ldc(m, LM_XE_EN), V(0.5)), lt(elld, V(0)));
                     Vec3<V> ellx = sup - nb * (elld * V(0.5));
@@ -1028,7 +1027,7 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
         V r1 = s.qw * dx + s.qx * cc + s.qy * dz - s.qz * dy;
         V r2 = s.qw * dy - s.qx * dz + s.qy * cc + s.qz * dx;
         V r3 = s.qw * dz + s.qx * dy - s.qy * dx + s.qz * cc;
-        V n = V(1) / vsqrt(r0 * r0 + r1 * r1 + r2 * r2 + r3 * r3);
+        V n = vrsqrt(r0 * r0 + r1 * r1 + r2 * r2 + r3 * r3);
         s.qw = r0 * n; s.qx = r1 * n; s.qy = r2 * n; s.qz = r3 * n;
     }
     s.th1 = s.th1 + h * s.thd1; s.th2 = s.th2 + h * s.thd2;
@@ -1047,7 +1046,7 @@ template <typename V>
 JB_HD void substep(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneState<V>& s, const V& ctrl, const SimOpts& o) {
     bool xtra = false;
     if (o.contacts && sc.grp == 0) {
-        V iq = V(1) / (s.qw * s.qw + s.qx * s.qx + s.qy * s.qy + s.qz * s.qz);
+        V iq = vrcp(s.qw * s.qw + s.qx * s.qx + s.qy * s.qy + s.qz * s.qz);
         // third row of the rotation matrix of the (not yet normalised) quaternion
         Vec3<V> nb = v3<V>(V(2) * (s.qx * s.qz - s.qw * s.qy) * iq, V(2) * (s.qy * s.qz + s.qw * s.qx) * iq,
                            (s.qw * s.qw - s.qx * s.qx - s.qy * s.qy + s.qz * s.qz) * iq);
