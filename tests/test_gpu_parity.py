@@ -326,3 +326,44 @@ def test_edge_cases_batch_sizes_and_layouts():
     with pytest.raises(_lib.JitterbugHipError, match="JB_E_MODEL"):
         g.set_model_params(bad)
     g.close()
+
+
+def test_open_loop_statistics_match_oracle():
+    """Open-loop rollouts are chaotic (contact activations), so beyond one control step GPU and oracle agree in DISTRIBUTION:
+    same reset streams, same action streams, 512 envs x 250 steps; compared: episode return, displacement from the origin,
+    height, uprightness (SURVEY.md §8d 'open-loop statistical agreement')."""
+    from jitterbug_amd.vec_env import JitterbugVecEnv
+    from oracle import oracle as O
+    n, steps = 512, 250
+    P = model.default_params()
+    g = JitterbugVecEnv(n, "move_from_origin", seed=12)
+    o = O.OracleEnv(n, "move_from_origin", P, seed=12)
+    g.reset(), o.reset()
+    rng = np.random.default_rng(3)
+    rg, ro = np.zeros(n), np.zeros(n)
+    for t in range(steps):
+        a = rng.uniform(-1, 1, size=n).astype(np.float32)
+        og, r1, _, _ = g.step(a)
+        oo, r2, _ = o.step(a)
+        rg += r1; ro += r2
+    qg, vg, _ = g.get_state()
+    qo, vo, _ = o.get_state()
+    dg, do = np.hypot(qg[:, 0], qg[:, 1]), np.hypot(qo[:, 0], qo[:, 1])
+    upg, upo = 1 - 2 * (qg[:, 4] ** 2 + qg[:, 5] ** 2), 1 - 2 * (qo[:, 4] ** 2 + qo[:, 5] ** 2)
+    print("return mean gpu %.2f oracle %.2f | displacement mean gpu %.4f oracle %.4f | upright>0.9 gpu %.3f oracle %.3f | z gpu %.4f oracle %.4f"
+          % (rg.mean(), ro.mean(), dg.mean(), do.mean(), (upg > 0.9).mean(), (upo > 0.9).mean(), qg[:, 2].mean(), qo[:, 2].mean()))
+    # the two are samples of the same distribution: means agree within a few standard errors
+    se = lambda x, y: np.sqrt(x.var() / n + y.var() / n)
+    assert abs(rg.mean() - ro.mean()) < 4 * se(rg, ro) + 1e-3
+    assert abs(dg.mean() - do.mean()) < 4 * se(dg, do) + 1e-4
+    assert abs(qg[:, 2].mean() - qo[:, 2].mean()) < 4 * se(qg[:, 2], qo[:, 2]) + 1e-5
+    assert abs((upg > 0.9).mean() - (upo > 0.9).mean()) < 0.05
+    # early in the rollout the trajectories still coincide closely for most envs
+    g2 = JitterbugVecEnv(n, "move_from_origin", seed=12); o2 = O.OracleEnv(n, "move_from_origin", P, seed=12)
+    g2.reset(), o2.reset()
+    rng = np.random.default_rng(3)
+    for t in range(5):
+        a = rng.uniform(-1, 1, size=n).astype(np.float32)
+        og, _, _, _ = g2.step(a); oo, _, _ = o2.step(a)
+    assert np.median(np.abs(og - oo).max(axis=1)) < 1e-4
+    g.close(); g2.close()
