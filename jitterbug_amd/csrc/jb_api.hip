@@ -156,11 +156,12 @@ __global__ __launch_bounds__(64) void jb_step_kernel(KArgs a, const float* __res
     s.st_xtra = 0.f; s.st_sweeps = 0.f; s.st_contact = 0.f; s.st_slots = 0.f;
 #endif
     const float ctrl = action[env];
-    SimOpts o; o.contacts = a.contacts; o.max_newton = a.max_newton; o.implicit_damp = 1; o.prof = nullptr;
+    SimOpts o; o.contacts = a.contacts; o.max_newton = a.max_newton; o.implicit_damp = 1; o.prof = nullptr; o.hist = nullptr;
 #ifdef JB_WAVE_STATS
     const unsigned long long rt_start = __builtin_amdgcn_s_memrealtime();
     unsigned long long prof_local[5] = {0, 0, 0, 0, 0};      // accumulated in registers, written once at the end
     o.prof = prof_local;
+    o.hist = a.wave_stats ? a.wave_stats + (size_t)16 * a.n : nullptr;
 #endif
 #pragma unroll 1
     for (int k = 0; k < a.substeps; k++) substep<float>(m, scr, s, ctrl, o);
@@ -389,8 +390,8 @@ int jb_create(const jb_config* cfg, jb_handle** out) {
     JB_HIP(hipMalloc(&h->d_qvel, sizeof(double) * 15 * N));
     JB_HIP(hipMalloc(&h->d_target, sizeof(double) * 3 * N));
 #ifdef JB_WAVE_STATS
-    JB_HIP(hipMalloc(&h->d_wave_stats, sizeof(unsigned long long) * 16 * N));
-    JB_HIP(hipMemset(h->d_wave_stats, 0, sizeof(unsigned long long) * 16 * N));
+    JB_HIP(hipMalloc(&h->d_wave_stats, sizeof(unsigned long long) * (16 * N + 64)));
+    JB_HIP(hipMemset(h->d_wave_stats, 0, sizeof(unsigned long long) * (16 * N + 64)));
 #endif
     JB_HIP(hipMemsetAsync(h->d_root, 0, sizeof(float) * ROOT_F * N, h->stream));
     JB_HIP(hipMemsetAsync(h->d_leg, 0, sizeof(float) * LEG_F * 4 * N, h->stream));

@@ -47,8 +47,19 @@ JB_D unsigned quad_sum_u(unsigned x) {
 }
 JB_D bool any_lane(bool m) { return __builtin_amdgcn_ballot_w64(m) != 0ull; }
 // helper groups: lanes L, L^off hold the same (env, leg) in different slot groups
-JB_D float xlane_xor(float x, int off) { return __shfl_xor(x, off, 64); }
-JB_D unsigned xlane_xor_u(unsigned x, int off) { return (unsigned)__shfl_xor((int)x, off, 64); }
+// xor_sum(x, off) = x + x[lane ^ off] without an LDS round trip: gfx950's v_permlane{16,32}_swap for off 16 / 32, DPP
+// row rotations inside a 16-lane row.  `sym2` promises that x already equals x[lane ^ 2*off] (the previous butterfly
+// stage), which makes a rotation by 4 as good as the xor.  `off` is a compile-time constant after inlining.
+JB_D unsigned xor_sum_bits(unsigned u, int off, bool sym2, bool is_float) {
+    auto add = [&](unsigned a, unsigned b) { return is_float ? __builtin_bit_cast(unsigned, __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b)) : a + b; };
+    if (off == 32) { auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false); return add(r[0], r[1]); }
+    if (off == 16) { auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false); return add(r[0], r[1]); }
+    if (off == 8) return add(u, (unsigned)__builtin_amdgcn_update_dpp(0, (int)u, 0x128, 0xF, 0xF, false));             // row_ror:8
+    if (off == 4 && sym2) return add(u, (unsigned)__builtin_amdgcn_update_dpp(0, (int)u, 0x124, 0xF, 0xF, false));     // row_ror:4
+    return add(u, (unsigned)__shfl_xor((int)u, off, 64));
+}
+JB_D float xor_sum(float x, int off, bool sym2) { return __builtin_bit_cast(float, xor_sum_bits(__builtin_bit_cast(unsigned, x), off, sym2, true)); }
+JB_D unsigned xor_sum_u(unsigned x, int off, bool sym2) { return xor_sum_bits(x, off, sym2, false); }
 JB_D unsigned wave_bcast_u(unsigned x) { return (unsigned)__builtin_amdgcn_readfirstlane((int)x); }   // value of the first active lane
 #endif
 
@@ -117,8 +128,8 @@ template <typename T> inline Quad<T> operator-(const Quad<T>& a) { Quad<T> r; fo
 template <typename T> inline Quad<T> quad_sum(const Quad<T>& x) { return Quad<T>((x.v[0] + x.v[1]) + (x.v[2] + x.v[3])); }
 inline UQuad quad_sum_u(const UQuad& x) { uint32_t s = (x.v[0] + x.v[1]) + (x.v[2] + x.v[3]); return UQuad{{s, s, s, s}}; }
 inline bool any_lane(const Mask4& m) { return m.v[0] || m.v[1] || m.v[2] || m.v[3]; }
-template <typename T> inline Quad<T> xlane_xor(const Quad<T>& x, int) { return x; }      // the host harness has one group
-inline UQuad xlane_xor_u(const UQuad& x, int) { return x; }
+template <typename T> inline Quad<T> xor_sum(const Quad<T>& x, int, bool) { return x; }      // the host harness has one group
+inline UQuad xor_sum_u(const UQuad& x, int, bool) { return x; }
 inline unsigned wave_bcast_u(unsigned x) { return x; }
 inline bool any_lane(bool m) { return m; }
 inline float quad_sum(float x) { return x; }

@@ -247,12 +247,16 @@ template <typename V> struct LaneScratch {
     JB_HD void st3(int i, const Vec3<V>& v) const { st(i, v.x); st(i + 1, v.y); st(i + 2, v.z); }
 };
 // sum over the helper groups (every group ends with the same total)
+// Butterfly over the group index, HIGH bit first: the order is part of the result's bits, and it is the same for every
+// envs-per-wave variant that has 4 groups.
 template <typename V> JB_HD V group_sum(const LaneScratch<V>& sc, V x) {
-    for (int off = sc.gstride; off < sc.gstride * sc.ngrp; off <<= 1) x = x + xlane_xor(x, off);
+    if (sc.ngrp == 4) { x = xor_sum(x, 2 * sc.gstride, false); x = xor_sum(x, sc.gstride, true); }
+    else if (sc.ngrp == 2) x = xor_sum(x, sc.gstride, false);
     return x;
 }
 template <typename V> JB_HD typename lane_traits<V>::uint group_sum_u(const LaneScratch<V>& sc, typename lane_traits<V>::uint x) {
-    for (int off = sc.gstride; off < sc.gstride * sc.ngrp; off <<= 1) x = x + xlane_xor_u(x, off);
+    if (sc.ngrp == 4) { x = xor_sum_u(x, 2 * sc.gstride, false); x = xor_sum_u(x, sc.gstride, true); }
+    else if (sc.ngrp == 2) x = xor_sum_u(x, sc.gstride, false);
     return x;
 }
 JB_HD constexpr int tri(int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
@@ -502,9 +506,12 @@ JB_HD int nth_set_bit(unsigned mask, int j) {
 // summed never depends on what the other envs of its wave are doing (results stay bit-identical for any batch split).
 // The common multi-contact case - foot + the three lower-leg cylinder points (slots 0,1,3,4) - lands on four groups.
 JB_HD constexpr int slot_group(int slot, int ngroups) {
-    return ngroups <= 1 ? 0 : (slot < 5 ? (ngroups == 4 ? (slot == 0 ? 0 : slot == 1 ? 1 : slot == 2 ? 0 : slot == 3 ? 2 : 3)
-                                                        : (slot == 1 || slot == 4 ? 1 : 0))
-                                        : ((slot - 5) & (ngroups - 1)));
+    // Leg slots 0-9 are placed by hand from the live-slot statistics of real rollouts (tools/wave_stats.py): a leg lying on
+    // the floor has foot, lower cylinder points 0/2/3, upper cylinder points 0/2/3 and the knee tip live, which this map
+    // spreads as two per group (4 groups) or four per group (2 groups).
+    constexpr int leg4[10] = {0, 1, 0, 2, 3, 1, 0, 2, 3, 0};
+    constexpr int leg2[10] = {0, 1, 0, 0, 1, 1, 0, 0, 1, 0};
+    return ngroups <= 1 ? 0 : slot < 10 ? (ngroups == 4 ? leg4[slot] : leg2[slot]) : ((slot - 10) & (ngroups - 1));
 }
 template <int G, int NG> struct GroupMask {
     static constexpr unsigned make() { unsigned mk = 0; for (int sl = 0; sl < 28; sl++) if (slot_group(sl, NG) == G) mk |= 1u << sl; return mk; }
@@ -666,6 +673,7 @@ struct SimOpts {
     int max_newton;      // cap on Newton iterations per substep
     int implicit_damp;   // 1: MuJoCo Euler implicit joint damping
     unsigned long long* prof;   // diagnostic builds: per-wave cycle accumulators [phaseA, check sweeps, full sweeps, solves, integrate]
+    unsigned long long* hist;   // diagnostic builds: global [0..27] live-slot counts over all-geom substeps, [28..35] rounds histogram, [36..43] same for ordinary substeps
 };
 
 // small-angle sin/cos for the leg hinges (|th| < 1: truncation < 1e-9), exact libm otherwise
@@ -675,9 +683,21 @@ template <typename V> JB_HD void sincos_small(const V& x, V& s, V& c) {
     c = V(1) + x2 * (V(-0.5) + x2 * (V(1.0 / 24) + x2 * (V(-1.0 / 720) + x2 * (V(1.0 / 40320) + x2 * (V(-1.0 / 3628800) + x2 * V(1.0 / 479001600))))));
 }
 
+#ifdef JB_WAVE_STATS
+#if defined(__HIPCC__)
+template <typename V> __device__ inline void stats_hist(const SimOpts& o, const LaneScratch<V>&, const SlotPlan& plan, bool xtra, bool any_contact) {
+    if (!o.hist || !any_contact || (threadIdx.x & 63) != 0) return;
+    if (xtra) for (int sl = 0; sl < 28; sl++) if (plan.live >> sl & 1u) atomicAdd(o.hist + sl, 1ull);
+    atomicAdd(o.hist + (xtra ? 28 : 36) + (plan.rounds < 7 ? plan.rounds : 7), 1ull);
+}
+#else
+template <typename V> inline void stats_hist(const SimOpts&, const LaneScratch<V>&, const SlotPlan&, bool, bool) {}
+#endif
+#endif
+
 // ----------------------------------------------------------------------------- the substep
 template <typename V>
-JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneState<V>& s, const V& ctrl, const SimOpts& o, const bool xtra) {
+JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneState<V>& s, const V& ctrl, const SimOpts& o, const bool xtra, const bool xbody) {
     using MK = typename lane_traits<V>::mask;
     using U = typename lane_traits<V>::uint;
     const V h = m.c[LM_H];
@@ -747,6 +767,7 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
                 V tipd = s.pz + dot(tip, nb) - ldc(m, LM_TIP_R);
                 live_slots |= cand_store(sc, 9, tip - nb * (ldc(m, LM_TIP_R) + tipd * V(0.5)), tipd, lt(tipd, V(0)));
                 any_con = mor(any_con, lt(tipd, V(0)));
+              if (xbody) {
                 // lane cylinder (root body: lane 2 screw1; motor body: lane 3 threadMass)
                 MK x_onm = gt(ldc(m, LM_X_ONM), V(0.5));
                 Vec3<V> xc_c = ldc3(m, LM_XC_C), xc_ax = ldc3(m, LM_XC_AX), xc_xa = ldc3(m, LM_XC_XA);
@@ -793,6 +814,7 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
                         any_con = mor(any_con, on);
                     }
                 }
+              }
             }
             any_contact = any_lane(any_con);
             env_con = neq_u(quad_sum_u(mbit(any_con)), zero_u<V>());
@@ -924,6 +946,7 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
         const V hb1 = o.implicit_damp ? h * m.c[LM_B1] : V(0), hb2 = o.implicit_damp ? h * m.c[LM_B2] : V(0);
 #ifdef JB_WAVE_STATS
         if (is_main && any_contact) { s.st_contact = s.st_contact + V(1); s.st_slots = s.st_slots + V((float)__builtin_popcount(plan.live)); }
+        stats_hist(o, sc, plan, xtra, any_contact);
 #endif
 #pragma unroll 1
         for (int it = 0;; it++) {
@@ -1044,32 +1067,35 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
 // touch the floor (common) or every geom of the model has to be tested (rare).
 template <typename V>
 JB_HD void substep(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneState<V>& s, const V& ctrl, const SimOpts& o) {
-    bool xtra = false;
+    unsigned xt = 0;          // bit 0: some upper leg may touch the floor, bit 1: some root / motor-body geom may
     if (o.contacts && sc.grp == 0) {
         V iq = vrcp(s.qw * s.qw + s.qx * s.qx + s.qy * s.qy + s.qz * s.qz);
         // third row of the rotation matrix of the (not yet normalised) quaternion
         Vec3<V> nb = v3<V>(V(2) * (s.qx * s.qz - s.qw * s.qy) * iq, V(2) * (s.qy * s.qz + s.qw * s.qx) * iq,
                            (s.qw * s.qw - s.qx * s.qx - s.qy * s.qy + s.qz * s.qz) * iq);
         // upper leg: sphere around the upper cylinder (+ slack for the shoulder angle)
-        auto near = mor(lt(s.pz + dot(ldv3(m, LM_BS_LEG_C), nb), m.c[LM_BS_LEG_R]), gt(vabs(s.th1), V(0.3)));
+        auto near_leg = mor(lt(s.pz + dot(ldv3(m, LM_BS_LEG_C), nb), m.c[LM_BS_LEG_R]), gt(vabs(s.th1), V(0.3)));
         // the lane's root / motor-body geoms: two oriented boxes (support function of a box along -n)
+        auto near_body = lt(V(1), V(0));
 #pragma unroll
         for (int k = 0; k < 2; k++) {
             const int b = LM_BX + 15 * k;
             Vec3<V> ax0 = ldv3(m, b + 3), ax1 = ldv3(m, b + 6), ax2 = ldv3(m, b + 9);
             V sup = vabs(dot(ax0, nb)) * m.c[b + 12] + vabs(dot(ax1, nb)) * m.c[b + 13] + vabs(dot(ax2, nb)) * m.c[b + 14];
-            near = mor(near, lt(s.pz + dot(ldv3(m, b), nb), sup));
+            near_body = mor(near_body, lt(s.pz + dot(ldv3(m, b), nb), sup));
         }
-        xtra = any_lane(near);
+        xt = (any_lane(near_leg) ? 1u : 0u) | (any_lane(near_body) ? 2u : 0u);
     }
-    xtra = wave_bcast_u(xtra ? 1u : 0u) != 0u;      // helper groups follow the main lanes' decision
+    xt = wave_bcast_u(xt);      // helper groups follow the main lanes' decision
+    bool xtra = xt != 0u;
+    const bool xbody = (xt & 2u) != 0u;
 #ifdef JB_NO_XTRA
     xtra = false;
 #endif
 #ifdef JB_WAVE_STATS
     if (xtra && sc.grp == 0) s.st_xtra = s.st_xtra + V(1);
 #endif
-    substep_impl<V>(m, sc, s, ctrl, o, xtra);
+    substep_impl<V>(m, sc, s, ctrl, o, xtra, xbody);
 }
 
 }  // namespace jb

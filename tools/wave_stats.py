@@ -12,9 +12,10 @@ rng = np.random.default_rng(0)
 for t in range(150):
     env.step(rng.uniform(-1, 1, size=n).astype(np.float32))
 L = _lib.load()
-buf = np.zeros((n, 16), dtype=np.uint64)
+buf = np.zeros((n + 4, 16), dtype=np.uint64)
 L.jb_debug_wave_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
-e = L.jb_debug_wave_stats(env._h, buf.ctypes.data, n)
+e = L.jb_debug_wave_stats(env._h, buf.ctypes.data, n + 4)
+hist = buf[n:].reshape(-1)
 nw = (n + e - 1) // e
 b = buf[:nw].astype(np.float64)
 cyc = b[:, 0] / 100.0   # shader cycles / 100
@@ -49,3 +50,9 @@ print("cycles/substep quantiles (no rare path) p10 p50 p90 p99 max:", np.round(q
 A = np.stack([np.ones(nx.sum()), b[nx, 2] / 50, b[nx, 11] / np.maximum(b[nx, 3], 1)], 1)
 coef = np.linalg.lstsq(A, b[nx, 0] / 50, rcond=None)[0]
 print("fit cycles/substep = %.0f + %.0f * fulls + %.0f * live_slots" % tuple(coef))
+
+print("all-geom substeps: live-slot counts (cumulative over the run) by slot:")
+names = ["foot"] + ["lowcyl%d" % i for i in range(4)] + ["upcyl%d" % i for i in range(4)] + ["tip"] + ["rcyl%d" % i for i in range(4)] + ["rell"] + ["box%d" % i for i in range(8)] + ["mcyl%d" % i for i in range(4)] + ["mell"]
+tot = max(1, int(hist[28:36].sum()))
+print("  " + "  ".join("%s %.2f" % (names[i], hist[i] / tot) for i in range(28)))
+print("rounds histogram all-geom substeps:", (hist[28:36] / tot).round(3), " ordinary:", (hist[36:44] / max(1, hist[36:44].sum())).round(3))
