@@ -58,6 +58,19 @@ JB_D unsigned xor_sum_bits(unsigned u, int off, bool sym2, bool is_float) {
     if (off == 4 && sym2) return add(u, (unsigned)__builtin_amdgcn_update_dpp(0, (int)u, 0x124, 0xF, 0xF, false));     // row_ror:4
     return add(u, (unsigned)__shfl_xor((int)u, off, 64));
 }
+// Transposed sum over 4 helper groups that sit in the four 16-lane rows of the wave: row g returns the total of v[g],
+// associated (g0 + g2) + (g1 + g3) like the butterfly of xor_sum (high group bit first).  Three swaps and three adds for
+// four values, no copies: v_permlane32_swap exchanges the upper half of its first operand with the lower half of the second,
+// v_permlane16_swap the odd rows of the first with the even rows of the second.
+JB_D float row_transpose_sum(float v0, float v1, float v2, float v3) {
+    auto f = [](unsigned u) { return __builtin_bit_cast(float, u); };
+    auto b = [](float x) { return __builtin_bit_cast(unsigned, x); };
+    auto r02 = __builtin_amdgcn_permlane32_swap(b(v0), b(v2), false, false);
+    auto r13 = __builtin_amdgcn_permlane32_swap(b(v1), b(v3), false, false);
+    float s02 = f(r02[0]) + f(r02[1]), s13 = f(r13[0]) + f(r13[1]);
+    auto r = __builtin_amdgcn_permlane16_swap(b(s02), b(s13), false, false);
+    return f(r[0]) + f(r[1]);
+}
 JB_D float xor_sum(float x, int off, bool sym2) { return __builtin_bit_cast(float, xor_sum_bits(__builtin_bit_cast(unsigned, x), off, sym2, true)); }
 JB_D unsigned xor_sum_u(unsigned x, int off, bool sym2) { return xor_sum_bits(x, off, sym2, false); }
 JB_D unsigned wave_bcast_u(unsigned x) { return (unsigned)__builtin_amdgcn_readfirstlane((int)x); }   // value of the first active lane
@@ -128,6 +141,7 @@ template <typename T> inline Quad<T> operator-(const Quad<T>& a) { Quad<T> r; fo
 template <typename T> inline Quad<T> quad_sum(const Quad<T>& x) { return Quad<T>((x.v[0] + x.v[1]) + (x.v[2] + x.v[3])); }
 inline UQuad quad_sum_u(const UQuad& x) { uint32_t s = (x.v[0] + x.v[1]) + (x.v[2] + x.v[3]); return UQuad{{s, s, s, s}}; }
 inline bool any_lane(const Mask4& m) { return m.v[0] || m.v[1] || m.v[2] || m.v[3]; }
+template <typename T> inline Quad<T> row_transpose_sum(const Quad<T>& v0, const Quad<T>&, const Quad<T>&, const Quad<T>&) { return v0; }
 template <typename T> inline Quad<T> xor_sum(const Quad<T>& x, int, bool) { return x; }      // the host harness has one group
 inline UQuad xor_sum_u(const UQuad& x, int, bool) { return x; }
 inline unsigned wave_bcast_u(unsigned x) { return x; }

@@ -282,6 +282,22 @@ template <typename V> JB_HD void acc_clear(NewtonAcc<V>& acc) {
     acc.bw0 = zero_u<V>(); acc.xh = zero_u<V>();
 }
 
+// the 52 additive values of the accumulator as a flat list (and back)
+template <typename V> JB_HD void acc_pack(const NewtonAcc<V>& a, V* v) {
+#pragma unroll
+    for (int i = 0; i < 21; i++) v[i] = a.A[i];
+#pragma unroll
+    for (int i = 0; i < 6; i++) { v[21 + 2 * i] = a.B[i][0]; v[22 + 2 * i] = a.B[i][1]; v[36 + i] = a.Bm[i]; v[43 + i] = a.rr[i]; }
+    v[33] = a.C11; v[34] = a.C12; v[35] = a.C22; v[42] = a.Cm; v[49] = a.rl[0]; v[50] = a.rl[1]; v[51] = a.rm;
+}
+template <typename V> JB_HD void acc_unpack(const V* v, NewtonAcc<V>& a) {
+#pragma unroll
+    for (int i = 0; i < 21; i++) a.A[i] = v[i];
+#pragma unroll
+    for (int i = 0; i < 6; i++) { a.B[i][0] = v[21 + 2 * i]; a.B[i][1] = v[22 + 2 * i]; a.Bm[i] = v[36 + i]; a.rr[i] = v[43 + i]; }
+    a.C11 = v[33]; a.C12 = v[34]; a.C22 = v[35]; a.Cm = v[42]; a.rl[0] = v[49]; a.rl[1] = v[50]; a.rm = v[51];
+}
+
 // Solve  [A B Bm; B^T C 0; Bm^T 0 Cm] y = rhs  where the matrix is M (scratch) + the contact terms in `acc`
 // (+ hb1/hb2 on the leg diagonal: implicit joint damping) and rhs = tau (scratch) + acc.r*.
 //   A, tau_root, Bm, Cm : replicated in the 4 lanes, added ONCE;  acc.A, acc.rr, acc.Bm/Cm/rm: lane-private
@@ -597,7 +613,22 @@ JB_HD void contact_sweep(const LaneModel<V>& m, const LaneScratch<V>& sc, bool x
     }
     if (plan.grouped) {
         acc.bw0 = group_sum_u<V>(sc, acc.bw0); acc.xh = group_sum_u<V>(sc, acc.xh);
-        if (mode == 0) {
+        if (mode == 0 && sc.ngrp == 4 && sc.gstride == 16) {
+            // Only the main lanes need the totals: reduce four values at a time so that row (= group) g ends with the total
+            // of value 4k+g, hand the totals over through the scratch (the overflow row entries are dead here) and let the
+            // main lanes read all of them.  Same association as group_sum, a quarter of its instructions.
+            V v[52];
+            acc_pack(acc, v);
+            constexpr int SC_RED = SC_ROWS + ROW_K * ROW_F;
+            static_assert(4 * ROW_F >= 52, "reduction buffer");
+#pragma unroll
+            for (int k = 0; k < 13; k++) sc.st(SC_RED + 4 * k + sc.grp, row_transpose_sum(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]));
+            if (sc.grp == 0) {
+#pragma unroll
+                for (int i = 0; i < 52; i++) v[i] = sc.ld(SC_RED + i);
+                acc_unpack(v, acc);
+            }
+        } else if (mode == 0) {
 #pragma unroll
             for (int i = 0; i < 21; i++) acc.A[i] = group_sum(sc, acc.A[i]);
 #pragma unroll
