@@ -159,7 +159,7 @@ __global__ __launch_bounds__(64) void jb_step_kernel(KArgs a, const float* __res
     SimOpts o; o.contacts = a.contacts; o.max_newton = a.max_newton; o.implicit_damp = 1; o.prof = nullptr; o.hist = nullptr;
 #ifdef JB_WAVE_STATS
     const unsigned long long rt_start = __builtin_amdgcn_s_memrealtime();
-    unsigned long long prof_local[5] = {0, 0, 0, 0, 0};      // accumulated in registers, written once at the end
+    unsigned long long prof_local[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // accumulated in registers, written once at the end
     o.prof = prof_local;
     o.hist = a.wave_stats ? a.wave_stats + (size_t)16 * a.n : nullptr;
 #endif
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(64) void jb_step_kernel(KArgs a, const float* __res
         unsigned long long* ws = a.wave_stats + (size_t)lblock * 16;
         ws[10] = __builtin_amdgcn_s_memrealtime() - rt_start;
         ws[0] = __builtin_amdgcn_s_memtime() - t_start;
-        for (int i = 0; i < 5; i++) ws[4 + i] = prof_local[i]; ws[1] = (unsigned long long)s.st_xtra; ws[2] = (unsigned long long)s.st_sweeps; ws[3] = (unsigned long long)s.st_contact; ws[11] = (unsigned long long)s.st_slots;
+        for (int i = 0; i < 5; i++) ws[4 + i] = prof_local[i]; ws[1] = (unsigned long long)s.st_xtra; ws[2] = (unsigned long long)s.st_sweeps; ws[3] = (unsigned long long)s.st_contact; ws[11] = (unsigned long long)s.st_slots; ws[12] = prof_local[5]; ws[13] = prof_local[6]; ws[14] = prof_local[7];
     }
 #endif
     {   // trailing mj_step1: derived quantities use the normalised quaternion

@@ -960,6 +960,7 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
         U prev_bw0 = zero_u<V>(), prev_xh = zero_u<V>();
         if (any_contact) {
             contact_rows_build_all<V>(m, sc, xtra, plan);
+            JB_PROF_ADD(o, 5);
             if (is_main) {      // warm start (world linear part rotated into the root frame)
                 Mat3<V> R;
 #pragma unroll
@@ -1006,41 +1007,28 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
                     if (is_main) s.st_sweeps = s.st_sweeps + V(1);
 #endif
                 } else if (is_main) {
-                    // At the minimiser  H y = tau + sum B^T W ahat,  so the constraint force is  qfrc = M y - tau.  Load
-                    // acc so that the solve below sees  rhs = tau + qfrc = M y  (replicated parts enter the quad sums as 1/4).
+                    // At the minimiser  H y = tau + sum B^T W ahat,  so the constraint force is  qfrc = M y - tau  and MuJoCo's
+                    // Euler step with implicit joint damping solves  (M + h diag(b)) qacc = tau + qfrc = M y,  i.e.
+                    //     qacc = y - d,   (M + h diag(b)) d = h diag(b) y        (nonzero only in the leg rows).
+                    // star_solve adds tau itself, so the contact envs cancel it (replicated parts enter the quad sums as 1/4).
+                    // An env without contacts has qfrc = 0 exactly, whatever the rest of its wave is doing: plain solve.
                     acc_clear(acc);
-                    V my[6];
 #pragma unroll
-                    for (int i = 0; i < 6; i++) {
-                        V t = sc.ld(SC_MBM + i) * ym - sc.ld(SC_TR + i);
-#pragma unroll
-                        for (int j = 0; j < 6; j++) t = t + sc.ld(SC_MA + tri(i, j)) * yr[j];
-                        my[i] = t;
-                    }
-                    V l0 = sc.ld(SC_MC) * yl[0] + sc.ld(SC_MC + 1) * yl[1] - sc.ld(SC_TL);
-                    V l1 = sc.ld(SC_MC + 1) * yl[0] + sc.ld(SC_MC + 2) * yl[1] - sc.ld(SC_TL + 1);
-                    V mm_ = sc.ld(SC_MCM) * ym - sc.ld(SC_TM);
-#pragma unroll
-                    for (int i = 0; i < 6; i++) {
-                        V b0 = sc.ld(SC_MB + 2 * i), b1 = sc.ld(SC_MB + 2 * i + 1);
-                        acc.rr[i] = V(0.25) * my[i] + b0 * yl[0] + b1 * yl[1];
-                        l0 = l0 + b0 * yr[i]; l1 = l1 + b1 * yr[i];
-                        mm_ = mm_ + sc.ld(SC_MBM + i) * yr[i];
-                    }
-                    acc.rl[0] = l0; acc.rl[1] = l1; acc.rm = V(0.25) * mm_;
-                    // an env without contacts has qfrc = 0 exactly, whatever the rest of its wave is doing
-#pragma unroll
-                    for (int i = 0; i < 6; i++) acc.rr[i] = sel(env_con, acc.rr[i], V(0));
-                    acc.rl[0] = sel(env_con, acc.rl[0], V(0)); acc.rl[1] = sel(env_con, acc.rl[1], V(0)); acc.rm = sel(env_con, acc.rm, V(0));
+                    for (int i = 0; i < 6; i++) acc.rr[i] = sel(env_con, V(-0.25) * sc.ld(SC_TR + i), V(0));
+                    acc.rl[0] = sel(env_con, hb1 * yl[0] - sc.ld(SC_TL), V(0));
+                    acc.rl[1] = sel(env_con, hb2 * yl[1] - sc.ld(SC_TL + 1), V(0));
+                    acc.rm = sel(env_con, V(-0.25) * sc.ld(SC_TM), V(0));
                 }
             }
+            JB_PROF_ADD(o, 7);
             if (is_main) {
                 V nyr[6], nyl[2], nym;
                 star_solve<V>(sc, acc, final_pass ? hb1 : V(0), final_pass ? hb2 : V(0), nyr, nyl, nym);
+                JB_PROF_ADD(o, 6);
                 if (final_pass) {
 #pragma unroll
-                    for (int i = 0; i < 6; i++) yr[i] = nyr[i];
-                    yl[0] = nyl[0]; yl[1] = nyl[1]; ym = nym;
+                    for (int i = 0; i < 6; i++) yr[i] = sel(env_con, yr[i] - nyr[i], nyr[i]);
+                    yl[0] = sel(env_con, yl[0] - nyl[0], nyl[0]); yl[1] = sel(env_con, yl[1] - nyl[1], nyl[1]); ym = sel(env_con, ym - nym, nym);
                 } else {
                     // envs whose active set already repeated keep their (exact) solution
 #pragma unroll
