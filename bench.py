@@ -29,12 +29,24 @@ N_ENVS_PER_GPU = 4096
 TASK = "move_from_origin"
 
 
-def cpu_baseline(n_cores, budget_s=12.0):
+def cpu_baseline(n_cores, task, budget_s=12.0):
     """The CPU fp64 oracle (a port/restatement, NOT MuJoCo) on the host cores, on a bounded sample of the same workload."""
     import numpy as np
     from jitterbug_amd import model
     from oracle import oracle as O
     P = model.default_params()
+    TASK = task
+    # one core first (SURVEY.md §8d asks for the 1-core rate next to the all-core one): 16 envs x a few control steps
+    e1 = O.OracleEnv(16, TASK, P, seed=0)
+    e1.reset()
+    r1 = np.random.default_rng(1)
+    e1.step(r1.uniform(-1, 1, size=16), nthreads=1)
+    t0 = time.perf_counter()
+    k1 = 0
+    while time.perf_counter() - t0 < 2.0:
+        e1.step(r1.uniform(-1, 1, size=16), nthreads=1)
+        k1 += 1
+    one_core = 16 * k1 / (time.perf_counter() - t0)
     n = 64 * n_cores
     env = O.OracleEnv(n, TASK, P, seed=0)
     env.reset()
@@ -47,7 +59,7 @@ def cpu_baseline(n_cores, budget_s=12.0):
     for _ in range(steps):
         env.step(rng.uniform(-1, 1, size=n), nthreads=n_cores)
     dt = time.perf_counter() - t0
-    return {"value": n * steps / dt, "unit": "env steps/s", "cores": n_cores, "kind": "port",
+    return {"value": n * steps / dt, "unit": "env steps/s", "cores": n_cores, "kind": "port", "one_core_value": one_core,
             "sample": "%d envs x %d control steps of %s, fp64 oracle (oracle/jb_oracle.c: Newton contact solve), OpenMP over envs" % (n, steps, TASK)}
 
 
@@ -62,7 +74,10 @@ def main():
     ap.add_argument("--no-also", action="store_true")
     ap.add_argument("--max-newton", type=int, default=12)
     ap.add_argument("--envs-per-wave", type=int, default=0)
+    ap.add_argument("--task", default=TASK, help="default move_from_origin (the BASELINE metric); move_to_pose is BASELINE configs[3]'s task")
+    ap.add_argument("--augmented", action="store_true", help="one randomised model per env (BASELINE configs[4], augment_Jitterbug semantics)")
     args = ap.parse_args()
+    task = args.task
 
     import numpy as np
     import torch
@@ -84,13 +99,17 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     n = args.envs_per_gpu
-    D = model.OBS_DIM[TASK]
+    D = model.OBS_DIM[task]
     K, W = args.steps, args.warmup
 
     def make_env(contacts):
         # the handle launches on torch's current stream so torch.cuda.Event brackets exactly these kernels
-        return JitterbugVecEnv(n, TASK, seed=0, device_id=local_rank, contacts=bool(contacts), env_offset=rank * n, max_newton=args.max_newton, envs_per_wave=args.envs_per_wave,
-                               stream=torch.cuda.current_stream(dev).cuda_stream)
+        env = JitterbugVecEnv(n, task, seed=0, device_id=local_rank, contacts=bool(contacts), env_offset=rank * n, max_newton=args.max_newton, envs_per_wave=args.envs_per_wave,
+                              stream=torch.cuda.current_stream(dev).cuda_stream)
+        if args.augmented:
+            from jitterbug_amd.augmented_jitterbug import augmented_params
+            env.set_model_params(augmented_params(n, seed=1000 + rank))
+        return env
 
     def run(contacts, steps, warmup, gather):
         env = make_env(contacts)
@@ -144,7 +163,7 @@ def main():
     also = None
     if not args.no_also and world == 1:
         w2, d2, _, _ = run(1 - args.contacts, max(50, K // 5), 20, gather=False)
-        also = {"workload": "%s N_envs=%d contacts %s (BASELINE configs[%d])" % (TASK, n, "off" if args.contacts else "on", 1 if args.contacts else 2),
+        also = {"workload": "%s N_envs=%d contacts %s (BASELINE configs[%d])" % (task, n, "off" if args.contacts else "on", 1 if args.contacts else 2),
                 "value": n * max(50, K // 5) / w2, "unit": "env steps/s"}
 
     if rank == 0:
@@ -153,23 +172,26 @@ def main():
         traffic = None
         try:
             raw = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_raw.json")))
-            if n == N_ENVS_PER_GPU and args.contacts:
+            if n == N_ENVS_PER_GPU and args.contacts and task == TASK and not args.augmented:
                 traffic = (raw["FETCH_SIZE_KB"] + raw["WRITE_SIZE_KB"]) * 1024.0
         except Exception:
             pass
         launch_s = dev_ms * 1e-3 / K                 # average duration of one jb_step_kernel launch, from HIP events on its stream
-        achieved = ALGO_BYTES_PER_ENV_STEP * n / launch_s / 1e9
+        # 317 B for move_from_origin (D=15); other tasks add 4 B per extra obs entry and the 12 B target read; per-env models add
+        # the lane constant table (202 x 4 floats) read once per step
+        algo_bytes = ALGO_BYTES_PER_ENV_STEP + 4 * (D - 15) + (12 if task != TASK else 0) + (202 * 4 * 4 if args.augmented else 0)
+        achieved = algo_bytes * n / launch_s / 1e9
         res = {
-            "metric": "env steps/s at N_envs=4096, move_from_origin",
+            "metric": "env steps/s at N_envs=%d, %s" % (n, task),
             "value": value, "unit": "env steps/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": wall_max * 1e3 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s, N_envs=%d per GPU, %s, 50 substeps/step, in-kernel auto-reset (BASELINE configs[%d])"
-                                   % (TASK, n, "full Newton contact solve" if args.contacts else "contacts off", 2 if args.contacts else 1),
+                                   % (task + (", one randomised model per env" if args.augmented else ""), n, "full Newton contact solve" if args.contacts else "contacts off", 2 if args.contacts else 1),
                        "global_envs": total_envs, "parallelism": "env-sharded x%d%s" % (world, ", RCCL gather of [N,D+2] to rank 0 per step" if world > 1 else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic,
-                         "kernel": "jb_step_kernel", "launch_ms": launch_s * 1e3, "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * n,
+                         "kernel": "jb_step_kernel", "launch_ms": launch_s * 1e3, "algorithmic_bytes_per_launch": algo_bytes * n,
                          "note": "path is fp32-VALU/latency bound, not HBM bound (SURVEY.md §8d): 317 B per env step vs ~1e5-1e6 dependent flops"},
             "solver_cap_hits": cap_hits, "finite": finite,
         }
@@ -177,7 +199,7 @@ def main():
             res["also"] = also
         if world == 1 and not args.no_cpu_baseline:
             cores = len(os.sched_getaffinity(0))
-            res["cpu_baseline"] = cpu_baseline(cores)
+            res["cpu_baseline"] = cpu_baseline(cores, task)
         print(json.dumps(res))
     if dist is not None:
         dist.destroy_process_group()

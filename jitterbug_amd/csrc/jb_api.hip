@@ -3,7 +3,7 @@
 // Layout in HBM (all fp32 unless noted), N environments, 4 lanes per environment:
 //   root [ROOT_F][N]      root pose/velocity, motor angle/rate/turns, warm-start accelerations, target
 //   leg  [LEG_F][4N]      per-leg hinge angles/rates and warm-start accelerations (lane-private, fully coalesced)
-//   lane_model [T][LM_COUNT][4]   per-lane constant tables (T = 1 shared, or N per-env)
+//   lane_model [T][LM_TABLE]      packed constant tables (jb_sim.hpp LM_INV; T = 1 shared, or N per-env)
 //   step_count[N] (i32), episode[N] (u32)
 // One launch of jb_step_kernel advances every env by one control step (cfg.substeps physics substeps),
 // then computes reward, done, optional in-kernel episode reset, and the observation row.
@@ -38,10 +38,10 @@ struct KArgs {
     unsigned long long* wave_stats;   // diagnostic builds (-DJB_WAVE_STATS): [n_waves][4] = cycles, rare-path substeps, Newton sweeps, contact substeps
 };
 
-// Stage the lane constant table(s) of this workgroup (one wave = a.epw envs) into LDS: one [LM_COUNT][4] copy for a
+// Stage the packed constant table(s) of this workgroup (one wave = a.epw envs) into LDS: one LM_TABLE copy for a
 // shared model, epw copies for per-env models.  Called by all 64 threads before the idle quads retire.
 __device__ __forceinline__ void stage_model(const KArgs& a, float* lds, int lblock, int quad, int leg, LaneModel<float>& m) {
-    const int tsz = LM_COUNT * 4;
+    const int tsz = LM_TABLE;
     if (a.per_env_model) {
         const int env0 = lblock * a.epw;
         for (int i = threadIdx.x; i < tsz * a.epw; i += blockDim.x) {
@@ -50,12 +50,13 @@ __device__ __forceinline__ void stage_model(const KArgs& a, float* lds, int lblo
             lds[i] = a.lane_model[(size_t)e * tsz + (i % tsz)];
         }
         __syncthreads();
-        m.c.tab = lds + quad * tsz + leg;
+        m.c.inv = lds + quad * tsz;
     } else {
         for (int i = threadIdx.x; i < tsz; i += blockDim.x) lds[i] = a.lane_model[i];
         __syncthreads();
-        m.c.tab = lds + leg;
+        m.c.inv = lds;
     }
+    m.c.tab = m.c.inv + LM_INV + leg;
 }
 __device__ __forceinline__ void load_state(const KArgs& a, int env, int lane, LaneState<float>& s) {
     const float* r = a.root + env;
@@ -207,8 +208,8 @@ __global__ __launch_bounds__(64) void jb_reset_kernel(KArgs a, const unsigned ch
     int env = t >> 2, leg = t & 3;
     if (env >= a.n) return;
     const int lane = env * 4 + leg;
-    const float* tab = a.lane_model + (a.per_env_model ? (size_t)env * LM_COUNT * 4 : 0);
-    const float target_z = tab[LM_TARGET_Z * 4 + leg], root_z0 = tab[LM_ROOT_Z0 * 4 + leg];
+    const float* tab = a.lane_model + (a.per_env_model ? (size_t)env * LM_TABLE : 0);
+    const float target_z = tab[lm_offset(LM_TARGET_Z, leg)], root_z0 = tab[lm_offset(LM_ROOT_Z0, leg)];
     LaneState<float> s;
     EnvCore<float> e;
     if (!mask || mask[env]) {
@@ -229,8 +230,8 @@ __global__ __launch_bounds__(64) void jb_observe_kernel(KArgs a, float* __restri
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     int env = t >> 2, leg = t & 3;
     if (env >= a.n) return;
-    const float* tab = a.lane_model + (a.per_env_model ? (size_t)env * LM_COUNT * 4 : 0);
-    const float target_z = tab[LM_TARGET_Z * 4 + leg];
+    const float* tab = a.lane_model + (a.per_env_model ? (size_t)env * LM_TABLE : 0);
+    const float target_z = tab[lm_offset(LM_TARGET_Z, leg)];
     LaneState<float> s;
     load_state(a, env, env * 4 + leg, s);
     EnvCore<float> e;
@@ -318,14 +319,11 @@ struct jb_handle {
 static dim3 grid_lanes(int n) { return dim3((unsigned)(((size_t)n * 4 + 63) / 64)); }
 
 static int upload_model(jb_handle* h, const double* params, int n_tables) {
-    std::vector<float> host((size_t)n_tables * LM_COUNT * 4);
-    float tmp[LM_COUNT];
-    for (int t = 0; t < n_tables; t++)
-        for (int leg = 0; leg < 4; leg++) {
-            int rc = build_lane_model<float>(params + (size_t)t * JB_NPARAM, leg, tmp);
-            if (rc) return fail(JB_E_MODEL, "parameter table " + std::to_string(t) + " not supported by the kernel (code " + std::to_string(rc) + ")");
-            for (int f = 0; f < LM_COUNT; f++) host[((size_t)t * LM_COUNT + f) * 4 + leg] = tmp[f];
-        }
+    std::vector<float> host((size_t)n_tables * LM_TABLE);
+    for (int t = 0; t < n_tables; t++) {
+        int rc = build_packed_model<float>(params + (size_t)t * JB_NPARAM, host.data() + (size_t)t * LM_TABLE);
+        if (rc) return fail(JB_E_MODEL, "parameter table " + std::to_string(t) + " not supported by the kernel (code " + std::to_string(rc) + ")");
+    }
     if ((size_t)n_tables != h->model_tables) {
         if (h->d_model) JB_HIP(hipFree(h->d_model));
         h->d_model = nullptr;
@@ -454,7 +452,7 @@ int jb_reset_device(jb_handle* h, const uint8_t* d_mask, float* d_obs_out) {
 int jb_step_device(jb_handle* h, const float* d_action, float* d_obs_out, float* d_reward_out, uint8_t* d_done_out) {
     if (!h || !d_action) return fail(JB_E_INVALID, "handle/action is NULL");
     const dim3 grid((unsigned)((h->cfg.n_envs + h->ka.epw - 1) / h->ka.epw));
-    const size_t lds_bytes = ((size_t)SC_COUNT * 4 * h->ka.epw + (size_t)LM_COUNT * 4 * (h->ka.per_env_model ? h->ka.epw : 1)) * sizeof(float);
+    const size_t lds_bytes = ((size_t)SC_COUNT * 4 * h->ka.epw + (size_t)LM_TABLE * (h->ka.per_env_model ? h->ka.epw : 1)) * sizeof(float);
 #define JB_LAUNCH_STEP(E) hipLaunchKernelGGL(jb_step_kernel<E>, grid, dim3(64), lds_bytes, h->stream, h->ka, d_action, d_obs_out, d_reward_out, d_done_out)
     switch (h->ka.epw) {
     case 1: JB_LAUNCH_STEP(1); break;

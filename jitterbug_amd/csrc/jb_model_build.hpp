@@ -160,4 +160,17 @@ template <typename T> inline int build_lane_model(const double* P, int leg, T* o
     return 0;
 }
 
+// the packed table of one env (LM_TABLE entries: jb_sim.hpp LM_INV): <0 when unsupported, -50 if an entry that is stored
+// once differs between the legs (a bug in the table layout, not in the model)
+template <typename T> inline int build_packed_model(const double* P, T* out) {
+    T tmp[4][LM_COUNT];
+    for (int leg = 0; leg < 4; leg++) { int rc = build_lane_model<T>(P, leg, tmp[leg]); if (rc) return rc; }
+    for (int i = 0; i < LM_INV; i++) {
+        for (int leg = 1; leg < 4; leg++) if (!(tmp[leg][i] == tmp[0][i])) return -50;
+        out[i] = tmp[0][i];
+    }
+    for (int i = LM_INV; i < LM_COUNT; i++) for (int leg = 0; leg < 4; leg++) out[lm_offset(i, leg)] = tmp[leg][i];
+    return 0;
+}
+
 }  // namespace jb

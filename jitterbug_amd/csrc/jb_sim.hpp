@@ -83,21 +83,30 @@ enum LM : int {
     LM_XC_EN = 170, LM_XC_C = 171 /*3*/, LM_XC_AX = 174 /*3*/, LM_XC_XA = 177 /*3*/, LM_XC_R = 180, LM_XC_H = 181,
     LM_XE_EN = 182, LM_XE_C = 183 /*3*/, LM_XE_R = 186 /*9*/, LM_XE_S = 195 /*3*/,
     LM_X_ONM = 198 /*1: the lane's cylinder+ellipsoid sit on the motor body*/,
-    LM_COUNT = 202
+    LM_COUNT = 202,
+    // Entries [0, LM_INV) (global options, root body, motor body) are the same for the 4 lanes of an env and are stored
+    // once; the rest is stored per lane.  Packed table: [LM_INV] then [LM_COUNT - LM_INV][4]  = LM_TABLE floats per env.
+    LM_INV = 49,
+    LM_TABLE = LM_INV + 4 * (LM_COUNT - LM_INV)
 };
+JB_HD constexpr int lm_offset(int i, int leg) { return i < LM_INV ? i : LM_INV + 4 * (i - LM_INV) + leg; }
 
-// The constant table is stored [LM_COUNT][4] (4 = lane of the quad) — on the device in LDS, one copy per
-// workgroup (shared model) or per env (per-env models).  Constants are read where they are used instead of
-// being pinned in registers for the whole control step: `m.c[LM_X]` is one ds_read_b32 with an immediate offset.
-// tab: device = table base already offset by the lane's leg; host Quad = the row base.
+// The packed constant table (LM_TABLE floats, see LM_INV) lives in LDS on the device, one copy per workgroup (shared
+// model) or per env (per-env models).  Constants are read where they are used instead of being pinned in registers for
+// the whole control step: `m.c[LM_X]` is one ds_read_b32 with an immediate offset.
+// inv: base of the env's table; tab: device = lane part already offset by the lane's leg, host Quad = the lane part.
 JB_HD float lane_from4(const float* p, float*) { return p[0]; }
 JB_HD double lane_from4(const double* p, double*) { return p[0]; }
+JB_HD float lane_bcast(const float* p, float*) { return p[0]; }
+JB_HD double lane_bcast(const double* p, double*) { return p[0]; }
 #if !defined(__HIPCC__)
 template <typename T> inline Quad<T> lane_from4(const T* p, Quad<T>*) { return Quad<T>(p[0], p[1], p[2], p[3]); }
+template <typename T> inline Quad<T> lane_bcast(const T* p, Quad<T>*) { return Quad<T>(p[0]); }
 #endif
 template <typename V> struct LaneConsts {
+    const typename lane_traits<V>::real* inv;
     const typename lane_traits<V>::real* tab;
-    JB_HD V operator[](int i) const { return lane_from4(tab + 4 * i, (V*)nullptr); }
+    JB_HD V operator[](int i) const { return i < LM_INV ? lane_bcast(inv + i, (V*)nullptr) : lane_from4(tab + 4 * (i - LM_INV), (V*)nullptr); }
 };
 template <typename V> struct LaneModel { LaneConsts<V> c; };
 template <typename V> JB_HD V ldc(const LaneModel<V>& m, int i) { return m.c[i]; }
@@ -229,9 +238,9 @@ enum SC : int {
                    cylinder | 5-8 upper cylinder, 9 knee tip | root body: 10-13 lane cylinder, 14 lane ellipsoid,
                    15-22 lane box vertices | motor body: 23-26 lane cylinder, 27 lane ellipsoid*/,
     SC_R = 200 /*9: root rotation matrix*/,
-    SC_ROWS = 212 /*(ROW_K + 4) x ROW_F: y-independent contact rows of the live slots of this substep (12 cached + one
+    SC_ROWS = 212 /*(ROW_K + 4) x ROW_F: y-independent contact rows of the live slots of this substep (8 cached + one
                     overflow entry per group, 19 floats each)*/,
-    SC_Y = 212 + 16 * 19 /*9: current Newton iterate [yr(6), yl(2), ym], shared with the helper groups*/,
+    SC_Y = 212 + 12 * 19 /*9: current Newton iterate [yr(6), yl(2), ym], shared with the helper groups*/,
     SC_ST = SC_Y + 9 /*6: w(3), thd1, thd2, phid for the helper groups*/,
     SC_COUNT = SC_ST + 6
 };
@@ -401,7 +410,8 @@ template <typename V> JB_HD V impedance(const LaneModel<V>& m, const V& dist) {
 //   J_sh(x,d) = (d x e1).(x - a1) = wS.x - oS,   J_kn(x,d) = wK.x - oK,   J_m(x,d) = (d x em).(x - am)
 JB_HD constexpr int slot_level(int slot) { return slot < 5 ? 2 : slot < 10 ? 1 : slot < 23 ? 0 : 3; }
 constexpr int ROW_F = 19;            // floats per cached contact: ang[3][3], jsh[3], j7[3], ahat[3], D
-constexpr int ROW_K = 12;            // cached live slots per substep; further ones share entry ROW_K and are rebuilt per pass
+constexpr int ROW_K = 8;             // cached live slots per substep (a leg lying on the floor has 8); further ones use the group's overflow entry and are rebuilt per pass
+static_assert(SC_Y == SC_ROWS + (ROW_K + 4) * ROW_F, "scratch layout: row cache size");
 
 template <typename V>
 JB_HD void contact_rows_build(const LaneModel<V>& m, const LaneScratch<V>& sc, bool xtra, int slot, int entry) {
@@ -411,7 +421,7 @@ JB_HD void contact_rows_build(const LaneModel<V>& m, const LaneScratch<V>& sc, b
     const V f_sh = V((level == 1 || level == 2) ? 1.0f : 0.0f), f_kn = V(level == 2 ? 1.0f : 0.0f), f_m = V(level == 3 ? 1.0f : 0.0f);
     const Vec3<V> x = sc.ld3(SC_CAND + 4 * slot);
     const V dist = sc.ld(SC_CAND + 4 * slot + 3);
-    const V tran = m.c[level == 2 ? LM_TRAN2 : level == 1 ? LM_TRAN1 : level == 0 ? LM_TRAN0 : LM_TRANM];
+    const V tran = level == 2 ? m.c[LM_TRAN2] : level == 1 ? m.c[LM_TRAN1] : level == 0 ? m.c[LM_TRAN0] : m.c[LM_TRANM];
     const V mu = m.c[LM_MU];
     const auto valid = lt(dist, V(0));
     V imp = impedance(m, dist);

@@ -12,11 +12,9 @@ template <typename T>
 static int run(const double* P, double* qpos, double* qvel, double ctrl, int nsub, int contacts, int max_newton, int implicit_damp, double* fail) {
     using V = Quad<T>;
     LaneModel<V> m;
-    T tab[4][LM_COUNT];
-    for (int l = 0; l < 4; l++) { int rc = build_lane_model<T>(P, l, tab[l]); if (rc) return rc; }
-    T tabT[LM_COUNT][4];
-    for (int i = 0; i < LM_COUNT; i++) for (int l = 0; l < 4; l++) tabT[i][l] = tab[l][i];
-    m.c.tab = &tabT[0][0];
+    T tab[LM_TABLE];
+    { int rc = build_packed_model<T>(P, tab); if (rc) return rc; }
+    m.c.inv = tab; m.c.tab = tab + LM_INV;
     LaneState<V> s;
     s.px = V(T(qpos[0])); s.py = V(T(qpos[1])); s.pz = V(T(qpos[2]));
     s.qw = V(T(qpos[3])); s.qx = V(T(qpos[4])); s.qy = V(T(qpos[5])); s.qz = V(T(qpos[6]));
