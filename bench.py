@@ -29,6 +29,23 @@ N_ENVS_PER_GPU = 4096
 TASK = "move_from_origin"
 
 
+def usable_cores():
+    """Host threads this process may really use: the affinity mask capped by the cgroup CPU quota (the GPU box hands out a share)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(per) + 0.5)))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, int(q / per + 0.5)))
+        except Exception:
+            pass
+    return n
+
+
 def cpu_baseline(n_cores, task, budget_s=12.0):
     """The CPU fp64 oracle (a port/restatement, NOT MuJoCo) on the host cores, on a bounded sample of the same workload."""
     import numpy as np
@@ -198,7 +215,7 @@ def main():
         if also:
             res["also"] = also
         if world == 1 and not args.no_cpu_baseline:
-            cores = len(os.sched_getaffinity(0))
+            cores = usable_cores()
             res["cpu_baseline"] = cpu_baseline(cores, task)
         print(json.dumps(res))
     if dist is not None:

@@ -1,0 +1,35 @@
+"""Condenses the rocprofv3 output of tools/collect_profiles.sh into <prefix>_kernel_stats.csv and <prefix>_pmc_raw.json."""
+import csv, glob, json, os, sys
+src, prefix = sys.argv[1], sys.argv[2]
+KERNEL = "jb_step_kernel"
+def find(d, pat):
+    r = glob.glob(os.path.join(src, d, "**", pat), recursive=True)
+    return r[0] if r else None
+out = {}
+st = find("stats", "*kernel_stats.csv")
+if st:
+    rows = list(csv.DictReader(open(st)))
+    with open(prefix + "_kernel_stats.csv", "w") as f:
+        w = csv.DictWriter(f, fieldnames=rows[0].keys(), quoting=csv.QUOTE_ALL); w.writeheader(); w.writerows(rows[:8])
+    for r in rows:
+        if KERNEL in r["Name"]:
+            out.update(kernel=r["Name"].split("(")[1].split(")")[-1] if False else r["Name"][:60], kernel_calls=int(r["Calls"]), kernel_avg_ns=float(r["AverageNs"]), kernel_min_ns=float(r["MinNs"]), kernel_max_ns=float(r["MaxNs"]))
+def counters(d):
+    f = find(d, "*counter_collection.csv")
+    acc, n, disp = {}, {}, {}
+    if not f: return acc, disp
+    for r in csv.DictReader(open(f)):
+        if KERNEL not in r["Kernel_Name"]: continue
+        k = r["Counter_Name"]; acc[k] = acc.get(k, 0.0) + float(r["Counter_Value"]); n[k] = n.get(k, 0) + 1
+        if not disp: disp = {x: r.get(x) for x in ("LDS_Block_Size", "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "Workgroup_Size", "Grid_Size") if x in r}
+    return {k: acc[k] / n[k] for k in acc}, disp
+sq = {}
+for d in ("pmc_sq1", "pmc_sq2", "pmc_sq3", "pmc_grbm"):
+    c, disp = counters(d); sq.update(c)
+    if disp: out["dispatch"] = disp
+out["sq"] = sq
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    v, _ = counters("pmc_" + c)
+    if c in v: out[c + "_KB"] = v[c]
+json.dump(out, open(prefix + "_pmc_raw.json", "w"), indent=1)
+print(json.dumps(out, indent=1))
