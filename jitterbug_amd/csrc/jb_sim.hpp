@@ -313,13 +313,24 @@ template <typename V> JB_HD void acc_unpack(const V* v, NewtonAcc<V>& a) {
 //   parts that are summed over the quad;  B, C, tau_leg: lane-private leg branch.
 // The own leg (2x2) and the motor (1x1) are eliminated onto the 6 root dofs; the 6x6 Schur complement is
 // Cholesky-factored redundantly by the 4 lanes.
+// The joint-space system of the substep, M = [A B Bm; B^T C 0; Bm^T 0 Cm] and tau.  Only the main lanes ever read it
+// (solves, final pass), so it lives in registers - in practice in the otherwise unused accumulation registers, one move
+// away - instead of making ~130 LDS round trips per substep.
+template <typename V> struct StarSys {
+    V A[21];        // root block, tri() order
+    V B[6][2];      // own leg coupling
+    V C[3];         // own leg block: 11, 12, 22
+    V Bm[6], Cm;    // motor coupling and block
+    V tr[6], tl[2], tm;   // applied + bias forces: root, own leg, motor
+};
+
 template <typename V>
-JB_HD void star_solve(const LaneScratch<V>& sc, const NewtonAcc<V>& acc, const V& hb1, const V& hb2, V (&yr)[6], V (&yl)[2], V& ym) {
+JB_HD void star_solve(const StarSys<V>& M, const NewtonAcc<V>& acc, const V& hb1, const V& hb2, V (&yr)[6], V (&yl)[2], V& ym) {
     V B[6][2];
 #pragma unroll
-    for (int i = 0; i < 6; i++) { B[i][0] = sc.ld(SC_MB + 2 * i) + acc.B[i][0]; B[i][1] = sc.ld(SC_MB + 2 * i + 1) + acc.B[i][1]; }
-    V C11 = sc.ld(SC_MC) + acc.C11 + hb1, C12 = sc.ld(SC_MC + 1) + acc.C12, C22 = sc.ld(SC_MC + 2) + acc.C22 + hb2;
-    V rl0 = sc.ld(SC_TL) + acc.rl[0], rl1 = sc.ld(SC_TL + 1) + acc.rl[1];
+    for (int i = 0; i < 6; i++) { B[i][0] = M.B[i][0] + acc.B[i][0]; B[i][1] = M.B[i][1] + acc.B[i][1]; }
+    V C11 = M.C[0] + acc.C11 + hb1, C12 = M.C[1] + acc.C12, C22 = M.C[2] + acc.C22 + hb2;
+    V rl0 = M.tl[0] + acc.rl[0], rl1 = M.tl[1] + acc.rl[1];
     V idet = vrcp(C11 * C22 - C12 * C12);
     V i11 = C22 * idet, i12 = -C12 * idet, i22 = C11 * idet;
     V S[21], r[6];
@@ -327,13 +338,13 @@ JB_HD void star_solve(const LaneScratch<V>& sc, const NewtonAcc<V>& acc, const V
     for (int i = 0; i < 6; i++) {
         V g0 = B[i][0] * i11 + B[i][1] * i12, g1 = B[i][0] * i12 + B[i][1] * i22;
 #pragma unroll
-        for (int j = 0; j <= i; j++) S[tri(i, j)] = quad_sum(acc.A[tri(i, j)] - (g0 * B[j][0] + g1 * B[j][1])) + sc.ld(SC_MA + tri(i, j));
-        r[i] = quad_sum(acc.rr[i] - (g0 * rl0 + g1 * rl1)) + sc.ld(SC_TR + i);
+        for (int j = 0; j <= i; j++) S[tri(i, j)] = quad_sum(acc.A[tri(i, j)] - (g0 * B[j][0] + g1 * B[j][1])) + M.A[tri(i, j)];
+        r[i] = quad_sum(acc.rr[i] - (g0 * rl0 + g1 * rl1)) + M.tr[i];
     }
     // motor branch
-    V bm[6], cm = sc.ld(SC_MCM), rmt = sc.ld(SC_TM);
+    V bm[6], cm = M.Cm, rmt = M.tm;
 #pragma unroll
-    for (int i = 0; i < 6; i++) bm[i] = sc.ld(SC_MBM + i);
+    for (int i = 0; i < 6; i++) bm[i] = M.Bm[i];
 #pragma unroll
     for (int i = 0; i < 6; i++) bm[i] = bm[i] + quad_sum(acc.Bm[i]);
     cm = cm + quad_sum(acc.Cm);
@@ -749,13 +760,14 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
     JB_PROF_T0();
 
     const bool is_main = (sc.grp == 0);
+    StarSys<V> sys;     // written and read by the main lanes only
+    Mat3<V> Rw;         // root rotation (main lanes)
     if (is_main) {   // ================= phase A: kinematics, composite inertia, bias forces, contact candidates -> scratch
         sc.st3(SC_ST, w); sc.st(SC_ST + 3, s.thd1); sc.st(SC_ST + 4, s.thd2); sc.st(SC_ST + 5, s.phid);      // for the helper groups
         V qn = vrsqrt(s.qw * s.qw + s.qx * s.qx + s.qy * s.qy + s.qz * s.qz);
         s.qw = s.qw * qn; s.qx = s.qx * qn; s.qy = s.qy * qn; s.qz = s.qz * qn;
         Mat3<V> R = quat2mat(s.qw, s.qx, s.qy, s.qz);
-#pragma unroll
-        for (int i = 0; i < 9; i++) sc.st(SC_R + i, R.m[i]);
+        Rw = R;
         Vec3<V> nb = v3<V>(R.m[6], R.m[7], R.m[8]);                 // R^T ez
         Vec3<V> u = mulT(R, v3<V>(s.vx, s.vy, s.vz));
         Vec3<V> AO = -mulT(R, ldv3(m, LM_GRAV));                    // fictitious root acceleration = -g (root coords)
@@ -881,29 +893,29 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
         Vec3<V> sK = cross(a2, e2), sS = cross(a1, e1), sM = cross(am, em);          // linear part of the joint motion vectors
         Vec3<V> fK = sK * m2 + cross(e2, h2), nK = mul(J2, e2) + cross(h2, sK);
         Vec3<V> fS = sS * m12 + cross(e1, h12), nS = mul(J12, e1) + cross(h12, sS);
-        sc.st(SC_MB + 0, nS.x); sc.st(SC_MB + 2, nS.y); sc.st(SC_MB + 4, nS.z); sc.st(SC_MB + 6, fS.x); sc.st(SC_MB + 8, fS.y); sc.st(SC_MB + 10, fS.z);
-        sc.st(SC_MB + 1, nK.x); sc.st(SC_MB + 3, nK.y); sc.st(SC_MB + 5, nK.z); sc.st(SC_MB + 7, fK.x); sc.st(SC_MB + 9, fK.y); sc.st(SC_MB + 11, fK.z);
-        sc.st(SC_MC + 0, dot(e1, nS) + dot(sS, fS));
-        sc.st(SC_MC + 1, dot(e1, nK) + dot(sS, fK));
-        sc.st(SC_MC + 2, dot(e2, nK) + dot(sK, fK));
+        sys.B[0][0] = nS.x; sys.B[1][0] = nS.y; sys.B[2][0] = nS.z; sys.B[3][0] = fS.x; sys.B[4][0] = fS.y; sys.B[5][0] = fS.z;
+        sys.B[0][1] = nK.x; sys.B[1][1] = nK.y; sys.B[2][1] = nK.z; sys.B[3][1] = fK.x; sys.B[4][1] = fK.y; sys.B[5][1] = fK.z;
+        sys.C[0] = dot(e1, nS) + dot(sS, fS);
+        sys.C[1] = dot(e1, nK) + dot(sS, fK);
+        sys.C[2] = dot(e2, nK) + dot(sK, fK);
         Vec3<V> hm = cm * mm;
         Sym3<V> Jm = about_origin(Im, mm, cm);
         Vec3<V> fM = sM * mm + cross(em, hm), nM = mul(Jm, em) + cross(hm, sM);
-        sc.st3(SC_MBM, nM); sc.st3(SC_MBM + 3, fM);
-        sc.st(SC_MCM, dot(em, nM) + dot(sM, fM));
+        sys.Bm[0] = nM.x; sys.Bm[1] = nM.y; sys.Bm[2] = nM.z; sys.Bm[3] = fM.x; sys.Bm[4] = fM.y; sys.Bm[5] = fM.z;
+        sys.Cm = dot(em, nM) + dot(sM, fM);
         {
             Vec3<V> ht = c0 * m0 + hm + qsum(h12);
             Sym3<V> Jt = about_origin(I0, m0, c0) + Jm + qsum(J12);
             V mt = m.c[LM_MTOT];
             V Z = V(0);
             // [[J, [h]x], [[h]x^T, m 1]] with [h]x = [[0,-hz,hy],[hz,0,-hx],[-hy,hx,0]]
-            sc.st(SC_MA + tri(0, 0), Jt.xx); sc.st(SC_MA + tri(1, 0), Jt.xy); sc.st(SC_MA + tri(1, 1), Jt.yy);
-            sc.st(SC_MA + tri(2, 0), Jt.xz); sc.st(SC_MA + tri(2, 1), Jt.yz); sc.st(SC_MA + tri(2, 2), Jt.zz);
-            sc.st(SC_MA + tri(3, 0), Z);     sc.st(SC_MA + tri(3, 1), ht.z);  sc.st(SC_MA + tri(3, 2), -ht.y);
-            sc.st(SC_MA + tri(4, 0), -ht.z); sc.st(SC_MA + tri(4, 1), Z);     sc.st(SC_MA + tri(4, 2), ht.x);
-            sc.st(SC_MA + tri(5, 0), ht.y);  sc.st(SC_MA + tri(5, 1), -ht.x); sc.st(SC_MA + tri(5, 2), Z);
-            sc.st(SC_MA + tri(3, 3), mt); sc.st(SC_MA + tri(4, 3), Z); sc.st(SC_MA + tri(4, 4), mt);
-            sc.st(SC_MA + tri(5, 3), Z); sc.st(SC_MA + tri(5, 4), Z); sc.st(SC_MA + tri(5, 5), mt);
+            sys.A[tri(0, 0)] = Jt.xx; sys.A[tri(1, 0)] = Jt.xy; sys.A[tri(1, 1)] = Jt.yy;
+            sys.A[tri(2, 0)] = Jt.xz; sys.A[tri(2, 1)] = Jt.yz; sys.A[tri(2, 2)] = Jt.zz;
+            sys.A[tri(3, 0)] = Z;     sys.A[tri(3, 1)] = ht.z;  sys.A[tri(3, 2)] = -ht.y;
+            sys.A[tri(4, 0)] = -ht.z; sys.A[tri(4, 1)] = Z;     sys.A[tri(4, 2)] = ht.x;
+            sys.A[tri(5, 0)] = ht.y;  sys.A[tri(5, 1)] = -ht.x; sys.A[tri(5, 2)] = Z;
+            sys.A[tri(3, 3)] = mt; sys.A[tri(4, 3)] = Z; sys.A[tri(4, 4)] = mt;
+            sys.A[tri(5, 3)] = Z; sys.A[tri(5, 4)] = Z; sys.A[tri(5, 5)] = mt;
         }
         JB_SCHED_FENCE();
 
@@ -939,14 +951,14 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
             V cM = dot(em, Nm + cross(rm, Fm));
             Vec3<V> bl = F0 + Fm + qsum(legF);
             Vec3<V> ba = N0 + cross(c0, F0) + Nm + cross(cm, Fm) + qsum(legN);
-            sc.st3(SC_TR, -ba); sc.st3(SC_TR + 3, -bl);
-            sc.st(SC_TL + 0, -cS - m.c[LM_K1] * s.th1 - m.c[LM_B1] * s.thd1);
-            sc.st(SC_TL + 1, -cK - m.c[LM_K2] * s.th2 - m.c[LM_B2] * s.thd2);
+            sys.tr[0] = -ba.x; sys.tr[1] = -ba.y; sys.tr[2] = -ba.z; sys.tr[3] = -bl.x; sys.tr[4] = -bl.y; sys.tr[5] = -bl.z;
+            sys.tl[0] = -cS - m.c[LM_K1] * s.th1 - m.c[LM_B1] * s.thd1;
+            sys.tl[1] = -cK - m.c[LM_K2] * s.th2 - m.c[LM_B2] * s.thd2;
             V uc = vmin(vmax(ctrl, m.c[LM_CTRL_LO]), m.c[LM_CTRL_HI]);
             V gear = m.c[LM_GEAR];
             V len = gear * (s.phi + s.turns * V(6.283185307179586));
             V force = m.c[LM_GAIN] * uc + m.c[LM_BIAS] + m.c[LM_BIAS + 1] * len + m.c[LM_BIAS + 2] * gear * s.phid;
-            sc.st(SC_TM, -cM + gear * force);
+            sys.tm = -cM + gear * force;
         }
     }
     JB_SCHED_FENCE();
@@ -972,10 +984,7 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
             contact_rows_build_all<V>(m, sc, xtra, plan);
             JB_PROF_ADD(o, 5);
             if (is_main) {      // warm start (world linear part rotated into the root frame)
-                Mat3<V> R;
-#pragma unroll
-                for (int i = 0; i < 9; i++) R.m[i] = sc.ld(SC_R + i);
-                Vec3<V> lw = mulT(R, v3<V>(s.wl[0], s.wl[1], s.wl[2]));
+                Vec3<V> lw = mulT(Rw, v3<V>(s.wl[0], s.wl[1], s.wl[2]));
                 yr[0] = s.wa[0]; yr[1] = s.wa[1]; yr[2] = s.wa[2]; yr[3] = lw.x; yr[4] = lw.y; yr[5] = lw.z;
                 yl[0] = s.wj[0]; yl[1] = s.wj[1]; ym = s.wm;
 #pragma unroll
@@ -1024,16 +1033,16 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
                     // An env without contacts has qfrc = 0 exactly, whatever the rest of its wave is doing: plain solve.
                     acc_clear(acc);
 #pragma unroll
-                    for (int i = 0; i < 6; i++) acc.rr[i] = sel(env_con, V(-0.25) * sc.ld(SC_TR + i), V(0));
-                    acc.rl[0] = sel(env_con, hb1 * yl[0] - sc.ld(SC_TL), V(0));
-                    acc.rl[1] = sel(env_con, hb2 * yl[1] - sc.ld(SC_TL + 1), V(0));
-                    acc.rm = sel(env_con, V(-0.25) * sc.ld(SC_TM), V(0));
+                    for (int i = 0; i < 6; i++) acc.rr[i] = sel(env_con, V(-0.25) * sys.tr[i], V(0));
+                    acc.rl[0] = sel(env_con, hb1 * yl[0] - sys.tl[0], V(0));
+                    acc.rl[1] = sel(env_con, hb2 * yl[1] - sys.tl[1], V(0));
+                    acc.rm = sel(env_con, V(-0.25) * sys.tm, V(0));
                 }
             }
             JB_PROF_ADD(o, 7);
             if (is_main) {
                 V nyr[6], nyl[2], nym;
-                star_solve<V>(sc, acc, final_pass ? hb1 : V(0), final_pass ? hb2 : V(0), nyr, nyl, nym);
+                star_solve<V>(sys, acc, final_pass ? hb1 : V(0), final_pass ? hb2 : V(0), nyr, nyl, nym);
                 JB_PROF_ADD(o, 6);
                 if (final_pass) {
 #pragma unroll
@@ -1057,10 +1066,7 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
     if (!is_main) return;
 
     // ================= phase C: integrate
-    Mat3<V> R;
-#pragma unroll
-    for (int i = 0; i < 9; i++) R.m[i] = sc.ld(SC_R + i);
-    Vec3<V> lin = mul(R, v3<V>(yr[3], yr[4], yr[5]));
+    Vec3<V> lin = mul(Rw, v3<V>(yr[3], yr[4], yr[5]));
     s.wa[0] = yr[0]; s.wa[1] = yr[1]; s.wa[2] = yr[2]; s.wl[0] = lin.x; s.wl[1] = lin.y; s.wl[2] = lin.z; s.wj[0] = yl[0]; s.wj[1] = yl[1]; s.wm = ym;
     // mj_advance: velocities, then positions with the new velocities
     s.wx = s.wx + h * yr[0]; s.wy = s.wy + h * yr[1]; s.wz = s.wz + h * yr[2];
