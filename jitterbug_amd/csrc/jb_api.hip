@@ -57,6 +57,7 @@ __device__ __forceinline__ void stage_model(const KArgs& a, float* lds, int lblo
         m.c.inv = lds;
     }
     m.c.tab = m.c.inv + LM_INV + leg;
+    m.c.preload();
 }
 __device__ __forceinline__ void load_state(const KArgs& a, int env, int lane, LaneState<float>& s) {
     const float* r = a.root + env;

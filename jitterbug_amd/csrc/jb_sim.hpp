@@ -106,7 +106,21 @@ template <typename T> inline Quad<T> lane_bcast(const T* p, Quad<T>*) { return Q
 template <typename V> struct LaneConsts {
     const typename lane_traits<V>::real* inv;
     const typename lane_traits<V>::real* tab;
-    JB_HD V operator[](int i) const { return i < LM_INV ? lane_bcast(inv + i, (V*)nullptr) : lane_from4(tab + 4 * (i - LM_INV), (V*)nullptr); }
+    // The entries used every substep are read from the table ONCE per kernel (preload()) and then live in registers: with
+    // one wave per SIMD the kernel owns all 512 registers of its lanes, and the allocator parks these long-lived values in
+    // the accumulation half, one v_accvgpr_read away - no LDS round trip, no s_waitcnt in the middle of the dynamics.
+    V hot[LM_HOT];
+    V tran0, tran1, tran2, tranm;   // the four per-body-level entries that are picked by a run-time level: kept out of the
+                                    // array so that the pick is a select of values, never an indexed access (which would
+                                    // force the whole array into scratch memory)
+    JB_HD V tran_of(int level) const { return level == 2 ? tran2 : level == 1 ? tran1 : level == 0 ? tran0 : tranm; }
+    JB_HD V table(int i) const { return i < LM_INV ? lane_bcast(inv + i, (V*)nullptr) : lane_from4(tab + 4 * (i - LM_INV), (V*)nullptr); }
+    JB_HD void preload() {
+#pragma unroll
+        for (int i = 0; i < LM_HOT; i++) hot[i] = table(i);
+        tran0 = table(LM_TRAN0); tran1 = table(LM_TRAN1); tran2 = table(LM_TRAN2); tranm = table(LM_TRANM);
+    }
+    JB_HD V operator[](int i) const { return i < LM_HOT ? hot[i] : table(i); }
 };
 template <typename V> struct LaneModel { LaneConsts<V> c; };
 template <typename V> JB_HD V ldc(const LaneModel<V>& m, int i) { return m.c[i]; }
@@ -432,7 +446,7 @@ JB_HD void contact_rows_build(const LaneModel<V>& m, const LaneScratch<V>& sc, b
     const V f_sh = V((level == 1 || level == 2) ? 1.0f : 0.0f), f_kn = V(level == 2 ? 1.0f : 0.0f), f_m = V(level == 3 ? 1.0f : 0.0f);
     const Vec3<V> x = sc.ld3(SC_CAND + 4 * slot);
     const V dist = sc.ld(SC_CAND + 4 * slot + 3);
-    const V tran = level == 2 ? m.c[LM_TRAN2] : level == 1 ? m.c[LM_TRAN1] : level == 0 ? m.c[LM_TRAN0] : m.c[LM_TRANM];
+    const V tran = m.c.tran_of(level);
     const V mu = m.c[LM_MU];
     const auto valid = lt(dist, V(0));
     V imp = impedance(m, dist);

@@ -14,7 +14,7 @@ static int run(const double* P, double* qpos, double* qvel, double ctrl, int nsu
     LaneModel<V> m;
     T tab[LM_TABLE];
     { int rc = build_packed_model<T>(P, tab); if (rc) return rc; }
-    m.c.inv = tab; m.c.tab = tab + LM_INV;
+    m.c.inv = tab; m.c.tab = tab + LM_INV; m.c.preload();
     LaneState<V> s;
     s.px = V(T(qpos[0])); s.py = V(T(qpos[1])); s.pz = V(T(qpos[2]));
     s.qw = V(T(qpos[3])); s.qx = V(T(qpos[4])); s.qy = V(T(qpos[5])); s.qz = V(T(qpos[6]));
