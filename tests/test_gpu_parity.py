@@ -367,3 +367,48 @@ def test_open_loop_statistics_match_oracle():
         og, _, _, _ = g2.step(a); oo, _, _ = o2.step(a)
     assert np.median(np.abs(og - oo).max(axis=1)) < 1e-4
     g.close(); g2.close()
+
+
+def test_full_episode_properties_at_config4_size():
+    """BASELINE configs[3] shape on one GPU (move_to_pose, 32768 envs): a whole 1000-step episode plus the auto-reset, checked
+    through size-independent properties - finite, unit quaternions, rewards in [0, 1], `done` exactly at the step limit,
+    targets re-drawn in their range at the reset, and the result does not depend on how the batch is split."""
+    from jitterbug_amd.vec_env import JitterbugVecEnv
+    n, task = 32768, "move_to_pose"
+    D = model.OBS_DIM[task]
+    env = JitterbugVecEnv(n, task, seed=21)
+    ob = env.reset()
+    assert ob.shape == (n, D)
+    _, _, tgt0 = env.get_state()
+    rng = np.random.default_rng(9)
+    ret = np.zeros(n)
+    first50 = []
+    for t in range(1, 1003):
+        a = rng.uniform(-1, 1, size=n).astype(np.float32)
+        ob, rw, dn, _ = env.step(a)
+        assert np.isfinite(ob).all() and np.isfinite(rw).all()
+        assert rw.min() >= 0.0 and rw.max() <= 1.0 + 1e-6
+        assert dn.all() if t == 1000 else not dn.any()
+        ret += rw
+        if t <= 50:
+            first50.append((a, ob.copy(), rw.copy()))
+        if t == 999:
+            q, v, tg = env.get_state()
+            assert np.abs(np.linalg.norm(q[:, 3:7], axis=1) - 1).max() < 1e-5
+            assert q[:, 2].min() > 0.0 and q[:, 2].max() < 0.08          # on / near the floor after 10 s
+            assert np.array_equal(tg, tgt0)                               # the target does not move within an episode
+    sc, ep, cap = env.counters()
+    assert (sc == 2).all() and (ep == 3).all()          # episodes: create, reset(), auto-reset
+    _, _, tgt1 = env.get_state()
+    r1 = np.hypot(tgt1[:, 0], tgt1[:, 1])
+    assert r1.min() >= 0.05 - 1e-6 and r1.max() < 0.2 + 1e-6 and not np.array_equal(tgt0, tgt1)     # new episode, new targets
+    assert 0.0 < ret.mean() < 1000.0
+    env.close()
+    # split invariance at this size: two shards of 16384 reproduce the first 50 steps bit for bit
+    for lo, hi in ((0, 16384), (16384, n)):
+        e = JitterbugVecEnv(hi - lo, task, seed=21, env_offset=lo)
+        e.reset()
+        for a, ob_ref, rw_ref in first50:
+            ob, rw, dn, _ = e.step(a[lo:hi])
+            assert np.array_equal(ob, ob_ref[lo:hi]) and np.array_equal(rw, rw_ref[lo:hi])
+        e.close()
