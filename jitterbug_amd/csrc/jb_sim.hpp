@@ -625,12 +625,9 @@ JB_HD void contact_rows_build_all(const LaneModel<V>& m, const LaneScratch<V>& s
 // every live candidate slot against the iterate y kept in the scratch (SC_Y); with helper groups the partial sums of the
 // groups are combined by cross-lane exchanges so that every group ends with the complete accumulator
 template <typename V>
-JB_HD void contact_sweep(const LaneModel<V>& m, const LaneScratch<V>& sc, bool xtra, const SlotPlan& plan, int mode, NewtonAcc<V>& acc) {
+JB_HD void contact_sweep(const LaneModel<V>& m, const LaneScratch<V>& sc, bool xtra, const SlotPlan& plan, int mode, const Vec3<V> (&dk)[3], NewtonAcc<V>& acc) {
     if (!plan.grouped && sc.grp != 0) return;
     acc_clear(acc);
-    Vec3<V> dk[3];
-#pragma unroll
-    for (int k = 0; k < 3; k++) dk[k] = sc.ld3(SC_DD + 12 * k);
     const V mu = m.c[LM_MU];
     V yr[6], yl[2], ym;
 #pragma unroll
@@ -991,10 +988,13 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
     V yr[6], yl[2], ym;
     {
         NewtonAcc<V> acc;
+        Vec3<V> dk[3];
         bool final_pass = !any_contact;
         MK unconverged = lt(V(0), V(1));
         U prev_bw0 = zero_u<V>(), prev_xh = zero_u<V>();
         if (any_contact) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) dk[k] = sc.ld3(SC_DD + 12 * k);     // contact-frame directions: once per substep, every lane
             contact_rows_build_all<V>(m, sc, xtra, plan);
             JB_PROF_ADD(o, 5);
             if (is_main) {      // warm start (world linear part rotated into the root frame)
@@ -1019,7 +1019,7 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
                 if (it > 0) {
                     // cheap pass: only the active set at the new iterate.  The ENV's set changed if any lane of the quad
                     // saw a different record; when nobody's changed, every y is the exact minimiser
-                    contact_sweep<V>(m, sc, xtra, plan, 2, acc);
+                    contact_sweep<V>(m, sc, xtra, plan, 2, dk, acc);
                     JB_PROF_ADD(o, 1);
                     unsigned fin = 0u;
                     if (is_main) {
@@ -1033,7 +1033,7 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
                     final_pass = wave_bcast_u(fin) != 0u;
                 }
                 if (!final_pass) {
-                    contact_sweep<V>(m, sc, xtra, plan, 0, acc);
+                    contact_sweep<V>(m, sc, xtra, plan, 0, dk, acc);
                     prev_bw0 = acc.bw0; prev_xh = acc.xh;
                     JB_PROF_ADD(o, 2);
 #ifdef JB_WAVE_STATS
