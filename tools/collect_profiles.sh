@@ -15,6 +15,7 @@ done
 echo "[prof] pmc SQ set 1"; rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU --output-format csv -d $OUT/pmc_sq1 -- $BENCH > $OUT/pmc_sq1.log 2>&1
 echo "[prof] pmc SQ set 2"; rocprofv3 --kernel-trace --pmc SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/pmc_sq2 -- $BENCH > $OUT/pmc_sq2.log 2>&1
 echo "[prof] pmc SQ set 3"; rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INST_CYCLES_SALU --output-format csv -d $OUT/pmc_sq3 -- $BENCH > $OUT/pmc_sq3.log 2>&1 || echo "[prof] set 3 not available"
+echo "[prof] pmc SQ set 4"; rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_IFETCH SQ_INST_LEVEL_LDS SQ_INSTS_VALU_TRANS_F32 --output-format csv -d $OUT/pmc_sq4 -- $BENCH > $OUT/pmc_sq4.log 2>&1 || echo "[prof] set 4 not available"
 echo "[prof] pmc GRBM"; rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_grbm -- $BENCH > $OUT/pmc_grbm.log 2>&1 || echo "[prof] grbm not available"
 cd $ROOT
 find $OUT -name "*.csv" | head -40

@@ -9,7 +9,8 @@ epw = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 env = JitterbugVecEnv(n, "move_from_origin", seed=0, envs_per_wave=epw)
 env.reset()
 rng = np.random.default_rng(0)
-for t in range(150):
+nsteps = int(sys.argv[3]) if len(sys.argv) > 3 else 150
+for t in range(nsteps):
     env.step(rng.uniform(-1, 1, size=n).astype(np.float32))
 L = _lib.load()
 buf = np.zeros((n + 4, 16), dtype=np.uint64)
