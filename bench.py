@@ -91,6 +91,7 @@ def main():
     ap.add_argument("--no-also", action="store_true")
     ap.add_argument("--max-newton", type=int, default=12)
     ap.add_argument("--envs-per-wave", type=int, default=0)
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the measured path); gloo is a CPU-staged rehearsal of the N>1 control flow")
     ap.add_argument("--task", default=TASK, help="default move_from_origin (the BASELINE metric); move_to_pose is BASELINE configs[3]'s task")
     ap.add_argument("--augmented", action="store_true", help="one randomised model per env (BASELINE configs[4], augment_Jitterbug semantics)")
     args = ap.parse_args()
@@ -108,12 +109,18 @@ def main():
         raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks (WORLD_SIZE=%d)" % (args.gpus, args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # JB_BENCH_DEVICE: rehearsal of the N>1 control flow on a box with one GPU (every rank on that device, gloo backend)
+    dev_index = int(os.environ.get("JB_BENCH_DEVICE", local_rank))
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)          # RCCL over xGMI
+        else:
+            dist.init_process_group(args.dist_backend)
+    local_rank = dev_index
 
     n = args.envs_per_gpu
     D = model.OBS_DIM[task]
@@ -133,23 +140,45 @@ def main():
         g = torch.Generator(device=dev)
         g.manual_seed(1234 + rank)
         actions = torch.rand((steps + warmup, n), generator=g, device=dev, dtype=torch.float32) * 2 - 1
-        out = torch.empty((n, D + 2), device=dev, dtype=torch.float32)       # packed row: obs | reward | done
         obs = torch.empty((n, D), device=dev, dtype=torch.float32)
         rew = torch.empty((n,), device=dev, dtype=torch.float32)
         done = torch.empty((n,), device=dev, dtype=torch.uint8)
-        gathered = [torch.empty_like(out) for _ in range(world)] if (gather and rank == 0) else None
+        # N > 1: the step kernel writes packed rows [obs | reward | done] itself (jb_step_rows_device) and rank 0 gathers them
+        # every step.  Two row buffers alternate so that the gather of step t (on RCCL's stream) overlaps the kernel of step
+        # t+1; a buffer is rewritten only after the gather that read it has been waited for.
+        nccl = gather and args.dist_backend == "nccl"
+        rows = [torch.empty((n, D + 2), device=dev, dtype=torch.float32) for _ in range(2)] if gather else None
+        stage = [torch.empty((n, D + 2), dtype=torch.float32).pin_memory() for _ in range(2)] if (gather and not nccl) else None
+        gathered = None
+        if gather and rank == 0:
+            gathered = [[torch.empty((n, D + 2), device=dev if nccl else "cpu", dtype=torch.float32) for _ in range(world)] for _ in range(2)]
+        pending = [None, None]
         env.reset_device(None, obs.data_ptr())
 
         def one(i):
-            env.step_device(actions[i].data_ptr(), obs.data_ptr(), rew.data_ptr(), done.data_ptr())
-            if gather:
-                out[:, :D] = obs
-                out[:, D] = rew
-                out[:, D + 1] = done
-                dist.gather(out, gathered, dst=0)
+            if not gather:
+                env.step_device(actions[i].data_ptr(), obs.data_ptr(), rew.data_ptr(), done.data_ptr())
+                return
+            b = i & 1
+            if pending[b] is not None:
+                pending[b].wait()
+                pending[b] = None
+            env.step_rows_device(actions[i].data_ptr(), rows[b].data_ptr())
+            if nccl:
+                pending[b] = dist.gather(rows[b], gathered[b] if rank == 0 else None, dst=0, async_op=True)
+            else:                                   # rehearsal: stage through the host
+                stage[b].copy_(rows[b])
+                dist.gather(stage[b], gathered[b] if rank == 0 else None, dst=0)
+
+        def drain():
+            for b in range(2):
+                if pending[b] is not None:
+                    pending[b].wait()
+                    pending[b] = None
 
         for i in range(warmup):
             one(i)
+        drain()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize(dev)
@@ -159,18 +188,23 @@ def main():
         for i in range(warmup, warmup + steps):
             one(i)
         ev1.record()
+        drain()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize(dev)
         wall = time.perf_counter() - t0
         dev_ms = ev0.elapsed_time(ev1)
         sc, ep, cap = env.counters()
-        finite = bool(torch.isfinite(obs).all().item())
+        last = rows[(warmup + steps - 1) & 1][:, :D] if gather else obs
+        finite = bool(torch.isfinite(last).all().item())
+        if gather and rank == 0:                    # the gathered block of the last step really holds every rank's rows
+            gl = gathered[(warmup + steps - 1) & 1]
+            finite = finite and all(bool(torch.isfinite(x).all().item()) for x in gl) and bool((gl[0].to(dev) == rows[(warmup + steps - 1) & 1]).all().item())
         env.close()
         return wall, dev_ms, float(cap.sum()), finite
 
     wall, dev_ms, cap_hits, finite = run(args.contacts, K, W, gather=(world > 1))
-    t = torch.tensor([wall], device=dev, dtype=torch.float64)
+    t = torch.tensor([wall], device=dev if args.dist_backend == "nccl" else "cpu", dtype=torch.float64)
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     wall_max = float(t.item())
@@ -205,7 +239,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s, N_envs=%d per GPU, %s, 50 substeps/step, in-kernel auto-reset (BASELINE configs[%d])"
                                    % (task + (", one randomised model per env" if args.augmented else ""), n, "full Newton contact solve" if args.contacts else "contacts off", 2 if args.contacts else 1),
-                       "global_envs": total_envs, "parallelism": "env-sharded x%d%s" % (world, ", RCCL gather of [N,D+2] to rank 0 per step" if world > 1 else "")},
+                       "global_envs": total_envs, "parallelism": "env-sharded x%d%s" % (world, (", %s gather of [N,D+2] rows to rank 0 every step, double-buffered" % ("RCCL" if args.dist_backend == "nccl" else args.dist_backend + " (rehearsal)")) if world > 1 else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic,
                          "kernel": "jb_step_kernel", "launch_ms": launch_s * 1e3, "algorithmic_bytes_per_launch": algo_bytes * n,

@@ -97,6 +97,9 @@ int jb_set_model_params(jb_handle* h, const double* params, int32_t n_tables);
 /* device-buffer entry points (asynchronous on the handle's stream) */
 int jb_reset_device(jb_handle* h, const uint8_t* d_mask /*nullable*/, float* d_obs_out /*nullable*/);
 int jb_step_device(jb_handle* h, const float* d_action, float* d_obs_out, float* d_reward_out, uint8_t* d_done_out);
+/* same step, one packed float row per env: rows[N, D+2] = [obs(D) | reward | done (0.0/1.0)] - the unit the north-star's
+ * per-step gather moves between GPUs, written by the step kernel itself */
+int jb_step_rows_device(jb_handle* h, const float* d_action, float* d_rows_out /*[N, D+2]*/);
 int jb_observe_device(jb_handle* h, float* d_obs_out, float* d_reward_out /*nullable*/);
 /* heuristic bang-bang policies of the reference (heuristic_policies.py:6-136) for the handle's task, evaluated on
  * observation rows [N,D] -> actions [N]; the device form lets a rollout chain observe -> act -> step without leaving HBM */

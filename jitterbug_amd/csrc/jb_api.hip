@@ -32,6 +32,7 @@ enum LegF : int { LF_TH1 = 0, LF_TH2 = 1, LF_THD1 = 2, LF_THD2 = 3, LF_WJ0 = 4, 
 struct KArgs {
     int n, task, substeps, step_limit, auto_reset, contacts, max_newton, random_pose, per_env_model;
     int epw;       // environments per wave (= per 64-thread workgroup) of the step kernel
+    int packed_rows;   // step kernel output: 0 = obs[N,D] + reward[N] + done[N]; 1 = one float row [obs(D) | reward | done] per env
     unsigned long long seed, env_offset;
     float* root; float* leg; const float* lane_model;
     int* step_count; unsigned* episode;
@@ -98,12 +99,12 @@ __device__ __forceinline__ void state_from_reset(const EnvCore<float>& e, LaneSt
     for (int i = 0; i < 3; i++) { s.wa[i] = 0.f; s.wl[i] = 0.f; }
     s.wj[0] = s.wj[1] = 0.f; s.wm = 0.f;
 }
-__device__ __forceinline__ void write_obs(const KArgs& a, int env, int leg, const EnvCore<float>& e, float target_z, float* obs_out) {
+__device__ __forceinline__ void write_obs(const KArgs& a, int env, int leg, const EnvCore<float>& e, float target_z, float* obs_out, int row_stride = 0) {
     if (!obs_out) return;
     float obs[19];
     observe<float>(a.task, e, target_z, obs, 1);
     const int D = obs_dim(a.task);
-    float* row = obs_out + (size_t)env * D;
+    float* row = obs_out + (size_t)env * (row_stride ? row_stride : D);
 #pragma unroll
     for (int j = 0; j < 19; j++) if ((j & 3) == leg && j < D) row[j] = obs[j];
 }
@@ -194,12 +195,17 @@ __global__ __launch_bounds__(64) void jb_step_kernel(KArgs a, const float* __res
         if (live && leg == 0) { a.episode[env] = ep + 1; store_target(a, env, e); }
     }
     if (!live) return;
-    write_obs(a, env, leg, e, target_z, obs_out);
+    const int D = obs_dim(a.task);
+    write_obs(a, env, leg, e, target_z, obs_out, a.packed_rows ? D + 2 : 0);
     store_state(a, env, lane, leg, s);
     if (leg == 0) {
         a.step_count[env] = sc;
-        if (reward_out) reward_out[env] = rew;
-        if (done_out) done_out[env] = done ? 1 : 0;
+        if (a.packed_rows) {
+            if (obs_out) { obs_out[(size_t)env * (D + 2) + D] = rew; obs_out[(size_t)env * (D + 2) + D + 1] = done ? 1.f : 0.f; }
+        } else {
+            if (reward_out) reward_out[env] = rew;
+            if (done_out) done_out[env] = done ? 1 : 0;
+        }
     }
 }
 
@@ -450,8 +456,9 @@ int jb_reset_device(jb_handle* h, const uint8_t* d_mask, float* d_obs_out) {
     JB_HIP(hipGetLastError());
     return JB_OK;
 }
-int jb_step_device(jb_handle* h, const float* d_action, float* d_obs_out, float* d_reward_out, uint8_t* d_done_out) {
+static int launch_step(jb_handle* h, const float* d_action, float* d_obs_out, float* d_reward_out, uint8_t* d_done_out, int packed_rows) {
     if (!h || !d_action) return fail(JB_E_INVALID, "handle/action is NULL");
+    h->ka.packed_rows = packed_rows;
     const dim3 grid((unsigned)((h->cfg.n_envs + h->ka.epw - 1) / h->ka.epw));
     const size_t lds_bytes = ((size_t)SC_COUNT * 4 * h->ka.epw + (size_t)LM_TABLE * (h->ka.per_env_model ? h->ka.epw : 1)) * sizeof(float);
 #define JB_LAUNCH_STEP(E) hipLaunchKernelGGL(jb_step_kernel<E>, grid, dim3(64), lds_bytes, h->stream, h->ka, d_action, d_obs_out, d_reward_out, d_done_out)
@@ -465,6 +472,13 @@ int jb_step_device(jb_handle* h, const float* d_action, float* d_obs_out, float*
 #undef JB_LAUNCH_STEP
     JB_HIP(hipGetLastError());
     return JB_OK;
+}
+int jb_step_device(jb_handle* h, const float* d_action, float* d_obs_out, float* d_reward_out, uint8_t* d_done_out) {
+    return launch_step(h, d_action, d_obs_out, d_reward_out, d_done_out, 0);
+}
+int jb_step_rows_device(jb_handle* h, const float* d_action, float* d_rows_out) {
+    if (!d_rows_out) return fail(JB_E_INVALID, "rows buffer is NULL");
+    return launch_step(h, d_action, d_rows_out, nullptr, nullptr, 1);
 }
 int jb_observe_device(jb_handle* h, float* d_obs_out, float* d_reward_out) {
     if (!h) return fail(JB_E_INVALID, "handle is NULL");

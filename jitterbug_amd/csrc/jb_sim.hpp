@@ -238,23 +238,20 @@ template <typename V> struct LaneState {
 };
 
 // ----------------------------------------------------------------------------- per-lane scratch
-// Values that are produced once per substep and consumed by several later phases (joint-space system, applied
-// forces, contact-frame direction data, contact candidates) live in a per-lane scratch instead of registers:
-// on the device this is LDS with element i of lane L at lds[i*64 + L] (conflict free); on the host a plain array.
-// This keeps the register-resident working set of each phase small enough that nothing spills to scratch memory.
+// Values that one group of lanes produces and another consumes later in the substep (contact-frame direction data, contact
+// candidates, cached contact rows, the Newton iterate, the reduction hand-over) live in a per-lane scratch: on the device
+// this is LDS with element i of lane L at lds[i*stride + L] (conflict free); on the host a plain array.  Helper lanes use
+// the addresses of the main lane they mirror.  (Lane-private long-lived values - model constants, the joint-space system -
+// are kept in registers instead, see LaneConsts / StarSys.)
 enum SC : int {
-    SC_MA = 0 /*21: root block of M, packed lower triangle, dof order [ang, lin]*/, SC_MB = 21 /*12: leg coupling [i*2+j]*/,
-    SC_MC = 33 /*3: C11 C12 C22*/, SC_MBM = 36 /*6: motor coupling*/, SC_MCM = 42,
-    SC_TR = 43 /*6: applied+bias force on the root dofs (replicated)*/, SC_TL = 49 /*2: own leg*/, SC_TM = 51 /*motor*/,
-    SC_DD = 52 /*3 directions x 12: d(3) wS(3) wK(3) oS oK du*/,
-    SC_CAND = 88 /*28 contact candidates x 4: position (3, root coords rel. root origin) and effective distance
+    SC_DD = 0 /*3 directions x 12: d(3) wS(3) wK(3) oS oK du*/,
+    SC_CAND = 36 /*28 contact candidates x 4: position (3, root coords rel. root origin) and effective distance
                    (the real distance when the candidate is a contact, +1 otherwise).  Slots: 0 foot, 1-4 lower-leg
                    cylinder | 5-8 upper cylinder, 9 knee tip | root body: 10-13 lane cylinder, 14 lane ellipsoid,
                    15-22 lane box vertices | motor body: 23-26 lane cylinder, 27 lane ellipsoid*/,
-    SC_R = 200 /*9: root rotation matrix*/,
-    SC_ROWS = 212 /*(ROW_K + 4) x ROW_F: y-independent contact rows of the live slots of this substep (8 cached + one
+    SC_ROWS = 148 /*(ROW_K + 4) x ROW_F: y-independent contact rows of the live slots of this substep (8 cached + one
                     overflow entry per group, 19 floats each)*/,
-    SC_Y = 212 + 12 * 19 /*9: current Newton iterate [yr(6), yl(2), ym], shared with the helper groups*/,
+    SC_Y = 148 + 12 * 19 /*9: current Newton iterate [yr(6), yl(2), ym], shared with the helper groups*/,
     SC_ST = SC_Y + 9 /*6: w(3), thd1, thd2, phid for the helper groups*/,
     SC_COUNT = SC_ST + 6
 };

@@ -39,11 +39,14 @@ def gather_rows(rows, sizes, dst=0, group=None):
     if rows.shape[0] < nmax:                       # pad to a common length (gather needs equal shapes)
         pad = torch.zeros((nmax - rows.shape[0], rows.shape[1]), dtype=rows.dtype, device=rows.device)
         rows = torch.cat([rows, pad], 0)
+    device = rows.device
+    if rows.is_cuda and dist.get_backend(group) == "gloo":      # gloo has no device gather: stage through the host (tests / rehearsal)
+        rows = rows.cpu()
     bufs = [torch.empty_like(rows) for _ in range(world)] if rank == dst else None
     dist.gather(rows.contiguous(), bufs, dst=dst, group=group)
     if rank != dst:
         return None
-    return torch.cat([b[:n] for b, n in zip(bufs, sizes)], 0)
+    return torch.cat([b[:n] for b, n in zip(bufs, sizes)], 0).to(device)
 
 
 def scatter_actions(actions_global, sizes, device, src=0, group=None):
@@ -52,6 +55,8 @@ def scatter_actions(actions_global, sizes, device, src=0, group=None):
     import torch.distributed as dist
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     nmax = max(sizes)
+    staged = torch.device(device).type == "cuda" and dist.get_backend(group) == "gloo"
+    final_device, device = device, ("cpu" if staged else device)
     out = torch.empty((nmax,), dtype=torch.float32, device=device)
     chunks = None
     if rank == src:
@@ -63,7 +68,7 @@ def scatter_actions(actions_global, sizes, device, src=0, group=None):
             chunks.append(c)
             lo += n
     dist.scatter(out, chunks, src=src, group=group)
-    return out[:sizes[rank]]
+    return out[:sizes[rank]].to(final_device)
 
 
 class ShardedJitterbugEnv:
@@ -85,8 +90,11 @@ class ShardedJitterbugEnv:
             from .vec_env import JitterbugVecEnv
 
             def local_env_factory(n_local, env_offset):
+                kw = dict(env_kwargs)
+                if self.device.type == "cuda" and "stream" not in kw:       # launch on torch's stream: ordered with the collectives
+                    kw["stream"] = torch.cuda.current_stream(self.device).cuda_stream
                 return JitterbugVecEnv(n_local, task, seed=seed, env_offset=env_offset,
-                                       device_id=self.device.index or 0, **env_kwargs)
+                                       device_id=self.device.index or 0, **kw)
         self.env = local_env_factory(self.n_local, self.lo)
         self.on_gpu = self.device.type == "cuda"
 
@@ -105,6 +113,13 @@ class ShardedJitterbugEnv:
         """Rank 0 passes actions for all N_global envs (other ranks pass None); returns (obs, reward, done) on rank 0."""
         import torch
         a = scatter_actions(actions_global, self.sizes, self.device, 0, self.group)
+        if self.on_gpu and hasattr(self.env, "step_rows_device"):
+            # device path: scatter -> step kernel writes the packed rows -> gather, nothing leaves HBM on the way
+            a = a.contiguous()
+            rows = torch.empty((self.n_local, self.env.obs_dim + 2), dtype=torch.float32, device=self.device)
+            self.env.step_rows_device(a.data_ptr(), rows.data_ptr())
+            out = gather_rows(rows, self.sizes, 0, self.group)
+            return None if out is None else unpack_rows(out)
         res = self.env.step(a.cpu().numpy())
         obs, rew, done = res[0], res[1], res[2]
         rows = pack_rows(self._to_tensor(obs, torch.float32), self._to_tensor(rew, torch.float32), self._to_tensor(done, torch.float32))

@@ -135,6 +135,10 @@ class JitterbugVecEnv:
     def step_device(self, action_ptr, obs_ptr, reward_ptr, done_ptr):
         _lib.check(self._L.jb_step_device(self._h, action_ptr, obs_ptr, reward_ptr, done_ptr))
 
+    def step_rows_device(self, action_ptr, rows_ptr):
+        """One packed float row [obs(D) | reward | done] per env, written by the step kernel (the unit of the multi-GPU gather)."""
+        _lib.check(self._L.jb_step_rows_device(self._h, action_ptr, rows_ptr))
+
     def reset_device(self, mask_ptr=None, obs_ptr=None):
         _lib.check(self._L.jb_reset_device(self._h, mask_ptr, obs_ptr))
 

@@ -412,3 +412,27 @@ def test_full_episode_properties_at_config4_size():
             ob, rw, dn, _ = e.step(a[lo:hi])
             assert np.array_equal(ob, ob_ref[lo:hi]) and np.array_equal(rw, rw_ref[lo:hi])
         e.close()
+
+
+def test_packed_rows_equal_separate_outputs():
+    """jb_step_rows_device writes [obs | reward | done] rows from the step kernel itself: bit-identical to jb_step_device."""
+    import torch
+    from jitterbug_amd.vec_env import JitterbugVecEnv
+    n, task = 1031, "move_to_pose"
+    D = model.OBS_DIM[task]
+    a_env = JitterbugVecEnv(n, task, seed=3, time_limit=0.07)         # 7 control steps per episode
+    b_env = JitterbugVecEnv(n, task, seed=3, time_limit=0.07)
+    a_env.reset(), b_env.reset()
+    dev = torch.device("cuda", 0)
+    rows = torch.empty((n, D + 2), device=dev, dtype=torch.float32)
+    g = torch.Generator(device="cpu"); g.manual_seed(1)
+    for t in range(9):                                      # crosses the (shortened) episode end: done = 1 and auto-reset rows
+        act = (torch.rand((n,), generator=g) * 2 - 1).to(torch.float32)
+        ob, rw, dn, _ = a_env.step(act.numpy())
+        act_d = act.to(dev)
+        b_env.step_rows_device(act_d.data_ptr(), rows.data_ptr())
+        b_env.synchronize()
+        r = rows.cpu().numpy()
+        assert np.array_equal(r[:, :D], ob) and np.array_equal(r[:, D], rw) and np.array_equal(r[:, D + 1] > 0.5, dn.astype(bool))
+        assert dn.all() if t == 6 else not dn.any()
+    a_env.close(); b_env.close()
