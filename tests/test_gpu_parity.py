@@ -436,3 +436,26 @@ def test_packed_rows_equal_separate_outputs():
         assert np.array_equal(r[:, :D], ob) and np.array_equal(r[:, D], rw) and np.array_equal(r[:, D + 1] > 0.5, dn.astype(bool))
         assert dn.all() if t == 6 else not dn.any()
     a_env.close(); b_env.close()
+
+
+def test_random_policy_returns_in_the_reference_figures_bands():
+    """Behavioural calibration against the only MuJoCo-derived numbers the reference holds: the training curves embedded in
+    fig-rl-perf.ipynb start (near-random policies, real MuJoCo) at a median episode return of ~800-830 for move_from_origin,
+    ~310-330 for move_in_direction and ~200-230 for face_direction.  A uniform-random policy on this simulator must land in
+    generous bands around those values (it does: 863 / 318 / 219, profiles/r01_policy_returns.txt) - a coarse statistical pin
+    of locomotion speed, vibration amplitude and turning, not a parity claim."""
+    from jitterbug_amd.vec_env import JitterbugVecEnv
+    bands = {"move_from_origin": (650, 950), "move_in_direction": (220, 420), "face_direction": (100, 400)}
+    n = 256
+    for task, (lo, hi) in bands.items():
+        env = JitterbugVecEnv(n, task, seed=0, auto_reset=False)
+        env.reset()
+        rng = np.random.default_rng(1)
+        ret = np.zeros(n)
+        for t in range(999):
+            _, rw, _, _ = env.step(rng.uniform(-1, 1, size=n).astype(np.float32))
+            ret += rw
+        env.close()
+        med = float(np.median(ret))
+        print("%s: random-policy median return %.0f (band %d-%d)" % (task, med, lo, hi))
+        assert lo <= med <= hi, (task, med)
