@@ -91,6 +91,7 @@ def main():
     ap.add_argument("--no-also", action="store_true")
     ap.add_argument("--max-newton", type=int, default=12)
     ap.add_argument("--envs-per-wave", type=int, default=0)
+    ap.add_argument("--seed", type=int, default=0, help="reset / action stream seed (the committed numbers use 0)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the measured path); gloo is a CPU-staged rehearsal of the N>1 control flow")
     ap.add_argument("--task", default=TASK, help="default move_from_origin (the BASELINE metric); move_to_pose is BASELINE configs[3]'s task")
     ap.add_argument("--augmented", action="store_true", help="one randomised model per env (BASELINE configs[4], augment_Jitterbug semantics)")
@@ -128,7 +129,7 @@ def main():
 
     def make_env(contacts):
         # the handle launches on torch's current stream so torch.cuda.Event brackets exactly these kernels
-        env = JitterbugVecEnv(n, task, seed=0, device_id=local_rank, contacts=bool(contacts), env_offset=rank * n, max_newton=args.max_newton, envs_per_wave=args.envs_per_wave,
+        env = JitterbugVecEnv(n, task, seed=args.seed, device_id=local_rank, contacts=bool(contacts), env_offset=rank * n, max_newton=args.max_newton, envs_per_wave=args.envs_per_wave,
                               stream=torch.cuda.current_stream(dev).cuda_stream)
         if args.augmented:
             from jitterbug_amd.augmented_jitterbug import augmented_params
@@ -138,7 +139,7 @@ def main():
     def run(contacts, steps, warmup, gather):
         env = make_env(contacts)
         g = torch.Generator(device=dev)
-        g.manual_seed(1234 + rank)
+        g.manual_seed(1234 + rank + 7919 * args.seed)
         actions = torch.rand((steps + warmup, n), generator=g, device=dev, dtype=torch.float32) * 2 - 1
         obs = torch.empty((n, D), device=dev, dtype=torch.float32)
         rew = torch.empty((n,), device=dev, dtype=torch.float32)

@@ -111,6 +111,22 @@ JB_HD float vmin(float a, float b) { return fminf(a, b); }
 JB_HD double vmin(double a, double b) { return fmin(a, b); }
 JB_HD float vmax(float a, float b) { return fmaxf(a, b); }
 JB_HD double vmax(double a, double b) { return fmax(a, b); }
+// sin and cos of an angle already wrapped to [-pi, pi] (the motor angle): quarter-turn reduction with a two-term pi/2 and
+// Taylor polynomials on [-pi/4, pi/4] (truncation < 3e-9), about a third of the instructions of sinf + cosf.  The fp64
+// host build keeps libm.
+JB_HD void vsincos_pi(float x, float& s, float& c) {
+    const float k = rintf(x * 0.636619772367581343f);
+    float r = fmaf(-k, 1.57079625129699707031f, x);
+    r = fmaf(-k, 7.54978941586159635336e-08f, r);
+    const float r2 = r * r;
+    const float sr = r + r * r2 * (-1.0f / 6 + r2 * (1.0f / 120 + r2 * (-1.0f / 5040 + r2 * (1.0f / 362880))));
+    const float cr = 1.0f + r2 * (-0.5f + r2 * (1.0f / 24 + r2 * (-1.0f / 720 + r2 * (1.0f / 40320 + r2 * (-1.0f / 3628800)))));
+    const int q = (int)k & 3;
+    const float a = (q & 1) ? cr : sr, b = (q & 1) ? sr : cr;
+    s = (q & 2) ? -a : a;
+    c = ((q + 1) & 2) ? -b : b;
+}
+JB_HD void vsincos_pi(double x, double& s, double& c) { s = sin(x); c = cos(x); }
 JB_HD float vfloor(float a) { return floorf(a); }
 JB_HD double vfloor(double a) { return floor(a); }
 
@@ -163,6 +179,7 @@ inline UQuad operator+(const UQuad& a, uint32_t b) { UQuad r; for (int i = 0; i 
 #define JB_QUN(name, fn) template <typename T> inline Quad<T> name(const Quad<T>& a) { Quad<T> r; for (int i = 0; i < 4; i++) r.v[i] = fn(a.v[i]); return r; }
 JB_QUN(vsqrt, vsqrt) JB_QUN(vrcp, vrcp) JB_QUN(vrsqrt, vrsqrt) JB_QUN(vabs, vabs) JB_QUN(vsin, vsin) JB_QUN(vcos, vcos) JB_QUN(vfloor, vfloor)
 #undef JB_QUN
+template <typename T> inline void vsincos_pi(const Quad<T>& x, Quad<T>& s, Quad<T>& c) { for (int i = 0; i < 4; i++) vsincos_pi(x.v[i], s.v[i], c.v[i]); }
 template <typename T> inline Quad<T> vmin(const Quad<T>& a, const Quad<T>& b) { Quad<T> r; for (int i = 0; i < 4; i++) r.v[i] = vmin(a.v[i], b.v[i]); return r; }
 template <typename T> inline Quad<T> vmax(const Quad<T>& a, const Quad<T>& b) { Quad<T> r; for (int i = 0; i < 4; i++) r.v[i] = vmax(a.v[i], b.v[i]); return r; }
 template <typename T> struct lane_traits<Quad<T>> { using mask = Mask4; using uint = UQuad; using real = T; };

@@ -156,6 +156,21 @@ template <typename T> inline int build_lane_model(const double* P, int leg, T* o
             T* bx = out + LM_BX;
             for (int i = 0; i < 3; i++) { bx[i] = T(c[i]); bx[12 + i] = T(r + margin); }
         }
+        // first-level test: one sphere around the lane's boxes (centre = mean of the box centres, radius reaches every corner)
+        double sc[3] = {0, 0, 0}, sr = 0;
+        int nb = 0;
+        for (int k = 0; k < 2; k++) if (out[LM_BX + 15 * k + 12] > T(0)) { for (int i = 0; i < 3; i++) sc[i] += (double)out[LM_BX + 15 * k + i]; nb++; }
+        for (int i = 0; i < 3; i++) sc[i] = nb ? sc[i] / nb : 0.0;
+        for (int k = 0; k < 2; k++) {
+            const T* bx = out + LM_BX + 15 * k;
+            if (!(bx[12] > T(0))) continue;
+            double dc = 0, dh = 0;
+            for (int i = 0; i < 3; i++) { dc += ((double)bx[i] - sc[i]) * ((double)bx[i] - sc[i]); dh += (double)bx[12 + i] * (double)bx[12 + i]; }
+            double rr = std::sqrt(dc) + std::sqrt(dh);
+            if (rr > sr) sr = rr;
+        }
+        for (int i = 0; i < 3; i++) out[LM_BS_BODY_C + i] = T(sc[i]);
+        out[LM_BS_BODY_R] = T(nb ? sr + margin : -1.0);
     }
     return 0;
 }

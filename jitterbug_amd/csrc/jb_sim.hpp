@@ -72,18 +72,22 @@ enum LM : int {
     //   LEG: sphere around upper cylinder + knee tip;  BX: two oriented boxes around the lane's root-body geoms
     //   (motor-body geoms: one axis-aligned cube centred on the motor axis, so it does not move with the motor angle)
     LM_BS_LEG_C = 105 /*3*/, LM_BS_LEG_R = 108,
-    LM_BX = 109 /*2 x 15: centre(3), axes(3x3, unit), half sizes(3) + margin: boxes bounding the lane's root/motor-body geoms*/,
-    LM_HOT = 139,
-    // ---------------- read only on the rare (all-geom) path
-    LM_UC_D = 139 /*3: upper cylinder centre - a1*/, LM_UC_AX = 142 /*3*/, LM_UC_XA = 145 /*3*/, LM_UC_R = 148, LM_UC_H = 149,
-    LM_DTIP = 150 /*3*/, LM_TIP_R = 153,
+    //   BODY: one sphere around all root / motor-body geoms of this lane - the cheap first test; the exact one (BX) runs only
+    //   when some lane's sphere reaches the floor
+    LM_BS_BODY_C = 109 /*3*/, LM_BS_BODY_R = 112,
+    LM_HOT = 113,
+    // ---------------- read only on the rare paths (from the table in LDS)
+    LM_BX = LM_HOT /*2 x 15: centre(3), axes(3x3, unit), half sizes(3) + margin: boxes bounding the lane's root/motor-body geoms*/,
+    LM_UC_D = LM_BX + 30 /*3: upper cylinder centre - a1*/, LM_UC_AX = LM_UC_D + 3 /*3*/, LM_UC_XA = LM_UC_D + 6 /*3*/, LM_UC_R = LM_UC_D + 9, LM_UC_H = LM_UC_D + 10,
+    LM_DTIP = LM_UC_D + 11 /*3*/, LM_TIP_R = LM_UC_D + 14,
     // lane-assigned geoms of the root / motor body (lane 0: coreBody1 box, lane 1: coreBody2 box,
     // lane 2: screw1 cylinder + screw2 ellipsoid, lane 3: threadMass cylinder + mass ellipsoid on the motor body)
-    LM_XB_EN = 154, LM_XB_C = 155 /*3*/, LM_XB_R = 158 /*9*/, LM_XB_S = 167 /*3*/,
-    LM_XC_EN = 170, LM_XC_C = 171 /*3*/, LM_XC_AX = 174 /*3*/, LM_XC_XA = 177 /*3*/, LM_XC_R = 180, LM_XC_H = 181,
-    LM_XE_EN = 182, LM_XE_C = 183 /*3*/, LM_XE_R = 186 /*9*/, LM_XE_S = 195 /*3*/,
-    LM_X_ONM = 198 /*1: the lane's cylinder+ellipsoid sit on the motor body*/,
-    LM_COUNT = 202,
+    LM_XB_EN = LM_UC_D + 15, LM_XB_C = LM_XB_EN + 1 /*3*/, LM_XB_R = LM_XB_EN + 4 /*9*/, LM_XB_S = LM_XB_EN + 13 /*3*/,
+    LM_XC_EN = LM_XB_EN + 16, LM_XC_C = LM_XC_EN + 1 /*3*/, LM_XC_AX = LM_XC_EN + 4 /*3*/, LM_XC_XA = LM_XC_EN + 7 /*3*/, LM_XC_R = LM_XC_EN + 10, LM_XC_H = LM_XC_EN + 11,
+    LM_XE_EN = LM_XC_EN + 12, LM_XE_C = LM_XE_EN + 1 /*3*/, LM_XE_R = LM_XE_EN + 4 /*9*/, LM_XE_S = LM_XE_EN + 13 /*3*/,
+    LM_X_ONM = LM_XE_EN + 16 /*1: the lane's cylinder+ellipsoid sit on the motor body*/,
+    LM_COUNT = LM_X_ONM + 4,
+
     // Entries [0, LM_INV) (global options, root body, motor body) are the same for the 4 lanes of an env and are stored
     // once; the rest is stored per lane.  Packed table: [LM_INV] then [LM_COUNT - LM_INV][4]  = LM_TABLE floats per env.
     LM_INV = 49,
@@ -798,7 +802,8 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
 
         // ---- motor body kinematics (replicated)
         Vec3<V> am = ldv3(m, LM_AM), em = ldv3(m, LM_EM);
-        V sp = vsin(s.phi), cp = vcos(s.phi);
+        V sp, cp;
+        vsincos_pi(s.phi, sp, cp);
         Mat3<V> Rm = rodrigues(em, sp, cp);
         Vec3<V> cm = am + mul(Rm, ldv3(m, LM_DCM));
         Sym3<V> Im = rotate(Rm, ldsym(m, LM_IM));
@@ -1121,14 +1126,18 @@ JB_HD void substep(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneState<V>
                            (s.qw * s.qw - s.qx * s.qx - s.qy * s.qy + s.qz * s.qz) * iq);
         // upper leg: sphere around the upper cylinder (+ slack for the shoulder angle)
         auto near_leg = mor(lt(s.pz + dot(ldv3(m, LM_BS_LEG_C), nb), m.c[LM_BS_LEG_R]), gt(vabs(s.th1), V(0.3)));
-        // the lane's root / motor-body geoms: two oriented boxes (support function of a box along -n)
-        auto near_body = lt(V(1), V(0));
+        // the lane's root / motor-body geoms: a bounding sphere first (at rest it clears the floor by 8 mm or more), and only
+        // when some lane's sphere reaches the floor the two oriented boxes (support function of a box along -n)
+        auto near_body = lt(s.pz + dot(ldv3(m, LM_BS_BODY_C), nb), m.c[LM_BS_BODY_R]);
+        if (any_lane(near_body)) {
+            near_body = lt(V(1), V(0));
 #pragma unroll
-        for (int k = 0; k < 2; k++) {
-            const int b = LM_BX + 15 * k;
-            Vec3<V> ax0 = ldv3(m, b + 3), ax1 = ldv3(m, b + 6), ax2 = ldv3(m, b + 9);
-            V sup = vabs(dot(ax0, nb)) * m.c[b + 12] + vabs(dot(ax1, nb)) * m.c[b + 13] + vabs(dot(ax2, nb)) * m.c[b + 14];
-            near_body = mor(near_body, lt(s.pz + dot(ldv3(m, b), nb), sup));
+            for (int k = 0; k < 2; k++) {
+                const int b = LM_BX + 15 * k;
+                Vec3<V> ax0 = ldv3(m, b + 3), ax1 = ldv3(m, b + 6), ax2 = ldv3(m, b + 9);
+                V sup = vabs(dot(ax0, nb)) * m.c[b + 12] + vabs(dot(ax1, nb)) * m.c[b + 13] + vabs(dot(ax2, nb)) * m.c[b + 14];
+                near_body = mor(near_body, lt(s.pz + dot(ldv3(m, b), nb), sup));
+            }
         }
         xt = (any_lane(near_leg) ? 1u : 0u) | (any_lane(near_body) ? 2u : 0u);
     }

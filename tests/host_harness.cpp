@@ -50,3 +50,5 @@ extern "C" int jbh_step(const double* P, double* qpos, double* qvel, double ctrl
                      : run<double>(P, qpos, qvel, ctrl, nsub, contacts, max_newton, implicit_damp, fail);
 }
 extern "C" int jbh_lm_count(void) { return LM_COUNT; }
+// the per-leg constant table (LM_COUNT doubles) for inspection by tests / tools
+extern "C" int jbh_lane_table(const double* P, int leg, double* out) { return build_lane_model<double>(P, leg, out); }
