@@ -110,6 +110,23 @@ int jb_policy(jb_handle* h, const float* obs, float* action);
 int jb_rollout_policy_device(jb_handle* h, int32_t n_steps, float* d_obs_inout, float* d_rewards, uint8_t* d_done_last);
 /* host-buffer form: starts from the handle's current state; rewards_out [n_steps,N] and obs_out [N,D] are nullable */
 int jb_rollout_policy(jb_handle* h, int32_t n_steps, float* rewards_out, float* obs_out);
+/* Observation-encoder hook (reference jitterbug.py:760-761 -> encode_obs :927-993): a tiny dense network applied to every
+ * observation row on the GPU.  n_layers <= JB_ENC_MAX_LAYERS dense layers; dims[0] must be the task's observation width and
+ * every width <= JB_ENC_MAX_WIDTH; acts[l] in JB_ACT_*; weights are the layers' [in][out] matrices concatenated, biases
+ * likewise.  vae = 1: the last layer's outputs are [mean(L) | std(L)] and the code is mean + std * eps with eps ~ N(0,1)
+ * (reference benchmarks/VAE.py:134-146; the reference draws eps from torch's global RNG, here it is a Philox stream keyed
+ * (seed, global env, call number)).  The autoencoder of benchmarks/autoencoder.py:71-106 is one tanh layer.  The reference's
+ * trained weight files are not in its repository; the caller supplies weights.  n_layers = 0 removes the encoder. */
+#define JB_ENC_MAX_LAYERS 4
+#define JB_ENC_MAX_WIDTH  32
+#define JB_ACT_LINEAR 0
+#define JB_ACT_TANH   1
+#define JB_ACT_RELU   2
+int jb_set_obs_encoder(jb_handle* h, int32_t n_layers, const int32_t* dims /*[n_layers+1]*/, const int32_t* acts /*[n_layers]*/,
+                       const float* weights, const float* biases, int32_t vae);
+int jb_encoded_dim(jb_handle* h);              /* width of an encoded row, 0 if no encoder is set */
+int jb_encode_device(jb_handle* h, const float* d_obs /*[N,D]*/, float* d_code_out /*[N, jb_encoded_dim]*/);
+int jb_encode(jb_handle* h, const float* obs, float* code_out);
 int jb_synchronize(jb_handle* h);
 void* jb_stream(jb_handle* h);                 /* the hipStream_t the handle launches on */
 

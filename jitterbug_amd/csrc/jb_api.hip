@@ -254,6 +254,46 @@ __global__ void jb_policy_kernel(int n, int task, const float* __restrict__ obs,
     action[env] = heuristic_policy<float>(task, obs + (size_t)env * obs_dim(task), 1);
 }
 
+// ---------------------------------------------------------------------------------------------- observation encoder (tiny dense network per row)
+struct EncArgs {
+    int n, n_layers, vae, in_dim, out_dim;
+    int dims[JB_ENC_MAX_LAYERS + 1], acts[JB_ENC_MAX_LAYERS], woff[JB_ENC_MAX_LAYERS], boff[JB_ENC_MAX_LAYERS];
+    const float* params;          // weights then biases
+    unsigned long long seed, env_offset;
+    unsigned call;
+};
+__global__ void jb_encode_kernel(EncArgs e, const float* __restrict__ obs, float* __restrict__ out) {
+    int env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= e.n) return;
+    float a[JB_ENC_MAX_WIDTH], b[JB_ENC_MAX_WIDTH];
+    for (int i = 0; i < e.in_dim; i++) a[i] = obs[(size_t)env * e.in_dim + i];
+    for (int l = 0; l < e.n_layers; l++) {
+        const int din = e.dims[l], dout = e.dims[l + 1];
+        const float* W = e.params + e.woff[l];
+        const float* bias = e.params + e.boff[l];
+        for (int j = 0; j < dout; j++) {
+            float t = bias[j];
+            for (int i = 0; i < din; i++) t = fmaf(a[i], W[i * dout + j], t);
+            b[j] = e.acts[l] == JB_ACT_TANH ? tanhf(t) : e.acts[l] == JB_ACT_RELU ? fmaxf(t, 0.f) : t;
+        }
+        for (int j = 0; j < dout; j++) a[j] = b[j];
+    }
+    if (e.vae) {   // code = mean + std * eps, eps ~ N(0,1) by Box-Muller on Philox words
+        const int L = e.out_dim;
+        for (int j0 = 0; j0 < L; j0 += 4) {
+            uint32_t r[4];
+            philox4x32(e.seed ^ 0x656E636F64657273ull, e.env_offset + (unsigned long long)env, e.call, (uint32_t)(j0 >> 2), r);
+            float u0 = ((float)(r[0] >> 8) + 0.5f) * (1.0f / 16777216.0f), u1 = ((float)(r[1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+            float u2 = ((float)(r[2] >> 8) + 0.5f) * (1.0f / 16777216.0f), u3 = ((float)(r[3] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+            float ra = sqrtf(-2.f * logf(u0)), rb = sqrtf(-2.f * logf(u2));
+            float eps[4] = {ra * cosf(6.2831853f * u1), ra * sinf(6.2831853f * u1), rb * cosf(6.2831853f * u3), rb * sinf(6.2831853f * u3)};
+            for (int k = 0; k < 4 && j0 + k < L; k++) out[(size_t)env * L + j0 + k] = a[j0 + k] + a[L + j0 + k] * eps[k];
+        }
+    } else {
+        for (int j = 0; j < e.out_dim; j++) out[(size_t)env * e.out_dim + j] = a[j];
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- state import / export (fp64 MuJoCo layout)
 __global__ void jb_export_kernel(KArgs a, double* __restrict__ qpos, double* __restrict__ qvel, double* __restrict__ target) {
     int env = blockIdx.x * blockDim.x + threadIdx.x;
@@ -321,6 +361,8 @@ struct jb_handle {
     double *d_qpos, *d_qvel, *d_target;
     unsigned long long* d_wave_stats;
     size_t model_tables;
+    EncArgs enc;          // observation encoder (n_layers = 0: none)
+    float* d_enc_params; float* d_code;
 };
 
 static dim3 grid_lanes(int n) { return dim3((unsigned)(((size_t)n * 4 + 63) / 64)); }
@@ -435,13 +477,69 @@ int jb_create(const jb_config* cfg, jb_handle** out) {
 int jb_destroy(jb_handle* h) {
     if (!h) return JB_OK;
     hipStreamSynchronize(h->stream);
-    void* bufs[] = {h->d_root, h->d_leg, h->d_model, h->d_step, h->d_episode, h->d_action, h->d_obs, h->d_reward, h->d_done, h->d_mask, h->d_qpos, h->d_qvel, h->d_target, h->d_wave_stats};
+    void* bufs[] = {h->d_root, h->d_leg, h->d_model, h->d_step, h->d_episode, h->d_action, h->d_obs, h->d_reward, h->d_done, h->d_mask, h->d_qpos, h->d_qvel, h->d_target, h->d_wave_stats, h->d_enc_params, h->d_code};
     for (void* b : bufs) if (b) hipFree(b);
     if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
     delete h;
     return JB_OK;
 }
 
+int jb_set_obs_encoder(jb_handle* h, int32_t n_layers, const int32_t* dims, const int32_t* acts, const float* weights, const float* biases, int32_t vae) {
+    if (!h) return fail(JB_E_INVALID, "handle is NULL");
+    JB_HIP(hipStreamSynchronize(h->stream));
+    if (h->d_enc_params) { hipFree(h->d_enc_params); h->d_enc_params = nullptr; }
+    if (h->d_code) { hipFree(h->d_code); h->d_code = nullptr; }
+    h->enc = EncArgs();
+    if (n_layers == 0) return JB_OK;
+    if (n_layers < 0 || n_layers > JB_ENC_MAX_LAYERS || !dims || !acts || !weights || !biases) return fail(JB_E_INVALID, "encoder: 1.." + std::to_string(JB_ENC_MAX_LAYERS) + " layers with dims/acts/weights/biases");
+    if (dims[0] != h->D) return fail(JB_E_INVALID, "encoder: dims[0] must be the observation width " + std::to_string(h->D));
+    size_t nw = 0, nb = 0;
+    for (int l = 0; l < n_layers; l++) {
+        if (dims[l] < 1 || dims[l] > JB_ENC_MAX_WIDTH || dims[l + 1] < 1 || dims[l + 1] > JB_ENC_MAX_WIDTH) return fail(JB_E_INVALID, "encoder: layer widths must be 1.." + std::to_string(JB_ENC_MAX_WIDTH));
+        if (acts[l] < JB_ACT_LINEAR || acts[l] > JB_ACT_RELU) return fail(JB_E_INVALID, "encoder: unknown activation");
+        nw += (size_t)dims[l] * dims[l + 1]; nb += (size_t)dims[l + 1];
+    }
+    if (vae && (dims[n_layers] & 1)) return fail(JB_E_INVALID, "encoder: a VAE head needs an even last width [mean | std]");
+    EncArgs e = EncArgs();
+    e.n = h->cfg.n_envs; e.n_layers = n_layers; e.vae = vae ? 1 : 0; e.in_dim = dims[0]; e.out_dim = vae ? dims[n_layers] / 2 : dims[n_layers];
+    size_t wo = 0, bo = nw;
+    for (int l = 0; l < n_layers; l++) {
+        e.dims[l] = dims[l]; e.acts[l] = acts[l]; e.woff[l] = (int)wo; e.boff[l] = (int)bo;
+        wo += (size_t)dims[l] * dims[l + 1]; bo += (size_t)dims[l + 1];
+    }
+    e.dims[n_layers] = dims[n_layers];
+    e.seed = h->cfg.seed; e.env_offset = h->cfg.env_offset; e.call = 0;
+    std::vector<float> host(nw + nb);
+    std::copy(weights, weights + nw, host.begin());
+    std::copy(biases, biases + nb, host.begin() + nw);
+    JB_HIP(hipMalloc(&h->d_enc_params, host.size() * sizeof(float)));
+    JB_HIP(hipMalloc(&h->d_code, sizeof(float) * (size_t)e.n * e.out_dim));
+    JB_HIP(hipMemcpy(h->d_enc_params, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
+    e.params = h->d_enc_params;
+    h->enc = e;
+    return JB_OK;
+}
+int jb_encoded_dim(jb_handle* h) { return h ? h->enc.out_dim * (h->enc.n_layers > 0) : JB_E_INVALID; }
+int jb_encode_device(jb_handle* h, const float* d_obs, float* d_code_out) {
+    if (!h || !d_obs || !d_code_out) return fail(JB_E_INVALID, "handle/obs/out is NULL");
+    if (h->enc.n_layers <= 0) return fail(JB_E_INVALID, "no observation encoder set (jb_set_obs_encoder)");
+    const int N = h->cfg.n_envs;
+    hipLaunchKernelGGL(jb_encode_kernel, dim3((unsigned)((N + 127) / 128)), dim3(128), 0, h->stream, h->enc, d_obs, d_code_out);
+    JB_HIP(hipGetLastError());
+    h->enc.call++;
+    return JB_OK;
+}
+int jb_encode(jb_handle* h, const float* obs, float* code_out) {
+    if (!h || !obs || !code_out) return fail(JB_E_INVALID, "handle/obs/out is NULL");
+    if (h->enc.n_layers <= 0) return fail(JB_E_INVALID, "no observation encoder set (jb_set_obs_encoder)");
+    const size_t N = (size_t)h->cfg.n_envs;
+    JB_HIP(hipMemcpyAsync(h->d_obs, obs, sizeof(float) * N * h->D, hipMemcpyHostToDevice, h->stream));
+    int rc = jb_encode_device(h, h->d_obs, h->d_code);
+    if (rc) return rc;
+    JB_HIP(hipMemcpyAsync(code_out, h->d_code, sizeof(float) * N * h->enc.out_dim, hipMemcpyDeviceToHost, h->stream));
+    JB_HIP(hipStreamSynchronize(h->stream));
+    return JB_OK;
+}
 int jb_num_envs(jb_handle* h) { return h ? h->cfg.n_envs : JB_E_INVALID; }
 void* jb_stream(jb_handle* h) { return h ? (void*)h->stream : nullptr; }
 int jb_synchronize(jb_handle* h) {

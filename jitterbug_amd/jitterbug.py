@@ -176,11 +176,15 @@ class Environment:
     """dm_control ``control.Environment`` for one Jitterbug (third party; built at reference jitterbug.py:84-90)."""
 
     def __init__(self, task, time_limit=DEFAULT_TIME_LIMIT, control_timestep=DEFAULT_CONTROL_TIMESTEP, flat_observation=False,
-                 device_id=0, **unused_environment_kwargs):
+                 device_id=0, obs_encoder=None, obs_encoder_vae=False, **unused_environment_kwargs):
         self._task = task
         self._flat_observation = flat_observation
+        self._obs_encoder = obs_encoder       # layer list (jitterbug_amd.encoders): observations become {'observations': code},
+                                              # what the reference's encode_obs returns (jitterbug.py:927-993).  Default: raw dict.
         self._venv = JitterbugVecEnv(1, task.task, seed=_seed_from(task.random), device_id=device_id, random_pose=task.random_pose,
                                      time_limit=time_limit, control_timestep=control_timestep, auto_reset=False)
+        if obs_encoder:
+            self._venv.set_obs_encoder(obs_encoder, vae=obs_encoder_vae)
         self._physics = Physics(self._venv)
         self._step_limit = float("inf") if time_limit == float("inf") else time_limit / (PHYSICS_TIMESTEP * self._venv.substeps)
         self._step_count = 0
@@ -203,11 +207,18 @@ class Environment:
         return specs.BoundedArray(shape=(1,), dtype=np.float64, minimum=-1.0, maximum=1.0)     # ctrlrange, reference jitterbug.xml:132-133
 
     def observation_spec(self):
+        if self._obs_encoder:
+            return collections.OrderedDict(observations=specs.Array((self._venv.encoded_dim,), np.float64, name="observations"))
         if self._flat_observation:
             return collections.OrderedDict(observations=specs.Array((self._venv.obs_dim,), np.float64, name="observations"))
         return collections.OrderedDict((name, specs.Array((w,), np.float64, name=name)) for name, w in _OBS_LAYOUT[self._task.task])
 
     def _observation(self, vec):
+        if self._obs_encoder:
+            return collections.OrderedDict(observations=self._venv.encode(vec[None, :])[0].astype(np.float64))
+        return self._observation_raw(vec)
+
+    def _observation_raw(self, vec):
         self._task.counter += 1
         vec = np.asarray(vec, dtype=np.float64)
         if self._flat_observation:

@@ -135,6 +135,37 @@ class JitterbugVecEnv:
     def step_device(self, action_ptr, obs_ptr, reward_ptr, done_ptr):
         _lib.check(self._L.jb_step_device(self._h, action_ptr, obs_ptr, reward_ptr, done_ptr))
 
+    # ------------------------------------------------------------------ observation encoder hook (reference jitterbug.py:760-761, 927-993)
+    def set_obs_encoder(self, layers, vae=False):
+        """layers: list of (W [in, out], b [out], activation in {'linear', 'tanh', 'relu'}) (see jitterbug_amd.encoders); None / [] removes it."""
+        acts = {"linear": 0, "tanh": 1, "relu": 2}
+        if not layers:
+            _lib.check(self._L.jb_set_obs_encoder(self._h, 0, None, None, None, None, 0))
+            return
+        dims = [int(np.asarray(layers[0][0]).shape[0])] + [int(np.asarray(W).shape[1]) for W, _, _ in layers]
+        a = np.array([acts[act] for _, _, act in layers], dtype=np.int32)
+        w = np.concatenate([np.asarray(W, dtype=np.float32).reshape(-1) for W, _, _ in layers])
+        b = np.concatenate([np.asarray(bb, dtype=np.float32).reshape(-1) for _, bb, _ in layers])
+        for (W, bb, _), din, dout in zip(layers, dims[:-1], dims[1:]):
+            assert np.asarray(W).shape == (din, dout) and np.asarray(bb).shape == (dout,), "layer shapes must chain"
+        d = np.array(dims, dtype=np.int32)
+        _lib.check(self._L.jb_set_obs_encoder(self._h, len(layers), d.ctypes.data, a.ctypes.data, _lib.ptr(w), _lib.ptr(b), int(bool(vae))))
+
+    @property
+    def encoded_dim(self):
+        return int(self._L.jb_encoded_dim(self._h))
+
+    def encode(self, obs):
+        """[N, D] observation rows -> [N, encoded_dim] codes (needs set_obs_encoder)."""
+        o = np.ascontiguousarray(obs, dtype=np.float32).reshape(self.num_envs, self.obs_dim)
+        n_out = self.encoded_dim
+        out = np.empty((self.num_envs, max(n_out, 1)), dtype=np.float32)
+        _lib.check(self._L.jb_encode(self._h, _lib.ptr(o), _lib.ptr(out)))
+        return out
+
+    def encode_device(self, obs_ptr, code_ptr):
+        _lib.check(self._L.jb_encode_device(self._h, obs_ptr, code_ptr))
+
     def step_rows_device(self, action_ptr, rows_ptr):
         """One packed float row [obs(D) | reward | done] per env, written by the step kernel (the unit of the multi-GPU gather)."""
         _lib.check(self._L.jb_step_rows_device(self._h, action_ptr, rows_ptr))
