@@ -8,8 +8,9 @@ Same names and call conventions as the reference for the hot path's surface:
     constructed at reference :84-90)
 All arithmetic of a step (50 substeps, reward, observation, episode reset) runs in the HIP library through the C ABI;
 this module only shapes its results into the reference's Python types.  The observation encoders the reference hard-wires
-at HEAD (use_VAE=True, reference :468-477, 760-761) are NOT applied: observations are the raw dict documented in the
-reference README (SURVEY.md finding 3)."""
+at HEAD (use_VAE=True, reference :468-477, 760-761) are NOT applied by default: observations are the raw dict documented in the
+reference README (SURVEY.md finding 3).  `Environment(obs_encoder=layers)` switches the hook on with caller-supplied weights
+(jitterbug_amd/encoders.py; the reference's weight files are not in its repository)."""
 import collections
 
 import numpy as np
