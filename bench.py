@@ -91,6 +91,7 @@ def main():
     ap.add_argument("--no-also", action="store_true")
     ap.add_argument("--max-newton", type=int, default=12)
     ap.add_argument("--envs-per-wave", type=int, default=0)
+    ap.add_argument("--actions", default="uniform", help="uniform (default, the metric's workload) | const1 (motor flat out: about half the robots tip over - diagnostic)")
     ap.add_argument("--seed", type=int, default=0, help="reset / action stream seed (the committed numbers use 0)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the measured path); gloo is a CPU-staged rehearsal of the N>1 control flow")
     ap.add_argument("--task", default=TASK, help="default move_from_origin (the BASELINE metric); move_to_pose is BASELINE configs[3]'s task")
@@ -141,6 +142,8 @@ def main():
         g = torch.Generator(device=dev)
         g.manual_seed(1234 + rank + 7919 * args.seed)
         actions = torch.rand((steps + warmup, n), generator=g, device=dev, dtype=torch.float32) * 2 - 1
+        if args.actions == "const1":
+            actions.fill_(1.0)
         obs = torch.empty((n, D), device=dev, dtype=torch.float32)
         rew = torch.empty((n,), device=dev, dtype=torch.float32)
         done = torch.empty((n,), device=dev, dtype=torch.uint8)

@@ -164,7 +164,7 @@ __global__ __launch_bounds__(64) void jb_step_kernel(KArgs a, const float* __res
     const unsigned long long rt_start = __builtin_amdgcn_s_memrealtime();
     unsigned long long prof_local[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // accumulated in registers, written once at the end
     o.prof = prof_local;
-    o.hist = a.wave_stats ? a.wave_stats + (size_t)16 * a.n : nullptr;
+    o.hist = a.wave_stats ? a.wave_stats + (size_t)16 * a.n + (size_t)64 * lblock : nullptr;
 #endif
 #pragma unroll 1
     for (int k = 0; k < a.substeps; k++) substep<float>(m, scr, s, ctrl, o);
@@ -437,8 +437,8 @@ int jb_create(const jb_config* cfg, jb_handle** out) {
     JB_HIP(hipMalloc(&h->d_qvel, sizeof(double) * 15 * N));
     JB_HIP(hipMalloc(&h->d_target, sizeof(double) * 3 * N));
 #ifdef JB_WAVE_STATS
-    JB_HIP(hipMalloc(&h->d_wave_stats, sizeof(unsigned long long) * (16 * N + 64)));
-    JB_HIP(hipMemset(h->d_wave_stats, 0, sizeof(unsigned long long) * (16 * N + 64)));
+    JB_HIP(hipMalloc(&h->d_wave_stats, sizeof(unsigned long long) * (size_t)(16 + 64) * N));
+    JB_HIP(hipMemset(h->d_wave_stats, 0, sizeof(unsigned long long) * (size_t)(16 + 64) * N));
 #endif
     JB_HIP(hipMemsetAsync(h->d_root, 0, sizeof(float) * ROOT_F * N, h->stream));
     JB_HIP(hipMemsetAsync(h->d_leg, 0, sizeof(float) * LEG_F * 4 * N, h->stream));

@@ -737,7 +737,7 @@ struct SimOpts {
     int max_newton;      // cap on Newton iterations per substep
     int implicit_damp;   // 1: MuJoCo Euler implicit joint damping
     unsigned long long* prof;   // diagnostic builds: per-wave cycle accumulators [phaseA, check sweeps, full sweeps, solves, integrate]
-    unsigned long long* hist;   // diagnostic builds: global [0..27] live-slot counts over all-geom substeps, [28..35] rounds histogram, [36..43] same for ordinary substeps
+    unsigned long long* hist;   // diagnostic builds: per-wave [0..27] live-slot counts over all-geom substeps, [28..35] rounds histogram, [36..43] same for ordinary substeps
 };
 
 // small-angle sin/cos for the leg hinges (|th| < 1: truncation < 1e-9), exact libm otherwise
@@ -750,9 +750,10 @@ template <typename V> JB_HD void sincos_small(const V& x, V& s, V& c) {
 #ifdef JB_WAVE_STATS
 #if defined(__HIPCC__)
 template <typename V> __device__ inline void stats_hist(const SimOpts& o, const LaneScratch<V>&, const SlotPlan& plan, bool xtra, bool any_contact) {
+    // o.hist is THIS wave's private row of 64 counters (no atomics: they would serialise the waves when many are on the rare path)
     if (!o.hist || !any_contact || (threadIdx.x & 63) != 0) return;
-    if (xtra) for (int sl = 0; sl < 28; sl++) if (plan.live >> sl & 1u) atomicAdd(o.hist + sl, 1ull);
-    atomicAdd(o.hist + (xtra ? 28 : 36) + (plan.rounds < 7 ? plan.rounds : 7), 1ull);
+    if (xtra) for (int sl = 0; sl < 28; sl++) if (plan.live >> sl & 1u) o.hist[sl] += 1ull;
+    o.hist[(xtra ? 28 : 36) + (plan.rounds < 7 ? plan.rounds : 7)] += 1ull;
 }
 #else
 template <typename V> inline void stats_hist(const SimOpts&, const LaneScratch<V>&, const SlotPlan&, bool, bool) {}

@@ -11,12 +11,12 @@ env.reset()
 rng = np.random.default_rng(0)
 nsteps = int(sys.argv[3]) if len(sys.argv) > 3 else 150
 for t in range(nsteps):
-    env.step(rng.uniform(-1, 1, size=n).astype(np.float32))
+    env.step((np.ones(n) if (len(sys.argv) > 4 and sys.argv[4] == 'const') else rng.uniform(-1, 1, size=n)).astype(np.float32))
 L = _lib.load()
-buf = np.zeros((n + 4, 16), dtype=np.uint64)
+buf = np.zeros((n * 5, 16), dtype=np.uint64)
 L.jb_debug_wave_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
-e = L.jb_debug_wave_stats(env._h, buf.ctypes.data, n + 4)
-hist = buf[n:].reshape(-1)
+e = L.jb_debug_wave_stats(env._h, buf.ctypes.data, n * 5)
+hist = buf[n:].reshape(-1, 64).sum(axis=0)
 nw = (n + e - 1) // e
 b = buf[:nw].astype(np.float64)
 cyc = b[:, 0] / 100.0   # shader cycles / 100
