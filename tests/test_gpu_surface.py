@@ -117,3 +117,28 @@ def test_sharded_env_two_ranks_one_gpu():
            "--master-port", "29533", os.path.join(root, "tests", "_sharded_gpu_worker.py")]
     r = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "SHARDED_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
+def test_integration_md_stub_runs_and_matches_vec_env():
+    """The ctypes stub printed in INTEGRATION.md is executed as written (only the library path is substituted)."""
+    import os
+    import numpy as np
+    from jitterbug_amd import _lib
+    from jitterbug_amd.vec_env import JitterbugVecEnv
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "INTEGRATION.md")).read()
+    a = src.index("```python") + len("```python")
+    code = src[a:src.index("```", a)].replace('C.CDLL("libjitterbug_hip.so")', 'C.CDLL(%r)' % _lib.LIB_PATH)
+    _lib.load()                                   # same HIP runtime preload as the package
+    ns = {}
+    exec(code, ns)
+    b = ns["HipBatch"](33, "move_to_position", seed=9)
+    v = JitterbugVecEnv(33, "move_to_position", seed=9)
+    assert np.array_equal(b.reset(), v.reset())
+    rng = np.random.default_rng(0)
+    for _ in range(3):
+        act = rng.uniform(-1, 1, size=33).astype(np.float32)
+        o1, r1, d1, _ = b.step(act)
+        o2, r2, d2, _ = v.step(act)
+        assert np.array_equal(o1, o2) and np.array_equal(r1, r2) and np.array_equal(d1, d2.astype(bool))
+    v.close()
