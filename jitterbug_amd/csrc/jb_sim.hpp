@@ -1028,6 +1028,18 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
                     if (is_main) {
                         MK changed = mor(neq_u(acc.bw0, prev_bw0), neq_u(acc.xh, prev_xh));
                         unconverged = neq_u(quad_sum_u(mbit(changed)), zero_u<V>());
+#if defined(JB_WAVE_STATS) && defined(__HIPCC__)
+                        if (o.hist && !xtra) {      // how many active-set bits flipped per unconverged env (ordinary substeps: exact records)
+                            const unsigned fl = quad_sum_u((unsigned)__builtin_popcount(acc.bw0 ^ prev_bw0));
+                            const bool unc = unconverged;
+                            const unsigned long long m_unc = __builtin_amdgcn_ballot_w64(unc), m_multi = __builtin_amdgcn_ballot_w64(unc && fl > 1u);
+                            const unsigned long long m1 = __builtin_amdgcn_ballot_w64(unc && fl == 1u), m2 = __builtin_amdgcn_ballot_w64(unc && fl == 2u), m3 = __builtin_amdgcn_ballot_w64(unc && fl == 3u), m4 = __builtin_amdgcn_ballot_w64(unc && fl >= 4u);
+                            if ((threadIdx.x & 63) == 0 && m_unc) {
+                                o.hist[44] += 1ull; if (!m_multi) o.hist[45] += 1ull;
+                                o.hist[46] += __builtin_popcountll(m1) / 4; o.hist[47] += __builtin_popcountll(m2) / 4; o.hist[48] += __builtin_popcountll(m3) / 4; o.hist[49] += __builtin_popcountll(m4) / 4;
+                            }
+                        }
+#endif
                         if (!any_lane(unconverged) || it >= o.max_newton) {
                             s.fail = s.fail + sel(unconverged, V(1), V(0));
                             fin = 1u;

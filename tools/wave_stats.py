@@ -58,3 +58,8 @@ names = ["foot"] + ["lowcyl%d" % i for i in range(4)] + ["upcyl%d" % i for i in 
 tot = max(1, int(hist[28:36].sum()))
 print("  " + "  ".join("%s %.2f" % (names[i], hist[i] / tot) for i in range(28)))
 print("rounds histogram all-geom substeps:", (hist[28:36] / tot).round(3), " ordinary:", (hist[36:44] / max(1, hist[36:44].sum())).round(3))
+
+if hist[44] > 0:
+    print("checks that found a changed set (ordinary substeps): %d; of those with at most ONE flipped bit in every unconverged env: %.3f" % (hist[44], hist[45] / hist[44]))
+    e = hist[46:50].astype(float)
+    print("flipped bits per unconverged env [1, 2, 3, 4+]:", (e / max(1.0, e.sum())).round(3))
