@@ -156,7 +156,7 @@ __global__ __launch_bounds__(64) void jb_step_kernel(KArgs a, const float* __res
         s.wj[0] = s.wj[1] = 0.f; s.wm = 0.f; s.fail = 0.f;
     }
 #ifdef JB_WAVE_STATS
-    s.st_xtra = 0.f; s.st_sweeps = 0.f; s.st_contact = 0.f; s.st_slots = 0.f;
+    s.st_xtra = 0.f; s.st_sweeps = 0.f; s.st_contact = 0.f; s.st_slots = 0.f; s.st_fast = 0.f;
 #endif
     const float ctrl = action[env];
     SimOpts o; o.contacts = a.contacts; o.max_newton = a.max_newton; o.implicit_damp = 1; o.prof = nullptr; o.hist = nullptr;
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(64) void jb_step_kernel(KArgs a, const float* __res
         unsigned long long* ws = a.wave_stats + (size_t)lblock * 16;
         ws[10] = __builtin_amdgcn_s_memrealtime() - rt_start;
         ws[0] = __builtin_amdgcn_s_memtime() - t_start;
-        for (int i = 0; i < 5; i++) ws[4 + i] = prof_local[i]; ws[1] = (unsigned long long)s.st_xtra; ws[2] = (unsigned long long)s.st_sweeps; ws[3] = (unsigned long long)s.st_contact; ws[11] = (unsigned long long)s.st_slots; ws[12] = prof_local[5]; ws[13] = prof_local[6]; ws[14] = prof_local[7];
+        for (int i = 0; i < 5; i++) ws[4 + i] = prof_local[i]; ws[1] = (unsigned long long)s.st_xtra; ws[2] = (unsigned long long)s.st_sweeps; ws[3] = (unsigned long long)s.st_contact; ws[11] = (unsigned long long)s.st_slots; ws[15] = (unsigned long long)s.st_fast; ws[12] = prof_local[5]; ws[13] = prof_local[6]; ws[14] = prof_local[7];
     }
 #endif
     {   // trailing mj_step1: derived quantities use the normalised quaternion

@@ -87,6 +87,22 @@ JB_HD bool mand(bool a, bool b) { return a && b; }
 JB_HD bool mor(bool a, bool b) { return a || b; }
 JB_HD bool mnot(bool a) { return !a; }
 JB_HD unsigned mbit(bool a) { return a ? 1u : 0u; }
+JB_HD unsigned popc_u(unsigned a) { return (unsigned)__builtin_popcount(a); }
+JB_HD unsigned xor_u(unsigned a, unsigned b) { return a ^ b; }
+JB_HD bool eq_u(unsigned a, unsigned b) { return a == b; }
+// The single flipped bit of an active-set record (5 bits per slot: pyramid edges n+t1, n-t1, n+t2, n-t2, valid): which cached
+// row it belongs to (entry = rank of the slot among the live slots) and which edge it is.  A lane without a flipped bit gets
+// is_flip = false and entry 0.
+JB_HD void flip_decode(unsigned diff, unsigned rec, unsigned live, unsigned& entry, bool& is_flip, bool& plus, bool& tan2, bool& on) {
+    is_flip = diff != 0u;
+    const unsigned pos = is_flip ? (unsigned)__builtin_ctz(diff) : 0u;
+    const unsigned slot = (pos * 205u) >> 10, b = pos - 5u * slot;
+    entry = (unsigned)__builtin_popcount(live & ((1u << slot) - 1u));
+    is_flip = is_flip && b < 4u;
+    plus = (b & 1u) == 0u; tan2 = b >= 2u; on = ((rec >> pos) & 1u) != 0u;
+}
+JB_HD float ld_gather(const float* p, int stride, unsigned idx) { return p[idx * stride]; }
+JB_HD double ld_gather(const double* p, int stride, unsigned idx) { return p[idx * stride]; }
 JB_HD bool neq_u(unsigned a, unsigned b) { return a != b; }
 JB_HD float vsqrt(float x) { return sqrtf(x); }
 JB_HD double vsqrt(double x) { return sqrt(x); }
@@ -172,6 +188,13 @@ inline Mask4 mand(const Mask4& a, const Mask4& b) { Mask4 r; for (int i = 0; i <
 inline Mask4 mor(const Mask4& a, const Mask4& b) { Mask4 r; for (int i = 0; i < 4; i++) r.v[i] = a.v[i] || b.v[i]; return r; }
 inline Mask4 mnot(const Mask4& a) { Mask4 r; for (int i = 0; i < 4; i++) r.v[i] = !a.v[i]; return r; }
 inline UQuad mbit(const Mask4& a) { UQuad r; for (int i = 0; i < 4; i++) r.v[i] = a.v[i] ? 1u : 0u; return r; }
+inline UQuad popc_u(const UQuad& a) { UQuad r; for (int i = 0; i < 4; i++) r.v[i] = (uint32_t)__builtin_popcount(a.v[i]); return r; }
+inline UQuad xor_u(const UQuad& a, const UQuad& b) { UQuad r; for (int i = 0; i < 4; i++) r.v[i] = a.v[i] ^ b.v[i]; return r; }
+inline Mask4 eq_u(const UQuad& a, const UQuad& b) { Mask4 r; for (int i = 0; i < 4; i++) r.v[i] = a.v[i] == b.v[i]; return r; }
+inline void flip_decode(const UQuad& diff, const UQuad& rec, unsigned live, UQuad& entry, Mask4& is_flip, Mask4& plus, Mask4& tan2, Mask4& on) {
+    for (int i = 0; i < 4; i++) flip_decode(diff.v[i], rec.v[i], live, entry.v[i], is_flip.v[i], plus.v[i], tan2.v[i], on.v[i]);
+}
+template <typename T> inline Quad<T> ld_gather(const Quad<T>* p, int stride, const UQuad& idx) { Quad<T> r; for (int i = 0; i < 4; i++) r.v[i] = p[idx.v[i] * stride].v[i]; return r; }
 inline Mask4 neq_u(const UQuad& a, const UQuad& b) { Mask4 r; for (int i = 0; i < 4; i++) r.v[i] = a.v[i] != b.v[i]; return r; }
 inline UQuad operator*(const UQuad& a, uint32_t b) { UQuad r; for (int i = 0; i < 4; i++) r.v[i] = a.v[i] * b; return r; }
 inline UQuad operator+(const UQuad& a, const UQuad& b) { UQuad r; for (int i = 0; i < 4; i++) r.v[i] = a.v[i] + b.v[i]; return r; }

@@ -237,6 +237,7 @@ template <typename V> struct LaneState {
     V wa[3], wl[3], wj[2], wm;
     V fail;                              // >0: the Newton iteration hit its cap in some substep
 #ifdef JB_WAVE_STATS
+    V st_fast;
     V st_xtra, st_sweeps, st_contact, st_slots;    // diagnostic build only: substeps on the rare path, Newton sweeps, substeps with contact, live slots summed over contact substeps
 #endif
 };
@@ -267,6 +268,7 @@ template <typename V> struct LaneScratch {
     int grp, ngrp, gstride;   // group of this lane (0 = main), number of groups (1, 2 or 4), lane distance between groups
     JB_HD V ld(int i) const { return p[i * stride]; }
     JB_HD void st(int i, const V& v) const { p[i * stride] = v; }
+    JB_HD V ldv(const typename lane_traits<V>::uint& i) const { return ld_gather(p, stride, i); }      // per-lane index
     JB_HD Vec3<V> ld3(int i) const { return v3<V>(ld(i), ld(i + 1), ld(i + 2)); }
     JB_HD void st3(int i, const Vec3<V>& v) const { st(i, v.x); st(i + 1, v.y); st(i + 2, v.z); }
 };
@@ -322,12 +324,6 @@ template <typename V> JB_HD void acc_unpack(const V* v, NewtonAcc<V>& a) {
     a.C11 = v[33]; a.C12 = v[34]; a.C22 = v[35]; a.Cm = v[42]; a.rl[0] = v[49]; a.rl[1] = v[50]; a.rm = v[51];
 }
 
-// Solve  [A B Bm; B^T C 0; Bm^T 0 Cm] y = rhs  where the matrix is M (scratch) + the contact terms in `acc`
-// (+ hb1/hb2 on the leg diagonal: implicit joint damping) and rhs = tau (scratch) + acc.r*.
-//   A, tau_root, Bm, Cm : replicated in the 4 lanes, added ONCE;  acc.A, acc.rr, acc.Bm/Cm/rm: lane-private
-//   parts that are summed over the quad;  B, C, tau_leg: lane-private leg branch.
-// The own leg (2x2) and the motor (1x1) are eliminated onto the 6 root dofs; the 6x6 Schur complement is
-// Cholesky-factored redundantly by the 4 lanes.
 // The joint-space system of the substep, M = [A B Bm; B^T C 0; Bm^T 0 Cm] and tau.  Only the main lanes ever read it
 // (solves, final pass), so it lives in registers - in practice in the otherwise unused accumulation registers, one move
 // away - instead of making ~130 LDS round trips per substep.
@@ -339,40 +335,44 @@ template <typename V> struct StarSys {
     V tr[6], tl[2], tm;   // applied + bias forces: root, own leg, motor
 };
 
-template <typename V>
-JB_HD void star_solve(const StarSys<V>& M, const NewtonAcc<V>& acc, const V& hb1, const V& hb2, V (&yr)[6], V (&yl)[2], V& ym) {
+// Factorisation of H = M + contact terms (+ hb on the leg diagonal): the leg 2x2 and motor 1x1 blocks inverted, the 6x6 Schur
+// complement Cholesky-factored (reciprocal pivots on the diagonal).  Kept by the caller between Newton passes: a pass
+// whose active set differs from the factored one by a single pyramid edge is a rank-one update of this factorisation.
+template <typename V> struct StarFactor {
+    V S[21];
     V B[6][2];
+    V i11, i12, i22;
+    V bm[6], icm;
+};
+template <typename V>
+JB_HD void star_factor(const StarSys<V>& M, const NewtonAcc<V>& acc, const V& hb1, const V& hb2, StarFactor<V>& F) {
 #pragma unroll
-    for (int i = 0; i < 6; i++) { B[i][0] = M.B[i][0] + acc.B[i][0]; B[i][1] = M.B[i][1] + acc.B[i][1]; }
+    for (int i = 0; i < 6; i++) { F.B[i][0] = M.B[i][0] + acc.B[i][0]; F.B[i][1] = M.B[i][1] + acc.B[i][1]; }
     V C11 = M.C[0] + acc.C11 + hb1, C12 = M.C[1] + acc.C12, C22 = M.C[2] + acc.C22 + hb2;
-    V rl0 = M.tl[0] + acc.rl[0], rl1 = M.tl[1] + acc.rl[1];
     V idet = vrcp(C11 * C22 - C12 * C12);
-    V i11 = C22 * idet, i12 = -C12 * idet, i22 = C11 * idet;
-    V S[21], r[6];
+    F.i11 = C22 * idet; F.i12 = -C12 * idet; F.i22 = C11 * idet;
+    V (&S)[21] = F.S;
 #pragma unroll
     for (int i = 0; i < 6; i++) {
-        V g0 = B[i][0] * i11 + B[i][1] * i12, g1 = B[i][0] * i12 + B[i][1] * i22;
+        V g0 = F.B[i][0] * F.i11 + F.B[i][1] * F.i12, g1 = F.B[i][0] * F.i12 + F.B[i][1] * F.i22;
 #pragma unroll
-        for (int j = 0; j <= i; j++) S[tri(i, j)] = quad_sum(acc.A[tri(i, j)] - (g0 * B[j][0] + g1 * B[j][1])) + M.A[tri(i, j)];
-        r[i] = quad_sum(acc.rr[i] - (g0 * rl0 + g1 * rl1)) + M.tr[i];
+        for (int j = 0; j <= i; j++) S[tri(i, j)] = quad_sum(acc.A[tri(i, j)] - (g0 * F.B[j][0] + g1 * F.B[j][1])) + M.A[tri(i, j)];
     }
     // motor branch
-    V bm[6], cm = M.Cm, rmt = M.tm;
+    V cm = M.Cm;
 #pragma unroll
-    for (int i = 0; i < 6; i++) bm[i] = M.Bm[i];
+    for (int i = 0; i < 6; i++) F.bm[i] = M.Bm[i];
 #pragma unroll
-    for (int i = 0; i < 6; i++) bm[i] = bm[i] + quad_sum(acc.Bm[i]);
+    for (int i = 0; i < 6; i++) F.bm[i] = F.bm[i] + quad_sum(acc.Bm[i]);
     cm = cm + quad_sum(acc.Cm);
-    rmt = rmt + quad_sum(acc.rm);
-    V icm = vrcp(cm);
+    F.icm = vrcp(cm);
 #pragma unroll
     for (int i = 0; i < 6; i++) {
-        V g = bm[i] * icm;
+        V g = F.bm[i] * F.icm;
 #pragma unroll
-        for (int j = 0; j <= i; j++) S[tri(i, j)] = S[tri(i, j)] - g * bm[j];
-        r[i] = r[i] - g * rmt;
+        for (int j = 0; j <= i; j++) S[tri(i, j)] = S[tri(i, j)] - g * F.bm[j];
     }
-    // Cholesky S = L L^T (in place, reciprocal pivots on the diagonal), forward/back substitution
+    // Cholesky S = L L^T (in place, reciprocal pivots on the diagonal)
 #pragma unroll
     for (int j = 0; j < 6; j++) {
         V t = S[tri(j, j)];
@@ -387,6 +387,23 @@ JB_HD void star_solve(const StarSys<V>& M, const NewtonAcc<V>& acc, const V& hb1
             for (int k = 0; k < j; k++) u = u - S[tri(i, k)] * S[tri(j, k)];
             S[tri(i, j)] = u * id;
         }
+    }
+}
+// H y = rhs with the factorisation above.  rr: lane-private parts of the root rhs (summed over the quad), tr: replicated
+// root rhs (added once), rl0/rl1: own leg rhs, rmt: total motor rhs (replicated).
+template <typename V>
+JB_HD void star_subst(const StarFactor<V>& F, const V (&rr)[6], const V (&tr)[6], const V& rl0, const V& rl1, const V& rmt, V (&yr)[6], V (&yl)[2], V& ym) {
+    const V (&S)[21] = F.S;
+    V r[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        V g0 = F.B[i][0] * F.i11 + F.B[i][1] * F.i12, g1 = F.B[i][0] * F.i12 + F.B[i][1] * F.i22;
+        r[i] = quad_sum(rr[i] - (g0 * rl0 + g1 * rl1)) + tr[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        V g = F.bm[i] * F.icm;
+        r[i] = r[i] - g * rmt;
     }
 #pragma unroll
     for (int i = 0; i < 6; i++) {
@@ -405,10 +422,21 @@ JB_HD void star_solve(const StarSys<V>& M, const NewtonAcc<V>& acc, const V& hb1
     // back-substitute the branches
     V t0 = rl0, t1 = rl1, tmm = rmt;
 #pragma unroll
-    for (int i = 0; i < 6; i++) { t0 = t0 - B[i][0] * yr[i]; t1 = t1 - B[i][1] * yr[i]; tmm = tmm - bm[i] * yr[i]; }
-    yl[0] = i11 * t0 + i12 * t1;
-    yl[1] = i12 * t0 + i22 * t1;
-    ym = tmm * icm;
+    for (int i = 0; i < 6; i++) { t0 = t0 - F.B[i][0] * yr[i]; t1 = t1 - F.B[i][1] * yr[i]; tmm = tmm - F.bm[i] * yr[i]; }
+    yl[0] = F.i11 * t0 + F.i12 * t1;
+    yl[1] = F.i12 * t0 + F.i22 * t1;
+    ym = tmm * F.icm;
+}
+// Solve  [A B Bm; B^T C 0; Bm^T 0 Cm] y = rhs  where the matrix is M + the contact terms in `acc` (+ hb1/hb2 on the leg
+// diagonal: implicit joint damping) and rhs = tau + acc.r*.
+//   A, tau_root, Bm, Cm : replicated in the 4 lanes, added ONCE;  acc.A, acc.rr, acc.Bm/Cm/rm: lane-private
+//   parts that are summed over the quad;  B, C, tau_leg: lane-private leg branch.
+// The own leg (2x2) and the motor (1x1) are eliminated onto the 6 root dofs; the 6x6 Schur complement is
+// Cholesky-factored redundantly by the 4 lanes.
+template <typename V>
+JB_HD void star_solve(const StarSys<V>& M, const NewtonAcc<V>& acc, const V& hb1, const V& hb2, StarFactor<V>& F, V (&yr)[6], V (&yl)[2], V& ym) {
+    star_factor<V>(M, acc, hb1, hb2, F);
+    star_subst<V>(F, acc.rr, M.tr, M.tl[0] + acc.rl[0], M.tl[1] + acc.rl[1], M.tm + quad_sum(acc.rm), yr, yl, ym);
 }
 
 // ----------------------------------------------------------------------------- contacts
@@ -546,6 +574,49 @@ JB_HD void contact_apply(const LaneScratch<V>& sc, const Vec3<V> (&dk)[3], const
             acc.rm = fma3(acc.rm, Bj[0][7], wa0, Bj[1][7], wa1, Bj[2][7], wa2);
         }
     }
+}
+
+// Rank-one Newton pass.  The active set at y differs from the factored one by ONE pyramid edge e of one cached contact of
+// this env (weight D, reference acceleration a): H' = H + s D e e^T, rhs' = rhs + s D a e with s = +1 (edge switched on) or
+// -1 (off), hence by Sherman-Morrison
+//     y' = y + z * s D (a - e.y) / (1 + s D e.z),      z = H^-1 e   (one substitution with the kept factorisation).
+// Only the lane whose leg carries the contact has a non-zero e; the leg slots 0-4 sit on the lower leg (columns: 6 root dofs,
+// shoulder, knee).  `diff` = new record xor factored record of this lane, `rec` = new record.
+template <typename V>
+JB_HD void rank_one_pass(const LaneScratch<V>& sc, const StarFactor<V>& F, const Vec3<V> (&dk)[3], const V& mu, unsigned live,
+                         const typename lane_traits<V>::uint& diff, const typename lane_traits<V>::uint& rec,
+                         const V (&yr)[6], const V (&yl)[2], const V& ym, V (&nyr)[6], V (&nyl)[2], V& nym) {
+    using MK = typename lane_traits<V>::mask;
+    using U = typename lane_traits<V>::uint;
+    U entry;
+    MK is_flip, plus, tan2, on;
+    flip_decode(diff, rec, live, entry, is_flip, plus, tan2, on);
+    const U e0 = entry * (unsigned)ROW_F + (unsigned)SC_ROWS;
+    const V sg = sel(plus, mu, -mu);                    // e = B_n + sg * B_t
+    V e[8];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        e[i] = sc.ldv(e0 + (unsigned)i) + sg * sel(tan2, sc.ldv(e0 + (unsigned)(6 + i)), sc.ldv(e0 + (unsigned)(3 + i)));
+    }
+    e[3] = dk[0].x + sg * sel(tan2, dk[2].x, dk[1].x); e[4] = dk[0].y + sg * sel(tan2, dk[2].y, dk[1].y); e[5] = dk[0].z + sg * sel(tan2, dk[2].z, dk[1].z);
+    e[6] = sc.ldv(e0 + 9u) + sg * sel(tan2, sc.ldv(e0 + 11u), sc.ldv(e0 + 10u));
+    e[7] = sc.ldv(e0 + 12u) + sg * sel(tan2, sc.ldv(e0 + 14u), sc.ldv(e0 + 13u));
+    const V ah = sc.ldv(e0 + 15u) + sg * sel(tan2, sc.ldv(e0 + 17u), sc.ldv(e0 + 16u));
+    const V sD = sel(is_flip, sel(on, sc.ldv(e0 + 18u), -sc.ldv(e0 + 18u)), V(0));
+#pragma unroll
+    for (int i = 0; i < 8; i++) e[i] = sel(is_flip, e[i], V(0));
+    V rr[6], zero6[6], zr[6], zl[2], zm;
+#pragma unroll
+    for (int i = 0; i < 6; i++) { rr[i] = e[i]; zero6[i] = V(0); }
+    star_subst<V>(F, rr, zero6, e[6], e[7], V(0), zr, zl, zm);
+    V ety = e[6] * yl[0] + e[7] * yl[1], etz = e[6] * zl[0] + e[7] * zl[1];
+#pragma unroll
+    for (int i = 0; i < 6; i++) { ety = ety + e[i] * yr[i]; etz = etz + e[i] * zr[i]; }
+    const V num = quad_sum(sD * (ah - ety)), den = V(1) + quad_sum(sD * etz);
+    const V c = num * vrcp(den);
+#pragma unroll
+    for (int i = 0; i < 6; i++) nyr[i] = yr[i] + c * zr[i];
+    nyl[0] = yl[0] + c * zl[0]; nyl[1] = yl[1] + c * zl[1]; nym = ym + c * zm;
 }
 
 // j-th set bit of a mask (j < popcount(mask))
@@ -991,9 +1062,11 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
     V yr[6], yl[2], ym;
     {
         NewtonAcc<V> acc;
+        StarFactor<V> fac;      // factorisation of the last Newton system (main lanes)
         Vec3<V> dk[3];
-        bool final_pass = !any_contact;
+        bool final_pass = !any_contact, full_pass = true;
         MK unconverged = lt(V(0), V(1));
+        MK fac_valid = lt(V(1), V(0)), fast_env = lt(V(1), V(0));
         U prev_bw0 = zero_u<V>(), prev_xh = zero_u<V>();
         if (any_contact) {
 #pragma unroll
@@ -1024,7 +1097,7 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
                     // saw a different record; when nobody's changed, every y is the exact minimiser
                     contact_sweep<V>(m, sc, xtra, plan, 2, dk, acc);
                     JB_PROF_ADD(o, 1);
-                    unsigned fin = 0u;
+                    unsigned fin = 0u, full = 1u;
                     if (is_main) {
                         MK changed = mor(neq_u(acc.bw0, prev_bw0), neq_u(acc.xh, prev_xh));
                         unconverged = neq_u(quad_sum_u(mbit(changed)), zero_u<V>());
@@ -1043,18 +1116,40 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
                         if (!any_lane(unconverged) || it >= o.max_newton) {
                             s.fail = s.fail + sel(unconverged, V(1), V(0));
                             fin = 1u;
+                        } else {
+                            // An env whose set differs from the factored one by a single pyramid edge of a leg slot (exact
+                            // records) takes a rank-one pass; the decision is the ENV's own (its records, its factorisation),
+                            // so its arithmetic never depends on its wave-mates.  A full pass runs only if some env needs one.
+                            const U dfl = xor_u(acc.bw0, prev_bw0);
+                            const MK one_flip = eq_u(quad_sum_u(popc_u(dfl)), zero_u<V>() + 1u);
+                            const MK xh_same = eq_u(quad_sum_u(mbit(neq_u(acc.xh, prev_xh))), zero_u<V>());
+                            fast_env = mand(mand(unconverged, fac_valid), mand(one_flip, xh_same));
+                            full = any_lane(mand(unconverged, mnot(fast_env))) ? 1u : 0u;
+                            if (any_lane(fast_env)) {
+                                V fyr[6], fyl[2], fym;
+                                rank_one_pass<V>(sc, fac, dk, m.c[LM_MU], plan.live, dfl, acc.bw0, yr, yl, ym, fyr, fyl, fym);
+#pragma unroll
+                                for (int i = 0; i < 6; i++) yr[i] = sel(fast_env, fyr[i], yr[i]);
+                                yl[0] = sel(fast_env, fyl[0], yl[0]); yl[1] = sel(fast_env, fyl[1], yl[1]); ym = sel(fast_env, fym, ym);
+#ifdef JB_WAVE_STATS
+                                s.st_fast = s.st_fast + V(1);
+#endif
+                            }
+                            prev_bw0 = acc.bw0; prev_xh = acc.xh;      // the sets the new iterates are solved for
                         }
                     }
                     final_pass = wave_bcast_u(fin) != 0u;
+                    full_pass = wave_bcast_u(full) != 0u;
                 }
-                if (!final_pass) {
+                if (!final_pass && full_pass) {
+                    // (reads the iterate of the check from the scratch: rank-one results are stored only after this pass)
                     contact_sweep<V>(m, sc, xtra, plan, 0, dk, acc);
                     prev_bw0 = acc.bw0; prev_xh = acc.xh;
                     JB_PROF_ADD(o, 2);
 #ifdef JB_WAVE_STATS
                     if (is_main) s.st_sweeps = s.st_sweeps + V(1);
 #endif
-                } else if (is_main) {
+                } else if (final_pass && is_main) {
                     // At the minimiser  H y = tau + sum B^T W ahat,  so the constraint force is  qfrc = M y - tau  and MuJoCo's
                     // Euler step with implicit joint damping solves  (M + h diag(b)) qacc = tau + qfrc = M y,  i.e.
                     //     qacc = y - d,   (M + h diag(b)) d = h diag(b) y        (nonzero only in the leg rows).
@@ -1071,17 +1166,25 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
             JB_PROF_ADD(o, 7);
             if (is_main) {
                 V nyr[6], nyl[2], nym;
-                star_solve<V>(sys, acc, final_pass ? hb1 : V(0), final_pass ? hb2 : V(0), nyr, nyl, nym);
-                JB_PROF_ADD(o, 6);
                 if (final_pass) {
+                    star_solve<V>(sys, acc, hb1, hb2, fac, nyr, nyl, nym);
+                    JB_PROF_ADD(o, 6);
 #pragma unroll
                     for (int i = 0; i < 6; i++) yr[i] = sel(env_con, yr[i] - nyr[i], nyr[i]);
                     yl[0] = sel(env_con, yl[0] - nyl[0], nyl[0]); yl[1] = sel(env_con, yl[1] - nyl[1], nyl[1]); ym = sel(env_con, ym - nym, nym);
                 } else {
-                    // envs whose active set already repeated keep their (exact) solution
+                    if (full_pass) {
+                        star_solve<V>(sys, acc, V(0), V(0), fac, nyr, nyl, nym);
+                        JB_PROF_ADD(o, 6);
+                        // envs whose active set already repeated keep their (exact) solution, rank-one envs theirs
+                        const MK take = mand(unconverged, mnot(fast_env));
 #pragma unroll
-                    for (int i = 0; i < 6; i++) yr[i] = sel(unconverged, nyr[i], yr[i]);
-                    yl[0] = sel(unconverged, nyl[0], yl[0]); yl[1] = sel(unconverged, nyl[1], yl[1]); ym = sel(unconverged, nym, ym);
+                        for (int i = 0; i < 6; i++) yr[i] = sel(take, nyr[i], yr[i]);
+                        yl[0] = sel(take, nyl[0], yl[0]); yl[1] = sel(take, nyl[1], yl[1]); ym = sel(take, nym, ym);
+                        fac_valid = mnot(fast_env);         // a rank-one env's factorisation is one edge behind its set
+                    } else {
+                        fac_valid = mand(fac_valid, mnot(fast_env));
+                    }
 #pragma unroll
                     for (int i = 0; i < 6; i++) sc.st(SC_Y + i, yr[i]);
                     sc.st(SC_Y + 6, yl[0]); sc.st(SC_Y + 7, yl[1]); sc.st(SC_Y + 8, ym);

@@ -25,6 +25,7 @@ print('real time us: mean %.1f max %.1f ; clock MHz %.0f' % (rt.mean(), rt.max()
 ph = b[:, 4:9]
 print('phase cycles per substep: A %.0f check %.0f full %.0f solve %.0f integrate %.0f ; sum/total %.2f' % (*(ph.mean(0)/50), ph.sum()/b[:,0].sum()))
 print("  finer: rows build + plan %.0f, star_solve calls %.0f, final-pass rhs + loop logic before the solve %.0f  (cycles per substep)" % tuple(b[:, 12:15].mean(0) / 50))
+print("rank-one passes per step (wave mean): %.1f" % b[:, 15].mean())
 print("epw", e, "waves", nw)
 print("wave time us: mean %.1f median %.1f p90 %.1f p99 %.1f max %.1f" % (cyc.mean(), np.median(cyc), np.quantile(cyc, .9), np.quantile(cyc, .99), cyc.max()))
 print("rare-path substeps/50: mean %.2f max %d  frac waves with any %.3f" % (b[:, 1].mean(), b[:, 1].max(), (b[:, 1] > 0).mean()))
