@@ -90,13 +90,18 @@ JB_HD unsigned mbit(bool a) { return a ? 1u : 0u; }
 JB_HD unsigned popc_u(unsigned a) { return (unsigned)__builtin_popcount(a); }
 JB_HD unsigned xor_u(unsigned a, unsigned b) { return a ^ b; }
 JB_HD bool eq_u(unsigned a, unsigned b) { return a == b; }
+JB_HD bool lt_u(unsigned a, unsigned b) { return a < b; }
+JB_HD unsigned or_u(unsigned a, unsigned b) { return a | b; }
 // The single flipped bit of an active-set record (5 bits per slot: pyramid edges n+t1, n-t1, n+t2, n-t2, valid): which cached
 // row it belongs to (entry = rank of the slot among the live slots) and which edge it is.  A lane without a flipped bit gets
 // is_flip = false and entry 0.
-JB_HD void flip_decode(unsigned diff, unsigned rec, unsigned live, unsigned& entry, bool& is_flip, bool& plus, bool& tan2, bool& on) {
+JB_HD void flip_decode(unsigned diff0, unsigned diff1, unsigned rec0, unsigned rec1, unsigned live, unsigned& entry, bool& is_flip, bool& plus, bool& tan2, bool& on) {
+    // word 0: slots 0-4, word 1: slots 5-9
+    const bool w1 = diff0 == 0u;
+    const unsigned diff = w1 ? diff1 : diff0, rec = w1 ? rec1 : rec0;
     is_flip = diff != 0u;
     const unsigned pos = is_flip ? (unsigned)__builtin_ctz(diff) : 0u;
-    const unsigned slot = (pos * 205u) >> 10, b = pos - 5u * slot;
+    const unsigned sl = (pos * 205u) >> 10, b = pos - 5u * sl, slot = sl + (w1 ? 5u : 0u);
     entry = (unsigned)__builtin_popcount(live & ((1u << slot) - 1u));
     is_flip = is_flip && b < 4u;
     plus = (b & 1u) == 0u; tan2 = b >= 2u; on = ((rec >> pos) & 1u) != 0u;
@@ -190,9 +195,11 @@ inline Mask4 mnot(const Mask4& a) { Mask4 r; for (int i = 0; i < 4; i++) r.v[i] 
 inline UQuad mbit(const Mask4& a) { UQuad r; for (int i = 0; i < 4; i++) r.v[i] = a.v[i] ? 1u : 0u; return r; }
 inline UQuad popc_u(const UQuad& a) { UQuad r; for (int i = 0; i < 4; i++) r.v[i] = (uint32_t)__builtin_popcount(a.v[i]); return r; }
 inline UQuad xor_u(const UQuad& a, const UQuad& b) { UQuad r; for (int i = 0; i < 4; i++) r.v[i] = a.v[i] ^ b.v[i]; return r; }
+inline Mask4 lt_u(const UQuad& a, uint32_t b) { Mask4 r; for (int i = 0; i < 4; i++) r.v[i] = a.v[i] < b; return r; }
+inline UQuad or_u(const UQuad& a, const UQuad& b) { UQuad r; for (int i = 0; i < 4; i++) r.v[i] = a.v[i] | b.v[i]; return r; }
 inline Mask4 eq_u(const UQuad& a, const UQuad& b) { Mask4 r; for (int i = 0; i < 4; i++) r.v[i] = a.v[i] == b.v[i]; return r; }
-inline void flip_decode(const UQuad& diff, const UQuad& rec, unsigned live, UQuad& entry, Mask4& is_flip, Mask4& plus, Mask4& tan2, Mask4& on) {
-    for (int i = 0; i < 4; i++) flip_decode(diff.v[i], rec.v[i], live, entry.v[i], is_flip.v[i], plus.v[i], tan2.v[i], on.v[i]);
+inline void flip_decode(const UQuad& diff0, const UQuad& diff1, const UQuad& rec0, const UQuad& rec1, unsigned live, UQuad& entry, Mask4& is_flip, Mask4& plus, Mask4& tan2, Mask4& on) {
+    for (int i = 0; i < 4; i++) flip_decode(diff0.v[i], diff1.v[i], rec0.v[i], rec1.v[i], live, entry.v[i], is_flip.v[i], plus.v[i], tan2.v[i], on.v[i]);
 }
 template <typename T> inline Quad<T> ld_gather(const Quad<T>* p, int stride, const UQuad& idx) { Quad<T> r; for (int i = 0; i < 4; i++) r.v[i] = p[idx.v[i] * stride].v[i]; return r; }
 inline Mask4 neq_u(const UQuad& a, const UQuad& b) { Mask4 r; for (int i = 0; i < 4; i++) r.v[i] = a.v[i] != b.v[i]; return r; }

@@ -295,7 +295,7 @@ template <typename V> struct NewtonAcc {
     V C11, C12, C22;
     V Bm[6], Cm;             // lane-private additive part of the motor branch
     V rr[6], rl[2], rm;      // additive rhs parts
-    typename lane_traits<V>::uint bw0;     // active-set record of the always-evaluated slots 0..4: 5 bits (valid + 4 pyramid edges) each, exact
+    typename lane_traits<V>::uint bw0, bw1;   // active-set records of the leg slots: 5 bits (4 pyramid edges + valid) each, exact; bw0: slots 0-4, bw1: slots 5-9
     typename lane_traits<V>::uint xh;      // polynomial hash of the records of the rarely-evaluated slots (lane-private, never summed across lanes)
 };
 template <typename V> JB_HD void acc_clear(NewtonAcc<V>& acc) {
@@ -305,7 +305,7 @@ template <typename V> JB_HD void acc_clear(NewtonAcc<V>& acc) {
     for (int i = 0; i < 6; i++) { acc.B[i][0] = V(0); acc.B[i][1] = V(0); acc.Bm[i] = V(0); acc.rr[i] = V(0); }
     acc.C11 = V(0); acc.C12 = V(0); acc.C22 = V(0); acc.Cm = V(0);
     acc.rl[0] = V(0); acc.rl[1] = V(0); acc.rm = V(0);
-    acc.bw0 = zero_u<V>(); acc.xh = zero_u<V>();
+    acc.bw0 = zero_u<V>(); acc.bw1 = zero_u<V>(); acc.xh = zero_u<V>();
 }
 
 // the 52 additive values of the accumulator as a flat list (and back)
@@ -532,6 +532,7 @@ JB_HD void contact_apply(const LaneScratch<V>& sc, const Vec3<V> (&dk)[3], const
     {   // active-set record: exact 5-bit fields for the always-evaluated slots 0..4, a lane-private hash for the rest
         U bits = (mbit(a1) + mbit(a2) * 2u + mbit(a3) * 4u + mbit(a4) * 8u + 16u);
         if (slot < 5) acc.bw0 = acc.bw0 + selu(valid, bits, zero_u<V>()) * (1u << (5 * slot));
+        else if (slot < 10) acc.bw1 = acc.bw1 + selu(valid, bits, zero_u<V>()) * (1u << (5 * (slot - 5)));
         else acc.xh = acc.xh * 0x9E3779B1u + selu(valid, bits, zero_u<V>() + 7u);
     }
     if (mode == 2) return;
@@ -577,20 +578,18 @@ JB_HD void contact_apply(const LaneScratch<V>& sc, const Vec3<V> (&dk)[3], const
 }
 
 // Rank-one Newton pass.  The active set at y differs from the factored one by ONE pyramid edge e of one cached contact of
-// this env (weight D, reference acceleration a): H' = H + s D e e^T, rhs' = rhs + s D a e with s = +1 (edge switched on) or
+// this env's legs (weight D, reference acceleration a): H' = H + s D e e^T, rhs' = rhs + s D a e with s = +1 (edge switched on) or
 // -1 (off), hence by Sherman-Morrison
 //     y' = y + z * s D (a - e.y) / (1 + s D e.z),      z = H^-1 e   (one substitution with the kept factorisation).
-// Only the lane whose leg carries the contact has a non-zero e; the leg slots 0-4 sit on the lower leg (columns: 6 root dofs,
-// shoulder, knee).  `diff` = new record xor factored record of this lane, `rec` = new record.
+// Only the lane whose leg carries the contact has a non-zero e; the leg slots sit on the lower leg (0-4: columns 6 root dofs,
+// shoulder, knee) or the upper leg (5-9: the cached knee column is zero).  entry / is_flip / plus / tan2 / on: flip_decode of
+// this lane's records (cached row of the contact, which edge, switched on or off).
 template <typename V>
-JB_HD void rank_one_pass(const LaneScratch<V>& sc, const StarFactor<V>& F, const Vec3<V> (&dk)[3], const V& mu, unsigned live,
-                         const typename lane_traits<V>::uint& diff, const typename lane_traits<V>::uint& rec,
+JB_HD void rank_one_pass(const LaneScratch<V>& sc, const StarFactor<V>& F, const Vec3<V> (&dk)[3], const V& mu,
+                         const typename lane_traits<V>::uint& entry, const typename lane_traits<V>::mask& is_flip, const typename lane_traits<V>::mask& plus,
+                         const typename lane_traits<V>::mask& tan2, const typename lane_traits<V>::mask& on,
                          const V (&yr)[6], const V (&yl)[2], const V& ym, V (&nyr)[6], V (&nyl)[2], V& nym) {
-    using MK = typename lane_traits<V>::mask;
     using U = typename lane_traits<V>::uint;
-    U entry;
-    MK is_flip, plus, tan2, on;
-    flip_decode(diff, rec, live, entry, is_flip, plus, tan2, on);
     const U e0 = entry * (unsigned)ROW_F + (unsigned)SC_ROWS;
     const V sg = sel(plus, mu, -mu);                    // e = B_n + sg * B_t
     V e[8];
@@ -716,7 +715,7 @@ JB_HD void contact_sweep(const LaneModel<V>& m, const LaneScratch<V>& sc, bool x
         contact_apply<V>(sc, dk, mu, slot, entry, lane_on, mode, yr, yl, ym, acc);
     }
     if (plan.grouped) {
-        acc.bw0 = group_sum_u<V>(sc, acc.bw0); acc.xh = group_sum_u<V>(sc, acc.xh);
+        acc.bw0 = group_sum_u<V>(sc, acc.bw0); acc.bw1 = group_sum_u<V>(sc, acc.bw1); acc.xh = group_sum_u<V>(sc, acc.xh);
         if (mode == 0 && sc.ngrp == 4 && sc.gstride == 16) {
             // Only the main lanes need the totals: reduce four values at a time so that row (= group) g ends with the total
             // of value 4k+g, hand the totals over through the scratch (the overflow row entries are dead here) and let the
@@ -1067,7 +1066,7 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
         bool final_pass = !any_contact, full_pass = true;
         MK unconverged = lt(V(0), V(1));
         MK fac_valid = lt(V(1), V(0)), fast_env = lt(V(1), V(0));
-        U prev_bw0 = zero_u<V>(), prev_xh = zero_u<V>();
+        U prev_bw0 = zero_u<V>(), prev_bw1 = zero_u<V>(), prev_xh = zero_u<V>();
         if (any_contact) {
 #pragma unroll
             for (int k = 0; k < 3; k++) dk[k] = sc.ld3(SC_DD + 12 * k);     // contact-frame directions: once per substep, every lane
@@ -1099,7 +1098,7 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
                     JB_PROF_ADD(o, 1);
                     unsigned fin = 0u, full = 1u;
                     if (is_main) {
-                        MK changed = mor(neq_u(acc.bw0, prev_bw0), neq_u(acc.xh, prev_xh));
+                        MK changed = mor(mor(neq_u(acc.bw0, prev_bw0), neq_u(acc.bw1, prev_bw1)), neq_u(acc.xh, prev_xh));
                         unconverged = neq_u(quad_sum_u(mbit(changed)), zero_u<V>());
 #if defined(JB_WAVE_STATS) && defined(__HIPCC__)
                         if (o.hist && !xtra) {      // how many active-set bits flipped per unconverged env (ordinary substeps: exact records)
@@ -1120,14 +1119,20 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
                             // An env whose set differs from the factored one by a single pyramid edge of a leg slot (exact
                             // records) takes a rank-one pass; the decision is the ENV's own (its records, its factorisation),
                             // so its arithmetic never depends on its wave-mates.  A full pass runs only if some env needs one.
-                            const U dfl = xor_u(acc.bw0, prev_bw0);
-                            const MK one_flip = eq_u(quad_sum_u(popc_u(dfl)), zero_u<V>() + 1u);
+                            const U dfl = xor_u(acc.bw0, prev_bw0), dfl1 = xor_u(acc.bw1, prev_bw1);
+                            const MK one_flip = eq_u(quad_sum_u(popc_u(dfl) + popc_u(dfl1)), zero_u<V>() + 1u);
                             const MK xh_same = eq_u(quad_sum_u(mbit(neq_u(acc.xh, prev_xh))), zero_u<V>());
-                            fast_env = mand(mand(unconverged, fac_valid), mand(one_flip, xh_same));
+                            U f_entry;
+                            MK f_is, f_plus, f_tan2, f_on;
+                            flip_decode(dfl, dfl1, acc.bw0, acc.bw1, plan.live, f_entry, f_is, f_plus, f_tan2, f_on);
+                            // the flipped contact's row must be in the row cache (beyond ROW_K live slots rows are rebuilt per pass)
+                            const MK undecodable = mand(neq_u(or_u(dfl, dfl1), zero_u<V>()), mnot(mand(f_is, lt_u(f_entry, (unsigned)ROW_K))));
+                            const MK rows_ok = eq_u(quad_sum_u(mbit(undecodable)), zero_u<V>());
+                            fast_env = mand(mand(unconverged, fac_valid), mand(mand(one_flip, xh_same), rows_ok));
                             full = any_lane(mand(unconverged, mnot(fast_env))) ? 1u : 0u;
                             if (any_lane(fast_env)) {
                                 V fyr[6], fyl[2], fym;
-                                rank_one_pass<V>(sc, fac, dk, m.c[LM_MU], plan.live, dfl, acc.bw0, yr, yl, ym, fyr, fyl, fym);
+                                rank_one_pass<V>(sc, fac, dk, m.c[LM_MU], f_entry, f_is, f_plus, f_tan2, f_on, yr, yl, ym, fyr, fyl, fym);
 #pragma unroll
                                 for (int i = 0; i < 6; i++) yr[i] = sel(fast_env, fyr[i], yr[i]);
                                 yl[0] = sel(fast_env, fyl[0], yl[0]); yl[1] = sel(fast_env, fyl[1], yl[1]); ym = sel(fast_env, fym, ym);
@@ -1135,7 +1140,7 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
                                 s.st_fast = s.st_fast + V(1);
 #endif
                             }
-                            prev_bw0 = acc.bw0; prev_xh = acc.xh;      // the sets the new iterates are solved for
+                            prev_bw0 = acc.bw0; prev_bw1 = acc.bw1; prev_xh = acc.xh;      // the sets the new iterates are solved for
                         }
                     }
                     final_pass = wave_bcast_u(fin) != 0u;
@@ -1144,7 +1149,7 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
                 if (!final_pass && full_pass) {
                     // (reads the iterate of the check from the scratch: rank-one results are stored only after this pass)
                     contact_sweep<V>(m, sc, xtra, plan, 0, dk, acc);
-                    prev_bw0 = acc.bw0; prev_xh = acc.xh;
+                    prev_bw0 = acc.bw0; prev_bw1 = acc.bw1; prev_xh = acc.xh;
                     JB_PROF_ADD(o, 2);
 #ifdef JB_WAVE_STATS
                     if (is_main) s.st_sweeps = s.st_sweeps + V(1);
