@@ -116,7 +116,10 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     dist = None
-    if world > 1:
+    # JB_BENCH_FORCE_DIST=1 (under torch.distributed.run with one rank): take the N>1 code path - process group, per-step
+    # gather, barrier, max-reduction - with a world of one, to exercise the real RCCL calls on a one-GPU box
+    force_dist = world == 1 and os.environ.get("JB_BENCH_FORCE_DIST") == "1"
+    if world > 1 or force_dist:
         import torch.distributed as dist
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)          # RCCL over xGMI
@@ -183,6 +186,7 @@ def main():
         for i in range(warmup):
             one(i)
         drain()
+        finite_warm = bool(torch.isfinite(rows[(warmup - 1) & 1] if (gather and warmup) else obs).all().item()) if warmup else True
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize(dev)
@@ -200,14 +204,14 @@ def main():
         dev_ms = ev0.elapsed_time(ev1)
         sc, ep, cap = env.counters()
         last = rows[(warmup + steps - 1) & 1][:, :D] if gather else obs
-        finite = bool(torch.isfinite(last).all().item())
+        finite = finite_warm and bool(torch.isfinite(last).all().item())      # checked after the warm-up and after the timed steps
         if gather and rank == 0:                    # the gathered block of the last step really holds every rank's rows
             gl = gathered[(warmup + steps - 1) & 1]
             finite = finite and all(bool(torch.isfinite(x).all().item()) for x in gl) and bool((gl[0].to(dev) == rows[(warmup + steps - 1) & 1]).all().item())
         env.close()
         return wall, dev_ms, float(cap.sum()), finite
 
-    wall, dev_ms, cap_hits, finite = run(args.contacts, K, W, gather=(world > 1))
+    wall, dev_ms, cap_hits, finite = run(args.contacts, K, W, gather=(dist is not None))
     t = torch.tensor([wall], device=dev if args.dist_backend == "nccl" else "cpu", dtype=torch.float64)
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -127,6 +127,9 @@ int jb_set_obs_encoder(jb_handle* h, int32_t n_layers, const int32_t* dims /*[n_
 int jb_encoded_dim(jb_handle* h);              /* width of an encoded row, 0 if no encoder is set */
 int jb_encode_device(jb_handle* h, const float* d_obs /*[N,D]*/, float* d_code_out /*[N, jb_encoded_dim]*/);
 int jb_encode(jb_handle* h, const float* obs, float* code_out);
+/* diagnostic: fill the device's LDS with NaN patterns on the handle's stream, so that a kernel reading scratch it did not write
+ * in the same launch fails deterministically (tests/test_gpu_parity.py::test_no_uninitialised_scratch_is_read) */
+int jb_debug_poison_lds(jb_handle* h);
 int jb_synchronize(jb_handle* h);
 void* jb_stream(jb_handle* h);                 /* the hipStream_t the handle launches on */
 

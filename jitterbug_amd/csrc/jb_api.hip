@@ -254,6 +254,16 @@ __global__ void jb_policy_kernel(int n, int task, const float* __restrict__ obs,
     action[env] = heuristic_policy<float>(task, obs + (size_t)env * obs_dim(task), 1);
 }
 
+// ---------------------------------------------------------------------------------------------- diagnostics
+// Fills LDS with NaN bit patterns (LDS keeps its contents between kernels): a step kernel that reads scratch it has not
+// written in the same launch then produces NaNs deterministically instead of depending on what ran before it.
+__global__ void jb_poison_lds_kernel(int n_floats, float* sink) {
+    extern __shared__ float lds[];
+    for (int i = threadIdx.x; i < n_floats; i += blockDim.x) lds[i] = __uint_as_float(0x7FC00000u + (unsigned)(i & 0xFFFF));
+    __syncthreads();
+    if (sink && lds[(threadIdx.x * 97) % n_floats] == 0.f) sink[0] = 1.f;     // keep the stores alive
+}
+
 // ---------------------------------------------------------------------------------------------- observation encoder (tiny dense network per row)
 struct EncArgs {
     int n, n_layers, vae, in_dim, out_dim;
@@ -538,6 +548,15 @@ int jb_encode(jb_handle* h, const float* obs, float* code_out) {
     if (rc) return rc;
     JB_HIP(hipMemcpyAsync(code_out, h->d_code, sizeof(float) * N * h->enc.out_dim, hipMemcpyDeviceToHost, h->stream));
     JB_HIP(hipStreamSynchronize(h->stream));
+    return JB_OK;
+}
+int jb_debug_poison_lds(jb_handle* h) {
+    if (!h) return fail(JB_E_INVALID, "handle is NULL");
+    hipDeviceProp_t prop;
+    JB_HIP(hipGetDeviceProperties(&prop, h->cfg.device_id));
+    const int bytes = 40 * 1024;                                   // 4 resident blocks cover a CU's 160 KB
+    hipLaunchKernelGGL(jb_poison_lds_kernel, dim3((unsigned)prop.multiProcessorCount * 8), dim3(256), bytes, h->stream, bytes / 4, (float*)nullptr);
+    JB_HIP(hipGetLastError());
     return JB_OK;
 }
 int jb_num_envs(jb_handle* h) { return h ? h->cfg.n_envs : JB_E_INVALID; }

@@ -102,7 +102,7 @@ JB_HD void flip_decode(unsigned diff0, unsigned diff1, unsigned rec0, unsigned r
     is_flip = diff != 0u;
     const unsigned pos = is_flip ? (unsigned)__builtin_ctz(diff) : 0u;
     const unsigned sl = (pos * 205u) >> 10, b = pos - 5u * sl, slot = sl + (w1 ? 5u : 0u);
-    entry = (unsigned)__builtin_popcount(live & ((1u << slot) - 1u));
+    entry = is_flip ? (unsigned)__builtin_popcount(live & ((1u << slot) - 1u)) : 0u;      // lanes without a flip read a row that exists
     is_flip = is_flip && b < 4u;
     plus = (b & 1u) == 0u; tan2 = b >= 2u; on = ((rec >> pos) & 1u) != 0u;
 }

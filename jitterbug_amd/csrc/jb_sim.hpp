@@ -611,7 +611,8 @@ JB_HD void rank_one_pass(const LaneScratch<V>& sc, const StarFactor<V>& F, const
     V ety = e[6] * yl[0] + e[7] * yl[1], etz = e[6] * zl[0] + e[7] * zl[1];
 #pragma unroll
     for (int i = 0; i < 6; i++) { ety = ety + e[i] * yr[i]; etz = etz + e[i] * zr[i]; }
-    const V num = quad_sum(sD * (ah - ety)), den = V(1) + quad_sum(sD * etz);
+    // (selects, not products with a zero weight: a lane without the flip may hold anything in these temporaries)
+    const V num = quad_sum(sel(is_flip, sD * (ah - ety), V(0))), den = V(1) + quad_sum(sel(is_flip, sD * etz, V(0)));
     const V c = num * vrcp(den);
 #pragma unroll
     for (int i = 0; i < 6; i++) nyr[i] = yr[i] + c * zr[i];

@@ -166,6 +166,10 @@ class JitterbugVecEnv:
     def encode_device(self, obs_ptr, code_ptr):
         _lib.check(self._L.jb_encode_device(self._h, obs_ptr, code_ptr))
 
+    def debug_poison_lds(self):
+        """Diagnostic: fill the GPU's LDS with NaN patterns (see jb_debug_poison_lds)."""
+        _lib.check(self._L.jb_debug_poison_lds(self._h))
+
     def step_rows_device(self, action_ptr, rows_ptr):
         """One packed float row [obs(D) | reward | done] per env, written by the step kernel (the unit of the multi-GPU gather)."""
         _lib.check(self._L.jb_step_rows_device(self._h, action_ptr, rows_ptr))

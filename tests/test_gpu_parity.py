@@ -459,3 +459,49 @@ def test_random_policy_returns_in_the_reference_figures_bands():
         med = float(np.median(ret))
         print("%s: random-policy median return %.0f (band %d-%d)" % (task, med, lo, hi))
         assert lo <= med <= hi, (task, med)
+
+
+def test_no_uninitialised_scratch_is_read():
+    """Regression (rank-one Newton pass, round 1): a lane without a flipped contact read a row-cache entry nobody had written
+    in that substep; the result depended on what the previous kernel had left in LDS.  LDS is poisoned with NaNs before every
+    launch: results must stay finite, reach the Newton cap only rarely, and equal an un-poisoned run bit for bit."""
+    from jitterbug_amd.vec_env import JitterbugVecEnv
+    n = 4096
+    rng = np.random.default_rng(0)
+    acts = rng.uniform(-1, 1, size=(120, n)).astype(np.float32)
+    outs = []
+    for poison in (True, False):
+        env = JitterbugVecEnv(n, "move_from_origin", seed=0)
+        env.reset()
+        obs_all = []
+        for t in range(120):
+            if poison:
+                env.debug_poison_lds()
+            ob, rw, dn, _ = env.step(acts[t])
+            assert np.isfinite(ob).all() and np.isfinite(rw).all(), "non-finite at step %d (poison=%s)" % (t, poison)
+            obs_all.append(ob)
+        sc, ep, cap = env.counters()
+        assert cap.sum() < 200, cap.sum()                     # Newton cap hits: ~1e-6 per substep
+        outs.append(np.stack(obs_all))
+        env.close()
+    assert np.array_equal(outs[0], outs[1])
+
+
+def test_all_geom_regime_stays_finite_with_poisoned_scratch():
+    """Same check where most waves take the all-geom path (motor flat out: about half the robots tip over)."""
+    from jitterbug_amd.vec_env import JitterbugVecEnv
+    n = 2048
+    env = JitterbugVecEnv(n, "move_to_pose", seed=4)
+    env.reset()
+    a = np.ones(n, dtype=np.float32)
+    for t in range(600):
+        if t % 3 == 0:
+            env.debug_poison_lds()
+        ob, rw, dn, _ = env.step(a)
+        assert np.isfinite(ob).all() and np.isfinite(rw).all(), "non-finite at step %d" % t
+    q, v, _ = env.get_state()
+    up = 1 - 2 * (q[:, 4] ** 2 + q[:, 5] ** 2)
+    assert (up < 0.5).mean() > 0.1                            # the regime really is the tipped-over one
+    sc, ep, cap = env.counters()
+    assert cap.sum() < 5000, cap.sum()
+    env.close()
