@@ -31,7 +31,12 @@ static int run(const double* P, double* qpos, double* qvel, double ctrl, int nsu
     SimOpts o; o.contacts = contacts; o.max_newton = max_newton; o.implicit_damp = implicit_damp; o.prof = nullptr; o.hist = nullptr;
     V scratch[SC_COUNT];
     LaneScratch<V> sc; sc.p = scratch; sc.stride = 1; sc.grp = 0; sc.ngrp = 1; sc.gstride = 4;
-    for (int i = 0; i < nsub; i++) substep<V>(m, sc, s, V(T(ctrl)), o);
+    for (int i = 0; i < nsub; i++) {
+        // poison the scratch: a substep must not read anything it has not written itself (on the device LDS keeps whatever
+        // the previous kernel left there)
+        for (int k = 0; k < SC_COUNT; k++) scratch[k] = V(std::numeric_limits<T>::quiet_NaN());
+        substep<V>(m, sc, s, V(T(ctrl)), o);
+    }
     // replicated quantities must agree across the quad
     for (int l = 1; l < 4; l++) if (s.px.v[l] != s.px.v[0] || s.qw.v[l] != s.qw.v[0] || s.wz.v[l] != s.wz.v[0] || s.phid.v[l] != s.phid.v[0]) return -100;
     T n = std::sqrt(s.qw.v[0] * s.qw.v[0] + s.qx.v[0] * s.qx.v[0] + s.qy.v[0] * s.qy.v[0] + s.qz.v[0] * s.qz.v[0]);
