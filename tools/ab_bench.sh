@@ -5,6 +5,6 @@ for lib in "$@"; do
   python - "$lib" <<PY
 import json, sys, os
 f = "gpurun_out/ab_%s.json" % os.path.basename(sys.argv[1])[:-3]
-d = json.loads(open(f).read().strip().split("\n")[-1]); print("%-28s %10.0f env-steps/s  launch %.4f ms  cap_hits %s" % (sys.argv[1], d["value"], d["roofline"]["launch_ms"], d["solver_cap_hits"]))
+d = json.loads(open(f).read().strip().split("\n")[-1]); print("%-28s %10.0f env-steps/s  launch %.4f ms  cap_hits %s  finite %s%s" % (sys.argv[1], d["value"], d["roofline"]["launch_ms"], d["solver_cap_hits"], d["finite"], "" if d["finite"] else "   <-- BROKEN BUILD, timing meaningless"))
 PY
 done
