@@ -205,6 +205,7 @@ def main():
         sc, ep, cap = env.counters()
         last = rows[(warmup + steps - 1) & 1][:, :D] if gather else obs
         finite = finite_warm and bool(torch.isfinite(last).all().item())      # checked after the warm-up and after the timed steps
+        finite = finite and float(cap.max()) < 1000.0                         # ... and no env ever ended a step non-finite (kernel-side flag)
         if gather and rank == 0:                    # the gathered block of the last step really holds every rank's rows
             gl = gathered[(warmup + steps - 1) & 1]
             finite = finite and all(bool(torch.isfinite(x).all().item()) for x in gl) and bool((gl[0].to(dev) == rows[(warmup + steps - 1) & 1]).all().item())

@@ -90,6 +90,8 @@ int jb_step(jb_handle* h, const float* action /*[N]*/, float* obs_out /*[N,D]*/,
 int jb_observe(jb_handle* h, float* obs_out /*[N,D]*/, float* reward_out /*[N] nullable*/);
 int jb_get_state(jb_handle* h, double* qpos /*[N,16]*/, double* qvel /*[N,15]*/, double* target /*[N,3]*/);
 int jb_set_state(jb_handle* h, const double* qpos, const double* qvel, const double* target);   /* any may be NULL = keep */
+/* solver_cap_hits: +1 for every substep whose Newton iteration hit max_newton, +1000 for every control step that ended in a
+ * non-finite state (never expected; the env stays non-finite until its next reset) - cumulative over the handle's life */
 int jb_get_counters(jb_handle* h, int32_t* step_count /*[N]*/, uint32_t* episode /*[N]*/, float* solver_cap_hits /*[N]*/);
 /* n_tables is 1 (shared) or N (one table per env); each table is JB_NPARAM doubles (jitterbug_model.h) */
 int jb_set_model_params(jb_handle* h, const double* params, int32_t n_tables);

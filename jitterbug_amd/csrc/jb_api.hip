@@ -177,6 +177,11 @@ __global__ __launch_bounds__(64) void jb_step_kernel(KArgs a, const float* __res
         for (int i = 0; i < 5; i++) ws[4 + i] = prof_local[i]; ws[1] = (unsigned long long)s.st_xtra; ws[2] = (unsigned long long)s.st_sweeps; ws[3] = (unsigned long long)s.st_contact; ws[11] = (unsigned long long)s.st_slots; ws[15] = (unsigned long long)s.st_fast; ws[12] = prof_local[5]; ws[13] = prof_local[6]; ws[14] = prof_local[7];
     }
 #endif
+    {   // a control step that ends in a non-finite state is recorded in the failure counter (+1000; Newton cap hits add 1 each)
+        const float chk = s.px + s.py + s.pz + s.qw + s.qx + s.qy + s.qz + s.vx + s.vy + s.vz + s.wx + s.wy + s.wz + s.phi + s.phid + s.th1 + s.th2 + s.thd1 + s.thd2;
+        const unsigned bad = quad_sum_u(fabsf(chk) < 1e30f ? 0u : 1u);
+        if (bad) s.fail += 1000.f;
+    }
     {   // trailing mj_step1: derived quantities use the normalised quaternion
         float n = 1.0f / sqrtf(s.qw * s.qw + s.qx * s.qx + s.qy * s.qy + s.qz * s.qz);
         s.qw *= n; s.qx *= n; s.qy *= n; s.qz *= n;

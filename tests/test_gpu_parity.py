@@ -505,3 +505,19 @@ def test_all_geom_regime_stays_finite_with_poisoned_scratch():
     sc, ep, cap = env.counters()
     assert cap.sum() < 5000, cap.sum()
     env.close()
+
+
+def test_non_finite_state_is_flagged_in_the_failure_counter():
+    """A control step that ends non-finite adds 1000 to the env's failure counter (jb_get_counters), and only that env's."""
+    from jitterbug_amd.vec_env import JitterbugVecEnv
+    env = JitterbugVecEnv(9, "move_from_origin", seed=1)
+    env.reset()
+    env.step(np.zeros(9, dtype=np.float32))
+    q, v, tg = env.get_state()
+    q[3, 0] = np.nan
+    env.set_state(q, v, tg)
+    ob, rw, dn, _ = env.step(np.zeros(9, dtype=np.float32))
+    sc, ep, cap = env.counters()
+    assert cap[3] >= 1000 and (np.delete(cap, 3) < 1000).all()
+    assert np.isfinite(np.delete(ob, 3, axis=0)).all() and not np.isfinite(ob[3]).all()     # wave-mates are unaffected
+    env.close()
