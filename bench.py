@@ -91,6 +91,7 @@ def main():
     ap.add_argument("--no-also", action="store_true")
     ap.add_argument("--max-newton", type=int, default=12)
     ap.add_argument("--envs-per-wave", type=int, default=0)
+    ap.add_argument("--no-rank-one", action="store_true", help="diagnostic: JB_FLAG_NO_RANK_ONE (every Newton pass is a full pass)")
     ap.add_argument("--actions", default="uniform", help="uniform (default, the metric's workload) | const1 (motor flat out: about half the robots tip over - diagnostic)")
     ap.add_argument("--seed", type=int, default=0, help="reset / action stream seed (the committed numbers use 0)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the measured path); gloo is a CPU-staged rehearsal of the N>1 control flow")
@@ -133,7 +134,7 @@ def main():
 
     def make_env(contacts):
         # the handle launches on torch's current stream so torch.cuda.Event brackets exactly these kernels
-        env = JitterbugVecEnv(n, task, seed=args.seed, device_id=local_rank, contacts=bool(contacts), env_offset=rank * n, max_newton=args.max_newton, envs_per_wave=args.envs_per_wave,
+        env = JitterbugVecEnv(n, task, seed=args.seed, device_id=local_rank, contacts=bool(contacts), env_offset=rank * n, max_newton=args.max_newton, envs_per_wave=args.envs_per_wave, flags=1 if args.no_rank_one else 0,
                               stream=torch.cuda.current_stream(dev).cuda_stream)
         if args.augmented:
             from jitterbug_amd.augmented_jitterbug import augmented_params

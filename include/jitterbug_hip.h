@@ -58,6 +58,8 @@ extern "C" {
 
 typedef struct jb_handle jb_handle;
 
+#define JB_FLAG_NO_RANK_ONE 1   /* diagnostic: every Newton pass is a full sweep + refactorisation (no rank-one passes) */
+
 typedef struct jb_config {
     int32_t  n_envs;        /* N >= 1 */
     int32_t  task_id;       /* JB_TASK_* */
@@ -72,7 +74,7 @@ typedef struct jb_config {
     int32_t  use_caller_stream; /* 1: launch on `stream` below even when it is NULL (the legacy default stream) */
     int32_t  envs_per_wave; /* environments per 64-lane wavefront (4 lanes each): 1..16, 0 = choose so that the batch
                                spreads over all SIMDs of the device (small batches use partially filled waves) */
-    int32_t  reserved1;
+    int32_t  flags;         /* JB_FLAG_* bits, 0 by default */
     uint64_t seed;          /* RNG key */
     uint64_t env_offset;    /* global index of env 0 (sharding: results do not depend on the split) */
     void*    stream;        /* hipStream_t to run on when use_caller_stream=1; otherwise the handle owns a stream */

@@ -25,7 +25,7 @@ class JitterbugHipError(RuntimeError):
 class Config(C.Structure):
     _fields_ = [("n_envs", C.c_int32), ("task_id", C.c_int32), ("device_id", C.c_int32), ("random_pose", C.c_int32),
                 ("contacts", C.c_int32), ("substeps", C.c_int32), ("step_limit", C.c_int32), ("auto_reset", C.c_int32),
-                ("max_newton", C.c_int32), ("use_caller_stream", C.c_int32), ("envs_per_wave", C.c_int32), ("reserved1", C.c_int32), ("seed", C.c_uint64), ("env_offset", C.c_uint64),
+                ("max_newton", C.c_int32), ("use_caller_stream", C.c_int32), ("envs_per_wave", C.c_int32), ("flags", C.c_int32), ("seed", C.c_uint64), ("env_offset", C.c_uint64),
                 ("stream", C.c_void_p)]
 
 

@@ -32,6 +32,7 @@ enum LegF : int { LF_TH1 = 0, LF_TH2 = 1, LF_THD1 = 2, LF_THD2 = 3, LF_WJ0 = 4, 
 struct KArgs {
     int n, task, substeps, step_limit, auto_reset, contacts, max_newton, random_pose, per_env_model;
     int epw;       // environments per wave (= per 64-thread workgroup) of the step kernel
+    int rank_one;      // 0: diagnostic, no rank-one Newton passes (jb_config.flags & JB_FLAG_NO_RANK_ONE)
     int packed_rows;   // step kernel output: 0 = obs[N,D] + reward[N] + done[N]; 1 = one float row [obs(D) | reward | done] per env
     unsigned long long seed, env_offset;
     float* root; float* leg; const float* lane_model;
@@ -159,7 +160,7 @@ __global__ __launch_bounds__(64) void jb_step_kernel(KArgs a, const float* __res
     s.st_xtra = 0.f; s.st_sweeps = 0.f; s.st_contact = 0.f; s.st_slots = 0.f; s.st_fast = 0.f;
 #endif
     const float ctrl = action[env];
-    SimOpts o; o.contacts = a.contacts; o.max_newton = a.max_newton; o.implicit_damp = 1; o.prof = nullptr; o.hist = nullptr;
+    SimOpts o; o.contacts = a.contacts; o.max_newton = a.max_newton; o.implicit_damp = 1; o.rank_one = a.rank_one; o.prof = nullptr; o.hist = nullptr;
 #ifdef JB_WAVE_STATS
     const unsigned long long rt_start = __builtin_amdgcn_s_memrealtime();
     unsigned long long prof_local[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // accumulated in registers, written once at the end
@@ -462,7 +463,7 @@ int jb_create(const jb_config* cfg, jb_handle** out) {
     KArgs& k = h->ka;
     k.n = cfg->n_envs; k.task = cfg->task_id; k.substeps = cfg->substeps; k.step_limit = cfg->step_limit; k.auto_reset = cfg->auto_reset;
     k.contacts = cfg->contacts; k.max_newton = h->cfg.max_newton; k.random_pose = cfg->random_pose; k.per_env_model = 0;
-    k.seed = cfg->seed; k.env_offset = cfg->env_offset;
+    k.seed = cfg->seed; k.env_offset = cfg->env_offset; k.rank_one = (cfg->flags & JB_FLAG_NO_RANK_ONE) ? 0 : 1;
     {   // envs per wave: fill every SIMD of the device before filling the lanes of a wave.  The kernel holds one wave
         // per SIMD (register budget), so the device runs (CUs x 4) waves at a time; LDS (scratch is per active lane)
         // allows 4 resident waves per CU up to 8 envs per wave.

@@ -807,6 +807,7 @@ struct SimOpts {
     int contacts;        // 0: contacts disabled (MuJoCo disableflags=contact)
     int max_newton;      // cap on Newton iterations per substep
     int implicit_damp;   // 1: MuJoCo Euler implicit joint damping
+    int rank_one;        // 1: single-edge changes of the active set are rank-one passes (0: diagnostic, always full passes)
     unsigned long long* prof;   // diagnostic builds: per-wave cycle accumulators [phaseA, check sweeps, full sweeps, solves, integrate]
     unsigned long long* hist;   // diagnostic builds: per-wave [0..27] live-slot counts over all-geom substeps, [28..35] rounds histogram, [36..43] same for ordinary substeps
 };
@@ -1130,6 +1131,7 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
                             const MK undecodable = mand(neq_u(or_u(dfl, dfl1), zero_u<V>()), mnot(mand(f_is, lt_u(f_entry, (unsigned)ROW_K))));
                             const MK rows_ok = eq_u(quad_sum_u(mbit(undecodable)), zero_u<V>());
                             fast_env = mand(mand(unconverged, fac_valid), mand(mand(one_flip, xh_same), rows_ok));
+                            if (!o.rank_one) fast_env = lt(V(1), V(0));
                             full = any_lane(mand(unconverged, mnot(fast_env))) ? 1u : 0u;
                             if (any_lane(fast_env)) {
                                 V fyr[6], fyl[2], fym;

@@ -31,7 +31,7 @@ class JitterbugVecEnv:
 
     def __init__(self, n_envs, task="move_from_origin", seed=0, device_id=0, random_pose=True, contacts=True,
                  time_limit=DEFAULT_TIME_LIMIT, control_timestep=DEFAULT_CONTROL_TIMESTEP, auto_reset=True,
-                 env_offset=0, max_newton=12, stream=None, params=None, envs_per_wave=0):
+                 env_offset=0, max_newton=12, stream=None, params=None, envs_per_wave=0, flags=0):
         if task not in TASKS:
             raise AssertionError("Invalid task {}, options are {}".format(task, list(TASKS)))   # reference jitterbug.py:425
         self._L = _lib.load()
@@ -55,6 +55,7 @@ class JitterbugVecEnv:
         cfg.auto_reset = int(bool(auto_reset))
         cfg.max_newton = int(max_newton)
         cfg.envs_per_wave = int(envs_per_wave)
+        cfg.flags = int(flags)
         cfg.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
         cfg.env_offset = int(env_offset)
         cfg.use_caller_stream = 0 if stream is None else 1

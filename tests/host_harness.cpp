@@ -28,7 +28,7 @@ static int run(const double* P, double* qpos, double* qvel, double ctrl, int nsu
     s.thd2 = V(T(qvel[7]), T(qvel[9]), T(qvel[11]), T(qvel[13]));
     for (int i = 0; i < 3; i++) { s.wa[i] = V(T(0)); s.wl[i] = V(T(0)); }
     s.wj[0] = s.wj[1] = V(T(0)); s.wm = V(T(0)); s.fail = V(T(0));
-    SimOpts o; o.contacts = contacts; o.max_newton = max_newton; o.implicit_damp = implicit_damp; o.prof = nullptr; o.hist = nullptr;
+    SimOpts o; o.contacts = contacts; o.max_newton = max_newton; o.implicit_damp = implicit_damp; o.rank_one = 1; o.prof = nullptr; o.hist = nullptr;
     V scratch[SC_COUNT];
     LaneScratch<V> sc; sc.p = scratch; sc.stride = 1; sc.grp = 0; sc.ngrp = 1; sc.gstride = 4;
     for (int i = 0; i < nsub; i++) {

@@ -521,3 +521,31 @@ def test_non_finite_state_is_flagged_in_the_failure_counter():
     assert cap[3] >= 1000 and (np.delete(cap, 3) < 1000).all()
     assert np.isfinite(np.delete(ob, 3, axis=0)).all() and not np.isfinite(ob[3]).all()     # wave-mates are unaffected
     env.close()
+
+
+@pytest.mark.parametrize("regime", ["uniform", "flat_out"])
+def test_rank_one_passes_agree_with_full_passes(regime):
+    """The rank-one Newton pass (Sherman-Morrison on the kept factorisation) and a full sweep + refactorisation compute the
+    same minimiser: two handles, one with JB_FLAG_NO_RANK_ONE, are stepped from IDENTICAL states (the reference handle's state
+    is copied over every control step) and must agree to fp32 round-off amplified over 50 substeps - the same tolerance as
+    against the oracle - in the ordinary regime and with half the robots on the floor."""
+    from jitterbug_amd.vec_env import JitterbugVecEnv
+    n, task = 1024, "move_to_pose"
+    a_env = JitterbugVecEnv(n, task, seed=6)
+    b_env = JitterbugVecEnv(n, task, seed=6, flags=1)
+    a_env.reset(), b_env.reset()
+    rng = np.random.default_rng(2)
+    ok = tot = 0
+    T = 60 if regime == "uniform" else 450
+    for t in range(T):
+        act = (rng.uniform(-1, 1, size=n) if regime == "uniform" else np.ones(n)).astype(np.float32)
+        b_env.set_state(*a_env.get_state())
+        oa, ra, _, _ = a_env.step(act)
+        if regime == "flat_out" and t < T - 50:
+            continue                                        # let the robots tip over first, compare the last 50 steps
+        ob, rb, _, _ = b_env.step(act)
+        good = np.abs(oa - ob) <= 1e-4 * np.abs(ob) + 1e-6
+        ok += good.sum(); tot += good.size
+    print("rank-one vs full passes (%s): %.5f of entries within tolerance" % (regime, ok / tot))
+    assert ok / tot >= 0.995
+    a_env.close(); b_env.close()
