@@ -231,10 +231,16 @@ def main():
         # HBM traffic per launch from the rocprofv3 PMC passes of the same workload (FETCH_SIZE + WRITE_SIZE, separate runs;
         # profiles/r01_pmc_summary.md).  It cannot be collected inside this process, so it is read from the committed summary.
         traffic = None
+        issue = None
         try:
             raw = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_raw.json")))
             if n == N_ENVS_PER_GPU and args.contacts and task == TASK and not args.augmented:
                 traffic = (raw["FETCH_SIZE_KB"] + raw["WRITE_SIZE_KB"]) * 1024.0
+                sq = raw["sq"]
+                issue = {"valu_issue_frac_of_wave_life": sq["SQ_ACTIVE_INST_VALU"] / sq["SQ_WAVE_CYCLES"],
+                         "any_issue_frac_of_wave_life": sq["SQ_ACTIVE_INST_ANY"] / sq["SQ_WAVE_CYCLES"],
+                         "waitcnt_frac_of_wave_life": sq.get("SQ_WAIT_ANY", 0.0) / sq["SQ_WAVE_CYCLES"],
+                         "source": "profiles/r01_pmc_raw.json (rocprofv3 PMC passes of this workload)"}
         except Exception:
             pass
         launch_s = dev_ms * 1e-3 / K                 # average duration of one jb_step_kernel launch, from HIP events on its stream
@@ -253,7 +259,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic,
                          "kernel": "jb_step_kernel", "launch_ms": launch_s * 1e3, "algorithmic_bytes_per_launch": algo_bytes * n,
-                         "note": "path is fp32-VALU/latency bound, not HBM bound (SURVEY.md §8d): 317 B per env step vs ~1e5-1e6 dependent flops"},
+                         "note": "path is fp32-VALU/latency bound, not HBM bound (SURVEY.md §8d): 317 B per env step vs ~1e5-1e6 dependent flops",
+                         "issue": issue},
             "solver_cap_hits": cap_hits, "finite": finite,
         }
         if also:
