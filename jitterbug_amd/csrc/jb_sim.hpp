@@ -1007,7 +1007,10 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
 
         // ---- bias forces (Newton-Euler with qacc = 0 in MuJoCo coordinates) and applied forces
         {
-            auto accel_at = [&](const Vec3<V>& x) { return AO + cross(w, cross(w, x)); };
+            // centripetal term  w x (w x r) = w (w.r) - r |w|^2  (9 flops + a shared |w|^2 instead of two cross products)
+            auto wxwx = [](const Vec3<V>& ww, const V& ww2, const Vec3<V>& r) { V d = dot(ww, r); return v3<V>(ww.x * d - r.x * ww2, ww.y * d - r.y * ww2, ww.z * d - r.z * ww2); };
+            const V w_2 = dot(w, w);
+            auto accel_at = [&](const Vec3<V>& x) { return AO + wxwx(w, w_2, x); };
             Vec3<V> F0 = accel_at(c0) * m0;
             Vec3<V> N0 = cross(w, mul(I0, w));
             // own leg
@@ -1015,14 +1018,15 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
             Vec3<V> w1 = w + e1 * s.thd1;
             Vec3<V> al1 = cross(w, e1) * s.thd1;
             Vec3<V> r1 = cc1 - a1;
-            Vec3<V> F1 = (Aa1 + cross(al1, r1) + cross(w1, cross(w1, r1))) * m1;
+            const V w1_2 = dot(w1, w1);
+            Vec3<V> F1 = (Aa1 + cross(al1, r1) + wxwx(w1, w1_2, r1)) * m1;
             Vec3<V> N1 = mul(I1, al1) + cross(w1, mul(I1, w1));
             Vec3<V> r12 = a2 - a1;
-            Vec3<V> Aa2 = Aa1 + cross(al1, r12) + cross(w1, cross(w1, r12));
+            Vec3<V> Aa2 = Aa1 + cross(al1, r12) + wxwx(w1, w1_2, r12);
             Vec3<V> w2 = w1 + e2 * s.thd2;
             Vec3<V> al2 = al1 + cross(w1, e2) * s.thd2;
             Vec3<V> r2 = cc2 - a2;
-            Vec3<V> F2 = (Aa2 + cross(al2, r2) + cross(w2, cross(w2, r2))) * m2;
+            Vec3<V> F2 = (Aa2 + cross(al2, r2) + wxwx(w2, dot(w2, w2), r2)) * m2;
             Vec3<V> N2 = mul(I2, al2) + cross(w2, mul(I2, w2));
             V cK = dot(e2, N2 + cross(r2, F2));
             V cS = dot(e1, N1 + cross(r1, F1) + N2 + cross(cc2 - a1, F2));
@@ -1032,7 +1036,7 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
             Vec3<V> wm = w + em * s.phid;
             Vec3<V> alm = cross(w, em) * s.phid;
             Vec3<V> rm = cm - am;
-            Vec3<V> Fm = (accel_at(am) + cross(alm, rm) + cross(wm, cross(wm, rm))) * mm;
+            Vec3<V> Fm = (accel_at(am) + cross(alm, rm) + wxwx(wm, dot(wm, wm), rm)) * mm;
             Vec3<V> Nm = mul(Im, alm) + cross(wm, mul(Im, wm));
             V cM = dot(em, Nm + cross(rm, Fm));
             Vec3<V> bl = F0 + Fm + qsum(legF);
