@@ -249,14 +249,14 @@ template <typename V> struct LaneState {
 // the addresses of the main lane they mirror.  (Lane-private long-lived values - model constants, the joint-space system -
 // are kept in registers instead, see LaneConsts / StarSys.)
 enum SC : int {
-    SC_DD = 0 /*3 directions x 12: d(3) wS(3) wK(3) oS oK du*/,
-    SC_CAND = 36 /*28 contact candidates x 4: position (3, root coords rel. root origin) and effective distance
+    SC_DD = 0 /*24: contact-frame directions d_k (3x3), own-leg hinge data e1 a1 e2 a2 (4x3), d_k.u (3)*/,
+    SC_CAND = 24 /*28 contact candidates x 4: position (3, root coords rel. root origin) and effective distance
                    (the real distance when the candidate is a contact, +1 otherwise).  Slots: 0 foot, 1-4 lower-leg
                    cylinder | 5-8 upper cylinder, 9 knee tip | root body: 10-13 lane cylinder, 14 lane ellipsoid,
                    15-22 lane box vertices | motor body: 23-26 lane cylinder, 27 lane ellipsoid*/,
-    SC_ROWS = 148 /*(ROW_K + 4) x ROW_F: y-independent contact rows of the live slots of this substep (8 cached + one
+    SC_ROWS = 136 /*(ROW_K + 4) x ROW_F: y-independent contact rows of the live slots of this substep (8 cached + one
                     overflow entry per group, 19 floats each)*/,
-    SC_Y = 148 + 12 * 19 /*9: current Newton iterate [yr(6), yl(2), ym], shared with the helper groups*/,
+    SC_Y = 136 + 12 * 19 /*9: current Newton iterate [yr(6), yl(2), ym], shared with the helper groups*/,
     SC_ST = SC_Y + 9 /*6: w(3), thd1, thd2, phid for the helper groups*/,
     SC_COUNT = SC_ST + 6
 };
@@ -460,8 +460,9 @@ template <typename V> JB_HD V impedance(const LaneModel<V>& m, const V& dist) {
 // residuals, plus the rank-3 update when it accumulates.
 // level: 0 root body, 1 upper leg (shoulder only), 2 lower leg (shoulder+knee), 3 motor body; column 7 of a row belongs
 // to the knee (level 2) or to the motor (level 3).
-// Direction data in the scratch (SC_DD + 12k): the rows are affine in the contact point x:
-//   J_sh(x,d) = (d x e1).(x - a1) = wS.x - oS,   J_kn(x,d) = wK.x - oK,   J_m(x,d) = (d x em).(x - am)
+// Direction data in the scratch (SC_DD): the three contact-frame directions d_k, the own leg's hinge axes / anchors and d_k.u.
+//   J_sh(x,d) = (d x e1).(x - a1) = d.(e1 x (x - a1)),   J_kn(x,d) = d.(e2 x (x - a2)),   J_m(x,d) = d.(em x (x - am)):
+// one cross product per hinge and contact, then a dot product per direction.
 JB_HD constexpr int slot_level(int slot) { return slot < 5 ? 2 : slot < 10 ? 1 : slot < 23 ? 0 : 3; }
 constexpr int ROW_F = 19;            // floats per cached contact: ang[3][3], jsh[3], j7[3], ahat[3], D
 constexpr int ROW_K = 8;             // cached live slots per substep (a leg lying on the floor has 8); further ones use the group's overflow entry and are rebuilt per pass
@@ -483,15 +484,17 @@ JB_HD void contact_rows_build(const LaneModel<V>& m, const LaneScratch<V>& sc, b
     const int e0 = SC_ROWS + ROW_F * entry;
     sc.st(e0 + 18, sel(valid, vrcp(V(2) * mu * mu * R0), V(0)));
     const V jdot = f_kn * thd2 + f_m * phid;                    // the rate column 7 multiplies
-    Vec3<V> em = ldv3(m, LM_EM), am = ldv3(m, LM_AM);
+    const Vec3<V> p1 = cross(sc.ld3(SC_DD + 9), x - sc.ld3(SC_DD + 12)), p2 = cross(sc.ld3(SC_DD + 15), x - sc.ld3(SC_DD + 18));
+    Vec3<V> pm = v3<V>(V(0), V(0), V(0));
+    if (xtra) pm = cross(ldv3(m, LM_EM), x - ldv3(m, LM_AM));
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-        const Vec3<V> d = sc.ld3(SC_DD + 12 * k);
+        const Vec3<V> d = sc.ld3(SC_DD + 3 * k);
         Vec3<V> ang = cross(x, d);
-        V jsh = f_sh * (dot(sc.ld3(SC_DD + 12 * k + 3), x) - sc.ld(SC_DD + 12 * k + 9));
-        V j7 = f_kn * (dot(sc.ld3(SC_DD + 12 * k + 6), x) - sc.ld(SC_DD + 12 * k + 10));
-        if (xtra) { Vec3<V> wM = cross(d, em); j7 = j7 + f_m * (dot(wM, x) - dot(wM, am)); }
-        V vel = dot(ang, w) + sc.ld(SC_DD + 12 * k + 11) + jsh * thd1 + j7 * jdot;
+        V jsh = f_sh * dot(d, p1);
+        V j7 = f_kn * dot(d, p2);
+        if (xtra) j7 = j7 + f_m * dot(d, pm);
+        V vel = dot(ang, w) + sc.ld(SC_DD + 21 + k) + jsh * thd1 + j7 * jdot;
         V ah = -m.c[LM_BB] * vel;
         if (k == 0) ah = ah - m.c[LM_KK] * imp * dist;
         sc.st3(e0 + 3 * k, ang);
@@ -962,10 +965,10 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
 #pragma unroll
                 for (int k = 0; k < 3; k++) {
                     Vec3<V> d = (k == 0) ? nb : (k == 1) ? v3<V>(R.m[3], R.m[4], R.m[5]) : v3<V>(-R.m[0], -R.m[1], -R.m[2]);
-                    Vec3<V> wS = cross(d, e1), wK = cross(d, e2);
-                    sc.st3(SC_DD + 12 * k, d); sc.st3(SC_DD + 12 * k + 3, wS); sc.st3(SC_DD + 12 * k + 6, wK);
-                    sc.st(SC_DD + 12 * k + 9, dot(wS, a1)); sc.st(SC_DD + 12 * k + 10, dot(wK, a2)); sc.st(SC_DD + 12 * k + 11, dot(d, u));
+                    sc.st3(SC_DD + 3 * k, d);
+                    sc.st(SC_DD + 21 + k, dot(d, u));
                 }
+                sc.st3(SC_DD + 9, e1); sc.st3(SC_DD + 12, a1); sc.st3(SC_DD + 15, e2); sc.st3(SC_DD + 18, a2);
             }
         }
         JB_SCHED_FENCE();
@@ -1075,7 +1078,7 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
         U prev_bw0 = zero_u<V>(), prev_bw1 = zero_u<V>(), prev_xh = zero_u<V>();
         if (any_contact) {
 #pragma unroll
-            for (int k = 0; k < 3; k++) dk[k] = sc.ld3(SC_DD + 12 * k);     // contact-frame directions: once per substep, every lane
+            for (int k = 0; k < 3; k++) dk[k] = sc.ld3(SC_DD + 3 * k);      // contact-frame directions: once per substep, every lane
             contact_rows_build_all<V>(m, sc, xtra, plan);
             JB_PROF_ADD(o, 5);
             if (is_main) {      // warm start (world linear part rotated into the root frame)
