@@ -702,7 +702,8 @@ JB_HD void contact_rows_build_all(const LaneModel<V>& m, const LaneScratch<V>& s
 template <typename V>
 JB_HD void contact_sweep(const LaneModel<V>& m, const LaneScratch<V>& sc, bool xtra, const SlotPlan& plan, int mode, const Vec3<V> (&dk)[3], NewtonAcc<V>& acc) {
     if (!plan.grouped && sc.grp != 0) return;
-    acc_clear(acc);
+    if (mode == 2) { acc.bw0 = zero_u<V>(); acc.bw1 = zero_u<V>(); acc.xh = zero_u<V>(); }      // the check only records the active set
+    else acc_clear(acc);
     const V mu = m.c[LM_MU];
     V yr[6], yl[2], ym;
 #pragma unroll
