@@ -344,11 +344,16 @@ template <typename V> struct StarFactor {
     V i11, i12, i22;
     V bm[6], icm;
 };
-template <typename V>
+// WITH_ACC = false: no contact terms (the final pass): the factorisation of M + hb alone; `acc` is not read.
+template <typename V, bool WITH_ACC = true>
 JB_HD void star_factor(const StarSys<V>& M, const NewtonAcc<V>& acc, const V& hb1, const V& hb2, StarFactor<V>& F) {
 #pragma unroll
-    for (int i = 0; i < 6; i++) { F.B[i][0] = M.B[i][0] + acc.B[i][0]; F.B[i][1] = M.B[i][1] + acc.B[i][1]; }
-    V C11 = M.C[0] + acc.C11 + hb1, C12 = M.C[1] + acc.C12, C22 = M.C[2] + acc.C22 + hb2;
+    for (int i = 0; i < 6; i++) {
+        F.B[i][0] = WITH_ACC ? M.B[i][0] + acc.B[i][0] : M.B[i][0];
+        F.B[i][1] = WITH_ACC ? M.B[i][1] + acc.B[i][1] : M.B[i][1];
+    }
+    V C11 = M.C[0] + hb1, C12 = M.C[1], C22 = M.C[2] + hb2;
+    if (WITH_ACC) { C11 = M.C[0] + acc.C11 + hb1; C12 = M.C[1] + acc.C12; C22 = M.C[2] + acc.C22 + hb2; }
     V idet = vrcp(C11 * C22 - C12 * C12);
     F.i11 = C22 * idet; F.i12 = -C12 * idet; F.i22 = C11 * idet;
     V (&S)[21] = F.S;
@@ -356,15 +361,20 @@ JB_HD void star_factor(const StarSys<V>& M, const NewtonAcc<V>& acc, const V& hb
     for (int i = 0; i < 6; i++) {
         V g0 = F.B[i][0] * F.i11 + F.B[i][1] * F.i12, g1 = F.B[i][0] * F.i12 + F.B[i][1] * F.i22;
 #pragma unroll
-        for (int j = 0; j <= i; j++) S[tri(i, j)] = quad_sum(acc.A[tri(i, j)] - (g0 * F.B[j][0] + g1 * F.B[j][1])) + M.A[tri(i, j)];
+        for (int j = 0; j <= i; j++) {
+            if (WITH_ACC) S[tri(i, j)] = quad_sum(acc.A[tri(i, j)] - (g0 * F.B[j][0] + g1 * F.B[j][1])) + M.A[tri(i, j)];
+            else S[tri(i, j)] = M.A[tri(i, j)] - quad_sum(g0 * F.B[j][0] + g1 * F.B[j][1]);
+        }
     }
     // motor branch
     V cm = M.Cm;
 #pragma unroll
     for (int i = 0; i < 6; i++) F.bm[i] = M.Bm[i];
+    if (WITH_ACC) {
 #pragma unroll
-    for (int i = 0; i < 6; i++) F.bm[i] = F.bm[i] + quad_sum(acc.Bm[i]);
-    cm = cm + quad_sum(acc.Cm);
+        for (int i = 0; i < 6; i++) F.bm[i] = F.bm[i] + quad_sum(acc.Bm[i]);
+        cm = cm + quad_sum(acc.Cm);
+    }
     F.icm = vrcp(cm);
 #pragma unroll
     for (int i = 0; i < 6; i++) {
@@ -1171,7 +1181,6 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
                     //     qacc = y - d,   (M + h diag(b)) d = h diag(b) y        (nonzero only in the leg rows).
                     // star_solve adds tau itself, so the contact envs cancel it (replicated parts enter the quad sums as 1/4).
                     // An env without contacts has qfrc = 0 exactly, whatever the rest of its wave is doing: plain solve.
-                    acc_clear(acc);
 #pragma unroll
                     for (int i = 0; i < 6; i++) acc.rr[i] = sel(env_con, V(-0.25) * sys.tr[i], V(0));
                     acc.rl[0] = sel(env_con, hb1 * yl[0] - sys.tl[0], V(0));
@@ -1183,7 +1192,8 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
             if (is_main) {
                 V nyr[6], nyl[2], nym;
                 if (final_pass) {
-                    star_solve<V>(sys, acc, hb1, hb2, fac, nyr, nyl, nym);
+                    star_factor<V, false>(sys, acc, hb1, hb2, fac);           // acc holds only right-hand sides here
+                    star_subst<V>(fac, acc.rr, sys.tr, sys.tl[0] + acc.rl[0], sys.tl[1] + acc.rl[1], sys.tm + quad_sum(acc.rm), nyr, nyl, nym);
                     JB_PROF_ADD(o, 6);
 #pragma unroll
                     for (int i = 0; i < 6; i++) yr[i] = sel(env_con, yr[i] - nyr[i], nyr[i]);
