@@ -27,7 +27,9 @@ template <typename T> inline int build_lane_model(const double* P, int leg, T* o
     out[LM_KK] = T(1.0 / (dmax * dmax * tc * tc * dr * dr));
     out[LM_BB] = T(2.0 / (dmax * tc));
     out[LM_IMP_D0] = T(P[JB_P_SOLIMP]); out[LM_IMP_DW] = T(P[JB_P_SOLIMP + 1]); out[LM_IMP_IW] = T(1.0 / P[JB_P_SOLIMP + 2]);
-    out[LM_IMP_MID] = T(P[JB_P_SOLIMP + 3]); out[LM_IMP_POW] = T(P[JB_P_SOLIMP + 4]);
+    out[LM_IMP_MID] = T(P[JB_P_SOLIMP + 3]);
+    if (!(P[JB_P_SOLIMP + 3] > 0.0 && P[JB_P_SOLIMP + 3] < 1.0)) return -6;      // midpoint must lie inside (0, 1)
+    out[LM_IMP_IMID] = T(1.0 / P[JB_P_SOLIMP + 3]); out[LM_IMP_I1MID] = T(1.0 / (1.0 - P[JB_P_SOLIMP + 3]));
     if (P[JB_P_SOLIMP + 4] != 2.0) return -2;
     out[LM_MU] = T(P[JB_P_FRICTION] * std::sqrt(1.0 / P[JB_P_IMPRATIO]));
     out[LM_FR2] = T(P[JB_P_FRICTION] * P[JB_P_FRICTION]);
@@ -37,7 +39,7 @@ template <typename T> inline int build_lane_model(const double* P, int leg, T* o
     double mtot = 0;
     for (int b = 0; b < JB_NBODY; b++) mtot += body(b)[JB_B_MASS];
     out[LM_MTOT] = T(mtot);
-    out[LM_TARGET_Z] = T(P[JB_P_TARGETZ]); out[LM_ROOT_Z0] = T(P[JB_P_ROOTPOS0 + 2]); out[LM_LANE] = T(leg);
+    out[LM_TARGET_Z] = T(P[JB_P_TARGETZ]); out[LM_ROOT_Z0] = T(P[JB_P_ROOTPOS0 + 2]);
 
     // root body
     out[LM_M0] = T(body(0)[JB_B_MASS]); put3(LM_C0, body(0) + JB_B_COM);

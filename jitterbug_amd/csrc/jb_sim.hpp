@@ -56,7 +56,7 @@ namespace jb {
 // (host) from the compiled parameter table of include/jitterbug_model.h.
 enum LM : int {
     // ---------------- used every substep
-    LM_H = 0, LM_GRAV = 1 /*3*/, LM_KK = 4, LM_BB = 5, LM_IMP_D0 = 6, LM_IMP_DW = 7, LM_IMP_IW /*1/width*/ = 8, LM_IMP_MID = 9, LM_IMP_POW = 10,
+    LM_H = 0, LM_GRAV = 1 /*3*/, LM_KK = 4, LM_BB = 5, LM_IMP_D0 = 6, LM_IMP_DW = 7, LM_IMP_IW /*1/width*/ = 8, LM_IMP_MID = 9, LM_IMP_IMID /*1/mid*/ = 10,
     LM_MU = 11, LM_FR2 = 12, LM_GEAR = 13, LM_GAIN = 14, LM_BIAS = 15 /*3*/, LM_CTRL_LO = 18, LM_CTRL_HI = 19, LM_MTOT = 20,
     // root body
     LM_M0 = 21, LM_C0 = 22 /*3*/, LM_I0 = 25 /*6*/, LM_TRAN0 = 31,
@@ -67,7 +67,7 @@ enum LM : int {
     LM_DC2 = 71 /*3: com2 - knee anchor*/, LM_I2 = 74 /*6*/, LM_M2 = 80, LM_K1 = 81, LM_B1 = 82, LM_K2 = 83, LM_B2 = 84, LM_TRAN1 = 85, LM_TRAN2 = 86,
     LM_DFOOT = 87 /*3*/, LM_FOOT_R = 90,
     LM_LC_D = 91 /*3: lower cylinder centre - knee anchor*/, LM_LC_AX = 94 /*3*/, LM_LC_XA = 97 /*3*/, LM_LC_R = 100, LM_LC_H = 101,
-    LM_TARGET_Z = 102, LM_ROOT_Z0 = 103, LM_LANE = 104 /* 0..3: which leg this lane owns */,
+    LM_TARGET_Z = 102, LM_ROOT_Z0 = 103, LM_IMP_I1MID = 104 /* 1/(1-mid) */,
     // broadphase spheres (root reference coordinates) for the rarely touching geoms of this lane:
     //   LEG: sphere around upper cylinder + knee tip;  BX: two oriented boxes around the lane's root-body geoms
     //   (motor-body geoms: one axis-aligned cube centred on the motor axis, so it does not move with the motor angle)
@@ -455,9 +455,9 @@ template <typename V> JB_HD V impedance(const LaneModel<V>& m, const V& dist) {
     V x = vmin(vabs(dist) * m.c[LM_IMP_IW], V(1));
     V mid = m.c[LM_IMP_MID];
     // power = 2 (MuJoCo default); other powers are rejected by the host when the table is built
-    V ya = x * x * vrcp(mid);
+    V ya = x * x * m.c[LM_IMP_IMID];
     V omx = V(1) - x;
-    V yb = V(1) - omx * omx * vrcp(V(1) - mid);
+    V yb = V(1) - omx * omx * m.c[LM_IMP_I1MID];
     V y = sel(lt(x, mid), ya, yb);
     return m.c[LM_IMP_D0] + y * (m.c[LM_IMP_DW] - m.c[LM_IMP_D0]);
 }
@@ -490,9 +490,10 @@ JB_HD void contact_rows_build(const LaneModel<V>& m, const LaneScratch<V>& sc, b
     const V mu = m.c[LM_MU];
     const auto valid = lt(dist, V(0));
     V imp = impedance(m, dist);
-    V R0 = (V(1) - imp) * vrcp(imp) * tran * (V(1) + m.c[LM_FR2]);
+    // weight of a pyramid edge  D = 1 / (2 mu^2 R),  R = (1 - d)/d * tran * (1 + mu^2)   (MuJoCo's diagApprox regulariser)
+    const V invD = (V(1) - imp) * (tran * ((V(1) + m.c[LM_FR2]) * (V(2) * mu * mu)));
     const int e0 = SC_ROWS + ROW_F * entry;
-    sc.st(e0 + 18, sel(valid, vrcp(V(2) * mu * mu * R0), V(0)));
+    sc.st(e0 + 18, sel(valid, imp * vrcp(invD), V(0)));
     const V jdot = f_kn * thd2 + f_m * phid;                    // the rate column 7 multiplies
     const Vec3<V> p1 = cross(sc.ld3(SC_DD + 9), x - sc.ld3(SC_DD + 12)), p2 = cross(sc.ld3(SC_DD + 15), x - sc.ld3(SC_DD + 18));
     Vec3<V> pm = v3<V>(V(0), V(0), V(0));
@@ -848,7 +849,7 @@ template <typename V> inline void stats_hist(const SimOpts&, const LaneScratch<V
 
 // ----------------------------------------------------------------------------- the substep
 template <typename V>
-JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneState<V>& s, const V& ctrl, const SimOpts& o, const bool xtra, const bool xbody) {
+JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneState<V>& s, const V& ctrl, const SimOpts& o, const bool xtra, const bool xbody, const Mat3<V>& Rw) {
     using MK = typename lane_traits<V>::mask;
     using U = typename lane_traits<V>::uint;
     const V h = m.c[LM_H];
@@ -860,13 +861,9 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
 
     const bool is_main = (sc.grp == 0);
     StarSys<V> sys;     // written and read by the main lanes only
-    Mat3<V> Rw;         // root rotation (main lanes)
     if (is_main) {   // ================= phase A: kinematics, composite inertia, bias forces, contact candidates -> scratch
         sc.st3(SC_ST, w); sc.st(SC_ST + 3, s.thd1); sc.st(SC_ST + 4, s.thd2); sc.st(SC_ST + 5, s.phid);      // for the helper groups
-        V qn = vrsqrt(s.qw * s.qw + s.qx * s.qx + s.qy * s.qy + s.qz * s.qz);
-        s.qw = s.qw * qn; s.qx = s.qx * qn; s.qy = s.qy * qn; s.qz = s.qz * qn;
-        Mat3<V> R = quat2mat(s.qw, s.qx, s.qy, s.qz);
-        Rw = R;
+        const Mat3<V>& R = Rw;                                       // root rotation of the normalised quaternion (substep())
         Vec3<V> nb = v3<V>(R.m[6], R.m[7], R.m[8]);                 // R^T ez
         Vec3<V> u = mulT(R, v3<V>(s.vx, s.vy, s.vz));
         Vec3<V> AO = -mulT(R, ldv3(m, LM_GRAV));                    // fictitious root acceleration = -g (root coords)
@@ -1261,11 +1258,14 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
 template <typename V>
 JB_HD void substep(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneState<V>& s, const V& ctrl, const SimOpts& o) {
     unsigned xt = 0;          // bit 0: some upper leg may touch the floor, bit 1: some root / motor-body geom may
+    Mat3<V> Rw;               // root rotation (main lanes): mj_kinematics normalises the quaternion first
+    if (sc.grp == 0) {
+        V qn = vrsqrt(s.qw * s.qw + s.qx * s.qx + s.qy * s.qy + s.qz * s.qz);
+        s.qw = s.qw * qn; s.qx = s.qx * qn; s.qy = s.qy * qn; s.qz = s.qz * qn;
+        Rw = quat2mat(s.qw, s.qx, s.qy, s.qz);
+    }
     if (o.contacts && sc.grp == 0) {
-        V iq = vrcp(s.qw * s.qw + s.qx * s.qx + s.qy * s.qy + s.qz * s.qz);
-        // third row of the rotation matrix of the (not yet normalised) quaternion
-        Vec3<V> nb = v3<V>(V(2) * (s.qx * s.qz - s.qw * s.qy) * iq, V(2) * (s.qy * s.qz + s.qw * s.qx) * iq,
-                           (s.qw * s.qw - s.qx * s.qx - s.qy * s.qy + s.qz * s.qz) * iq);
+        const Vec3<V> nb = v3<V>(Rw.m[6], Rw.m[7], Rw.m[8]);         // floor normal in root coordinates
         // upper leg: sphere around the upper cylinder (+ slack for the shoulder angle)
         auto near_leg = mor(lt(s.pz + dot(ldv3(m, LM_BS_LEG_C), nb), m.c[LM_BS_LEG_R]), gt(vabs(s.th1), V(0.3)));
         // the lane's root / motor-body geoms: a bounding sphere first (at rest it clears the floor by 8 mm or more), and only
@@ -1292,7 +1292,7 @@ JB_HD void substep(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneState<V>
 #ifdef JB_WAVE_STATS
     if (xtra && sc.grp == 0) s.st_xtra = s.st_xtra + V(1);
 #endif
-    substep_impl<V>(m, sc, s, ctrl, o, xtra, xbody);
+    substep_impl<V>(m, sc, s, ctrl, o, xtra, xbody, Rw);
 }
 
 }  // namespace jb
