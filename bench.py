@@ -153,33 +153,55 @@ def main():
         done = torch.empty((n,), device=dev, dtype=torch.uint8)
         # N > 1: the step kernel writes packed rows [obs | reward | done] itself (jb_step_rows_device) and rank 0 gathers them
         # every step.  Two row buffers alternate so that the gather of step t (on RCCL's stream) overlaps the kernel of step
-        # t+1; a buffer is rewritten only after the gather that read it has been waited for.
+        # t+1; a buffer is rewritten only after the gather that read it has been waited for (three buffers with RCCL, so that the
+        # step kernel never waits for the gather issued just before it).
         nccl = gather and args.dist_backend == "nccl"
-        rows = [torch.empty((n, D + 2), device=dev, dtype=torch.float32) for _ in range(2)] if gather else None
+        NB = 3 if nccl else 2                   # row buffers in flight
+        rows = [torch.empty((n, D + 2), device=dev, dtype=torch.float32) for _ in range(NB)] if gather else None
         stage = [torch.empty((n, D + 2), dtype=torch.float32).pin_memory() for _ in range(2)] if (gather and not nccl) else None
         gathered = None
         if gather and rank == 0:
-            gathered = [[torch.empty((n, D + 2), device=dev if nccl else "cpu", dtype=torch.float32) for _ in range(world)] for _ in range(2)]
-        pending = [None, None]
+            gathered = [[torch.empty((n, D + 2), device=dev if nccl else "cpu", dtype=torch.float32) for _ in range(world)] for _ in range(NB)]
+        pending = [None] * NB
         env.reset_device(None, obs.data_ptr())
+
+        # RCCL's gather kernel cannot share a SIMD with a step-kernel wave (one wave per SIMD, ~460 registers), so a gather issued
+        # right behind step t delays the start of step t+1 by its own duration.  It is therefore issued one step LATE, from a
+        # side stream that waits only for step t's event: by then step t+1 occupies the device and the gather runs in its tail,
+        # on the SIMDs whose waves have already finished.
+        side = torch.cuda.Stream(device=dev) if nccl else None
+        step_done = [torch.cuda.Event() for _ in range(NB)] if nccl else None
+        late = [None]                               # index of the step whose rows still have to be sent
+
+        def send(j):
+            b = j % NB
+            with torch.cuda.stream(side):
+                side.wait_event(step_done[b])
+                pending[b] = dist.gather(rows[b], gathered[b] if rank == 0 else None, dst=0, async_op=True)
 
         def one(i):
             if not gather:
                 env.step_device(actions[i].data_ptr(), obs.data_ptr(), rew.data_ptr(), done.data_ptr())
                 return
-            b = i & 1
+            b = i % NB
             if pending[b] is not None:
-                pending[b].wait()
+                pending[b].wait()                   # (current stream waits: the buffer is free to be rewritten)
                 pending[b] = None
             env.step_rows_device(actions[i].data_ptr(), rows[b].data_ptr())
             if nccl:
-                pending[b] = dist.gather(rows[b], gathered[b] if rank == 0 else None, dst=0, async_op=True)
+                step_done[b].record()
+                if late[0] is not None:
+                    send(late[0])
+                late[0] = i
             else:                                   # rehearsal: stage through the host
                 stage[b].copy_(rows[b])
                 dist.gather(stage[b], gathered[b] if rank == 0 else None, dst=0)
 
         def drain():
-            for b in range(2):
+            if nccl and late[0] is not None:
+                send(late[0])
+                late[0] = None
+            for b in range(NB):
                 if pending[b] is not None:
                     pending[b].wait()
                     pending[b] = None
@@ -187,7 +209,7 @@ def main():
         for i in range(warmup):
             one(i)
         drain()
-        finite_warm = bool(torch.isfinite(rows[(warmup - 1) & 1] if (gather and warmup) else obs).all().item()) if warmup else True
+        finite_warm = bool(torch.isfinite(rows[(warmup - 1) % NB] if (gather and warmup) else obs).all().item()) if warmup else True
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize(dev)
@@ -204,12 +226,12 @@ def main():
         wall = time.perf_counter() - t0
         dev_ms = ev0.elapsed_time(ev1)
         sc, ep, cap = env.counters()
-        last = rows[(warmup + steps - 1) & 1][:, :D] if gather else obs
+        last = rows[(warmup + steps - 1) % NB][:, :D] if gather else obs
         finite = finite_warm and bool(torch.isfinite(last).all().item())      # checked after the warm-up and after the timed steps
         finite = finite and float(cap.max()) < 1000.0                         # ... and no env ever ended a step non-finite (kernel-side flag)
         if gather and rank == 0:                    # the gathered block of the last step really holds every rank's rows
-            gl = gathered[(warmup + steps - 1) & 1]
-            finite = finite and all(bool(torch.isfinite(x).all().item()) for x in gl) and bool((gl[0].to(dev) == rows[(warmup + steps - 1) & 1]).all().item())
+            gl = gathered[(warmup + steps - 1) % NB]
+            finite = finite and all(bool(torch.isfinite(x).all().item()) for x in gl) and bool((gl[0].to(dev) == rows[(warmup + steps - 1) % NB]).all().item())
         env.close()
         return wall, dev_ms, float(cap.sum()), finite
 
