@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define JB_ABI_VERSION 1
+#define JB_ABI_VERSION 2
 
 #define JB_OK            0
 #define JB_E_INVALID    -1   /* bad argument */
@@ -109,6 +109,13 @@ int jb_observe_device(jb_handle* h, float* d_obs_out, float* d_reward_out /*null
  * observation rows [N,D] -> actions [N]; the device form lets a rollout chain observe -> act -> step without leaving HBM */
 int jb_policy_device(jb_handle* h, const float* d_obs, float* d_action);
 int jb_policy(jb_handle* h, const float* obs, float* action);
+/* the reference policies' keyword arguments (heuristic_policies.py:28 kick_angle = 45 deg, speed = 0.3; :64,:81,:98
+ * angle_threshold = 20 deg); the defaults are set at jb_create */
+int jb_set_policy_params(jb_handle* h, float kick_angle, float speed, float angle_threshold);
+/* the four reward terms of every env, terms[N,4] = [position, heading, velocity, upright]: Jitterbug.position_reward /
+ * heading_reward / velocity_reward / upright_reward, reference jitterbug.py:840-889 (whatever the handle's task) */
+int jb_reward_terms_device(jb_handle* h, float* d_terms_out /*[N,4]*/);
+int jb_reward_terms(jb_handle* h, float* terms_out /*[N,4]*/);
 /* n_steps of (policy -> step) chained on the stream, the loop of benchmarks/evaluate_policy.py:29-33 for the whole batch;
  * d_obs_inout [N,D] holds the current observations on entry and the last ones on return; d_rewards [n_steps,N] nullable */
 int jb_rollout_policy_device(jb_handle* h, int32_t n_steps, float* d_obs_inout, float* d_rewards, uint8_t* d_done_last);

@@ -14,7 +14,7 @@ JB_OK = 0
 ERR_NAMES = {-1: "JB_E_INVALID", -2: "JB_E_NODEVICE", -3: "JB_E_HIP", -4: "JB_E_MODEL"}
 
 EXPORTS = ["jb_default_config", "jb_create", "jb_destroy", "jb_reset", "jb_step", "jb_observe", "jb_get_state", "jb_set_state",
-           "jb_get_counters", "jb_set_model_params", "jb_policy", "jb_policy_device", "jb_rollout_policy_device", "jb_rollout_policy", "jb_reset_device", "jb_step_device", "jb_step_rows_device", "jb_observe_device", "jb_debug_poison_lds", "jb_set_obs_encoder", "jb_encoded_dim", "jb_encode_device", "jb_encode", "jb_synchronize",
+           "jb_get_counters", "jb_set_model_params", "jb_policy", "jb_policy_device", "jb_set_policy_params", "jb_reward_terms", "jb_reward_terms_device", "jb_rollout_policy_device", "jb_rollout_policy", "jb_reset_device", "jb_step_device", "jb_step_rows_device", "jb_observe_device", "jb_debug_poison_lds", "jb_set_obs_encoder", "jb_encoded_dim", "jb_encode_device", "jb_encode", "jb_synchronize",
            "jb_stream", "jb_obs_dim", "jb_num_envs", "jb_device_count", "jb_abi_version", "jb_default_model_params", "jb_last_error"]
 
 
@@ -80,6 +80,9 @@ def load():
     L.jb_encode_device.argtypes = [vp, fp, fp]
     L.jb_encode.argtypes = [vp, fp, fp]
     L.jb_policy.argtypes = [vp, fp, fp]
+    L.jb_set_policy_params.argtypes = [vp, C.c_float, C.c_float, C.c_float]
+    L.jb_reward_terms.argtypes = [vp, fp]
+    L.jb_reward_terms_device.argtypes = [vp, fp]
     L.jb_policy_device.argtypes = [vp, fp, fp]
     L.jb_rollout_policy_device.argtypes = [vp, C.c_int32, fp, fp, u8p]
     L.jb_rollout_policy.argtypes = [vp, C.c_int32, fp, fp]

@@ -87,7 +87,8 @@ __device__ __forceinline__ void store_state(const KArgs& a, int env, int lane, i
 #pragma unroll
     for (int f = 0; f < 24; f++) if ((f & 3) == leg) r[f * N] = vals[f];
 }
-__device__ __forceinline__ void core_from_state(const KArgs& a, int env, const LaneState<float>& s, EnvCore<float>& e) {
+__device__ __forceinline__ void core_from_state(const KArgs& a, int env, const LaneState<float>& s, const float (&c0)[3], EnvCore<float>& e) {
+    e.cx = c0[0]; e.cy = c0[1]; e.cz = c0[2];
     e.px = s.px; e.py = s.py; e.pz = s.pz; e.qw = s.qw; e.qx = s.qx; e.qy = s.qy; e.qz = s.qz;
     e.vx = s.vx; e.vy = s.vy; e.vz = s.vz; e.wx = s.wx; e.wy = s.wy; e.wz = s.wz; e.phi = s.phi; e.phid = s.phid;
     e.tx = a.root[(RF_TGT + 0) * a.n + env]; e.ty = a.root[(RF_TGT + 1) * a.n + env]; e.tpsi = a.root[(RF_TGT + 2) * a.n + env];
@@ -189,7 +190,8 @@ __global__ __launch_bounds__(64) void jb_step_kernel(KArgs a, const float* __res
     }
     int sc = a.step_count[env] + 1;
     EnvCore<float> e;
-    core_from_state(a, env, s, e);
+    const float c0[3] = {m.c[LM_C0], m.c[LM_C0 + 1], m.c[LM_C0 + 2]};
+    core_from_state(a, env, s, c0, e);
     const float target_z = m.c[LM_TARGET_Z];
     const float rew = reward<float>(a.task, e, target_z);
     const bool done = sc >= a.step_limit;
@@ -223,8 +225,10 @@ __global__ __launch_bounds__(64) void jb_reset_kernel(KArgs a, const unsigned ch
     const int lane = env * 4 + leg;
     const float* tab = a.lane_model + (a.per_env_model ? (size_t)env * LM_TABLE : 0);
     const float target_z = tab[lm_offset(LM_TARGET_Z, leg)], root_z0 = tab[lm_offset(LM_ROOT_Z0, leg)];
+    const float c0[3] = {tab[lm_offset(LM_C0, leg)], tab[lm_offset(LM_C0 + 1, leg)], tab[lm_offset(LM_C0 + 2, leg)]};
     LaneState<float> s;
     EnvCore<float> e;
+    e.cx = c0[0]; e.cy = c0[1]; e.cz = c0[2];
     if (!mask || mask[env]) {
         unsigned ep = a.episode[env];
         episode_reset<float>(a.task, a.random_pose, a.seed, a.env_offset + (unsigned long long)env, ep, root_z0, e);
@@ -234,7 +238,7 @@ __global__ __launch_bounds__(64) void jb_reset_kernel(KArgs a, const unsigned ch
         if (leg == 0) { a.episode[env] = ep + 1; a.step_count[env] = 0; store_target(a, env, e); }
     } else {
         load_state(a, env, lane, s);
-        core_from_state(a, env, s, e);
+        core_from_state(a, env, s, c0, e);
     }
     write_obs(a, env, leg, e, target_z, obs_out);
 }
@@ -245,19 +249,37 @@ __global__ __launch_bounds__(64) void jb_observe_kernel(KArgs a, float* __restri
     if (env >= a.n) return;
     const float* tab = a.lane_model + (a.per_env_model ? (size_t)env * LM_TABLE : 0);
     const float target_z = tab[lm_offset(LM_TARGET_Z, leg)];
+    const float c0[3] = {tab[lm_offset(LM_C0, leg)], tab[lm_offset(LM_C0 + 1, leg)], tab[lm_offset(LM_C0 + 2, leg)]};
     LaneState<float> s;
     load_state(a, env, env * 4 + leg, s);
     EnvCore<float> e;
-    core_from_state(a, env, s, e);
+    core_from_state(a, env, s, c0, e);
     write_obs(a, env, leg, e, target_z, obs_out);
     if (leg == 0 && reward_out) reward_out[env] = reward<float>(a.task, e, target_z);
 }
 
 // ---------------------------------------------------------------------------------------------- heuristic policies
-__global__ void jb_policy_kernel(int n, int task, const float* __restrict__ obs, float* __restrict__ action) {
+__global__ void jb_policy_kernel(int n, int task, PolicyParams<float> pp, const float* __restrict__ obs, float* __restrict__ action) {
     int env = blockIdx.x * blockDim.x + threadIdx.x;
     if (env >= n) return;
-    action[env] = heuristic_policy<float>(task, obs + (size_t)env * obs_dim(task), 1);
+    action[env] = heuristic_policy<float>(task, obs + (size_t)env * obs_dim(task), 1, pp);
+}
+
+// the four reward terms [P, H, V, U] of every env (reference jitterbug.py:840-889), whatever the handle's task
+__global__ __launch_bounds__(64) void jb_reward_terms_kernel(KArgs a, float* __restrict__ terms_out) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    int env = t >> 2, leg = t & 3;
+    if (env >= a.n) return;
+    const float* tab = a.lane_model + (a.per_env_model ? (size_t)env * LM_TABLE : 0);
+    const float target_z = tab[lm_offset(LM_TARGET_Z, leg)];
+    const float c0[3] = {tab[lm_offset(LM_C0, leg)], tab[lm_offset(LM_C0 + 1, leg)], tab[lm_offset(LM_C0 + 2, leg)]};
+    LaneState<float> s;
+    load_state(a, env, env * 4 + leg, s);
+    EnvCore<float> e;
+    core_from_state(a, env, s, c0, e);
+    float out[4];
+    reward_terms<float>(e, target_z, out);
+    terms_out[(size_t)env * 4 + leg] = out[leg];
 }
 
 // ---------------------------------------------------------------------------------------------- diagnostics
@@ -378,8 +400,18 @@ struct jb_handle {
     unsigned long long* d_wave_stats;
     size_t model_tables;
     EncArgs enc;          // observation encoder (n_layers = 0: none)
+    PolicyParams<float> policy;      // keyword arguments of the reference's heuristic policies
+    float* d_terms;
     float* d_enc_params; float* d_code;
 };
+
+// Every entry point that allocates or launches first makes the handle's device current (a process may hold handles on several
+// GPUs, or switch devices with torch.cuda.set_device after jb_create).
+#define JB_ENTER(h)                                                              \
+    do {                                                                         \
+        if (!(h)) return fail(JB_E_INVALID, "handle is NULL");                   \
+        JB_HIP(hipSetDevice((h)->cfg.device_id));                                \
+    } while (0)
 
 static dim3 grid_lanes(int n) { return dim3((unsigned)(((size_t)n * 4 + 63) / 64)); }
 
@@ -421,22 +453,8 @@ int jb_default_config(jb_config* cfg, int32_t n_envs, int32_t task_id) {
     return JB_OK;
 }
 
-int jb_create(const jb_config* cfg, jb_handle** out) {
-    if (!cfg || !out) return fail(JB_E_INVALID, "cfg/out is NULL");
-    *out = nullptr;
-    if (cfg->n_envs < 1) return fail(JB_E_INVALID, "n_envs must be >= 1");
-    if (cfg->task_id < 0 || cfg->task_id >= JB_NTASK) return fail(JB_E_INVALID, "unknown task_id");
-    if (cfg->substeps < 1 || cfg->step_limit < 1) return fail(JB_E_INVALID, "substeps and step_limit must be >= 1");
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(JB_E_NODEVICE, "no HIP device available (there is no CPU fallback)");
-    if (cfg->device_id < 0 || cfg->device_id >= ndev) return fail(JB_E_INVALID, "device_id out of range");
-    JB_HIP(hipSetDevice(cfg->device_id));
-    jb_handle* h = new (std::nothrow) jb_handle();
-    if (!h) return fail(JB_E_INVALID, "out of host memory");
-    std::memset(h, 0, sizeof *h);
-    h->cfg = *cfg;
-    if (h->cfg.max_newton <= 0) h->cfg.max_newton = 12;
-    h->D = obs_dim(cfg->task_id);
+static int create_impl(jb_handle* h) {      // every failure returns through jb_create, which destroys the partly built handle
+    const jb_config* cfg = &h->cfg;
     const size_t N = (size_t)cfg->n_envs;
     if (cfg->use_caller_stream) { h->stream = (hipStream_t)cfg->stream; h->own_stream = false; }
     else { JB_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)); h->own_stream = true; }
@@ -452,6 +470,7 @@ int jb_create(const jb_config* cfg, jb_handle** out) {
     JB_HIP(hipMalloc(&h->d_qpos, sizeof(double) * 16 * N));
     JB_HIP(hipMalloc(&h->d_qvel, sizeof(double) * 15 * N));
     JB_HIP(hipMalloc(&h->d_target, sizeof(double) * 3 * N));
+    JB_HIP(hipMalloc(&h->d_terms, sizeof(float) * 4 * N));
 #ifdef JB_WAVE_STATS
     JB_HIP(hipMalloc(&h->d_wave_stats, sizeof(unsigned long long) * (size_t)(16 + 64) * N));
     JB_HIP(hipMemset(h->d_wave_stats, 0, sizeof(unsigned long long) * (size_t)(16 + 64) * N));
@@ -482,18 +501,46 @@ int jb_create(const jb_config* cfg, jb_handle** out) {
     }
     k.root = h->d_root; k.leg = h->d_leg; k.step_count = h->d_step; k.episode = h->d_episode; k.wave_stats = h->d_wave_stats;
     int rc = upload_model(h, JB_DEFAULT_PARAMS, 1);
-    if (rc) { jb_destroy(h); return rc; }
+    if (rc) return rc;
     rc = jb_reset_device(h, nullptr, nullptr);     // every env starts in a valid episode-0 state
-    if (rc) { jb_destroy(h); return rc; }
+    if (rc) return rc;
     JB_HIP(hipStreamSynchronize(h->stream));
+    return JB_OK;
+}
+
+int jb_create(const jb_config* cfg, jb_handle** out) {
+    if (!cfg || !out) return fail(JB_E_INVALID, "cfg/out is NULL");
+    *out = nullptr;
+    if (cfg->n_envs < 1) return fail(JB_E_INVALID, "n_envs must be >= 1");
+    if (cfg->task_id < 0 || cfg->task_id >= JB_NTASK) return fail(JB_E_INVALID, "unknown task_id");
+    if (cfg->substeps < 1 || cfg->step_limit < 1) return fail(JB_E_INVALID, "substeps and step_limit must be >= 1");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(JB_E_NODEVICE, "no HIP device available (there is no CPU fallback)");
+    if (cfg->device_id < 0 || cfg->device_id >= ndev) return fail(JB_E_INVALID, "device_id out of range");
+    JB_HIP(hipSetDevice(cfg->device_id));
+    jb_handle* h = new (std::nothrow) jb_handle();
+    if (!h) return fail(JB_E_INVALID, "out of host memory");
+    std::memset(h, 0, sizeof *h);
+    h->cfg = *cfg;
+    if (h->cfg.max_newton <= 0) h->cfg.max_newton = 12;
+    h->D = obs_dim(cfg->task_id);
+    h->policy = default_policy_params<float>();
+    const int rc = create_impl(h);
+    if (rc) {                               // one cleanup path: stream, every buffer allocated so far, the handle (keep the message)
+        const std::string msg = g_err;
+        jb_destroy(h);
+        g_err = msg;
+        return rc;
+    }
     *out = h;
     return JB_OK;
 }
 
 int jb_destroy(jb_handle* h) {
     if (!h) return JB_OK;
-    hipStreamSynchronize(h->stream);
-    void* bufs[] = {h->d_root, h->d_leg, h->d_model, h->d_step, h->d_episode, h->d_action, h->d_obs, h->d_reward, h->d_done, h->d_mask, h->d_qpos, h->d_qvel, h->d_target, h->d_wave_stats, h->d_enc_params, h->d_code};
+    hipSetDevice(h->cfg.device_id);
+    if (h->stream || !h->own_stream) hipStreamSynchronize(h->stream);
+    void* bufs[] = {h->d_terms, h->d_root, h->d_leg, h->d_model, h->d_step, h->d_episode, h->d_action, h->d_obs, h->d_reward, h->d_done, h->d_mask, h->d_qpos, h->d_qvel, h->d_target, h->d_wave_stats, h->d_enc_params, h->d_code};
     for (void* b : bufs) if (b) hipFree(b);
     if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
     delete h;
@@ -501,7 +548,7 @@ int jb_destroy(jb_handle* h) {
 }
 
 int jb_set_obs_encoder(jb_handle* h, int32_t n_layers, const int32_t* dims, const int32_t* acts, const float* weights, const float* biases, int32_t vae) {
-    if (!h) return fail(JB_E_INVALID, "handle is NULL");
+    JB_ENTER(h);
     JB_HIP(hipStreamSynchronize(h->stream));
     if (h->d_enc_params) { hipFree(h->d_enc_params); h->d_enc_params = nullptr; }
     if (h->d_code) { hipFree(h->d_code); h->d_code = nullptr; }
@@ -538,6 +585,7 @@ int jb_set_obs_encoder(jb_handle* h, int32_t n_layers, const int32_t* dims, cons
 int jb_encoded_dim(jb_handle* h) { return h ? h->enc.out_dim * (h->enc.n_layers > 0) : JB_E_INVALID; }
 int jb_encode_device(jb_handle* h, const float* d_obs, float* d_code_out) {
     if (!h || !d_obs || !d_code_out) return fail(JB_E_INVALID, "handle/obs/out is NULL");
+    JB_ENTER(h);
     if (h->enc.n_layers <= 0) return fail(JB_E_INVALID, "no observation encoder set (jb_set_obs_encoder)");
     const int N = h->cfg.n_envs;
     hipLaunchKernelGGL(jb_encode_kernel, dim3((unsigned)((N + 127) / 128)), dim3(128), 0, h->stream, h->enc, d_obs, d_code_out);
@@ -547,6 +595,7 @@ int jb_encode_device(jb_handle* h, const float* d_obs, float* d_code_out) {
 }
 int jb_encode(jb_handle* h, const float* obs, float* code_out) {
     if (!h || !obs || !code_out) return fail(JB_E_INVALID, "handle/obs/out is NULL");
+    JB_ENTER(h);
     if (h->enc.n_layers <= 0) return fail(JB_E_INVALID, "no observation encoder set (jb_set_obs_encoder)");
     const size_t N = (size_t)h->cfg.n_envs;
     JB_HIP(hipMemcpyAsync(h->d_obs, obs, sizeof(float) * N * h->D, hipMemcpyHostToDevice, h->stream));
@@ -557,7 +606,7 @@ int jb_encode(jb_handle* h, const float* obs, float* code_out) {
     return JB_OK;
 }
 int jb_debug_poison_lds(jb_handle* h) {
-    if (!h) return fail(JB_E_INVALID, "handle is NULL");
+    JB_ENTER(h);
     hipDeviceProp_t prop;
     JB_HIP(hipGetDeviceProperties(&prop, h->cfg.device_id));
     const int bytes = 40 * 1024;                                   // 4 resident blocks cover a CU's 160 KB
@@ -568,19 +617,20 @@ int jb_debug_poison_lds(jb_handle* h) {
 int jb_num_envs(jb_handle* h) { return h ? h->cfg.n_envs : JB_E_INVALID; }
 void* jb_stream(jb_handle* h) { return h ? (void*)h->stream : nullptr; }
 int jb_synchronize(jb_handle* h) {
-    if (!h) return fail(JB_E_INVALID, "handle is NULL");
+    JB_ENTER(h);
     JB_HIP(hipStreamSynchronize(h->stream));
     return JB_OK;
 }
 
 int jb_reset_device(jb_handle* h, const uint8_t* d_mask, float* d_obs_out) {
-    if (!h) return fail(JB_E_INVALID, "handle is NULL");
+    JB_ENTER(h);
     hipLaunchKernelGGL(jb_reset_kernel, grid_lanes(h->cfg.n_envs), dim3(64), 0, h->stream, h->ka, d_mask, d_obs_out);
     JB_HIP(hipGetLastError());
     return JB_OK;
 }
 static int launch_step(jb_handle* h, const float* d_action, float* d_obs_out, float* d_reward_out, uint8_t* d_done_out, int packed_rows) {
     if (!h || !d_action) return fail(JB_E_INVALID, "handle/action is NULL");
+    JB_ENTER(h);
     h->ka.packed_rows = packed_rows;
     const dim3 grid((unsigned)((h->cfg.n_envs + h->ka.epw - 1) / h->ka.epw));
     const size_t lds_bytes = ((size_t)SC_COUNT * 4 * h->ka.epw + (size_t)LM_TABLE * (h->ka.per_env_model ? h->ka.epw : 1)) * sizeof(float);
@@ -604,14 +654,14 @@ int jb_step_rows_device(jb_handle* h, const float* d_action, float* d_rows_out) 
     return launch_step(h, d_action, d_rows_out, nullptr, nullptr, 1);
 }
 int jb_observe_device(jb_handle* h, float* d_obs_out, float* d_reward_out) {
-    if (!h) return fail(JB_E_INVALID, "handle is NULL");
+    JB_ENTER(h);
     hipLaunchKernelGGL(jb_observe_kernel, grid_lanes(h->cfg.n_envs), dim3(64), 0, h->stream, h->ka, d_obs_out, d_reward_out);
     JB_HIP(hipGetLastError());
     return JB_OK;
 }
 
 int jb_reset(jb_handle* h, const uint8_t* mask, float* obs_out) {
-    if (!h) return fail(JB_E_INVALID, "handle is NULL");
+    JB_ENTER(h);
     const size_t N = (size_t)h->cfg.n_envs;
     if (mask) JB_HIP(hipMemcpyAsync(h->d_mask, mask, N, hipMemcpyHostToDevice, h->stream));
     int rc = jb_reset_device(h, mask ? h->d_mask : nullptr, obs_out ? h->d_obs : nullptr);
@@ -622,6 +672,7 @@ int jb_reset(jb_handle* h, const uint8_t* mask, float* obs_out) {
 }
 int jb_step(jb_handle* h, const float* action, float* obs_out, float* reward_out, uint8_t* done_out) {
     if (!h || !action) return fail(JB_E_INVALID, "handle/action is NULL");
+    JB_ENTER(h);
     const size_t N = (size_t)h->cfg.n_envs;
     JB_HIP(hipMemcpyAsync(h->d_action, action, sizeof(float) * N, hipMemcpyHostToDevice, h->stream));
     int rc = jb_step_device(h, h->d_action, h->d_obs, h->d_reward, h->d_done);
@@ -634,6 +685,7 @@ int jb_step(jb_handle* h, const float* action, float* obs_out, float* reward_out
 }
 int jb_observe(jb_handle* h, float* obs_out, float* reward_out) {
     if (!h || !obs_out) return fail(JB_E_INVALID, "handle/obs_out is NULL");
+    JB_ENTER(h);
     const size_t N = (size_t)h->cfg.n_envs;
     int rc = jb_observe_device(h, h->d_obs, reward_out ? h->d_reward : nullptr);
     if (rc) return rc;
@@ -644,8 +696,9 @@ int jb_observe(jb_handle* h, float* obs_out, float* reward_out) {
 }
 int jb_policy_device(jb_handle* h, const float* d_obs, float* d_action) {
     if (!h || !d_obs || !d_action) return fail(JB_E_INVALID, "handle/obs/action is NULL");
+    JB_ENTER(h);
     const int N = h->cfg.n_envs;
-    hipLaunchKernelGGL(jb_policy_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, h->stream, N, h->cfg.task_id, d_obs, d_action);
+    hipLaunchKernelGGL(jb_policy_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, h->stream, N, h->cfg.task_id, h->policy, d_obs, d_action);
     JB_HIP(hipGetLastError());
     return JB_OK;
 }
@@ -665,6 +718,7 @@ int jb_rollout_policy_device(jb_handle* h, int32_t n_steps, float* d_obs_inout /
 }
 int jb_rollout_policy(jb_handle* h, int32_t n_steps, float* rewards_out /*[K,N] host, nullable*/, float* obs_out /*[N,D] host, nullable*/) {
     if (!h || n_steps < 0) return fail(JB_E_INVALID, "handle is NULL or n_steps < 0");
+    JB_ENTER(h);
     const size_t N = (size_t)h->cfg.n_envs;
     float* d_rew = nullptr;
     if (rewards_out && n_steps > 0) JB_HIP(hipMalloc(&d_rew, sizeof(float) * N * (size_t)n_steps));
@@ -679,6 +733,7 @@ int jb_rollout_policy(jb_handle* h, int32_t n_steps, float* rewards_out /*[K,N] 
 }
 int jb_policy(jb_handle* h, const float* obs, float* action) {
     if (!h || !obs || !action) return fail(JB_E_INVALID, "handle/obs/action is NULL");
+    JB_ENTER(h);
     const size_t N = (size_t)h->cfg.n_envs;
     JB_HIP(hipMemcpyAsync(h->d_obs, obs, sizeof(float) * N * h->D, hipMemcpyHostToDevice, h->stream));
     int rc = jb_policy_device(h, h->d_obs, h->d_action);
@@ -687,8 +742,29 @@ int jb_policy(jb_handle* h, const float* obs, float* action) {
     JB_HIP(hipStreamSynchronize(h->stream));
     return JB_OK;
 }
-int jb_get_state(jb_handle* h, double* qpos, double* qvel, double* target) {
+int jb_set_policy_params(jb_handle* h, float kick_angle, float speed, float angle_threshold) {
     if (!h) return fail(JB_E_INVALID, "handle is NULL");
+    if (!(kick_angle >= 0.f) || !(angle_threshold >= 0.f) || !std::isfinite(speed)) return fail(JB_E_INVALID, "policy parameters: kick_angle, angle_threshold >= 0 and a finite speed");
+    h->policy.kick_angle = kick_angle; h->policy.speed = speed; h->policy.angle_threshold = angle_threshold;
+    return JB_OK;
+}
+int jb_reward_terms_device(jb_handle* h, float* d_terms_out) {
+    if (!h || !d_terms_out) return fail(JB_E_INVALID, "handle/terms is NULL");
+    JB_ENTER(h);
+    hipLaunchKernelGGL(jb_reward_terms_kernel, grid_lanes(h->cfg.n_envs), dim3(64), 0, h->stream, h->ka, d_terms_out);
+    JB_HIP(hipGetLastError());
+    return JB_OK;
+}
+int jb_reward_terms(jb_handle* h, float* terms_out) {
+    if (!h || !terms_out) return fail(JB_E_INVALID, "handle/terms is NULL");
+    int rc = jb_reward_terms_device(h, h->d_terms);
+    if (rc) return rc;
+    JB_HIP(hipMemcpyAsync(terms_out, h->d_terms, sizeof(float) * 4 * (size_t)h->cfg.n_envs, hipMemcpyDeviceToHost, h->stream));
+    JB_HIP(hipStreamSynchronize(h->stream));
+    return JB_OK;
+}
+int jb_get_state(jb_handle* h, double* qpos, double* qvel, double* target) {
+    JB_ENTER(h);
     const size_t N = (size_t)h->cfg.n_envs;
     hipLaunchKernelGGL(jb_export_kernel, dim3((unsigned)((N + 127) / 128)), dim3(128), 0, h->stream, h->ka, qpos ? h->d_qpos : nullptr, qvel ? h->d_qvel : nullptr,
                        target ? h->d_target : nullptr);
@@ -700,7 +776,7 @@ int jb_get_state(jb_handle* h, double* qpos, double* qvel, double* target) {
     return JB_OK;
 }
 int jb_set_state(jb_handle* h, const double* qpos, const double* qvel, const double* target) {
-    if (!h) return fail(JB_E_INVALID, "handle is NULL");
+    JB_ENTER(h);
     const size_t N = (size_t)h->cfg.n_envs;
     if (qpos) JB_HIP(hipMemcpyAsync(h->d_qpos, qpos, sizeof(double) * 16 * N, hipMemcpyHostToDevice, h->stream));
     if (qvel) JB_HIP(hipMemcpyAsync(h->d_qvel, qvel, sizeof(double) * 15 * N, hipMemcpyHostToDevice, h->stream));
@@ -712,7 +788,7 @@ int jb_set_state(jb_handle* h, const double* qpos, const double* qvel, const dou
     return JB_OK;
 }
 int jb_get_counters(jb_handle* h, int32_t* step_count, uint32_t* episode, float* solver_cap_hits) {
-    if (!h) return fail(JB_E_INVALID, "handle is NULL");
+    JB_ENTER(h);
     const size_t N = (size_t)h->cfg.n_envs;
     JB_HIP(hipStreamSynchronize(h->stream));
     if (step_count) JB_HIP(hipMemcpy(step_count, h->d_step, sizeof(int) * N, hipMemcpyDeviceToHost));
@@ -731,6 +807,7 @@ int jb_debug_wave_stats(jb_handle* h, unsigned long long* out, int32_t n_waves) 
 #endif
 int jb_set_model_params(jb_handle* h, const double* params, int32_t n_tables) {
     if (!h || !params) return fail(JB_E_INVALID, "handle/params is NULL");
+    JB_ENTER(h);
     if (n_tables != 1 && n_tables != h->cfg.n_envs) return fail(JB_E_INVALID, "n_tables must be 1 or n_envs");
     JB_HIP(hipStreamSynchronize(h->stream));
     return upload_model(h, params, n_tables);

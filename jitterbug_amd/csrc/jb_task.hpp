@@ -32,10 +32,12 @@ template <typename T> struct EnvCore {        // the part of the state the task 
     T vx, vy, vz, wx, wy, wz;                 // root velocity (world linear, body angular)
     T phi, phid;                              // motor angle (wrapped or not) and rate
     T tx, ty, tpsi;                           // target x, y, yaw
+    T cx, cy, cz;                             // the root body's OWN centre of mass in root coordinates (model constant): the
+                                              // point the reference's framelinvel sensor measures at, see vel_in_target
 };
 
 // reference jitterbug.py:601-666.  Draw order: angle, radius, yaw, then (random_pose) rotation angle, axis x, axis y.
-// Returns the root quaternion and the target; everything else resets to qpos0 / zero.
+// Returns the root quaternion and the target; everything else resets to qpos0 / zero (the model constants cx, cy, cz are not touched).
 template <typename T>
 JB_HD void episode_reset(int task, int random_pose, uint64_t seed, uint64_t env, uint32_t episode, T root_z0, EnvCore<T>& e) {
     uint32_t r0[4], r1[4];
@@ -96,10 +98,22 @@ template <typename T> JB_HD void target_in_body(const EnvCore<T>& e, T target_z,
     o[1] = R01 * dx + R11 * dy + R21 * dz;
     o[2] = R02 * dx + R12 * dy + R22 * dz;
 }
-// Jitterbug linear velocity in the target frame (framelinvel of a free body == qvel[0:3])   (reference :292-303)
+// The reference's sensor `jitterbug_framelinvel` (jitterbug.xml:121, objtype="body"): MuJoCo's mj_objectVelocity measures an
+// mjOBJ_BODY object at the body's INERTIAL frame (xipos: the root body's own centre of mass), world axes - only "xbody" means
+// the joint frame.  So the sensor reads  v + R (w_body x c0),  not qvel[0:3].
+template <typename T> JB_HD void framelinvel(const EnvCore<T>& e, T (&o)[3]) {
+    T lx = e.wy * e.cz - e.wz * e.cy, ly = e.wz * e.cx - e.wx * e.cz, lz = e.wx * e.cy - e.wy * e.cx;
+    T w = e.qw, x = e.qx, y = e.qy, z = e.qz;
+    o[0] = e.vx + (w * w + x * x - y * y - z * z) * lx + T(2) * (x * y - w * z) * ly + T(2) * (x * z + w * y) * lz;
+    o[1] = e.vy + T(2) * (x * y + w * z) * lx + (w * w - x * x + y * y - z * z) * ly + T(2) * (y * z - w * x) * lz;
+    o[2] = e.vz + T(2) * (x * z - w * y) * lx + T(2) * (y * z + w * x) * ly + (w * w - x * x - y * y + z * z) * lz;
+}
+// Jitterbug linear velocity (the sensor above) in the target frame   (reference :292-303)
 template <typename T> JB_HD void vel_in_target(const EnvCore<T>& e, T (&o)[3]) {
     T c = vcos(e.tpsi), s = vsin(e.tpsi);
-    o[0] = c * e.vx + s * e.vy; o[1] = -s * e.vx + c * e.vy; o[2] = e.vz;
+    T v[3];
+    framelinvel(e, v);
+    o[0] = c * v[0] + s * v[1]; o[1] = -s * v[0] + c * v[1]; o[2] = v[2];
 }
 
 // reference jitterbug.py:673-763: 15 common entries then the task's extras, in dict order; _norm :668-671
@@ -133,6 +147,23 @@ template <typename T> JB_HD void observe(int task, const EnvCore<T>& e, T target
 //   upright   gaussian, bounds (1,1), margin .5                        -> 0.1^(((1-Rzz)/.5)^2), 1 when Rzz == 1
 //   heading   cosine,   bounds (0,0), margin pi/2, value_at_margin 0   -> (1+cos(2 dpsi))/2 for |dpsi| < pi/2 else 0
 //   velocity  linear,   bounds (.1,inf), margin .1, value_at_margin 0  -> clamp(v/.1, 0, 1)
+// the four reward terms on their own (reference :840-889: heading_reward, velocity_reward, position_reward, upright_reward),
+// out = [P, H, V, U]; reward() below combines the ones its task uses
+template <typename T> JB_HD void reward_terms(const EnvCore<T>& e, T target_z, T (&out)[4]) {
+    const T LN01 = T(-2.302585092994046);
+    T Rzz = e.qw * e.qw - e.qx * e.qx - e.qy * e.qy + e.qz * e.qz;
+    T du = vabs(T(1) - Rzz) * T(2);
+    out[3] = (Rzz == T(1)) ? T(1) : vexp(LN01 * du * du);
+    T t3[3];
+    target_in_body(e, target_z, t3);
+    T d = vsqrt(t3[0] * t3[0] + t3[1] * t3[1] + t3[2] * t3[2]), dn = d * T(20);
+    out[0] = (d == T(0)) ? T(1) : vexp(LN01 * dn * dn);
+    T a = angle_to_target(e), x = vabs(a) / T(1.5707963267948966);
+    out[1] = (a == T(0)) ? T(1) : (x < T(1) ? T(0.5) * (T(1) + vcos(T(3.141592653589793) * x)) : T(0));
+    vel_in_target(e, t3);
+    T v = t3[0];
+    out[2] = (v >= T(0.1)) ? T(1) : ((T(0.1) - v) * T(10) < T(1) ? T(1) - (T(0.1) - v) * T(10) : T(0));
+}
 template <typename T> JB_HD T reward(int task, const EnvCore<T>& e, T target_z) {
     const T LN01 = T(-2.302585092994046);     // ln 0.1
     T Rzz = e.qw * e.qw - e.qx * e.qx - e.qy * e.qy + e.qz * e.qz;
@@ -165,33 +196,34 @@ template <typename T> JB_HD T reward(int task, const EnvCore<T>& e, T target_z) 
 
 // ---- heuristic bang-bang policies on a flat (normalised) observation row; reference heuristic_policies.py:6-136.
 // They read the normalised observation entries and compare them with thresholds in radians, exactly like the reference.
+template <typename T> struct PolicyParams { T kick_angle, speed, angle_threshold; };     // reference keyword arguments :28, :64, :81, :98
+template <typename T> JB_HD PolicyParams<T> default_policy_params() { PolicyParams<T> p; p.kick_angle = T(0.7853981633974483); p.speed = T(0.3); p.angle_threshold = T(0.3490658503988659); return p; }
 template <typename T> JB_HD T policy_face(T angle) {                                  // :6-25
     T v = T(3) * angle / T(3.141592653589793);
     v = v > T(1) ? T(1) : (v < T(-1) ? T(-1) : v);
     return T(0.9) * v;
 }
-template <typename T> JB_HD T policy_forward(T motor_angle, T motor_vel, T offset) {  // :28-56
-    const T kick = T(0.7853981633974483), speed = T(0.3);
-    if (motor_angle < offset - kick) return speed;
-    if (motor_angle > offset + kick) return -speed;
-    return motor_vel > T(0) ? speed : -speed;
+template <typename T> JB_HD T policy_forward(T motor_angle, T motor_vel, T offset, const PolicyParams<T>& pp) {  // :28-56
+    if (motor_angle < offset - pp.kick_angle) return pp.speed;
+    if (motor_angle > offset + pp.kick_angle) return -pp.speed;
+    return motor_vel > T(0) ? pp.speed : -pp.speed;
 }
-template <typename T> JB_HD T heuristic_policy(int task, const T* obs, int stride) {
-    const T PI = T(3.141592653589793), Q = T(0.7853981633974483), H = T(1.5707963267948966), THR = T(0.3490658503988659);
+template <typename T> JB_HD T heuristic_policy(int task, const T* obs, int stride, const PolicyParams<T>& pp) {
+    const T PI = T(3.141592653589793), Q = T(0.7853981633974483), H = T(1.5707963267948966), THR = pp.angle_threshold;
     const T ma = obs[13 * stride], mv = obs[14 * stride];
-    if (task == TASK_MOVE_FROM_ORIGIN) return policy_forward(ma, mv, T(0));           // :59-61
+    if (task == TASK_MOVE_FROM_ORIGIN) return policy_forward(ma, mv, T(0), pp);       // :59-61
     if (task == TASK_FACE_DIRECTION) return policy_face(obs[15 * stride]);
     if (task == TASK_MOVE_IN_DIRECTION || task == TASK_MOVE_TO_POSITION) {            // :64-95, 120-136
         T ang = (task == TASK_MOVE_IN_DIRECTION) ? obs[15 * stride] : vatan2(obs[15 * stride], -obs[16 * stride]);
         T off = T(0);
         if (ang > Q && ang <= PI) { off = H; ang = vabs(vabs(ang) - H); }
         else if (ang >= -PI && ang < -Q) { off = -H; ang = -vabs(vabs(ang) - H); }
-        return vabs(ang) > THR ? policy_face(ang) : policy_forward(ma, mv, off);
+        return vabs(ang) > THR ? policy_face(ang) : policy_forward(ma, mv, off, pp);
     }
     T dx = obs[15 * stride], dy = obs[16 * stride];                                   // move_to_pose :98-118
     T ang = vatan2(dx, -dy);
     if (vabs(ang) > THR) return policy_face(ang);
-    if (vsqrt(dx * dx + dy * dy) > T(0.01)) return policy_forward(ma, mv, T(0));
+    if (vsqrt(dx * dx + dy * dy) > T(0.01)) return policy_forward(ma, mv, T(0), pp);
     return policy_face(obs[18 * stride]);
 }
 

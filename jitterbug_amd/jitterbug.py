@@ -46,17 +46,76 @@ def _wrap(angle):
     return np.pi if a == -np.pi else a
 
 
+class _Indexer:
+    """`physics.named.data.qpos['root']`-style access (dm_control's named indexing, third party) for the names the
+    reference's hot path uses (reference jitterbug.py:182-296, 886)."""
+
+    def __init__(self, getter):
+        self._get = getter
+
+    def __getitem__(self, key):
+        return self._get(key)
+
+
+class _NamedData:
+    def __init__(self, ph):
+        def qpos(k):
+            q = ph._state()[0]
+            return {"root": q[0:7], "jointMass": q[15:16]}[k] if isinstance(k, str) else q[k]
+
+        def qvel(k):
+            v = ph._state()[1]
+            return {"root": v[0:6], "jointMass": v[14:15]}[k] if isinstance(k, str) else v[k]
+
+        def xmat(k):
+            body, comp = k if isinstance(k, tuple) else (k, None)
+            R = _quat2mat(ph._state()[0][3:7]) if body == "jitterbug" else _quat2mat(ph.target_position_quat())
+            return R.reshape(-1) if comp is None else R["xyz".index(comp[0]), "xyz".index(comp[1])]
+
+        self.qpos, self.qvel, self.xmat = _Indexer(qpos), _Indexer(qvel), _Indexer(xmat)
+        self.geom_xpos = _Indexer(lambda k: {"target": ph.target_position_xyz()}[k])
+        self.xquat = _Indexer(lambda k: {"target": ph.target_position_quat(), "jitterbug": ph._state()[0][3:7]}[k])
+        self.xpos = _Indexer(lambda k: {"target": ph.target_position_xyz(), "jitterbug": ph._state()[0][0:3]}[k])
+        self.sensordata = _Indexer(lambda k: {"jitterbug_framelinvel": ph.jitterbug_framelinvel()}[k])
+
+
+class _Named:
+    def __init__(self, ph):
+        self.data = _NamedData(ph)
+
+
 class Physics:
-    """Accessors of the reference's Physics class, evaluated on the state held by the GPU env (env index 0)."""
+    """Accessors of the reference's Physics class (reference jitterbug.py:177-317), evaluated on the state held by the GPU env
+    (env `index` of the batch).  The state is fetched from the device once per simulator change (the env bumps
+    `state_version` on every reset / step / set_state) and cached, so a reward assembled from a dozen accessors costs one
+    device round trip, not a dozen."""
 
     def __init__(self, venv, index=0):
         self._venv = venv
         self._i = index
-        self._target_z = float(model.default_params()[model.P_TARGETZ])
+        self._cache = None
+        self._cache_version = -1
+        self.named = _Named(self)
 
     def _state(self):
-        q, v, t = self._venv.get_state()
-        return q[self._i], v[self._i], t[self._i]
+        if self._cache is None or self._cache_version != self._venv.state_version:
+            q, v, t = self._venv.get_state()
+            self._cache = (q[self._i], v[self._i], t[self._i])
+            self._cache_version = self._venv.state_version
+        return self._cache
+
+    @property
+    def _params(self):
+        return self._venv.model_params(self._i)
+
+    @property
+    def _target_z(self):
+        return float(self._params[model.P_TARGETZ])
+
+    @property
+    def _root_ipos(self):
+        """the root body's own centre of mass in root coordinates (MuJoCo body_ipos)"""
+        return self._params[model.P_BODY + model.B_COM:model.P_BODY + model.B_COM + 3]
 
     # --- state vectors (MuJoCo layout) ---------------------------------------------------------
     def qpos(self):
@@ -64,6 +123,9 @@ class Physics:
 
     def qvel(self):
         return self._state()[1]
+
+    def get_state(self):
+        return np.concatenate(self._state()[:2])
 
     def timestep(self):
         return PHYSICS_TIMESTEP
@@ -120,8 +182,14 @@ class Physics:
         q, _, _ = self._state()
         return _quat2mat(q[3:7]).T @ (self.target_position_xyz() - q[:3])
 
+    def jitterbug_framelinvel(self):
+        """sensordata['jitterbug_framelinvel'] (reference jitterbug.xml:121, objtype="body"): MuJoCo measures a body object at
+        its inertial frame, i.e. at the root body's own centre of mass, in world axes:  v + R (w_body x ipos)."""
+        q, v, _ = self._state()
+        return v[0:3] + _quat2mat(q[3:7]) @ np.cross(v[3:6], self._root_ipos)
+
     def jitterbug_velocity_in_target_frame(self):      # :292-303
-        return _quat2mat(self.target_position_quat()).T @ self.jitterbug_velocity_xyz()
+        return _quat2mat(self.target_position_quat()).T @ self.jitterbug_framelinvel()
 
     def angle_jitterbug_to_target(self):               # :305-317
         return np.array([_wrap(self.target_direction_yaw() - self.jitterbug_direction_yaw())])
@@ -132,7 +200,21 @@ class Physics:
 
 
 class Jitterbug:
-    """The reference's task object: configuration + observation/reward access (reference jitterbug.py:320-925)."""
+    """The reference's task object: configuration + observation / reward / episode-start access (reference jitterbug.py:320-925).
+    The methods that take `physics` evaluate on the GPU env behind it (jb_observe, jb_reward_terms, jb_reset through the C ABI);
+    they exist so that code written against the reference's task API (`env.task.get_observation(env.physics)`, ...) runs."""
+
+    # Approximate min / max ranges of the observation entries (reference jitterbug.py:324-347; the GPU observation kernel
+    # applies the same numbers; pinned against the reference's literals by tests/golden/norm_tables.json)
+    _NORM_ALL = np.array([[-2.0, 2.0], [-2.0, 2.0], [0.0, 0.1], [-1.0, 1.0], [-1.0, 1.0], [-1.0, 1.0], [-1.0, 1.0],
+                          [-1.0, 1.0], [-1.0, 1.0], [-1.0, 1.0], [-35.0, 35.0], [-35.0, 35.0], [-35.0, 35.0],
+                          [-np.pi, np.pi], [-180.0, 180.0]])
+    _NORM_TASKS = dict(                                         # reference :350-372
+        move_from_origin=np.array([]),
+        face_direction=np.array([[-np.pi, np.pi]]),
+        move_in_direction=np.array([[-np.pi, np.pi], [-1.0, 1.0], [-1.0, 1.0], [-1.0, 1.0]]),
+        move_to_position=np.array([[-3.0, 3.0], [-3.0, 3.0], [-0.1, 0.1]]),
+        move_to_pose=np.array([[-3.0, 3.0], [-3.0, 3.0], [-0.1, 0.1], [-np.pi, np.pi]]))
 
     def __init__(self, random=None, task="move_from_origin", random_pose=True, norm_obs=False):
         assert task in TASK_NAMES, "Invalid task {}, options are {}".format(task, TASK_NAMES)      # :425
@@ -146,6 +228,41 @@ class Jitterbug:
     @staticmethod
     def _norm(v, min, max):                 # :668-671
         return (v - min) / (max - min) * 2.0 - 1.0
+
+    # --- reference task API --------------------------------------------------------------------------
+    def initialize_episode(self, physics):  # :601-666
+        """Starts a new episode of the env behind `physics`: target and (random_pose) root orientation are re-drawn on the GPU
+        from the env's Philox stream (one counter-based stream instead of the reference's mixed RNGs)."""
+        mask = np.zeros(physics._venv.num_envs, dtype=np.uint8)
+        mask[physics._i] = 1
+        physics._venv.reset(mask)
+
+    def get_observation(self, physics):     # :673-763
+        """The (normalised) observation dict of the env behind `physics`, computed by the observation kernel."""
+        obs, _ = physics._venv.observe()
+        self.counter += 1                   # :758
+        return self.split_observation(obs[physics._i])
+
+    def _terms(self, physics):
+        return physics._venv.reward_terms()[physics._i].astype(np.float64)
+
+    def position_reward(self, physics):     # :868-880
+        return float(self._terms(physics)[0])
+
+    def heading_reward(self, physics):      # :840-852
+        return float(self._terms(physics)[1])
+
+    def velocity_reward(self, physics):     # :854-866
+        return float(self._terms(physics)[2])
+
+    def upright_reward(self, physics):      # :882-889
+        return float(self._terms(physics)[3])
+
+    def get_reward(self, physics):          # :891-925
+        if physics._venv.task != self.task:
+            raise ValueError("physics belongs to task {!r}, not {!r}".format(physics._venv.task, self.task))
+        _, rew = physics._venv.observe()
+        return float(rew[physics._i])
 
     def split_observation(self, vec):
         out = collections.OrderedDict()

@@ -68,6 +68,9 @@ class JitterbugVecEnv:
         self._rew = np.zeros(self.num_envs, dtype=np.float32)
         self._done = np.zeros(self.num_envs, dtype=np.uint8)
         self._pending = None
+        self._infos = None
+        self._params = None              # host copy of the per-env / shared parameter table(s) when set_model_params was used
+        self.state_version = 0           # bumped by every call that changes the simulator state (Physics caches on it)
         if params is not None:
             self.set_model_params(params)
 
@@ -87,12 +90,24 @@ class JitterbugVecEnv:
     def reset(self, mask=None):
         m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
         _lib.check(self._L.jb_reset(self._h, _lib.ptr(m), _lib.ptr(self._obs)))
+        self.state_version += 1
         return self._obs.copy()
 
     def step(self, actions):
         a = np.ascontiguousarray(np.broadcast_to(np.asarray(actions, dtype=np.float32).reshape(-1), (self.num_envs,)))
         _lib.check(self._L.jb_step(self._h, _lib.ptr(a), _lib.ptr(self._obs), _lib.ptr(self._rew), _lib.ptr(self._done)))
-        return self._obs.copy(), self._rew.copy(), self._done.astype(bool), [{} for _ in range(self.num_envs)] if self.num_envs <= 64 else None
+        self.state_version += 1
+        return self._obs.copy(), self._rew.copy(), self._done.astype(bool), self._empty_infos()
+
+    def _empty_infos(self):
+        """VecEnv `infos`: always a list of N dicts (stable-baselines consumers index infos[i]); the dicts are fresh per call
+        for small batches and one re-used list of empty dicts for large ones (built once: 65 536 dict allocations per step
+        would cost more than the step)."""
+        if self.num_envs <= 64:
+            return [{} for _ in range(self.num_envs)]
+        if self._infos is None:
+            self._infos = [{} for _ in range(self.num_envs)]
+        return self._infos
 
     def step_async(self, actions):
         self._pending = actions
@@ -118,6 +133,7 @@ class JitterbugVecEnv:
             return None if a is None else np.ascontiguousarray(np.asarray(a, dtype=np.float64).reshape(self.num_envs, w))
         q, v, t = prep(qpos, model.NQ), prep(qvel, model.NV), prep(target, 3)
         _lib.check(self._L.jb_set_state(self._h, _lib.ptr(q), _lib.ptr(v), _lib.ptr(t)))
+        self.state_version += 1
 
     def counters(self):
         sc = np.zeros(self.num_envs, dtype=np.int32)
@@ -131,10 +147,29 @@ class JitterbugVecEnv:
         n_tables = 1 if p.ndim == 1 else p.shape[0]
         assert p.size == n_tables * model.NPARAM
         _lib.check(self._L.jb_set_model_params(self._h, _lib.ptr(p), n_tables))
+        self._params = p.reshape(n_tables, model.NPARAM).copy()
+        self.state_version += 1
+
+    def model_params(self, index=0):
+        """The parameter table (float64[NPARAM]) env `index` is simulated with."""
+        if self._params is None:
+            return model.default_params()
+        return self._params[index if self._params.shape[0] > 1 else 0]
+
+    def reward_terms(self):
+        """[N, 4] = position, heading, velocity, upright reward terms of the current state (reference jitterbug.py:840-889)."""
+        out = np.zeros((self.num_envs, 4), dtype=np.float32)
+        _lib.check(self._L.jb_reward_terms(self._h, _lib.ptr(out)))
+        return out
+
+    def set_policy_params(self, kick_angle=np.deg2rad(45), speed=0.3, angle_threshold=np.deg2rad(20)):
+        """Keyword arguments of the reference's heuristic policies (heuristic_policies.py:28, 64, 81, 98) for policy() / rollouts."""
+        _lib.check(self._L.jb_set_policy_params(self._h, float(kick_angle), float(speed), float(angle_threshold)))
 
     # ------------------------------------------------------------------ device-buffer API (raw pointers; torch tensors via .data_ptr())
     def step_device(self, action_ptr, obs_ptr, reward_ptr, done_ptr):
         _lib.check(self._L.jb_step_device(self._h, action_ptr, obs_ptr, reward_ptr, done_ptr))
+        self.state_version += 1
 
     # ------------------------------------------------------------------ observation encoder hook (reference jitterbug.py:760-761, 927-993)
     def set_obs_encoder(self, layers, vae=False):
@@ -174,9 +209,11 @@ class JitterbugVecEnv:
     def step_rows_device(self, action_ptr, rows_ptr):
         """One packed float row [obs(D) | reward | done] per env, written by the step kernel (the unit of the multi-GPU gather)."""
         _lib.check(self._L.jb_step_rows_device(self._h, action_ptr, rows_ptr))
+        self.state_version += 1
 
     def reset_device(self, mask_ptr=None, obs_ptr=None):
         _lib.check(self._L.jb_reset_device(self._h, mask_ptr, obs_ptr))
+        self.state_version += 1
 
     def observe_device(self, obs_ptr, reward_ptr=None):
         _lib.check(self._L.jb_observe_device(self._h, obs_ptr, reward_ptr))
@@ -195,11 +232,13 @@ class JitterbugVecEnv:
         """n_steps of heuristic policy -> step chained on the GPU from the current state; returns (rewards [n_steps, N], last obs)."""
         rew = np.zeros((int(n_steps), self.num_envs), dtype=np.float32)
         _lib.check(self._L.jb_rollout_policy(self._h, int(n_steps), _lib.ptr(rew), _lib.ptr(self._obs)))
+        self.state_version += 1
         return rew, self._obs.copy()
 
     def rollout_policy_device(self, n_steps, obs_ptr, rewards_ptr=None, done_ptr=None):
         """n_steps of heuristic policy -> step, chained on the GPU (device pointers; asynchronous)."""
         _lib.check(self._L.jb_rollout_policy_device(self._h, int(n_steps), obs_ptr, rewards_ptr, done_ptr))
+        self.state_version += 1
 
     def synchronize(self):
         _lib.check(self._L.jb_synchronize(self._h))

@@ -719,11 +719,21 @@ static void target_in_jb_frame(const double* P, const double* qpos, const double
     quat2mat(R, qpos + 3);
     matTvec3(out, R, d);
 }
-static void vel_in_target_frame(const double* qvel, double psi, double* out) {   /* :292-303; framelinvel == qvel[0:3] */
-    double Rt[9], tq[4];
+/* sensor jitterbug_framelinvel (reference jitterbug.xml:121, objtype="body"): MuJoCo's mj_objectVelocity takes an mjOBJ_BODY
+ * object at the body's inertial frame (xipos = the root body's own COM), world axes:  v + R (w_body x ipos). */
+void jbo_framelinvel(const double* P, const double* qpos, const double* qvel, double* out) {
+    double R[9], l[3], lw[3];
+    quat2mat(R, qpos + 3);
+    cross3(l, qvel + 3, P + JB_P_BODY + JB_B_COM);
+    matvec3(lw, R, l);
+    for (int i = 0; i < 3; i++) out[i] = qvel[i] + lw[i];
+}
+static void vel_in_target_frame(const double* P, const double* qpos, const double* qvel, double psi, double* out) {   /* :292-303 */
+    double Rt[9], tq[4], v[3];
     target_quat(psi, tq);
     quat2mat(Rt, tq);
-    matTvec3(out, Rt, qvel);
+    jbo_framelinvel(P, qpos, qvel, v);
+    matTvec3(out, Rt, v);
 }
 
 int jbo_obs_dim(int task) { static const int d[JB_NTASK] = {15, 16, 19, 18, 19}; return (task >= 0 && task < JB_NTASK) ? d[task] : -1; }
@@ -743,7 +753,7 @@ void jbo_observation(const double* P, int task, const double* qpos, const double
         obs[15] = norm_(angle_to_target(qpos, target[2]), -M_PI, M_PI); break;
     case JB_TASK_MOVE_IN_DIRECTION:
         obs[15] = norm_(angle_to_target(qpos, target[2]), -M_PI, M_PI);
-        vel_in_target_frame(qvel, target[2], t3);
+        vel_in_target_frame(P, qpos, qvel, target[2], t3);
         for (int i = 0; i < 3; i++) obs[16 + i] = norm_(t3[i], -1, 1);
         break;
     case JB_TASK_MOVE_TO_POSITION:
@@ -777,7 +787,7 @@ double jbo_reward(const double* P, int task, const double* qpos, const double* q
     target_in_jb_frame(P, qpos, target, t3);
     pos_r = tolerance(sqrt(dot3(t3, t3)), 0, 0, 0.05, 0.1, 0);                             /* :868-880 */
     head_r = tolerance(angle_to_target(qpos, target[2]), 0, 0, M_PI / 2, 0.0, 1);          /* :840-852 */
-    vel_in_target_frame(qvel, target[2], t3);
+    vel_in_target_frame(P, qpos, qvel, target[2], t3);
     vel_r = tolerance(t3[0], 0.1, INFINITY, 0.1, 0.0, 2);                                  /* :854-866 */
     switch (task) {                                                                        /* :891-925 */
     case JB_TASK_MOVE_FROM_ORIGIN: r = 1 - pos_r; break;
@@ -794,7 +804,7 @@ void jbo_reward_terms(const double* P, const double* qpos, const double* qvel, c
     target_in_jb_frame(P, qpos, target, t3);
     out[0] = tolerance(sqrt(dot3(t3, t3)), 0, 0, 0.05, 0.1, 0);
     out[1] = tolerance(angle_to_target(qpos, target[2]), 0, 0, M_PI / 2, 0.0, 1);
-    vel_in_target_frame(qvel, target[2], t3);
+    vel_in_target_frame(P, qpos, qvel, target[2], t3);
     out[2] = tolerance(t3[0], 0.1, INFINITY, 0.1, 0.0, 2);
     out[3] = tolerance(R[8], 1, 1, 0.5, 0.1, 0);
 }

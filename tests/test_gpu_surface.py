@@ -142,3 +142,98 @@ def test_integration_md_stub_runs_and_matches_vec_env():
         o2, r2, d2, _ = v.step(act)
         assert np.array_equal(o1, o2) and np.array_equal(r1, r2) and np.array_equal(d1, d2.astype(bool))
     v.close()
+
+
+def test_task_object_methods_of_the_reference():
+    """Jitterbug.get_observation / get_reward / the four reward terms / initialize_episode take a `physics`, like the reference
+    (jitterbug.py:601, 673, 840-925); here they run the GPU kernels (jb_observe, jb_reward_terms, jb_reset) and must agree with the
+    oracle evaluated on the state the Physics accessors report."""
+    from jitterbug_amd import suite
+    from oracle import oracle as O
+    P = model.default_params()
+    for task in model.TASKS:
+        env = suite.load("jitterbug", task, task_kwargs=dict(random=5))
+        env.reset()
+        for _ in range(3):
+            ts = env.step(0.7)
+        ph, tk = env.physics, env.task
+        calls0 = _count_state_fetches(ph)
+        q, v = ph.qpos(), ph.qvel()
+        tgt = np.array([ph.target_position_xyz()[0], ph.target_position_xyz()[1], ph.target_direction_yaw() % (2 * np.pi)])
+        obs = tk.get_observation(ph)
+        assert isinstance(obs, collections.OrderedDict) and list(obs) == list(ts.observation)
+        np.testing.assert_allclose(np.concatenate(list(obs.values())), O.observation(P, task, q, v, tgt), rtol=1e-5, atol=2e-6)
+        for k in obs:
+            np.testing.assert_array_equal(obs[k], ts.observation[k])           # same kernel arithmetic as the step's own row
+        assert tk.get_reward(ph) == pytest.approx(ts.reward, abs=1e-7)
+        terms = O.reward_terms(P, q, v, tgt)
+        assert tk.position_reward(ph) == pytest.approx(terms["P"], abs=1e-5)
+        assert tk.heading_reward(ph) == pytest.approx(terms["H"], abs=1e-5)
+        assert tk.velocity_reward(ph) == pytest.approx(terms["V"], abs=1e-4)
+        assert tk.upright_reward(ph) == pytest.approx(terms["U"], abs=1e-5)
+        # the reference's sensor through physics.named, and the named state views
+        np.testing.assert_allclose(ph.named.data.sensordata["jitterbug_framelinvel"], ph.jitterbug_framelinvel())
+        np.testing.assert_array_equal(ph.named.data.qpos["root"], q[:7])
+        assert ph.named.data.qvel["jointMass"][0] == v[14] and ph.named.data.xmat["jitterbug", "zz"] == pytest.approx(ph.upright())
+        np.testing.assert_allclose(ph.named.data.geom_xpos["target"], ph.target_position_xyz())
+        # all of the above cost ONE state fetch (cached per simulator change)
+        assert _count_state_fetches(ph) - calls0 <= 1
+        # initialize_episode: a new episode for this env (velocities zero, new target for the target tasks)
+        tk.initialize_episode(ph)
+        assert np.all(ph.qvel() == 0) and ph.jitterbug_position_xyz()[2] == pytest.approx(0.035, abs=1e-6)
+        if task in ("move_to_position", "move_to_pose"):
+            assert 0.05 - 1e-6 <= np.hypot(*ph.target_position_xyz()[:2]) < 0.2 + 1e-6
+            assert not np.allclose(ph.target_position_xyz()[:2], tgt[:2])
+        env.close()
+
+
+def _count_state_fetches(ph):
+    """number of device state fetches the env has served (instrumented once per Physics object)"""
+    venv = ph._venv
+    if not hasattr(venv, "_fetches"):
+        venv._fetches = 0
+        orig = venv.get_state
+
+        def counted():
+            venv._fetches += 1
+            return orig()
+        venv.get_state = counted
+    return venv._fetches
+
+
+def test_vec_env_infos_is_always_a_list():
+    from jitterbug_amd.vec_env import JitterbugVecEnv
+    for n in (3, 64, 65, 300):
+        env = JitterbugVecEnv(n, "move_from_origin")
+        env.reset()
+        _, _, _, infos = env.step(np.zeros(n, dtype=np.float32))
+        assert isinstance(infos, list) and len(infos) == n and infos[n - 1] == {}
+        env.close()
+
+
+def test_velocity_in_target_frame_uses_the_body_com_sensor():
+    """move_in_direction with a spinning robot: obs[16:19] and the velocity reward follow framelinvel at the root body's own COM
+    (jitterbug.xml:121, objtype="body"), GPU vs oracle."""
+    from jitterbug_amd.vec_env import JitterbugVecEnv
+    from oracle import oracle as O
+    P = model.default_params()
+    n = 64
+    rng = np.random.default_rng(2)
+    q = np.tile(model.qpos0(), (n, 1))
+    quat = rng.normal(size=(n, 4)); q[:, 3:7] = quat / np.linalg.norm(quat, axis=1, keepdims=True)
+    v = np.zeros((n, 15)); v[:, :3] = rng.normal(size=(n, 3)) * 0.1; v[:, 3:6] = rng.normal(size=(n, 3)) * 15
+    t = np.stack([np.zeros(n), np.zeros(n), rng.uniform(0, 2 * np.pi, n)], 1)
+    env = JitterbugVecEnv(n, "move_in_direction")
+    env.set_state(q, v, t)
+    og, rg = env.observe()
+    terms = env.reward_terms()
+    differs = 0
+    for i in range(n):
+        oo = O.observation(P, "move_in_direction", q[i], v[i], t[i])
+        np.testing.assert_allclose(og[i], oo, rtol=1e-5, atol=2e-6)
+        assert abs(rg[i] - O.reward(P, "move_in_direction", q[i], v[i], t[i])) < 1e-5
+        assert abs(terms[i, 2] - O.reward_terms(P, q[i], v[i], t[i])["V"]) < 1e-5
+        c, s = np.cos(t[i, 2]), np.sin(t[i, 2])
+        differs += abs(oo[16] - (c * v[i, 0] + s * v[i, 1])) > 1e-2
+    assert differs > n // 2                                # the COM offset matters at these spin rates
+    env.close()

@@ -10,7 +10,8 @@ import pytest
 from jitterbug_amd import heuristic_policies as hp
 from jitterbug_amd import model
 
-GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "policy_golden.json")))["cases"]
+_G = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "policy_golden.json")))
+GOLD, GOLD_KW = _G["cases"], _G["kwargs_cases"]
 
 
 @pytest.mark.parametrize("task", model.TASKS)
@@ -27,6 +28,51 @@ def test_python_policies_match_reference(task):
     for c in cases[:10]:
         ts = TimeStep(StepType.MID, 0.0, 1.0, t.split_observation(np.array(c["obs"])))
         assert hp.POLICIES[task](ts) == pytest.approx(c["action"], abs=1e-15)
+
+
+def test_keyword_arguments_match_reference():
+    """kick_angle / speed / orientation, angle_threshold, angle_to_target (reference heuristic_policies.py:6, 28, 64, 81, 98, 120):
+    golden outputs of the reference functions called WITH those keyword arguments."""
+    from jitterbug_amd.jitterbug import Jitterbug
+    from jitterbug_amd.specs import StepType, TimeStep
+    seen = collections.Counter()
+    for c in GOLD_KW:
+        ts = TimeStep(StepType.MID, 0.0, 1.0, Jitterbug(task=c["task"]).split_observation(np.array(c["obs"])))
+        if c["fn"] == "optimal_orientation_to_move":
+            a, orient = hp.optimal_orientation_to_move(ts, **c["kwargs"])
+            assert a == pytest.approx(c["action"], abs=1e-15) and orient == c["orientation"]
+        else:
+            assert getattr(hp, c["fn"])(ts, **c["kwargs"]) == pytest.approx(c["action"], abs=1e-15), c
+        seen[c["fn"]] += 1
+    assert set(seen) == {"move_forward", "move_in_direction", "move_to_position", "move_to_pose", "face_direction", "optimal_orientation_to_move"}
+    # batch form with the same keyword arguments
+    for c in GOLD_KW:
+        if c["fn"] in ("move_in_direction", "move_to_position", "move_to_pose"):
+            assert hp.policy_batch(c["task"], np.array(c["obs"]), **c["kwargs"]) == pytest.approx(c["action"], abs=1e-15)
+
+
+@pytest.mark.gpu
+def test_device_policy_keyword_arguments():
+    """jb_set_policy_params: the device policy with non-default kick_angle / speed / angle_threshold against the golden vectors."""
+    from jitterbug_amd.vec_env import JitterbugVecEnv
+    n_checked = 0
+    for c in GOLD_KW:
+        if c["fn"] == "move_forward" and c["kwargs"]["orientation"] in ("forward", "backward"):
+            kw = dict(kick_angle=c["kwargs"]["kick_angle"], speed=c["kwargs"]["speed"])
+        elif c["fn"] in ("move_in_direction", "move_to_position", "move_to_pose"):
+            kw = dict(angle_threshold=c["kwargs"]["angle_threshold"])
+        else:
+            continue
+        if n_checked >= 60:
+            break
+        env = JitterbugVecEnv(1, c["task"])
+        env.set_policy_params(**kw)
+        obs = np.array([c["obs"]], dtype=np.float32)
+        exp32 = hp.policy_batch(c["task"], obs.astype(np.float64), **kw)
+        assert abs(env.policy(obs)[0] - exp32[0]) < 2e-6
+        env.close()
+        n_checked += 1
+    assert n_checked == 60
 
 
 @pytest.mark.gpu
