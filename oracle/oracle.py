@@ -22,8 +22,8 @@ OBS_DIM = (15, 16, 19, 18, 19)
 
 
 def build(force=False):
-    src = os.path.join(_HERE, "jb_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("jb_oracle.c", "jb_clearance.c")]
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s"], stdout=subprocess.DEVNULL)
     return _SO
 
@@ -80,6 +80,13 @@ def lib():
         L.jbo_env_set_state.argtypes = [C.c_void_p, _dp, _dp, _dp]
         L.jbo_env_get_counters.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.jbo_env_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
+        L.jbo_pair_clearance.argtypes = [_dp, _dp, C.c_void_p]
+        L.jbo_pair_clearance.restype = C.c_double
+        L.jbo_geom_distance.argtypes = [_dp, _dp, C.c_int, C.c_int]
+        L.jbo_geom_distance.restype = C.c_double
+        L.jbo_num_tested_pairs.argtypes = [_dp]
+        L.jbo_pair_clearance_batch.argtypes = [_dp, C.c_int, C.c_int, _dp, _dp, C.c_void_p, C.c_int]
+        L.jbo_geom_world.argtypes = [_dp, _dp, C.c_int, _dp, _dp, _dp]
         assert L.jbo_debug_size() == C.sizeof(Debug), (L.jbo_debug_size(), C.sizeof(Debug))
         _lib = L
     return _lib
@@ -168,6 +175,32 @@ def reward_terms(P, qpos, qvel, target):
 def tolerance(x, bounds=(0.0, 0.0), margin=0.0, value_at_margin=0.1, sigmoid="gaussian"):
     kind = dict(gaussian=0, cosine=1, linear=2)[sigmoid]
     return lib().jbo_tolerance(float(x), float(bounds[0]), float(bounds[1]), float(margin), float(value_at_margin), kind)
+
+
+def pair_clearance(P, qpos):
+    """Minimum distance over the geom pairs MuJoCo's filters would test (jb_clearance.c).  qpos [16] -> (distance, (gi, gj));
+    qpos [n,16] -> (distances [n], pairs [n,2]); P may be one table or one per row."""
+    P = np.ascontiguousarray(P, dtype=np.float64)
+    q = np.ascontiguousarray(qpos, dtype=np.float64)
+    if q.ndim == 1:
+        pair = np.zeros(2, dtype=np.int32)
+        d = lib().jbo_pair_clearance(_p(P), _p(q), pair.ctypes.data)
+        return d, (int(pair[0]), int(pair[1]))
+    n = q.shape[0]
+    out = np.zeros(n)
+    pairs = np.zeros((n, 2), dtype=np.int32)
+    lib().jbo_pair_clearance_batch(_p(P), int(P.ndim == 2), n, _p(q), _p(out), pairs.ctypes.data, 0)
+    return out, pairs
+
+
+def geom_distance(P, qpos, gi, gj):
+    return lib().jbo_geom_distance(_p(np.ascontiguousarray(P, dtype=np.float64)), _p(np.ascontiguousarray(qpos, dtype=np.float64)), int(gi), int(gj))
+
+
+def geom_world(P, qpos, gi):
+    c, R, s = np.zeros(3), np.zeros(9), np.zeros(3)
+    lib().jbo_geom_world(_p(np.ascontiguousarray(P, dtype=np.float64)), _p(np.ascontiguousarray(qpos, dtype=np.float64)), int(gi), _p(c), _p(R), _p(s))
+    return c, R.reshape(3, 3), s
 
 
 class OracleEnv:

@@ -1,0 +1,96 @@
+"""Geom-geom clearance (oracle/jb_clearance.c).  The reference model gives every jitterbug geom the default contype = conaffinity = 1
+(jitterbug.xml:44-107; only the target opts out, :115-116), so MuJoCo tests every geom pair whose bodies differ and are not
+parent and child.  The HIP kernel and the oracle's substep collide with the floor only; these tests measure the distance that
+leaves - by GJK on the four primitive types - and pin the measuring tool itself against a brute-force surface sampling."""
+import itertools
+
+import numpy as np
+import pytest
+
+from jitterbug_amd import model
+from oracle import oracle as O
+
+
+def _surface(P, q, gi, n=48):
+    c, R, s = O.geom_world(P, q, gi)
+    t = int(P[model.P_GEOM + gi * model.GEOM_STRIDE + model.G_TYPE])
+    if t == model.GEOM_SPHERE:
+        u = np.random.default_rng(0).normal(size=(n * n, 3))
+        pts = u / np.linalg.norm(u, axis=1, keepdims=True) * s[0]
+    elif t == model.GEOM_CYLINDER:
+        th = np.linspace(0, 2 * np.pi, 2 * n, endpoint=False)
+        T, Z = np.meshgrid(th, np.linspace(-s[1], s[1], 4 * n))
+        side = np.stack([s[0] * np.cos(T).ravel(), s[0] * np.sin(T).ravel(), Z.ravel()], 1)
+        T2, R2 = np.meshgrid(th, np.linspace(0, s[0], 8))
+        caps = [np.stack([R2.ravel() * np.cos(T2).ravel(), R2.ravel() * np.sin(T2).ravel(), np.full(T2.size, z)], 1) for z in (-s[1], s[1])]
+        pts = np.concatenate([side] + caps)
+    elif t == model.GEOM_ELLIPSOID:
+        T, Ph = np.meshgrid(np.linspace(0, np.pi, 2 * n), np.linspace(0, 2 * np.pi, 4 * n))
+        pts = np.stack([s[0] * np.sin(T).ravel() * np.cos(Ph).ravel(), s[1] * np.sin(T).ravel() * np.sin(Ph).ravel(), s[2] * np.cos(T).ravel()], 1)
+    else:
+        g = np.linspace(-1, 1, n)
+        A, B = [x.ravel() for x in np.meshgrid(g, g)]
+        faces = []
+        for ax in range(3):
+            o = [i for i in range(3) if i != ax]
+            for sg in (-1, 1):
+                p = np.zeros((A.size, 3)); p[:, ax] = sg; p[:, o[0]] = A; p[:, o[1]] = B
+                faces.append(p * s)
+        pts = np.concatenate(faces)
+    return c + pts @ R.T
+
+
+def test_pairs_tested_are_mujocos_filter(params):
+    """different bodies, not parent and child: 160 of the 231 geom pairs"""
+    bodies = [int(params[model.P_GEOM + g * model.GEOM_STRIDE + model.G_BODY]) for g in range(model.NGEOM)]
+    n = sum(1 for gi, gj in itertools.combinations(range(model.NGEOM), 2)
+            if bodies[gi] != bodies[gj] and model.BODY_PARENT[bodies[gi]] != bodies[gj] and model.BODY_PARENT[bodies[gj]] != bodies[gi])
+    assert n == 160 == O.lib().jbo_num_tested_pairs(O._p(np.ascontiguousarray(params)))
+
+
+def test_gjk_distance_matches_surface_sampling(params):
+    from scipy.spatial import cKDTree
+    rng = np.random.default_rng(1)
+    pairs = [(4, 12), (4, 21), (8, 16), (12, 20), (6, 0), (7, 1), (4, 16), (3, 14), (21, 13), (2, 10)]      # every primitive type on some side
+    for trial in range(3):
+        q = model.qpos0(params)
+        q[7:15] = rng.normal(size=8) * 0.15
+        q[15] = rng.uniform(0, 2 * np.pi)
+        quat = rng.normal(size=4); q[3:7] = quat / np.linalg.norm(quat)
+        for gi, gj in pairs:
+            d_gjk = O.geom_distance(params, q, gi, gj)
+            d_brute = cKDTree(_surface(params, q, gi)).query(_surface(params, q, gj))[0].min()
+            assert d_gjk <= d_brute + 1e-9 and d_brute - d_gjk < 4e-5 + 0.01 * d_brute, (gi, gj, d_gjk, d_brute)   # sampling only over-estimates
+
+
+def test_rest_pose_clearances(params):
+    """At qpos0 the nearest tested pair is upper leg 2 / upper leg 1 (and its mirror 3 / 4), whose shoulder ends sit 2.2 mm apart
+    (jitterbug.xml:55, 83: (0.005, 0.0035, 0.05) vs (0.003, 0.0035, 0.049), radii 0.61 mm): 0.857 mm of air.  The eccentric mass
+    clears the front upper legs by >= 2.7 mm whatever the motor angle."""
+    q = model.qpos0(params)
+    d, pair = O.pair_clearance(params, q)
+    assert pair in ((4, 12), (8, 16)) and d == pytest.approx(8.57e-4, abs=2e-6)
+    assert d < np.hypot(0.002, 0.001) - 2 * 0.00061 + 1e-9          # never more than the end-to-end gap
+    qs = np.tile(q, (720, 1))
+    qs[:, 15] = np.linspace(0, 2 * np.pi, 720, endpoint=False)
+    dm = np.array([min(O.geom_distance(params, qq, g, m) for g in (4, 8, 12, 16) for m in (20, 21)) for qq in qs])
+    assert 2.7e-3 < dm.min() < 3.2e-3
+    # ... but a front shoulder deflected by 0.2 rad does reach it: the measurement can fail, so passing it means something
+    bad = q.copy(); bad[7] = 0.21; bad[15] = 6.07
+    assert O.geom_distance(params, bad, 4, 21) == 0.0
+
+
+def test_oracle_rollout_keeps_every_pair_apart(params):
+    n = 48
+    for regime in ("uniform", "flat_out"):
+        o = O.OracleEnv(n, "move_from_origin", params, seed=3)
+        o.reset()
+        rng = np.random.default_rng(0)
+        worst, max_hinge = 1.0, 0.0
+        for t in range(120):
+            o.step(rng.uniform(-1, 1, n) if regime == "uniform" else np.ones(n))
+            q, _, _ = o.get_state()
+            worst = min(worst, O.pair_clearance(params, q)[0].min())
+            max_hinge = max(max_hinge, np.abs(q[:, 7:15]).max())
+        print(regime, "min pair clearance %.2f mm, max |leg hinge| %.3f rad" % (worst * 1e3, max_hinge))
+        assert worst > 5e-4 and max_hinge < 0.19

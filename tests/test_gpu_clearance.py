@@ -1,0 +1,49 @@
+"""GPU property test for the geom-geom contacts the simulator leaves out: over full-length rollouts of the HIP path
+at BASELINE size, in the regimes where legs are loaded hardest, the minimum distance over every geom pair MuJoCo's filters would
+test (oracle/jb_clearance.c, 160 pairs, exact GJK) must stay positive - then MuJoCo would not have generated a geom-geom contact
+either, and floor-only collision is not an approximation on these trajectories.  Reference: jitterbug.xml:44-107 (every jitterbug
+geom has the default contype/conaffinity), :115-116 (the target geoms are the only opt-outs)."""
+import numpy as np
+import pytest
+
+from jitterbug_amd import model
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("regime", ["uniform", "flat_out_plus", "flat_out_minus", "augmented"])
+def test_no_geom_pair_ever_touches(regime):
+    from jitterbug_amd import augmented_jitterbug as aj
+    from jitterbug_amd.vec_env import JitterbugVecEnv
+    from oracle import oracle as O
+    n, steps, every = 4096, 1000, 4
+    P = model.default_params()
+    kw = {}
+    if regime == "augmented":
+        P = aj.augmented_params(n, seed=11)            # config 5: one perturbed model per env (leg ends move by sigma = 3 mm)
+        kw["params"] = P
+    env = JitterbugVecEnv(n, "move_to_pose", seed=8, **kw)
+    env.reset()
+    rng = np.random.default_rng(5)
+    worst, worst_pair, max_hinge = np.inf, None, 0.0
+    tipped = 0.0
+    for t in range(steps):
+        if regime in ("uniform", "augmented"):
+            a = rng.uniform(-1, 1, size=n).astype(np.float32)
+        else:
+            a = np.full(n, 1.0 if regime == "flat_out_plus" else -1.0, dtype=np.float32)       # about half the robots tip over
+        env.step(a)
+        if t % every == every - 1 or t > steps - 50:
+            q, _, _ = env.get_state()
+            d, pairs = O.pair_clearance(P, q)
+            i = int(d.argmin())
+            if d[i] < worst:
+                worst, worst_pair = float(d[i]), (int(pairs[i, 0]), int(pairs[i, 1]), t, i)
+            max_hinge = max(max_hinge, float(np.abs(q[:, 7:15]).max()))
+            tipped = float(((1 - 2 * (q[:, 4] ** 2 + q[:, 5] ** 2)) < 0.5).mean())
+    env.close()
+    print("%s: min pair clearance %.3f mm (geoms %s), max |leg hinge| %.3f rad, tipped over at the end %.1f %%"
+          % (regime, worst * 1e3, worst_pair, max_hinge, 100 * tipped))
+    assert worst > 0.0, (worst, worst_pair)
+    if regime.startswith("flat_out"):
+        assert tipped > 0.1                              # the regime really has robots lying on their legs
