@@ -26,7 +26,7 @@ using namespace jb;
 
 namespace {
 
-enum RootF : int { RF_P = 0, RF_Q = 3, RF_V = 7, RF_W = 10, RF_PHI = 13, RF_PHID = 14, RF_TURNS = 15, RF_WA = 16, RF_WL = 19, RF_WM = 22, RF_FAIL = 23, RF_TGT = 24, ROOT_F = 27 };
+enum RootF : int { RF_P = 0, RF_Q = 3, RF_V = 7, RF_W = 10, RF_PHI = 13, RF_PHID = 14, RF_TURNS = 15, RF_WA = 16, RF_WL = 19, RF_WM = 22, RF_FAIL = 23, RF_TGT = 24, RF_LO = 27 /*5: low-order words of z and the quaternion*/, ROOT_F = 32 };
 enum LegF : int { LF_TH1 = 0, LF_TH2 = 1, LF_THD1 = 2, LF_THD2 = 3, LF_WJ0 = 4, LF_WJ1 = 5, LEG_F = 6 };
 
 struct KArgs {
@@ -72,6 +72,7 @@ __device__ __forceinline__ void load_state(const KArgs& a, int env, int lane, La
 #pragma unroll
     for (int i = 0; i < 3; i++) { s.wa[i] = r[(RF_WA + i) * N]; s.wl[i] = r[(RF_WL + i) * N]; }
     s.wm = r[RF_WM * N]; s.fail = r[RF_FAIL * N];
+    s.pz_lo = r[(RF_LO + 0) * N]; s.qw_lo = r[(RF_LO + 1) * N]; s.qx_lo = r[(RF_LO + 2) * N]; s.qy_lo = r[(RF_LO + 3) * N]; s.qz_lo = r[(RF_LO + 4) * N];
     const float* l = a.leg + lane;
     const int L = 4 * N;
     s.th1 = l[LF_TH1 * L]; s.th2 = l[LF_TH2 * L]; s.thd1 = l[LF_THD1 * L]; s.thd2 = l[LF_THD2 * L]; s.wj[0] = l[LF_WJ0 * L]; s.wj[1] = l[LF_WJ1 * L];
@@ -86,6 +87,9 @@ __device__ __forceinline__ void store_state(const KArgs& a, int env, int lane, i
                             s.wa[0], s.wa[1], s.wa[2], s.wl[0], s.wl[1], s.wl[2], s.wm, s.fail};
 #pragma unroll
     for (int f = 0; f < 24; f++) if ((f & 3) == leg) r[f * N] = vals[f];
+    const float los[5] = {s.pz_lo, s.qw_lo, s.qx_lo, s.qy_lo, s.qz_lo};
+#pragma unroll
+    for (int f = 0; f < 5; f++) if ((f & 3) == leg) r[(RF_LO + f) * N] = los[f];
 }
 __device__ __forceinline__ void core_from_state(const KArgs& a, int env, const LaneState<float>& s, const float (&c0)[3], EnvCore<float>& e) {
     e.cx = c0[0]; e.cy = c0[1]; e.cz = c0[2];
@@ -95,6 +99,7 @@ __device__ __forceinline__ void core_from_state(const KArgs& a, int env, const L
 }
 __device__ __forceinline__ void state_from_reset(const EnvCore<float>& e, LaneState<float>& s) {
     s.px = e.px; s.py = e.py; s.pz = e.pz; s.qw = e.qw; s.qx = e.qx; s.qy = e.qy; s.qz = e.qz;
+    s.pz_lo = s.qw_lo = s.qx_lo = s.qy_lo = s.qz_lo = 0.f;
     s.vx = s.vy = s.vz = s.wx = s.wy = s.wz = 0.f; s.phi = 0.f; s.phid = 0.f; s.turns = 0.f;
     s.th1 = s.th2 = s.thd1 = s.thd2 = 0.f;
 #pragma unroll
@@ -153,6 +158,7 @@ __global__ __launch_bounds__(64) void jb_step_kernel(KArgs a, const float* __res
     if (grp == 0) load_state(a, env, lane, s);
     else {
         s.px = s.py = s.pz = 0.f; s.qw = 1.f; s.qx = s.qy = s.qz = 0.f; s.vx = s.vy = s.vz = s.wx = s.wy = s.wz = 0.f;
+        s.pz_lo = s.qw_lo = s.qx_lo = s.qy_lo = s.qz_lo = 0.f;
         s.phi = s.phid = s.turns = 0.f; s.th1 = s.th2 = s.thd1 = s.thd2 = 0.f;
         for (int i = 0; i < 3; i++) { s.wa[i] = 0.f; s.wl[i] = 0.f; }
         s.wj[0] = s.wj[1] = 0.f; s.wm = 0.f; s.fail = 0.f;
@@ -168,6 +174,7 @@ __global__ __launch_bounds__(64) void jb_step_kernel(KArgs a, const float* __res
     o.prof = prof_local;
     o.hist = a.wave_stats ? a.wave_stats + (size_t)16 * a.n + (size_t)64 * lblock : nullptr;
 #endif
+    normalise_state(s);          // mj_kinematics normalises the free-joint quaternion; phase C keeps it normalised from here on
 #pragma unroll 1
     for (int k = 0; k < a.substeps; k++) substep<float>(m, scr, s, ctrl, o);
     if (grp != 0) return;                        // helper lanes only take part in the substeps
@@ -184,10 +191,7 @@ __global__ __launch_bounds__(64) void jb_step_kernel(KArgs a, const float* __res
         const unsigned bad = quad_sum_u(fabsf(chk) < 1e30f ? 0u : 1u);
         if (bad) s.fail += 1000.f;
     }
-    {   // trailing mj_step1: derived quantities use the normalised quaternion
-        float n = 1.0f / sqrtf(s.qw * s.qw + s.qx * s.qx + s.qy * s.qy + s.qz * s.qz);
-        s.qw *= n; s.qx *= n; s.qy *= n; s.qz *= n;
-    }
+    // (trailing mj_step1: derived quantities use the normalised quaternion - phase C leaves hi + lo normalised to ~1e-14)
     int sc = a.step_count[env] + 1;
     EnvCore<float> e;
     const float c0[3] = {m.c[LM_C0], m.c[LM_C0 + 1], m.c[LM_C0 + 2]};
@@ -341,6 +345,7 @@ __global__ void jb_export_kernel(KArgs a, double* __restrict__ qpos, double* __r
     if (qpos) {
         double* q = qpos + (size_t)env * 16;
         for (int i = 0; i < 7; i++) q[i] = r[i * N];
+        for (int i = 0; i < 5; i++) q[2 + i] += (double)r[(RF_LO + i) * N];          // height and quaternion are held as hi + lo
         for (int l = 0; l < 4; l++) { q[7 + 2 * l] = a.leg[LF_TH1 * L + env * 4 + l]; q[8 + 2 * l] = a.leg[LF_TH2 * L + env * 4 + l]; }
         q[15] = (double)r[RF_PHI * N] + 6.283185307179586 * (double)r[RF_TURNS * N];
     }
@@ -360,6 +365,7 @@ __global__ void jb_import_kernel(KArgs a, const double* __restrict__ qpos, const
     if (qpos) {
         const double* q = qpos + (size_t)env * 16;
         for (int i = 0; i < 7; i++) r[i * N] = (float)q[i];
+        for (int i = 0; i < 5; i++) r[(RF_LO + i) * N] = (float)(q[2 + i] - (double)(float)q[2 + i]);
         for (int l = 0; l < 4; l++) { a.leg[LF_TH1 * L + env * 4 + l] = (float)q[7 + 2 * l]; a.leg[LF_TH2 * L + env * 4 + l] = (float)q[8 + 2 * l]; }
         double k = floor((q[15] + 3.141592653589793) / 6.283185307179586);
         r[RF_PHI * N] = (float)(q[15] - k * 6.283185307179586); r[RF_TURNS * N] = (float)k;

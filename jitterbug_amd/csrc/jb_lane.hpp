@@ -148,6 +148,19 @@ JB_HD void vsincos_pi(float x, float& s, float& c) {
     c = ((q + 1) & 2) ? -b : b;
 }
 JB_HD void vsincos_pi(double x, double& s, double& c) { s = sin(x); c = cos(x); }
+// products / fused products that the compiler may not re-fuse: the error-free transformations of the compensated position
+// state (jb_sim.hpp, two_sum / sq_err) rely on a*b being rounded exactly once
+#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+JB_HD float vmul_rn(float a, float b) { return __fmul_rn(a, b); }
+JB_HD float vadd_rn(float a, float b) { return __fadd_rn(a, b); }
+#else
+JB_HD float vmul_rn(float a, float b) { volatile float r = a * b; return r; }
+JB_HD float vadd_rn(float a, float b) { volatile float r = a + b; return r; }
+#endif
+JB_HD double vmul_rn(double a, double b) { volatile double r = a * b; return r; }
+JB_HD double vadd_rn(double a, double b) { volatile double r = a + b; return r; }
+JB_HD float vfma(float a, float b, float c) { return fmaf(a, b, c); }
+JB_HD double vfma(double a, double b, double c) { return fma(a, b, c); }
 JB_HD float vfloor(float a) { return floorf(a); }
 JB_HD double vfloor(double a) { return floor(a); }
 
@@ -207,6 +220,9 @@ inline UQuad operator*(const UQuad& a, uint32_t b) { UQuad r; for (int i = 0; i 
 inline UQuad operator+(const UQuad& a, const UQuad& b) { UQuad r; for (int i = 0; i < 4; i++) r.v[i] = a.v[i] + b.v[i]; return r; }
 inline UQuad operator+(const UQuad& a, uint32_t b) { UQuad r; for (int i = 0; i < 4; i++) r.v[i] = a.v[i] + b; return r; }
 #define JB_QUN(name, fn) template <typename T> inline Quad<T> name(const Quad<T>& a) { Quad<T> r; for (int i = 0; i < 4; i++) r.v[i] = fn(a.v[i]); return r; }
+template <typename T> inline Quad<T> vmul_rn(const Quad<T>& a, const Quad<T>& b) { Quad<T> r; for (int i = 0; i < 4; i++) r.v[i] = vmul_rn(a.v[i], b.v[i]); return r; }
+template <typename T> inline Quad<T> vadd_rn(const Quad<T>& a, const Quad<T>& b) { Quad<T> r; for (int i = 0; i < 4; i++) r.v[i] = vadd_rn(a.v[i], b.v[i]); return r; }
+template <typename T> inline Quad<T> vfma(const Quad<T>& a, const Quad<T>& b, const Quad<T>& c) { Quad<T> r; for (int i = 0; i < 4; i++) r.v[i] = vfma(a.v[i], b.v[i], c.v[i]); return r; }
 JB_QUN(vsqrt, vsqrt) JB_QUN(vrcp, vrcp) JB_QUN(vrsqrt, vrsqrt) JB_QUN(vabs, vabs) JB_QUN(vsin, vsin) JB_QUN(vcos, vcos) JB_QUN(vfloor, vfloor)
 #undef JB_QUN
 template <typename T> inline void vsincos_pi(const Quad<T>& x, Quad<T>& s, Quad<T>& c) { for (int i = 0; i < 4; i++) vsincos_pi(x.v[i], s.v[i], c.v[i]); }

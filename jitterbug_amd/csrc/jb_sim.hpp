@@ -228,6 +228,9 @@ template <typename V> JB_HD Mat3<V> quat2mat(const V& w, const V& x, const V& y,
 template <typename V> struct LaneState {
     // replicated in the 4 lanes of a quad
     V px, py, pz, qw, qx, qy, qz;        // root pose (world)
+    V pz_lo, qw_lo, qx_lo, qy_lo, qz_lo; // low-order words of the height and the quaternion: these five are integrated with
+                                         // compensated sums (phase C), so that 50 substeps of fp32 rounding do not move a foot
+                                         // across the floor plane (contact activation is the model's one discontinuity)
     V vx, vy, vz;                        // root linear velocity (world)
     V wx, wy, wz;                        // root angular velocity (body frame)
     V phi, phid, turns;                  // motor angle wrapped to [-pi, pi), rate, whole turns
@@ -768,13 +771,13 @@ template <typename V> struct CylContacts {
     typename lane_traits<V>::mask on[4];
 };
 template <typename V>
-JB_HD void cylinder_floor(const Vec3<V>& c, const Vec3<V>& ax_in, const Vec3<V>& xa, const V& rad, const V& half, const Vec3<V>& nb, const V& pz,
+JB_HD void cylinder_floor(const Vec3<V>& c, const Vec3<V>& ax_in, const Vec3<V>& xa, const V& rad, const V& half, const Vec3<V>& nb, const V& pz, const V& pz_lo,
                           const typename lane_traits<V>::mask& enabled, CylContacts<V>& out) {
     V prj = dot(ax_in, nb);
     auto flip = gt(prj, V(0));
     Vec3<V> ax = v3<V>(sel(flip, -ax_in.x, ax_in.x), sel(flip, -ax_in.y, ax_in.y), sel(flip, -ax_in.z, ax_in.z));
     prj = sel(flip, -prj, prj);
-    V dist0 = pz + dot(c, nb);
+    V dist0 = (pz + dot(c, nb)) + pz_lo;
     Vec3<V> vec = ax * prj - nb;
     V len2 = dot(vec, vec);
     auto degenerate = lt(len2, V(1e-20));
@@ -847,6 +850,40 @@ template <typename V> inline void stats_hist(const SimOpts&, const LaneScratch<V
 #endif
 #endif
 
+// ---- compensated arithmetic for the position state.  two_sum: s + e == a + b exactly (Knuth); the adds are pinned with
+// vadd_rn so that no optimisation re-associates them.
+template <typename V> JB_HD void two_sum(const V a, const V b, V& s, V& e) {      // (by value: callers pass `s` as an input too)
+    s = vadd_rn(a, b);
+    const V bb = vadd_rn(s, -a);
+    e = vadd_rn(vadd_rn(a, -vadd_rn(s, -bb)), vadd_rn(b, -bb));
+}
+// (hi, lo) += d, result renormalised so that hi is the rounding of the sum
+template <typename V> JB_HD void comp_add(V& hi, V& lo, const V& d) {
+    V s, e;
+    two_sum(hi, d, s, e);
+    const V l = lo + e;
+    hi = vadd_rn(s, l);
+    lo = vadd_rn(l, -vadd_rn(hi, -s));
+}
+// |q|^2 - 1 of a quaternion held as hi + lo, to ~1e-14: exact squares (fma residuals) and a compensated sum
+template <typename V> JB_HD V quat_norm_excess(const V (&h)[4], const V (&l)[4]) {
+    V p[4], r[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { p[k] = vmul_rn(h[k], h[k]); r[k] = vfma(h[k], h[k], -p[k]); }
+    V s, e1, e2, e3;
+    two_sum(p[0], p[1], s, e1);
+    two_sum(s, p[2], s, e2);
+    two_sum(s, p[3], s, e3);
+    const V small = ((e1 + e2) + e3) + ((r[0] + r[1]) + (r[2] + r[3])) + V(2) * ((h[0] * l[0] + h[1] * l[1]) + (h[2] * l[2] + h[3] * l[3]));
+    return vadd_rn(s, V(-1)) + small;       // s is within a few ulp of 1: the subtraction is exact
+}
+// q <- q / |q| for |q| = 1 + O(1e-6): first-order correction, applied to the hi/lo pair
+template <typename V> JB_HD void quat_normalise_comp(V (&h)[4], V (&l)[4]) {
+    const V half_eps = V(0.5) * quat_norm_excess(h, l);
+#pragma unroll
+    for (int k = 0; k < 4; k++) comp_add(h[k], l[k], -h[k] * half_eps);
+}
+
 // ----------------------------------------------------------------------------- the substep
 template <typename V>
 JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneState<V>& s, const V& ctrl, const SimOpts& o, const bool xtra, const bool xbody, const Mat3<V>& Rw) {
@@ -899,22 +936,22 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
         //      kinematic quantities are still live)
         if (o.contacts) {
             Vec3<V> foot = a2 + mul(R12, ldv3(m, LM_DFOOT));
-            V fdist = s.pz + dot(foot, nb) - m.c[LM_FOOT_R];
+            V fdist = (s.pz + dot(foot, nb) - m.c[LM_FOOT_R]) + s.pz_lo;
             MK fon = lt(fdist, V(0));
             live_slots |= cand_store(sc, 0, foot - nb * (m.c[LM_FOOT_R] + fdist * V(0.5)), fdist, fon);
             CylContacts<V> lc;
             MK all_on = lt(V(0), V(1));
-            cylinder_floor(a2 + mul(R12, ldv3(m, LM_LC_D)), mul(R12, ldv3(m, LM_LC_AX)), mul(R12, ldv3(m, LM_LC_XA)), m.c[LM_LC_R], m.c[LM_LC_H], nb, s.pz, all_on, lc);
+            cylinder_floor(a2 + mul(R12, ldv3(m, LM_LC_D)), mul(R12, ldv3(m, LM_LC_AX)), mul(R12, ldv3(m, LM_LC_XA)), m.c[LM_LC_R], m.c[LM_LC_H], nb, s.pz, s.pz_lo, all_on, lc);
             live_slots |= cand_store_cyl(sc, 1, lc, all_on);
             MK any_con = mor(fon, lc.on[0]);
             if (xtra) {
                 // every remaining geom of the model against the floor
                 CylContacts<V> cy;
-                cylinder_floor(a1 + mul(R1, ldc3(m, LM_UC_D)), mul(R1, ldc3(m, LM_UC_AX)), mul(R1, ldc3(m, LM_UC_XA)), ldc(m, LM_UC_R), ldc(m, LM_UC_H), nb, s.pz, all_on, cy);
+                cylinder_floor(a1 + mul(R1, ldc3(m, LM_UC_D)), mul(R1, ldc3(m, LM_UC_AX)), mul(R1, ldc3(m, LM_UC_XA)), ldc(m, LM_UC_R), ldc(m, LM_UC_H), nb, s.pz, s.pz_lo, all_on, cy);
                 live_slots |= cand_store_cyl(sc, 5, cy, all_on);
                 any_con = mor(any_con, cy.on[0]);
                 Vec3<V> tip = a1 + mul(R1, ldc3(m, LM_DTIP));
-                V tipd = s.pz + dot(tip, nb) - ldc(m, LM_TIP_R);
+                V tipd = (s.pz + dot(tip, nb) - ldc(m, LM_TIP_R)) + s.pz_lo;
                 live_slots |= cand_store(sc, 9, tip - nb * (ldc(m, LM_TIP_R) + tipd * V(0.5)), tipd, lt(tipd, V(0)));
                 any_con = mor(any_con, lt(tipd, V(0)));
               if (xbody) {
@@ -922,7 +959,7 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
                 MK x_onm = gt(ldc(m, LM_X_ONM), V(0.5));
                 Vec3<V> xc_c = ldc3(m, LM_XC_C), xc_ax = ldc3(m, LM_XC_AX), xc_xa = ldc3(m, LM_XC_XA);
                 cylinder_floor(sel_v3(x_onm, am + mul(Rm, xc_c - am), xc_c), sel_v3(x_onm, mul(Rm, xc_ax), xc_ax), sel_v3(x_onm, mul(Rm, xc_xa), xc_xa),
-                               ldc(m, LM_XC_R), ldc(m, LM_XC_H), nb, s.pz, gt(ldc(m, LM_XC_EN), V(0.5)), cy);
+                               ldc(m, LM_XC_R), ldc(m, LM_XC_H), nb, s.pz, s.pz_lo, gt(ldc(m, LM_XC_EN), V(0.5)), cy);
                 live_slots |= cand_store_cyl(sc, 10, cy, mnot(x_onm));
                 live_slots |= cand_store_cyl(sc, 23, cy, x_onm);
                 any_con = mor(any_con, cy.on[0]);
@@ -939,7 +976,7 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
                     Vec3<V> sz = ldc3(m, LM_XE_S);
                     V iden = vrsqrt(sz.x * sz.x * dl.x * dl.x + sz.y * sz.y * dl.y * dl.y + sz.z * sz.z * dl.z * dl.z);
                     Vec3<V> sup = ec + mul(Re, v3<V>(sz.x * sz.x * dl.x * iden, sz.y * sz.y * dl.y * iden, sz.z * sz.z * dl.z * iden));
-                    V elld = s.pz + dot(sup, nb);
+                    V elld = (s.pz + dot(sup, nb)) + s.pz_lo;
                     MK ellon = mand(gt(ldc(m, LM_XE_EN), V(0.5)), lt(elld, V(0)));
                     Vec3<V> ellx = sup - nb * (elld * V(0.5));
                     live_slots |= cand_store(sc, 14, ellx, elld, mand(ellon, mnot(x_onm)));
@@ -957,7 +994,7 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
                     for (int vtx = 0; vtx < 8; vtx++) {
                         Vec3<V> l = v3<V>((vtx & 1) ? bs.x : -bs.x, (vtx & 2) ? bs.y : -bs.y, (vtx & 4) ? bs.z : -bs.z);
                         Vec3<V> pnt = bc + mul(Rb, l);
-                        V d = s.pz + dot(pnt, nb);
+                        V d = (s.pz + dot(pnt, nb)) + s.pz_lo;
                         MK on = mand(mand(ben, lt(d, V(0))), lt(cnt, V(3.5)));
                         cnt = cnt + sel(on, V(1), V(0));
                         live_slots |= cand_store(sc, 15 + vtx, pnt - nb * (d * V(0.5)), d, on);
@@ -1227,21 +1264,25 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
     s.wx = s.wx + h * yr[0]; s.wy = s.wy + h * yr[1]; s.wz = s.wz + h * yr[2];
     s.vx = s.vx + h * lin.x; s.vy = s.vy + h * lin.y; s.vz = s.vz + h * lin.z;
     s.thd1 = s.thd1 + h * yl[0]; s.thd2 = s.thd2 + h * yl[1]; s.phid = s.phid + h * ym;
-    s.px = s.px + h * s.vx; s.py = s.py + h * s.vy; s.pz = s.pz + h * s.vz;
-    {   // q <- q * exp(h w / 2)
+    s.px = s.px + h * s.vx; s.py = s.py + h * s.vy;
+    comp_add(s.pz, s.pz_lo, h * s.vz);
+    {   // q <- q * exp(h w / 2), as  q + [q (cos a - 1) + (q x-terms) sin(a)/|w|]: the bracket is ~1e-3 |q|, so computing it in
+        // fp32 and adding it to the hi/lo pair with a compensated sum keeps the quaternion to ~1e-11 over a control step
         V wn2 = s.wx * s.wx + s.wy * s.wy + s.wz * s.wz;
         V half = V(0.5) * h;
-        // sin(a)/|w| and cos(a) with a = h|w|/2 (tiny): series in a^2
+        // sin(a)/|w| and cos(a) - 1 with a = h|w|/2 (tiny): series in a^2
         V a2_ = half * half * wn2;
         V sc_ = half * (V(1) + a2_ * (V(-1.0 / 6) + a2_ * (V(1.0 / 120) + a2_ * V(-1.0 / 5040))));
-        V cc = V(1) + a2_ * (V(-0.5) + a2_ * (V(1.0 / 24) + a2_ * V(-1.0 / 720)));
+        V cm1 = a2_ * (V(-0.5) + a2_ * (V(1.0 / 24) + a2_ * V(-1.0 / 720)));
         V dx = s.wx * sc_, dy = s.wy * sc_, dz = s.wz * sc_;
-        V r0 = s.qw * cc - s.qx * dx - s.qy * dy - s.qz * dz;
-        V r1 = s.qw * dx + s.qx * cc + s.qy * dz - s.qz * dy;
-        V r2 = s.qw * dy - s.qx * dz + s.qy * cc + s.qz * dx;
-        V r3 = s.qw * dz + s.qx * dy - s.qy * dx + s.qz * cc;
-        V n = vrsqrt(r0 * r0 + r1 * r1 + r2 * r2 + r3 * r3);
-        s.qw = r0 * n; s.qx = r1 * n; s.qy = r2 * n; s.qz = r3 * n;
+        V qh[4] = {s.qw, s.qx, s.qy, s.qz}, ql[4] = {s.qw_lo, s.qx_lo, s.qy_lo, s.qz_lo};
+        const V d0 = qh[0] * cm1 - qh[1] * dx - qh[2] * dy - qh[3] * dz;
+        const V d1 = qh[0] * dx + qh[1] * cm1 + qh[2] * dz - qh[3] * dy;
+        const V d2 = qh[0] * dy - qh[1] * dz + qh[2] * cm1 + qh[3] * dx;
+        const V d3 = qh[0] * dz + qh[1] * dy - qh[2] * dx + qh[3] * cm1;
+        comp_add(qh[0], ql[0], d0); comp_add(qh[1], ql[1], d1); comp_add(qh[2], ql[2], d2); comp_add(qh[3], ql[3], d3);
+        quat_normalise_comp(qh, ql);          // (mj_kinematics normalises at the start of the next substep: same thing)
+        s.qw = qh[0]; s.qx = qh[1]; s.qy = qh[2]; s.qz = qh[3]; s.qw_lo = ql[0]; s.qx_lo = ql[1]; s.qy_lo = ql[2]; s.qz_lo = ql[3];
     }
     s.th1 = s.th1 + h * s.thd1; s.th2 = s.th2 + h * s.thd2;
     {
@@ -1253,17 +1294,22 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
     JB_PROF_ADD(o, 4);
 }
 
+// mj_kinematics normalises the free-joint quaternion; here once when a state enters the simulator (kernel start, host harness)
+template <typename V> JB_HD void normalise_state(LaneState<V>& s) {
+    V qn = vrsqrt(s.qw * s.qw + s.qx * s.qx + s.qy * s.qy + s.qz * s.qz);       // bring |q| to 1 +- 1e-6 first (an imported state may be far off)
+    V qh[4] = {s.qw * qn, s.qx * qn, s.qy * qn, s.qz * qn}, ql[4] = {s.qw_lo * qn, s.qx_lo * qn, s.qy_lo * qn, s.qz_lo * qn};
+    quat_normalise_comp(qh, ql);
+    quat_normalise_comp(qh, ql);
+    s.qw = qh[0]; s.qx = qh[1]; s.qy = qh[2]; s.qz = qh[3]; s.qw_lo = ql[0]; s.qx_lo = ql[1]; s.qy_lo = ql[2]; s.qz_lo = ql[3];
+}
+
 // One physics substep.  A wave-uniform broadphase decides whether only the foot sphere + lower-leg cylinder can
 // touch the floor (common) or every geom of the model has to be tested (rare).
 template <typename V>
 JB_HD void substep(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneState<V>& s, const V& ctrl, const SimOpts& o) {
     unsigned xt = 0;          // bit 0: some upper leg may touch the floor, bit 1: some root / motor-body geom may
     Mat3<V> Rw;               // root rotation (main lanes): mj_kinematics normalises the quaternion first
-    if (sc.grp == 0) {
-        V qn = vrsqrt(s.qw * s.qw + s.qx * s.qx + s.qy * s.qy + s.qz * s.qz);
-        s.qw = s.qw * qn; s.qx = s.qx * qn; s.qy = s.qy * qn; s.qz = s.qz * qn;
-        Rw = quat2mat(s.qw, s.qx, s.qy, s.qz);
-    }
+    if (sc.grp == 0) Rw = quat2mat(s.qw, s.qx, s.qy, s.qz);      // the quaternion is kept normalised: normalise_state() once per kernel, phase C after every substep
     if (o.contacts && sc.grp == 0) {
         const Vec3<V> nb = v3<V>(Rw.m[6], Rw.m[7], Rw.m[8]);         // floor normal in root coordinates
         // upper leg: sphere around the upper cylinder (+ slack for the shoulder angle)

@@ -75,6 +75,10 @@ typedef struct {
     int nsolve;
     int overflow;
     double resid_max;
+    double margin_min;   /* smallest |distance| of any contact CANDIDATE point (touching or not) seen by collide(): how close the
+                            step came to a contact switching on or off exactly at a substep boundary.  Contact activation is the
+                            one discontinuity of the model (dist < 0, MuJoCo margin 0): a step whose margin_min is below the
+                            position error of an fp32 run can legitimately differ from it by one substep's contact impulse. */
 } jbo_stats;
 
 /* ------------------------------------------------------------------ small math */
@@ -257,7 +261,8 @@ static int add_contact(Contact* c, int n, double dist, const double* pos, int bo
     c[n].body = body; c[n].geom = geom; c[n].slot = slot;
     return n + 1;
 }
-static int collide(const double* P, const Kin* k, int feet_only, Contact* con, int* overflow) {
+#define MARGIN(d) do { double _a = fabs(d); if (_a < *margin) *margin = _a; } while (0)
+static int collide(const double* P, const Kin* k, int feet_only, Contact* con, int* overflow, double* margin) {
     static const double nz[3] = {0, 0, 1};
     int n = 0;
     for (int g = 0; g < JB_NGEOM; g++) {
@@ -272,6 +277,7 @@ static int collide(const double* P, const Kin* k, int feet_only, Contact* con, i
         int n0 = n;
         if (type == JB_GEOM_SPHERE) {
             double dist = c[2] - sz[0];
+            MARGIN(dist);
             if (dist < 0) { for (int i = 0; i < 3; i++) pos[i] = c[i] - nz[i] * (sz[0] + 0.5 * dist); n = add_contact(con, n, dist, pos, b, g, 0); }
         } else if (type == JB_GEOM_ELLIPSOID) {
             /* support point of the ellipsoid in direction -n */
@@ -282,6 +288,7 @@ static int collide(const double* P, const Kin* k, int feet_only, Contact* con, i
             matvec3(sw, Rg, s);
             for (int i = 0; i < 3; i++) sw[i] += c[i];
             double dist = sw[2];
+            MARGIN(dist);
             if (dist < 0) { for (int i = 0; i < 3; i++) pos[i] = sw[i] - nz[i] * 0.5 * dist; n = add_contact(con, n, dist, pos, b, g, 0); }
         } else if (type == JB_GEOM_BOX) {
             int cnt = 0;
@@ -289,6 +296,7 @@ static int collide(const double* P, const Kin* k, int feet_only, Contact* con, i
                 double l[3] = {(v & 1 ? sz[0] : -sz[0]), (v & 2 ? sz[1] : -sz[1]), (v & 4 ? sz[2] : -sz[2])}, vec[3];
                 matvec3(vec, Rg, l);
                 double dist = c[2] + vec[2];
+                MARGIN(dist);
                 if (dist < 0) {
                     for (int i = 0; i < 3; i++) pos[i] = c[i] + vec[i] - nz[i] * 0.5 * dist;
                     n = add_contact(con, n, dist, pos, b, g, cnt); cnt++;
@@ -307,15 +315,18 @@ static int collide(const double* P, const Kin* k, int feet_only, Contact* con, i
             double ax[3] = {axis[0] * sz[1], axis[1] * sz[1], axis[2] * sz[1]};
             prjaxis *= sz[1];
             double d1 = dist0 + prjaxis + prjvec;
+            MARGIN(d1);
             if (d1 < 0) {
                 for (int i = 0; i < 3; i++) pos[i] = c[i] + vec[i] + ax[i] - nz[i] * 0.5 * d1;
                 n = add_contact(con, n, d1, pos, b, g, 0);
                 double d2 = dist0 - prjaxis + prjvec;
+                MARGIN(d2);
                 if (d2 < 0) {
                     for (int i = 0; i < 3; i++) pos[i] = c[i] + vec[i] - ax[i] - nz[i] * 0.5 * d2;
                     n = add_contact(con, n, d2, pos, b, g, 1);
                 }
                 double prjvec1 = -0.5 * prjvec, d3 = dist0 + prjaxis + prjvec1;
+                MARGIN(d3);
                 if (d3 < 0) {
                     double vec1[3];
                     cross3(vec1, vec, ax);
@@ -382,7 +393,9 @@ static void substep(const double* P, double* qpos, double* qvel, double ctrl, co
     memset(qfc, 0, sizeof qfc);
     Contact con[MAXCON];
     int ncon = 0, overflow = 0;
-    if (o->contacts) ncon = collide(P, &k, o->feet_only, con, &overflow);
+    double margin = INFINITY;
+    if (o->contacts) ncon = collide(P, &k, o->feet_only, con, &overflow, &margin);
+    if (st && margin < st->margin_min) st->margin_min = margin;
     if (dbg) { dbg->ncon = ncon; dbg->nrow = 0; memcpy(dbg->M, M, sizeof M); memcpy(dbg->bias, bias, sizeof bias); memcpy(dbg->tau, tau, sizeof tau); }
 
     if (ncon > 0 || dbg) {
@@ -818,6 +831,7 @@ typedef struct {
     double* P;          /* [NPARAM] or [n, NPARAM] */
     double *qpos, *qvel, *target, *warm;
     int *step_count; uint32_t* episode;
+    double* margin;      /* [n]: jbo_stats.margin_min of each env's last control step */
     jbo_stats stats;
 } jbo_env;
 
@@ -832,14 +846,14 @@ jbo_env* jbo_env_create(int n, int task, int random_pose, int nsub, int step_lim
     e->P = malloc(sizeof(double) * np); memcpy(e->P, P, sizeof(double) * np);
     e->qpos = calloc((size_t)n * NQ, sizeof(double)); e->qvel = calloc((size_t)n * NV, sizeof(double));
     e->target = calloc((size_t)n * 3, sizeof(double)); e->warm = calloc((size_t)n * WARM_SIZE, sizeof(double));
-    e->step_count = calloc(n, sizeof(int)); e->episode = calloc(n, sizeof(uint32_t));
+    e->step_count = calloc(n, sizeof(int)); e->episode = calloc(n, sizeof(uint32_t)); e->margin = calloc(n, sizeof(double));
     /* like jb_create: a created env is already in a valid state (reset #0); the first explicit reset is #1 */
     for (int i = 0; i < n; i++) { jbo_reset(envP(e, i), e->task, e->random_pose, e->seed, e->env_offset + (uint64_t)i, 0, e->qpos + (size_t)i * NQ, e->qvel + (size_t)i * NV, e->target + (size_t)i * 3); e->episode[i] = 1; }
     return e;
 }
 void jbo_env_destroy(jbo_env* e) {
     if (!e) return;
-    free(e->P); free(e->qpos); free(e->qvel); free(e->target); free(e->warm); free(e->step_count); free(e->episode); free(e);
+    free(e->P); free(e->qpos); free(e->qvel); free(e->target); free(e->warm); free(e->step_count); free(e->episode); free(e->margin); free(e);
 }
 static void env_reset_one(jbo_env* e, int i) {
     jbo_reset(envP(e, i), e->task, e->random_pose, e->seed, e->env_offset + (uint64_t)i, e->episode[i],
@@ -873,7 +887,9 @@ void jbo_env_step(jbo_env* e, const double* action, double* obs, double* reward,
 #endif
         for (int i = 0; i < e->n; i++) {
             double* qp = e->qpos + (size_t)i * NQ; double* qv = e->qvel + (size_t)i * NV; double* tg = e->target + (size_t)i * 3;
+            st.margin_min = INFINITY;
             jbo_step_physics(envP(e, i), qp, qv, action[i], e->nsub, &e->opts, e->warm + (size_t)i * WARM_SIZE, &st);
+            e->margin[i] = st.margin_min;
             e->step_count[i]++;
             if (reward) reward[i] = jbo_reward(envP(e, i), e->task, qp, qv, tg);
             int d = e->step_count[i] >= e->step_limit;
@@ -910,6 +926,7 @@ void jbo_env_get_counters(const jbo_env* e, int* step_count, uint32_t* episode) 
     if (episode) memcpy(episode, e->episode, sizeof(uint32_t) * e->n);
 }
 void jbo_env_stats(const jbo_env* e, jbo_stats* out) { *out = e->stats; }
+void jbo_env_get_margin(const jbo_env* e, double* out) { memcpy(out, e->margin, sizeof(double) * e->n); }
 int jbo_max_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

@@ -35,7 +35,7 @@ class Opts(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("ncon_last", C.c_int), ("ncon_max", C.c_int), ("sweeps_total", C.c_int), ("sweeps_max", C.c_int),
-                ("nsolve", C.c_int), ("overflow", C.c_int), ("resid_max", C.c_double)]
+                ("nsolve", C.c_int), ("overflow", C.c_int), ("resid_max", C.c_double), ("margin_min", C.c_double)]
 
 
 class Debug(C.Structure):
@@ -80,6 +80,7 @@ def lib():
         L.jbo_env_set_state.argtypes = [C.c_void_p, _dp, _dp, _dp]
         L.jbo_env_get_counters.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.jbo_env_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
+        L.jbo_env_get_margin.argtypes = [C.c_void_p, _dp]
         L.jbo_pair_clearance.argtypes = [_dp, _dp, C.c_void_p]
         L.jbo_pair_clearance.restype = C.c_double
         L.jbo_geom_distance.argtypes = [_dp, _dp, C.c_int, C.c_int]
@@ -255,6 +256,12 @@ class OracleEnv:
         ep = np.zeros(self.n, dtype=np.uint32)
         lib().jbo_env_get_counters(self._h, sc.ctypes.data, ep.ctypes.data)
         return sc, ep
+
+    def margins(self):
+        """Per env: the smallest |distance| of any contact candidate point during the last control step (jbo_stats.margin_min)."""
+        m = np.zeros(self.n)
+        lib().jbo_env_get_margin(self._h, _p(m))
+        return m
 
     def stats(self):
         s = Stats()

@@ -18,6 +18,9 @@ static int run(const double* P, double* qpos, double* qvel, double ctrl, int nsu
     LaneState<V> s;
     s.px = V(T(qpos[0])); s.py = V(T(qpos[1])); s.pz = V(T(qpos[2]));
     s.qw = V(T(qpos[3])); s.qx = V(T(qpos[4])); s.qy = V(T(qpos[5])); s.qz = V(T(qpos[6]));
+    // low-order words of the compensated position state (what jb_set_state imports): value - (double)(T)value
+    auto lo = [](double x) { return V(T(x - (double)T(x))); };
+    s.pz_lo = lo(qpos[2]); s.qw_lo = lo(qpos[3]); s.qx_lo = lo(qpos[4]); s.qy_lo = lo(qpos[5]); s.qz_lo = lo(qpos[6]);
     s.vx = V(T(qvel[0])); s.vy = V(T(qvel[1])); s.vz = V(T(qvel[2]));
     s.wx = V(T(qvel[3])); s.wy = V(T(qvel[4])); s.wz = V(T(qvel[5]));
     double ph = qpos[15], k = std::floor((ph + M_PI) / (2 * M_PI));
@@ -31,6 +34,7 @@ static int run(const double* P, double* qpos, double* qvel, double ctrl, int nsu
     SimOpts o; o.contacts = contacts; o.max_newton = max_newton; o.implicit_damp = implicit_damp; o.rank_one = 1; o.prof = nullptr; o.hist = nullptr;
     V scratch[SC_COUNT];
     LaneScratch<V> sc; sc.p = scratch; sc.stride = 1; sc.grp = 0; sc.ngrp = 1; sc.gstride = 4;
+    normalise_state(s);
     for (int i = 0; i < nsub; i++) {
         // poison the scratch: a substep must not read anything it has not written itself (on the device LDS keeps whatever
         // the previous kernel left there)
@@ -40,8 +44,9 @@ static int run(const double* P, double* qpos, double* qvel, double ctrl, int nsu
     // replicated quantities must agree across the quad
     for (int l = 1; l < 4; l++) if (s.px.v[l] != s.px.v[0] || s.qw.v[l] != s.qw.v[0] || s.wz.v[l] != s.wz.v[0] || s.phid.v[l] != s.phid.v[0]) return -100;
     T n = std::sqrt(s.qw.v[0] * s.qw.v[0] + s.qx.v[0] * s.qx.v[0] + s.qy.v[0] * s.qy.v[0] + s.qz.v[0] * s.qz.v[0]);
-    qpos[0] = s.px.v[0]; qpos[1] = s.py.v[0]; qpos[2] = s.pz.v[0];
-    qpos[3] = s.qw.v[0] / n; qpos[4] = s.qx.v[0] / n; qpos[5] = s.qy.v[0] / n; qpos[6] = s.qz.v[0] / n;
+    qpos[0] = s.px.v[0]; qpos[1] = s.py.v[0]; qpos[2] = (double)s.pz.v[0] + (double)s.pz_lo.v[0];
+    qpos[3] = ((double)s.qw.v[0] + (double)s.qw_lo.v[0]) / n; qpos[4] = ((double)s.qx.v[0] + (double)s.qx_lo.v[0]) / n;
+    qpos[5] = ((double)s.qy.v[0] + (double)s.qy_lo.v[0]) / n; qpos[6] = ((double)s.qz.v[0] + (double)s.qz_lo.v[0]) / n;
     qvel[0] = s.vx.v[0]; qvel[1] = s.vy.v[0]; qvel[2] = s.vz.v[0]; qvel[3] = s.wx.v[0]; qvel[4] = s.wy.v[0]; qvel[5] = s.wz.v[0];
     for (int l = 0; l < 4; l++) { qpos[7 + 2 * l] = s.th1.v[l]; qpos[8 + 2 * l] = s.th2.v[l]; qvel[6 + 2 * l] = s.thd1.v[l]; qvel[7 + 2 * l] = s.thd2.v[l]; }
     qpos[15] = (double)s.phi.v[0] + 2 * M_PI * (double)s.turns.v[0]; qvel[14] = s.phid.v[0];

@@ -2,13 +2,10 @@
 
 Tolerance (north_star: fp64 -> fp32, 1e-4 relative): an observation / reward entry PASSES when
     |gpu - oracle| <= 1e-4 * |oracle| + 1e-6.
-Teacher-forced comparison: every control step the oracle's (qpos, qvel, target) is copied into
-the GPU env, both advance one control step (50 substeps) with the same action.  Contact activation is
-discontinuous, so an env whose foot crosses the floor within fp32 resolution of a substep boundary can differ
-by one substep's contact impulse; and that difference is then amplified by the remaining substeps of the control step.  The tests therefore
-require >= 99.5 % of entries inside the tolerance, at most 0.05 % of entries off by more than 1e-2, and print
-next to it the ORACLE'S OWN sensitivity to rounding its input state to fp32 (what the GPU receives through
-jb_set_state), which shows the same rare outliers and so separates conditioning from kernel error."""
+Teacher-forced comparison: every control step the oracle's (qpos, qvel, target) is copied into the GPU env
+(jb_set_state keeps the fp64 height and quaternion as hi + lo fp32 words), both advance one control step (50 substeps) with the
+same action, over 1000 steps x 64 envs on all five tasks.  What is asserted, and why it is conditioned on the oracle's
+contact-switch margin, is explained above MARGIN_TOL below."""
 import numpy as np
 import pytest
 
@@ -89,51 +86,72 @@ def test_state_roundtrip():
     g.close()
 
 
-def _teacher_forced(task, n, steps, seed, contacts=True):
+# Conditioning of an env-step.  Contact activation (dist < 0, MuJoCo margin 0) is the model's one discontinuity: a candidate point
+# that crosses the floor plane within the POSITION ERROR of an fp32 run at a substep boundary switches on one substep earlier or
+# later than in fp64, and the two runs then differ by one substep's contact impulse (~1e-3 in the velocities) - in ANY fp32
+# implementation, MuJoCo's own included.  The oracle reports how close each env-step came to that (jbo_stats.margin_min: the
+# smallest |distance| of any contact candidate at any of the 50 substep boundaries).  tools/flip_study.py (the kernel source on the
+# host in fp32 vs the oracle) shows every out-of-tolerance env-step has margin < 1e-8 m (10 nm; fp32 resolves the 35 mm body
+# height to 3.7 nm), and none above.  So the protocol asserts the north-star tolerance on EVERY entry of every env-step whose
+# margin is at least MARGIN_TOL, and separately bounds how many env-steps fall below it and the overall fraction.
+MARGIN_TOL = 3e-8       # metres
+
+
+def _teacher_forced(task, n, steps, seed, contacts=True, params=None):
     from oracle import oracle as O
-    g, o = _envs(n, task, seed=seed, auto_reset=False, contacts=contacts)
-    o32 = O.OracleEnv(n, task, model.default_params(), seed=seed, opts=O.default_opts(contacts=int(contacts)))   # oracle fed fp32-rounded states
+    P = model.default_params() if params is None else params
+    per_env = P.ndim == 2
+    from jitterbug_amd.vec_env import JitterbugVecEnv
+    g = JitterbugVecEnv(n, task, seed=seed, auto_reset=False, contacts=contacts, params=P if per_env else None)
+    okw = dict(opts=O.default_opts(contacts=int(contacts)), per_env_model=per_env)
+    o = O.OracleEnv(n, task, P, seed=seed, **okw)
     g.reset(), o.reset()
     rng = np.random.default_rng(seed)
-    ok = tot = okr = big = big32 = ok32 = 0
-    worst = worst32 = 0.0
+    tot = ok = okr = big = 0
+    well_tot = well_ok = well_big = ill_steps = ill_bad_steps = 0
+    worst = worst_well = 0.0
     for t in range(steps):
         a = rng.uniform(-1, 1, size=n)
         q, v, tg = o.get_state()
         g.set_state(q, v, tg)
-        o32.set_state(q.astype(np.float32), v.astype(np.float32), tg.astype(np.float32))
         og, rg, dg, _ = g.step(a)
         oo, ro, do = o.step(a, auto_reset=False)
-        o3, _, _ = o32.step(a.astype(np.float32), auto_reset=False)
+        well = o.margins() >= MARGIN_TOL if contacts else np.ones(n, bool)
         og = og.astype(np.float64)
         w = _within(og, oo)
+        err = np.abs(og - oo)
         ok += w.sum(); tot += w.size
-        ok32 += _within(o3, oo).sum()
         okr += _within(rg.astype(np.float64), ro).sum()
-        big += (np.abs(og - oo) > 1e-2).sum()
-        big32 += (np.abs(o3 - oo) > 1e-2).sum()
-        worst = max(worst, np.abs(og - oo).max())
-        worst32 = max(worst32, np.abs(o3 - oo).max())
+        big += (err > 1e-2).sum()
+        worst = max(worst, err.max())
+        well_tot += w[well].size; well_ok += w[well].sum(); well_big += (err[well] > 1e-2).sum()
+        if well.any():
+            worst_well = max(worst_well, err[well].max())
+        ill_steps += (~well).sum(); ill_bad_steps += (~w[~well].all(axis=1)).sum() if (~well).any() else 0
         assert np.array_equal(dg, do.astype(bool))
     sc, ep, cap = g.counters()
     g.close()
-    return dict(frac=ok / tot, worst=worst, frac_reward=okr / (n * steps), cap=cap.sum(), frac_big=big / tot,
-                oracle_fp32_input=dict(frac=ok32 / tot, worst=worst32, frac_big=big32 / tot))
+    return dict(frac=ok / tot, worst=worst, frac_reward=okr / (n * steps), cap=float(cap.sum()), frac_big=big / tot,
+                well_frac=well_ok / max(well_tot, 1), well_big=int(well_big), worst_well=worst_well,
+                ill_frac=ill_steps / (n * steps), ill_steps=int(ill_steps), ill_bad_steps=int(ill_bad_steps))
 
 
-@pytest.mark.parametrize("task", ["move_from_origin", "move_to_pose", "move_in_direction"])
+@pytest.mark.parametrize("task", model.TASKS)
 def test_step_teacher_forced_contacts(task):
-    r = _teacher_forced(task, 64, 120, seed=3)
+    """SURVEY 8(d) protocol in full: 64 envs x 1000 control steps (one whole episode), every task, teacher-forced."""
+    r = _teacher_forced(task, 64, 1000, seed=3)
     print("teacher-forced", task, r)
-    assert r["frac"] >= 0.995 and r["frac_reward"] >= 0.995
-    assert r["frac_big"] <= 5e-4 and r["worst"] < 0.5
+    assert r["well_frac"] == 1.0 and r["well_big"] == 0, r          # every entry of every well-conditioned env-step within 1e-4 rel + 1e-6
+    assert r["ill_frac"] < 0.015, r                                  # env-steps within 30 nm of a contact switch: ~0.5 %
+    assert r["frac"] >= 0.999 and r["frac_reward"] >= 0.999, r      # overall, ill-conditioned env-steps included (~0.9996)
     assert r["cap"] == 0
 
 
 def test_step_teacher_forced_contacts_off():
-    r = _teacher_forced("move_from_origin", 64, 40, seed=4, contacts=False)
+    """BASELINE configs[1] (contacts off: free-body dynamics): no discontinuity, every entry within tolerance over a whole episode."""
+    r = _teacher_forced("move_from_origin", 64, 1000, seed=4, contacts=False)
     print("teacher-forced contacts off:", r)
-    assert r["frac"] >= 0.9999 and r["worst"] <= 2e-5
+    assert r["frac"] == 1.0 and r["worst"] <= 2e-5, r
 
 
 def test_all_geoms_contact_parity():
@@ -236,28 +254,15 @@ def test_sharding_invariance_and_determinism_full_size():
 
 
 def test_per_env_randomised_models():
-    """BASELINE config 5 semantics: one perturbed model per env (jb_set_model_params with N tables) vs the oracle."""
+    """BASELINE config 5 semantics: one perturbed model per env (jb_set_model_params with N tables) vs the oracle, at a batch that fills
+    whole waves with per-env constant tables in LDS (256 envs = 64 waves of 4), over 200 control steps."""
     from jitterbug_amd import augmented_jitterbug as aj
-    from jitterbug_amd.vec_env import JitterbugVecEnv
-    from oracle import oracle as O
-    n = 50
+    n = 256
     P = aj.augmented_params(n, seed=5)
-    g = JitterbugVecEnv(n, "move_to_pose", seed=6, auto_reset=False, params=P)
-    o = O.OracleEnv(n, "move_to_pose", P, seed=6, per_env_model=True)
-    np.testing.assert_allclose(g.reset(), o.reset(), rtol=2e-6, atol=2e-6)
-    rng = np.random.default_rng(0)
-    ok = tot = 0
-    for t in range(40):
-        a = rng.uniform(-1, 1, size=n)
-        g.set_state(*o.get_state())
-        og, rg, dg, _ = g.step(a)
-        oo, ro, do = o.step(a, auto_reset=False)
-        w = _within(og.astype(np.float64), oo)
-        ok += w.sum(); tot += w.size
-    print("per-env models: frac within tolerance", ok / tot)
-    assert ok / tot >= 0.995
-    # and the shared-model path is unaffected by having used per-env tables on another handle
-    g.close()
+    r = _teacher_forced("move_to_pose", n, 200, seed=6, params=P)
+    print("per-env models:", r)
+    assert r["well_frac"] == 1.0 and r["well_big"] == 0, r
+    assert r["ill_frac"] < 0.02 and r["frac"] >= 0.999, r
 
 
 def test_edge_cases_batch_sizes_and_layouts():
