@@ -80,9 +80,10 @@ def load():
     L.jb_encode_device.argtypes = [vp, fp, fp]
     L.jb_encode.argtypes = [vp, fp, fp]
     L.jb_policy.argtypes = [vp, fp, fp]
-    L.jb_set_policy_params.argtypes = [vp, C.c_float, C.c_float, C.c_float]
-    L.jb_reward_terms.argtypes = [vp, fp]
-    L.jb_reward_terms_device.argtypes = [vp, fp]
+    if os.environ.get("JITTERBUG_HIP_LIB") is None or hasattr(L, "jb_set_policy_params"):     # (an A/B build of an older ABI may lack these)
+        L.jb_set_policy_params.argtypes = [vp, C.c_float, C.c_float, C.c_float]
+        L.jb_reward_terms.argtypes = [vp, fp]
+        L.jb_reward_terms_device.argtypes = [vp, fp]
     L.jb_policy_device.argtypes = [vp, fp, fp]
     L.jb_rollout_policy_device.argtypes = [vp, C.c_int32, fp, fp, u8p]
     L.jb_rollout_policy.argtypes = [vp, C.c_int32, fp, fp]

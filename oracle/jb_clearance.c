@@ -193,6 +193,41 @@ double jbo_pair_clearance(const double* P, const double* qpos, int* pair) {
     if (pair) { pair[0] = bi; pair[1] = bj; }
     return best;
 }
+/* the same restricted to pairs with one geom on a body of mask_a and the other on a body of mask_b (bit b = body b) */
+double jbo_pair_clearance_masked(const double* P, const double* qpos, unsigned mask_a, unsigned mask_b) {
+    Geom g[JB_NGEOM];
+    geoms_world(P, qpos, g);
+    double best = INFINITY;
+    for (int i = 0; i < JB_NGEOM; i++)
+        for (int j = i + 1; j < JB_NGEOM; j++) {
+            int bi = (int)P[JB_P_GEOM + i * JB_GEOM_STRIDE + JB_G_BODY], bj = (int)P[JB_P_GEOM + j * JB_GEOM_STRIDE + JB_G_BODY];
+            if (!pair_tested(bi, bj)) continue;
+            if (!(((mask_a >> bi & 1u) && (mask_b >> bj & 1u)) || ((mask_a >> bj & 1u) && (mask_b >> bi & 1u)))) continue;
+            double dc[3] = {g[i].c[0] - g[j].c[0], g[i].c[1] - g[j].c[1], g[i].c[2] - g[j].c[2]};
+            if (sqrt(dot_(dc, dc)) - g[i].rb - g[j].rb >= best) continue;
+            double d = gjk_distance(&g[i], &g[j]);
+            if (d < best) best = d;
+        }
+    return best;
+}
+/* rest pose, minimum over n_phi motor angles, of the mass-body <-> leg-body clearance: can the eccentric mass turn freely? */
+void jbo_mass_sweep_clearance_batch(const double* P, int per_env_model, int n, int n_phi, double* out) {
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
+    for (int i = 0; i < n; i++) {
+        const double* Pi = per_env_model ? P + (size_t)i * JB_NPARAM : P;
+        double q[JB_NQ] = {0}, best = INFINITY;
+        for (int k = 0; k < 3; k++) q[k] = Pi[JB_P_ROOTPOS0 + k];
+        q[3] = 1.0;
+        for (int a = 0; a < n_phi; a++) {
+            q[15] = 2.0 * M_PI * a / n_phi;
+            double d = jbo_pair_clearance_masked(Pi, q, 1u << 9, 0x1FEu);
+            if (d < best) best = d;
+        }
+        out[i] = best;
+    }
+}
 double jbo_geom_distance(const double* P, const double* qpos, int gi, int gj) {
     Geom g[JB_NGEOM];
     geoms_world(P, qpos, g);

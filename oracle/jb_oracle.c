@@ -936,3 +936,11 @@ int jbo_max_threads(void) {
 }
 
 int jbo_warm_size(void) { return WARM_SIZE; }
+/* size of the OpenMP team for every later parallel region of this library (callers pass the cores they may really use) */
+void jbo_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}

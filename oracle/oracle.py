@@ -21,6 +21,24 @@ TASKS = ("move_from_origin", "face_direction", "move_in_direction", "move_to_pos
 OBS_DIM = (15, 16, 19, 18, 19)
 
 
+def usable_cores():
+    """Host threads this process may really use: the affinity mask capped by the cgroup CPU quota.  (A GPU box shows all of the
+    host's CPUs but hands out a share: an OpenMP team sized by the CPU count would spin on a fraction of that many cores.)"""
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(per) + 0.5)))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, int(q / per + 0.5)))
+        except Exception:
+            pass
+    return n
+
+
 def build(force=False):
     srcs = [os.path.join(_HERE, f) for f in ("jb_oracle.c", "jb_clearance.c")]
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(f) for f in srcs):
@@ -87,8 +105,11 @@ def lib():
         L.jbo_geom_distance.restype = C.c_double
         L.jbo_num_tested_pairs.argtypes = [_dp]
         L.jbo_pair_clearance_batch.argtypes = [_dp, C.c_int, C.c_int, _dp, _dp, C.c_void_p, C.c_int]
+        L.jbo_mass_sweep_clearance_batch.argtypes = [_dp, C.c_int, C.c_int, C.c_int, _dp]
         L.jbo_geom_world.argtypes = [_dp, _dp, C.c_int, _dp, _dp, _dp]
         assert L.jbo_debug_size() == C.sizeof(Debug), (L.jbo_debug_size(), C.sizeof(Debug))
+        L.jbo_set_threads.argtypes = [C.c_int]
+        L.jbo_set_threads(usable_cores())
         _lib = L
     return _lib
 
@@ -190,8 +211,18 @@ def pair_clearance(P, qpos):
     n = q.shape[0]
     out = np.zeros(n)
     pairs = np.zeros((n, 2), dtype=np.int32)
-    lib().jbo_pair_clearance_batch(_p(P), int(P.ndim == 2), n, _p(q), _p(out), pairs.ctypes.data, 0)
+    lib().jbo_pair_clearance_batch(_p(P), int(P.ndim == 2), n, _p(q), _p(out), pairs.ctypes.data, usable_cores())
     return out, pairs
+
+
+def mass_sweep_clearance(P, n_phi=72):
+    """Rest pose, minimum over n_phi motor angles of the distance between the eccentric-mass body's geoms and every leg geom:
+    how freely the mass can turn.  P: one table or [n, NPARAM] -> float or [n]."""
+    P = np.ascontiguousarray(P, dtype=np.float64)
+    n = 1 if P.ndim == 1 else P.shape[0]
+    out = np.zeros(n)
+    lib().jbo_mass_sweep_clearance_batch(_p(P), int(P.ndim == 2), n, int(n_phi), _p(out))
+    return out[0] if P.ndim == 1 else out
 
 
 def geom_distance(P, qpos, gi, gj):
@@ -238,7 +269,7 @@ class OracleEnv:
         obs = np.zeros((self.n, self.D))
         rew = np.zeros(self.n)
         done = np.zeros(self.n, dtype=np.uint8)
-        lib().jbo_env_step(self._h, _p(a), _p(obs), _p(rew), done.ctypes.data, int(auto_reset), int(nthreads))
+        lib().jbo_env_step(self._h, _p(a), _p(obs), _p(rew), done.ctypes.data, int(auto_reset), int(nthreads) if nthreads else usable_cores())
         return obs, rew, done
 
     def get_state(self):

@@ -151,7 +151,7 @@ def test_step_teacher_forced_contacts_off():
     """BASELINE configs[1] (contacts off: free-body dynamics): no discontinuity, every entry within tolerance over a whole episode."""
     r = _teacher_forced("move_from_origin", 64, 1000, seed=4, contacts=False)
     print("teacher-forced contacts off:", r)
-    assert r["frac"] == 1.0 and r["worst"] <= 2e-5, r
+    assert r["frac"] == 1.0 and r["frac_big"] == 0.0, r          # (10 s of free fall: |z| reaches 490 m, so only the relative tolerance is meaningful)
 
 
 def test_all_geoms_contact_parity():
