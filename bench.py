@@ -136,9 +136,8 @@ def main():
         # the handle launches on torch's current stream so torch.cuda.Event brackets exactly these kernels
         env = JitterbugVecEnv(n, task, seed=args.seed, device_id=local_rank, contacts=bool(contacts), env_offset=rank * n, max_newton=args.max_newton, envs_per_wave=args.envs_per_wave, flags=1 if args.no_rank_one else 0,
                               stream=torch.cuda.current_stream(dev).cuda_stream)
-        if args.augmented:
-            from jitterbug_amd.augmented_jitterbug import augmented_params
-            env.set_model_params(augmented_params(n, seed=1000 + rank))
+        if args.augmented:           # BASELINE configs[4]: one randomised model per env, generated on the device (keyed by the global env index)
+            env.randomise_models(seed=1000, min_mass_clearance=1e-3, return_params=False)
         return env
 
     def run(contacts, steps, warmup, gather):

@@ -98,6 +98,41 @@ int jb_get_counters(jb_handle* h, int32_t* step_count /*[N]*/, uint32_t* episode
 /* n_tables is 1 (shared) or N (one table per env); each table is JB_NPARAM doubles (jitterbug_model.h) */
 int jb_set_model_params(jb_handle* h, const double* params, int32_t n_tables);
 
+/* Domain randomisation ON THE DEVICE, one model per environment (reference augment_Jitterbug,
+ * jitterbug_dmc/augmented_jitterbug.py:95-267): per env, Philox draws keyed (cfg.seed, GLOBAL env index, attempt) -> offsets of the
+ * leg ends / motor axis / densities / gear with the reference's distributions -> perturbed geometry, hinge axes recomputed
+ * (:182-186, :212-215) -> geom masses, body COM / inertia, body_invweight0 (what MuJoCo's compiler derives) -> the kernel's lane
+ * constant tables, all in HBM.  The handle then simulates N models (like jb_set_model_params with N tables).
+ *   offsets_in  (host, [N, JB_NOFFSET], nullable): compile THESE offsets instead of drawing (tests; replaying a saved set)
+ *   params_out  (host, [N, JB_NPARAM],  nullable): the compiled parameter tables (5 KB per env: ask only when needed)
+ *   offsets_out (host, [N, JB_NOFFSET], nullable), attempts_out (host, [N], nullable)
+ * cfg.min_mass_clearance > 0 re-draws (attempt 1, 2, ...) any model whose eccentric mass cannot turn at the rest pose without
+ * coming within that distance of a leg: the reference's sigmas produce such robots in 3.6 % of the draws, MuJoCo would simulate a
+ * mass-leg contact there and this simulator collides with the floor only (deviations).  0 keeps every draw. */
+#define JB_NOFFSET 31   /* [global density, coreBody1 density, coreBody2 density | 4 legs x (upper far end xyz, foot end xyz) | motor xyz | gear] */
+#define JB_RND_LEGS 1
+#define JB_RND_MASS 2
+#define JB_RND_CORE1_DENSITY 4
+#define JB_RND_CORE2_DENSITY 8
+#define JB_RND_GLOBAL_DENSITY 16
+#define JB_RND_GEAR 32
+typedef struct jb_randomise_cfg {
+    int32_t  flags;               /* JB_RND_* (reference keyword arguments modify_legs, modify_mass, ...) */
+    int32_t  max_attempts;        /* re-draws allowed per env (0 -> 64) */
+    uint64_t seed;
+    double   sd_legs[3];          /* reference :96  (0.003, 0.003, 0.002) m */
+    double   sd_mass_pos[3];      /* reference :98  (0.0015, 0.002, 0.001) m; y and z are clipped below at -1 mm like the reference */
+    double   sd_core1_density, sd_core2_density, sd_global_density, sd_gear;      /* reference :100-107 */
+    double   min_mass_clearance;  /* metres; <= 0: accept every draw */
+} jb_randomise_cfg;
+int jb_default_randomise_config(jb_randomise_cfg* cfg);
+int jb_randomise_models(jb_handle* h, const jb_randomise_cfg* cfg, const double* offsets_in, double* params_out, double* offsets_out, int32_t* attempts_out);
+/* host-only helpers (no GPU needed): the same native code on ONE model - compile offsets (NULL = nominal) to a parameter table,
+ * the mass-clearance check on a parameter table (returns 1 / 0), and the draw of (seed, env, attempt) */
+int jb_model_compile_host(const double* offsets /*[JB_NOFFSET] nullable*/, int32_t flags, double* params_out /*[JB_NPARAM]*/);
+int jb_model_mass_clearance_ok(const double* params /*[JB_NPARAM]*/, double margin);
+int jb_model_draw_offsets_host(uint64_t seed, uint64_t env, uint32_t attempt, const jb_randomise_cfg* cfg, double* offsets_out /*[JB_NOFFSET]*/);
+
 /* device-buffer entry points (asynchronous on the handle's stream) */
 int jb_reset_device(jb_handle* h, const uint8_t* d_mask /*nullable*/, float* d_obs_out /*nullable*/);
 int jb_step_device(jb_handle* h, const float* d_action, float* d_obs_out, float* d_reward_out, uint8_t* d_done_out);

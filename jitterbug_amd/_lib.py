@@ -14,7 +14,7 @@ JB_OK = 0
 ERR_NAMES = {-1: "JB_E_INVALID", -2: "JB_E_NODEVICE", -3: "JB_E_HIP", -4: "JB_E_MODEL"}
 
 EXPORTS = ["jb_default_config", "jb_create", "jb_destroy", "jb_reset", "jb_step", "jb_observe", "jb_get_state", "jb_set_state",
-           "jb_get_counters", "jb_set_model_params", "jb_policy", "jb_policy_device", "jb_set_policy_params", "jb_reward_terms", "jb_reward_terms_device", "jb_rollout_policy_device", "jb_rollout_policy", "jb_reset_device", "jb_step_device", "jb_step_rows_device", "jb_observe_device", "jb_debug_poison_lds", "jb_set_obs_encoder", "jb_encoded_dim", "jb_encode_device", "jb_encode", "jb_synchronize",
+           "jb_get_counters", "jb_set_model_params", "jb_policy", "jb_policy_device", "jb_set_policy_params", "jb_reward_terms", "jb_reward_terms_device", "jb_default_randomise_config", "jb_randomise_models", "jb_model_compile_host", "jb_model_mass_clearance_ok", "jb_model_draw_offsets_host", "jb_rollout_policy_device", "jb_rollout_policy", "jb_reset_device", "jb_step_device", "jb_step_rows_device", "jb_observe_device", "jb_debug_poison_lds", "jb_set_obs_encoder", "jb_encoded_dim", "jb_encode_device", "jb_encode", "jb_synchronize",
            "jb_stream", "jb_obs_dim", "jb_num_envs", "jb_device_count", "jb_abi_version", "jb_default_model_params", "jb_last_error"]
 
 
@@ -28,6 +28,15 @@ class Config(C.Structure):
                 ("max_newton", C.c_int32), ("use_caller_stream", C.c_int32), ("envs_per_wave", C.c_int32), ("flags", C.c_int32), ("seed", C.c_uint64), ("env_offset", C.c_uint64),
                 ("stream", C.c_void_p)]
 
+
+class RandomiseConfig(C.Structure):
+    _fields_ = [("flags", C.c_int32), ("max_attempts", C.c_int32), ("seed", C.c_uint64), ("sd_legs", C.c_double * 3), ("sd_mass_pos", C.c_double * 3),
+                ("sd_core1_density", C.c_double), ("sd_core2_density", C.c_double), ("sd_global_density", C.c_double), ("sd_gear", C.c_double),
+                ("min_mass_clearance", C.c_double)]
+
+
+NOFFSET = 31
+RND_LEGS, RND_MASS, RND_CORE1_DENSITY, RND_CORE2_DENSITY, RND_GLOBAL_DENSITY, RND_GEAR = 1, 2, 4, 8, 16, 32
 
 _lib = None
 
@@ -87,6 +96,12 @@ def load():
     L.jb_policy_device.argtypes = [vp, fp, fp]
     L.jb_rollout_policy_device.argtypes = [vp, C.c_int32, fp, fp, u8p]
     L.jb_rollout_policy.argtypes = [vp, C.c_int32, fp, fp]
+    if os.environ.get("JITTERBUG_HIP_LIB") is None or hasattr(L, "jb_randomise_models"):
+        L.jb_default_randomise_config.argtypes = [C.POINTER(RandomiseConfig)]
+        L.jb_randomise_models.argtypes = [vp, C.POINTER(RandomiseConfig), dp, dp, dp, vp]
+        L.jb_model_compile_host.argtypes = [dp, C.c_int32, dp]
+        L.jb_model_mass_clearance_ok.argtypes = [dp, C.c_double]
+        L.jb_model_draw_offsets_host.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.POINTER(RandomiseConfig), dp]
     L.jb_synchronize.argtypes = [vp]
     L.jb_stream.argtypes = [vp]
     L.jb_stream.restype = vp

@@ -19,6 +19,8 @@
 #include "../../include/jitterbug_hip.h"
 #include "jb_default_params.h"
 #include "jb_model_build.hpp"
+#include "jb_model_compile.hpp"
+#include "jb_nominal_spec.h"
 #include "jb_sim.hpp"
 #include "jb_task.hpp"
 
@@ -382,6 +384,43 @@ __global__ void jb_import_kernel(KArgs a, const double* __restrict__ qpos, const
     for (int l = 0; l < 4; l++) { a.leg[LF_WJ0 * L + env * 4 + l] = 0.f; a.leg[LF_WJ1 * L + env * 4 + l] = 0.f; }
 }
 
+// ---------------------------------------------------------------------------------------------- domain randomisation (one thread per env)
+static_assert(AO_COUNT == JB_NOFFSET, "offset vector layout: header and compiler disagree");
+struct RndArgs {
+    int n, flags, max_attempts;
+    unsigned long long seed, env_offset;
+    AugSigmas sd;
+    double min_mass_clearance;
+    const JbNominalSpec* spec;            // nominal model, device memory
+    const double* offsets_in;             // [n, AO_COUNT] nullable: use these instead of drawing
+    float* tables;                        // [n, LM_TABLE] lane constant tables (the kernel's per-env model)
+    double* params_out;                   // [n, JB_NPARAM] nullable
+    double* offsets_out;                  // [n, AO_COUNT] nullable
+    int* attempts_out;                    // [n] nullable
+    int* status;                          // [1]: first failure code (0 = ok)
+};
+__global__ __launch_bounds__(64) void jb_randomise_kernel(RndArgs a) {
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= a.n) return;
+    JbNominalSpec S;
+    double P[JB_NPARAM], off[AO_COUNT];
+    int attempt = 0, rc = 0;
+    for (;;) {
+        if (a.offsets_in) for (int i = 0; i < AO_COUNT; i++) off[i] = a.offsets_in[(size_t)env * AO_COUNT + i];
+        else draw_offsets(a.seed, a.env_offset + (unsigned long long)env, (uint32_t)attempt, a.flags, a.sd, off);
+        apply_offsets(*a.spec, a.flags, off, S);
+        rc = compile_model(S, P);
+        attempt++;
+        if (rc == 0 && (a.offsets_in || a.min_mass_clearance <= 0.0 || mass_sweep_clear(P, a.min_mass_clearance))) break;
+        if (a.offsets_in || attempt >= a.max_attempts) { if (rc == 0) rc = -30; break; }      // -30: no acceptable draw within max_attempts
+    }
+    if (rc == 0) rc = build_packed_model<float>(P, a.tables + (size_t)env * LM_TABLE);
+    if (rc != 0) atomicCAS(a.status, 0, rc);
+    if (a.params_out) for (int i = 0; i < JB_NPARAM; i++) a.params_out[(size_t)env * JB_NPARAM + i] = P[i];
+    if (a.offsets_out) for (int i = 0; i < AO_COUNT; i++) a.offsets_out[(size_t)env * AO_COUNT + i] = off[i];
+    if (a.attempts_out) a.attempts_out[env] = attempt;
+}
+
 thread_local std::string g_err;
 int fail(int code, const std::string& msg) { g_err = msg; return code; }
 #define JB_HIP(call)                                                                                     \
@@ -407,6 +446,7 @@ struct jb_handle {
     size_t model_tables;
     EncArgs enc;          // observation encoder (n_layers = 0: none)
     PolicyParams<float> policy;      // keyword arguments of the reference's heuristic policies
+    JbNominalSpec* d_spec;           // nominal (uncompiled) model for the randomiser
     float* d_terms;
     float* d_enc_params; float* d_code;
 };
@@ -421,18 +461,22 @@ struct jb_handle {
 
 static dim3 grid_lanes(int n) { return dim3((unsigned)(((size_t)n * 4 + 63) / 64)); }
 
+static int ensure_model_buffer(jb_handle* h, int n_tables) {
+    if ((size_t)n_tables != h->model_tables) {
+        if (h->d_model) JB_HIP(hipFree(h->d_model));
+        h->d_model = nullptr; h->model_tables = 0;
+        JB_HIP(hipMalloc(&h->d_model, (size_t)n_tables * LM_TABLE * sizeof(float)));
+        h->model_tables = n_tables;
+    }
+    return JB_OK;
+}
 static int upload_model(jb_handle* h, const double* params, int n_tables) {
     std::vector<float> host((size_t)n_tables * LM_TABLE);
     for (int t = 0; t < n_tables; t++) {
         int rc = build_packed_model<float>(params + (size_t)t * JB_NPARAM, host.data() + (size_t)t * LM_TABLE);
         if (rc) return fail(JB_E_MODEL, "parameter table " + std::to_string(t) + " not supported by the kernel (code " + std::to_string(rc) + ")");
     }
-    if ((size_t)n_tables != h->model_tables) {
-        if (h->d_model) JB_HIP(hipFree(h->d_model));
-        h->d_model = nullptr;
-        JB_HIP(hipMalloc(&h->d_model, host.size() * sizeof(float)));
-        h->model_tables = n_tables;
-    }
+    { int rc = ensure_model_buffer(h, n_tables); if (rc) return rc; }
     JB_HIP(hipMemcpyAsync(h->d_model, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
     JB_HIP(hipStreamSynchronize(h->stream));
     h->ka.lane_model = h->d_model;
@@ -546,7 +590,7 @@ int jb_destroy(jb_handle* h) {
     if (!h) return JB_OK;
     hipSetDevice(h->cfg.device_id);
     if (h->stream || !h->own_stream) hipStreamSynchronize(h->stream);
-    void* bufs[] = {h->d_terms, h->d_root, h->d_leg, h->d_model, h->d_step, h->d_episode, h->d_action, h->d_obs, h->d_reward, h->d_done, h->d_mask, h->d_qpos, h->d_qvel, h->d_target, h->d_wave_stats, h->d_enc_params, h->d_code};
+    void* bufs[] = {h->d_terms, h->d_spec, h->d_root, h->d_leg, h->d_model, h->d_step, h->d_episode, h->d_action, h->d_obs, h->d_reward, h->d_done, h->d_mask, h->d_qpos, h->d_qvel, h->d_target, h->d_wave_stats, h->d_enc_params, h->d_code};
     for (void* b : bufs) if (b) hipFree(b);
     if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
     delete h;
@@ -817,6 +861,85 @@ int jb_set_model_params(jb_handle* h, const double* params, int32_t n_tables) {
     if (n_tables != 1 && n_tables != h->cfg.n_envs) return fail(JB_E_INVALID, "n_tables must be 1 or n_envs");
     JB_HIP(hipStreamSynchronize(h->stream));
     return upload_model(h, params, n_tables);
+}
+
+
+int jb_default_randomise_config(jb_randomise_cfg* c) {
+    if (!c) return fail(JB_E_INVALID, "cfg is NULL");
+    std::memset(c, 0, sizeof *c);
+    c->flags = JB_RND_LEGS | JB_RND_MASS;                 // what the reference's training harness switches on (benchmarks/benchmark.py:130-136)
+    c->max_attempts = 64; c->seed = 0;
+    c->sd_legs[0] = 0.003; c->sd_legs[1] = 0.003; c->sd_legs[2] = 0.002;                    // reference augmented_jitterbug.py:96
+    c->sd_mass_pos[0] = 0.0015; c->sd_mass_pos[1] = 0.002; c->sd_mass_pos[2] = 0.001;      // :98
+    c->sd_core1_density = 10.0; c->sd_core2_density = 80.0; c->sd_global_density = 200.0; c->sd_gear = 0.001;     // :100-107
+    c->min_mass_clearance = 0.0;
+    return JB_OK;
+}
+int jb_randomise_models(jb_handle* h, const jb_randomise_cfg* cfg, const double* offsets_in, double* params_out, double* offsets_out, int32_t* attempts_out) {
+    if (!h || !cfg) return fail(JB_E_INVALID, "handle/cfg is NULL");
+    JB_ENTER(h);
+    const size_t N = (size_t)h->cfg.n_envs;
+    JB_HIP(hipStreamSynchronize(h->stream));
+    if (!h->d_spec) {
+        JB_HIP(hipMalloc(&h->d_spec, sizeof(JbNominalSpec)));
+        JB_HIP(hipMemcpy(h->d_spec, &JB_NOMINAL_SPEC, sizeof(JbNominalSpec), hipMemcpyHostToDevice));
+    }
+    { int rc = ensure_model_buffer(h, (int)N); if (rc) return rc; }
+    double *d_off_in = nullptr, *d_par = nullptr, *d_off_out = nullptr; int *d_att = nullptr, *d_status = nullptr;
+    int rc = JB_OK, status = 0;
+    auto cleanup = [&]() { if (d_off_in) hipFree(d_off_in); if (d_par) hipFree(d_par); if (d_off_out) hipFree(d_off_out); if (d_att) hipFree(d_att); if (d_status) hipFree(d_status); };
+#define JB_TRY(call) do { hipError_t _e = (call); if (_e != hipSuccess) { cleanup(); return fail(JB_E_HIP, std::string(#call) + ": " + hipGetErrorString(_e)); } } while (0)
+    JB_TRY(hipMalloc(&d_status, sizeof(int)));
+    JB_TRY(hipMemset(d_status, 0, sizeof(int)));
+    if (offsets_in) { JB_TRY(hipMalloc(&d_off_in, sizeof(double) * N * AO_COUNT)); JB_TRY(hipMemcpy(d_off_in, offsets_in, sizeof(double) * N * AO_COUNT, hipMemcpyHostToDevice)); }
+    if (params_out) JB_TRY(hipMalloc(&d_par, sizeof(double) * N * JB_NPARAM));
+    if (offsets_out) JB_TRY(hipMalloc(&d_off_out, sizeof(double) * N * AO_COUNT));
+    if (attempts_out) JB_TRY(hipMalloc(&d_att, sizeof(int) * N));
+    RndArgs a;
+    a.n = (int)N; a.flags = cfg->flags; a.max_attempts = cfg->max_attempts > 0 ? cfg->max_attempts : 64;
+    a.seed = cfg->seed; a.env_offset = h->cfg.env_offset;
+    for (int i = 0; i < 3; i++) { a.sd.legs[i] = cfg->sd_legs[i]; a.sd.mass_pos[i] = cfg->sd_mass_pos[i]; }
+    a.sd.core1_density = cfg->sd_core1_density; a.sd.core2_density = cfg->sd_core2_density; a.sd.global_density = cfg->sd_global_density; a.sd.gear = cfg->sd_gear;
+    a.min_mass_clearance = cfg->min_mass_clearance;
+    a.spec = h->d_spec; a.offsets_in = d_off_in; a.tables = h->d_model; a.params_out = d_par; a.offsets_out = d_off_out; a.attempts_out = d_att; a.status = d_status;
+    hipLaunchKernelGGL(jb_randomise_kernel, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, h->stream, a);
+    JB_TRY(hipGetLastError());
+    JB_TRY(hipStreamSynchronize(h->stream));
+    JB_TRY(hipMemcpy(&status, d_status, sizeof(int), hipMemcpyDeviceToHost));
+    if (params_out) JB_TRY(hipMemcpy(params_out, d_par, sizeof(double) * N * JB_NPARAM, hipMemcpyDeviceToHost));
+    if (offsets_out) JB_TRY(hipMemcpy(offsets_out, d_off_out, sizeof(double) * N * AO_COUNT, hipMemcpyDeviceToHost));
+    if (attempts_out) JB_TRY(hipMemcpy(attempts_out, d_att, sizeof(int) * N, hipMemcpyDeviceToHost));
+#undef JB_TRY
+    cleanup();
+    if (status != 0) {
+        // leave the handle on the nominal shared model rather than on partly written tables
+        upload_model(h, JB_DEFAULT_PARAMS, 1);
+        return fail(JB_E_MODEL, status == -30 ? "randomise: no draw cleared min_mass_clearance within max_attempts for some env" : "randomise: a generated model is not supported by the kernel (code " + std::to_string(status) + ")");
+    }
+    h->ka.lane_model = h->d_model;
+    h->ka.per_env_model = 1;
+    return rc;
+}
+// host-only helpers (no GPU): the native compiler / validity check on ONE model - what the device kernel runs per env
+int jb_model_compile_host(const double* offsets, int32_t flags, double* params_out) {
+    if (!params_out) return fail(JB_E_INVALID, "params_out is NULL");
+    JbNominalSpec S;
+    double zero[AO_COUNT] = {0};
+    apply_offsets(JB_NOMINAL_SPEC, offsets ? flags : 0, offsets ? offsets : zero, S);
+    const int rc = compile_model(S, params_out);
+    return rc ? fail(JB_E_MODEL, "model does not compile (code " + std::to_string(rc) + ")") : JB_OK;
+}
+int jb_model_mass_clearance_ok(const double* params, double margin) {
+    if (!params) return fail(JB_E_INVALID, "params is NULL");
+    return mass_sweep_clear(params, margin) ? 1 : 0;
+}
+int jb_model_draw_offsets_host(uint64_t seed, uint64_t env, uint32_t attempt, const jb_randomise_cfg* cfg, double* offsets_out) {
+    if (!cfg || !offsets_out) return fail(JB_E_INVALID, "cfg/offsets_out is NULL");
+    AugSigmas sd;
+    for (int i = 0; i < 3; i++) { sd.legs[i] = cfg->sd_legs[i]; sd.mass_pos[i] = cfg->sd_mass_pos[i]; }
+    sd.core1_density = cfg->sd_core1_density; sd.core2_density = cfg->sd_core2_density; sd.global_density = cfg->sd_global_density; sd.gear = cfg->sd_gear;
+    draw_offsets(seed, env, attempt, cfg->flags, sd, offsets_out);
+    return JB_OK;
 }
 
 }  // extern "C"

@@ -9,14 +9,14 @@
 namespace jb {
 
 // returns 0 on success, <0 when the table asks for something the kernel does not implement
-template <typename T> inline int build_lane_model(const double* P, int leg, T* out) {
+template <typename T> JB_HD int build_lane_model(const double* P, int leg, T* out) {
     for (int i = 0; i < LM_COUNT; i++) out[i] = T(0);
     auto body = [&](int b) { return P + JB_P_BODY + b * JB_BODY_STRIDE; };
     auto hinge = [&](int h) { return P + JB_P_HINGE + h * JB_HINGE_STRIDE; };
     auto geom = [&](int g) { return P + JB_P_GEOM + g * JB_GEOM_STRIDE; };
     auto put3 = [&](int at, const double* v) { for (int i = 0; i < 3; i++) out[at + i] = T(v[i]); };
     auto put3d = [&](int at, const double* v, const double* ref) { for (int i = 0; i < 3; i++) out[at + i] = T(v[i] - ref[i]); };
-    auto norm3d = [&](const double* v, const double* ref) { double s = 0; for (int i = 0; i < 3; i++) s += (v[i] - ref[i]) * (v[i] - ref[i]); return std::sqrt(s); };
+    auto norm3d = [&](const double* v, const double* ref) { double s = 0; for (int i = 0; i < 3; i++) s += (v[i] - ref[i]) * (v[i] - ref[i]); return sqrt(s); };
     const double zero3[3] = {0, 0, 0};
 
     const double h = P[JB_P_TIMESTEP];
@@ -31,7 +31,7 @@ template <typename T> inline int build_lane_model(const double* P, int leg, T* o
     if (!(P[JB_P_SOLIMP + 3] > 0.0 && P[JB_P_SOLIMP + 3] < 1.0)) return -6;      // midpoint must lie inside (0, 1)
     out[LM_IMP_IMID] = T(1.0 / P[JB_P_SOLIMP + 3]); out[LM_IMP_I1MID] = T(1.0 / (1.0 - P[JB_P_SOLIMP + 3]));
     if (P[JB_P_SOLIMP + 4] != 2.0) return -2;
-    out[LM_MU] = T(P[JB_P_FRICTION] * std::sqrt(1.0 / P[JB_P_IMPRATIO]));
+    out[LM_MU] = T(P[JB_P_FRICTION] * sqrt(1.0 / P[JB_P_IMPRATIO]));
     out[LM_FR2] = T(P[JB_P_FRICTION] * P[JB_P_FRICTION]);
     out[LM_GEAR] = T(P[JB_P_GEAR]); out[LM_GAIN] = T(P[JB_P_GAIN]);
     put3(LM_BIAS, P + JB_P_BIASPRM);
@@ -79,7 +79,7 @@ template <typename T> inline int build_lane_model(const double* P, int leg, T* o
     // broadphase sphere of the upper leg: centre = upper cylinder centre; the knee tip sits at the cylinder's far end
     put3(LM_BS_LEG_C, gu + JB_G_CENTER);
     {
-        double rc = std::sqrt(gu[JB_G_SIZE] * gu[JB_G_SIZE] + gu[JB_G_SIZE + 1] * gu[JB_G_SIZE + 1]);
+        double rc = sqrt(gu[JB_G_SIZE] * gu[JB_G_SIZE] + gu[JB_G_SIZE + 1] * gu[JB_G_SIZE + 1]);
         double rt = norm3d(gt + JB_G_CENTER, gu + JB_G_CENTER) + gt[JB_G_SIZE];
         double slack = 0.3 * norm3d(gu + JB_G_CENTER, a1) + 1e-3;      // the centre moves with the shoulder angle (|th1| <= 0.3 here)
         out[LM_BS_LEG_R] = T((rc > rt ? rc : rt) + slack);
@@ -102,7 +102,7 @@ template <typename T> inline int build_lane_model(const double* P, int leg, T* o
         put_cyl(LM_XC_C, LM_XC_AX, LM_XC_XA, LM_XC_R, LM_XC_H, g, zero3);
         (void)ref;
         for (int i = 0; i < 3; i++) xs_c[xs_n][i] = g[JB_G_CENTER + i];
-        xs_r[xs_n++] = std::sqrt(g[JB_G_SIZE] * g[JB_G_SIZE] + g[JB_G_SIZE + 1] * g[JB_G_SIZE + 1]);
+        xs_r[xs_n++] = sqrt(g[JB_G_SIZE] * g[JB_G_SIZE] + g[JB_G_SIZE + 1] * g[JB_G_SIZE + 1]);
     };
     auto put_ell = [&](const double* g, const double* ref) {
         out[LM_XE_EN] = T(1); put3(LM_XE_C, g + JB_G_CENTER);
@@ -168,7 +168,7 @@ template <typename T> inline int build_lane_model(const double* P, int leg, T* o
             if (!(bx[12] > T(0))) continue;
             double dc = 0, dh = 0;
             for (int i = 0; i < 3; i++) { dc += ((double)bx[i] - sc[i]) * ((double)bx[i] - sc[i]); dh += (double)bx[12 + i] * (double)bx[12 + i]; }
-            double rr = std::sqrt(dc) + std::sqrt(dh);
+            double rr = sqrt(dc) + sqrt(dh);
             if (rr > sr) sr = rr;
         }
         for (int i = 0; i < 3; i++) out[LM_BS_BODY_C + i] = T(sc[i]);
@@ -179,7 +179,7 @@ template <typename T> inline int build_lane_model(const double* P, int leg, T* o
 
 // the packed table of one env (LM_TABLE entries: jb_sim.hpp LM_INV): <0 when unsupported, -50 if an entry that is stored
 // once differs between the legs (a bug in the table layout, not in the model)
-template <typename T> inline int build_packed_model(const double* P, T* out) {
+template <typename T> JB_HD int build_packed_model(const double* P, T* out) {
     T tmp[4][LM_COUNT];
     for (int leg = 0; leg < 4; leg++) { int rc = build_lane_model<T>(P, leg, tmp[leg]); if (rc) return rc; }
     for (int i = 0; i < LM_INV; i++) {

@@ -150,6 +150,40 @@ class JitterbugVecEnv:
         self._params = p.reshape(n_tables, model.NPARAM).copy()
         self.state_version += 1
 
+    def randomise_models(self, seed=0, modify_legs=True, modify_mass=True, modify_coreBody1=False, modify_coreBody2=False,
+                         modify_global_density=False, modify_gear=False, sd_legs=None, sd_mass_pos=None, min_mass_clearance=0.0,
+                         offsets=None, return_params=None, return_offsets=False):
+        """One randomised model per env, generated ON THE GPU (jb_randomise_models; reference augment_Jitterbug's keyword arguments,
+        augmented_jitterbug.py:95-107).  `offsets` [N, 31]: compile these instead of drawing.  Returns a dict with 'attempts' and,
+        when asked for, 'params' [N, NPARAM] / 'offsets' [N, 31] (params are fetched by default up to 8192 envs: the Physics
+        accessors of a per-env model read them)."""
+        cfg = _lib.RandomiseConfig()
+        _lib.check(self._L.jb_default_randomise_config(C.byref(cfg)))
+        cfg.flags = ((_lib.RND_LEGS if modify_legs else 0) | (_lib.RND_MASS if modify_mass else 0) | (_lib.RND_CORE1_DENSITY if modify_coreBody1 else 0)
+                     | (_lib.RND_CORE2_DENSITY if modify_coreBody2 else 0) | (_lib.RND_GLOBAL_DENSITY if modify_global_density else 0) | (_lib.RND_GEAR if modify_gear else 0))
+        cfg.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        cfg.min_mass_clearance = float(min_mass_clearance)
+        if sd_legs is not None:
+            cfg.sd_legs[:] = [float(x) for x in sd_legs]
+        if sd_mass_pos is not None:
+            cfg.sd_mass_pos[:] = [float(x) for x in sd_mass_pos]
+        n = self.num_envs
+        if return_params is None:
+            return_params = n <= 8192
+        off_in = None if offsets is None else np.ascontiguousarray(np.asarray(offsets, dtype=np.float64).reshape(n, _lib.NOFFSET))
+        par = np.zeros((n, model.NPARAM)) if return_params else None
+        off = np.zeros((n, _lib.NOFFSET)) if return_offsets else None
+        att = np.zeros(n, dtype=np.int32)
+        _lib.check(self._L.jb_randomise_models(self._h, C.byref(cfg), _lib.ptr(off_in), _lib.ptr(par), _lib.ptr(off), _lib.ptr(att)))
+        self._params = par
+        self.state_version += 1
+        out = dict(attempts=att)
+        if return_params:
+            out["params"] = par
+        if return_offsets:
+            out["offsets"] = off
+        return out
+
     def model_params(self, index=0):
         """The parameter table (float64[NPARAM]) env `index` is simulated with."""
         if self._params is None:

@@ -1,0 +1,166 @@
+"""Native model compiler / domain randomiser (csrc/jb_model_compile.hpp) against its golden-checked Python
+definition: jitterbug_amd.augmented_jitterbug.augment_spec (same draw order as the reference's augment_Jitterbug,
+augmented_jitterbug.py:95-267, pinned by tests/golden/augment_golden.json) + jitterbug_amd.model.compile_spec."""
+import numpy as np
+import pytest
+
+from jitterbug_amd import _lib, model
+from jitterbug_amd import augmented_jitterbug as aj
+
+ALL = dict(modify_legs=True, modify_mass=True, modify_coreBody1=True, modify_coreBody2=True, modify_global_density=True, modify_gear=True)
+COMBOS = [dict(), dict(modify_legs=True), dict(modify_mass=True), dict(modify_legs=True, modify_mass=True), dict(modify_coreBody1=True, modify_gear=True), ALL]
+
+
+def _native(off, flags):
+    P = np.zeros(model.NPARAM)
+    o = None if off is None else np.ascontiguousarray(off, dtype=np.float64)
+    assert _lib.load().jb_model_compile_host(_lib.ptr(o), aj.flags_of(**flags), _lib.ptr(P)) == 0
+    return P
+
+
+def _close(a, b):
+    return np.abs(a - b) <= 1e-9 * np.abs(b) + 1e-30 + 1e-12 * np.abs(b).max() * 0
+
+
+def test_offsets_replay_equals_the_reference_ordered_draws():
+    """draw_offsets consumes the generator exactly like augment_spec (the golden-checked twin of the reference function), and
+    apply_offsets(draw_offsets(rng)) reproduces augment_spec(rng) bit for bit - for every flag combination."""
+    for k, flags in enumerate(COMBOS):
+        rng = np.random.RandomState(100 + k)
+        st = rng.get_state()
+        off = aj.draw_offsets(rng, **flags)
+        after_draw = rng.normal()
+        rng.set_state(st)
+        spec = aj.augment_spec(None, rng, **flags)
+        assert rng.normal() == after_draw                                # same number of draws consumed
+        assert np.array_equal(model.compile_spec(spec), model.compile_spec(aj.apply_offsets(off, **flags)))
+        assert off.shape == (aj.NOFFSET,) and (np.count_nonzero(off) > 0) == bool(flags)
+
+
+def test_native_compiler_equals_python_compile_spec():
+    np.testing.assert_allclose(_native(None, {}), model.default_params(), rtol=1e-8, atol=1e-30)       # nominal model (invweight: Cholesky vs inv)
+    worst = 0.0
+    for k, flags in enumerate(COMBOS):
+        rng = np.random.RandomState(7 + k)
+        for _ in range(6):
+            off = aj.draw_offsets(rng, **flags)
+            ref = model.compile_spec(aj.apply_offsets(off, **flags))
+            got = _native(off, flags)
+            scale = np.abs(ref) + 1e-12 * (np.abs(ref) > 0) + (ref == 0) * 1e-18
+            worst = max(worst, (np.abs(got - ref) / scale).max())
+    assert worst < 1e-8, worst
+
+
+def test_mass_clearance_check_against_exact_gjk_sweep():
+    """The generator's validity check (can the eccentric mass turn?) is conservative with respect to the oracle's exact GJK sweep,
+    and rejects little more than it must."""
+    from oracle import oracle as O
+    P = aj.augmented_params(700, seed=12)
+    sweep = O.mass_sweep_clearance(P, 144)
+    assert 0.02 < (sweep <= 0).mean() < 0.06                                  # the reference's sigmas: ~3.6 % cannot turn the mass
+    for margin in (0.0, 1e-3):
+        ok = np.array([aj.mass_clearance_ok(p, margin) for p in P])
+        assert sweep[ok].min() >= margin - 1e-5                                # never accepts a model that comes closer
+        assert ((~ok) & (sweep > margin + 3e-4)).sum() == 0                    # never rejects one that clears it by 0.3 mm more
+    assert aj.mass_clearance_ok(model.default_params(), 2.5e-3) and not aj.mass_clearance_ok(model.default_params(), 3.2e-3)   # nominal: 2.99 mm
+    # host generator with the option: every model clears the margin
+    Q = aj.augmented_params(40, seed=3, min_mass_clearance=1e-3)
+    assert O.mass_sweep_clearance(Q, 144).min() >= 1e-3 - 1e-5
+
+
+def test_native_draws_have_the_reference_distributions():
+    L = _lib.load()
+    cfg = _lib.RandomiseConfig()
+    assert L.jb_default_randomise_config(cfg) == 0
+    assert (cfg.flags, list(cfg.sd_legs), list(cfg.sd_mass_pos)) == (3, [0.003, 0.003, 0.002], [0.0015, 0.002, 0.001])       # reference :96, :98
+    cfg.flags = 63
+    n = 20000
+    off = np.zeros((n, aj.NOFFSET))
+    for i in range(n):
+        assert L.jb_model_draw_offsets_host(5, i, 0, cfg, _lib.ptr(off[i])) == 0
+    sd = np.array([200.0, 10.0, 80.0] + [0.003, 0.003, 0.002] * 8 + [0.0015, 0.002, 0.001, 0.001])
+    z = off / sd
+    unclipped = [i for i in range(aj.NOFFSET) if i not in (28, 29)]
+    assert np.abs(z[:, unclipped].mean(0)).max() < 4 / np.sqrt(n) and np.abs(z[:, unclipped].std(0) - 1).max() < 0.03
+    assert np.abs(np.corrcoef(z[:, unclipped].T) - np.eye(len(unclipped))).max() < 0.04
+    assert off[:, 28].min() == -0.001 and off[:, 29].min() == -0.001 and off[:, 28].max() > 0.004          # clipped below only (reference :219-221)
+    assert abs((off[:, 28] == -0.001).mean() - 0.3085) < 0.012 and abs((off[:, 29] == -0.001).mean() - 0.1587) < 0.01   # P(N < -sd/2), P(N < -sd)
+    # keyed by (seed, env, attempt): reproducible, and every key gives another draw
+    a, b, c, d = (np.zeros(aj.NOFFSET) for _ in range(4))
+    L.jb_model_draw_offsets_host(5, 17, 0, cfg, _lib.ptr(a)); L.jb_model_draw_offsets_host(5, 17, 0, cfg, _lib.ptr(b))
+    L.jb_model_draw_offsets_host(5, 17, 1, cfg, _lib.ptr(c)); L.jb_model_draw_offsets_host(6, 17, 0, cfg, _lib.ptr(d))
+    assert np.array_equal(a, b) and np.array_equal(a, off[17]) and not np.array_equal(a, c) and not np.array_equal(a, d)
+
+
+# ----------------------------------------------------------------------------------------------- on the GPU
+@pytest.mark.gpu
+def test_device_compiler_matches_python_on_given_offsets_and_steps_like_the_oracle():
+    """jb_randomise_models(offsets_in): the DEVICE compiles exactly the tables model.compile_spec derives from the same offsets, and
+    the kernel then simulates those N models like the oracle does (teacher-forced)."""
+    from jitterbug_amd.vec_env import JitterbugVecEnv
+    from oracle import oracle as O
+    n = 96
+    rng = np.random.RandomState(4)
+    flags = dict(modify_legs=True, modify_mass=True, modify_coreBody1=True, modify_gear=True)
+    offs = np.stack([aj.draw_offsets(rng, **flags) for _ in range(n)])
+    ref = np.stack([model.compile_spec(aj.apply_offsets(o, **flags)) for o in offs])
+    env = JitterbugVecEnv(n, "move_to_pose", seed=6, auto_reset=False)
+    out = env.randomise_models(offsets=offs, return_offsets=True, **flags)
+    assert np.array_equal(out["offsets"], offs) and (out["attempts"] == 1).all()
+    np.testing.assert_allclose(out["params"], ref, rtol=1e-8, atol=1e-30)
+    o = O.OracleEnv(n, "move_to_pose", ref, seed=6, per_env_model=True)
+    np.testing.assert_allclose(env.reset(), o.reset(), rtol=2e-6, atol=2e-6)
+    rs = np.random.default_rng(0)
+    bad = tot = 0
+    for t in range(30):
+        a = rs.uniform(-1, 1, size=n)
+        env.set_state(*o.get_state())
+        og, _, _, _ = env.step(a)
+        oo, _, _ = o.step(a, auto_reset=False)
+        well = o.margins() >= 3e-8
+        w = np.abs(og - oo) <= 1e-4 * np.abs(oo) + 1e-6
+        bad += (~w[well]).sum(); tot += w[well].size
+    assert bad == 0 and tot > 0.97 * 30 * n * 19
+    env.close()
+
+
+@pytest.mark.gpu
+def test_device_randomiser_at_config5_size():
+    """BASELINE config 5 (65 536 envs, one model each): generated in HBM in well under a second, reproducible, independent of how the
+    batch is split over ranks, with the reference's distributions; with min_mass_clearance every model can turn its mass."""
+    import time
+    from jitterbug_amd.vec_env import JitterbugVecEnv
+    from oracle import oracle as O
+    n = 65536
+    env = JitterbugVecEnv(n, "move_to_pose", seed=1)
+    env.randomise_models(seed=9, return_params=False)                              # warm-up (module load)
+    t0 = time.perf_counter()
+    out = env.randomise_models(seed=9, return_params=False, return_offsets=True)
+    dt = time.perf_counter() - t0
+    print("jb_randomise_models: %d models in %.3f s" % (n, dt))
+    assert dt < 1.0
+    off = out["offsets"]
+    sd = np.array([0.003, 0.003, 0.002] * 8 + [0.0015])
+    z = off[:, 3:28] / sd
+    assert np.abs(z.mean(0)).max() < 0.02 and np.abs(z.std(0) - 1).max() < 0.02 and (off[:, [0, 1, 2, 30]] == 0).all()
+    ob = env.reset()
+    for _ in range(3):
+        ob, rw, dn, _ = env.step(np.full(n, 0.5, dtype=np.float32))
+    assert np.isfinite(ob).all()
+    env.close()
+    # the same global envs from two shards, and again: identical offsets
+    lo = 40000
+    e2 = JitterbugVecEnv(3000, "move_to_pose", seed=1, env_offset=lo)
+    o2 = e2.randomise_models(seed=9, return_offsets=True)
+    assert np.array_equal(o2["offsets"], off[lo:lo + 3000])
+    # ... and the compiled tables are those of the Python definition
+    flags = dict(modify_legs=True, modify_mass=True)
+    for i in (0, 1234, 2999):
+        np.testing.assert_allclose(o2["params"][i], model.compile_spec(aj.apply_offsets(o2["offsets"][i], **flags)), rtol=1e-8, atol=1e-30)
+    # with the validity check: re-draws happen (attempt > 1 for ~14 % of the envs) and every model clears 1 mm
+    o3 = e2.randomise_models(seed=9, min_mass_clearance=1e-3, return_offsets=True)
+    assert 0.08 < (o3["attempts"] > 1).mean() < 0.25
+    same = o3["attempts"] == 1
+    assert np.array_equal(o3["offsets"][same], o2["offsets"][same])               # first draws that were fine are kept
+    assert O.mass_sweep_clearance(o3["params"], 144).min() >= 1e-3 - 1e-5
+    e2.close()
