@@ -89,6 +89,7 @@ def main():
     ap.add_argument("--contacts", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true")
+    ap.add_argument("--no-host-rate", action="store_true", help="skip the host-buffer (jb_step) rate measured next to the headline")
     ap.add_argument("--max-newton", type=int, default=12)
     ap.add_argument("--envs-per-wave", type=int, default=0)
     ap.add_argument("--no-rank-one", action="store_true", help="diagnostic: JB_FLAG_NO_RANK_ONE (every Newton pass is a full pass)")
@@ -132,83 +133,50 @@ def main():
     D = model.OBS_DIM[task]
     K, W = args.steps, args.warmup
 
-    def make_env(contacts):
-        # the handle launches on torch's current stream so torch.cuda.Event brackets exactly these kernels
-        env = JitterbugVecEnv(n, task, seed=args.seed, device_id=local_rank, contacts=bool(contacts), env_offset=rank * n, max_newton=args.max_newton, envs_per_wave=args.envs_per_wave, flags=1 if args.no_rank_one else 0,
-                              stream=torch.cuda.current_stream(dev).cuda_stream)
-        if args.augmented:           # BASELINE configs[4]: one randomised model per env, generated on the device (keyed by the global env index)
-            env.randomise_models(seed=1000, min_mass_clearance=1e-3, return_params=False)
-        return env
-
     def run(contacts, steps, warmup, gather):
-        env = make_env(contacts)
         g = torch.Generator(device=dev)
         g.manual_seed(1234 + rank + 7919 * args.seed)
         actions = torch.rand((steps + warmup, n), generator=g, device=dev, dtype=torch.float32) * 2 - 1
         if args.actions == "const1":
             actions.fill_(1.0)
+        env_kw = dict(contacts=bool(contacts), max_newton=args.max_newton, envs_per_wave=args.envs_per_wave, flags=1 if args.no_rank_one else 0)
+        if gather:
+            # N > 1: the PRODUCT's sharded env (jitterbug_amd/distributed.py), pipelined: the step kernel writes packed rows
+            # [obs | reward | done] itself and rank 0 gathers them every step over RCCL, one step late from a side stream, three row
+            # buffers rotating (see ShardedJitterbugEnv).  Actions are resident on every rank (local_actions).
+            from jitterbug_amd.distributed import ShardedJitterbugEnv
+            sh = ShardedJitterbugEnv(n * world, task, seed=args.seed, device=dev, pipeline_depth=2, **env_kw)
+            env = sh.env
+        else:
+            # the handle launches on torch's current stream so torch.cuda.Event brackets exactly these kernels
+            sh = None
+            env = JitterbugVecEnv(n, task, seed=args.seed, device_id=local_rank, env_offset=rank * n, stream=torch.cuda.current_stream(dev).cuda_stream, **env_kw)
+        if args.augmented:           # BASELINE configs[4]: one randomised model per env, generated on the device (keyed by the global env index)
+            env.randomise_models(seed=1000, min_mass_clearance=1e-3, return_params=False)
         obs = torch.empty((n, D), device=dev, dtype=torch.float32)
         rew = torch.empty((n,), device=dev, dtype=torch.float32)
         done = torch.empty((n,), device=dev, dtype=torch.uint8)
-        # N > 1: the step kernel writes packed rows [obs | reward | done] itself (jb_step_rows_device) and rank 0 gathers them
-        # every step.  Two row buffers alternate so that the gather of step t (on RCCL's stream) overlaps the kernel of step
-        # t+1; a buffer is rewritten only after the gather that read it has been waited for (three buffers with RCCL, so that the
-        # step kernel never waits for the gather issued just before it).
-        nccl = gather and args.dist_backend == "nccl"
-        NB = 3 if nccl else 2                   # row buffers in flight
-        rows = [torch.empty((n, D + 2), device=dev, dtype=torch.float32) for _ in range(NB)] if gather else None
-        stage = [torch.empty((n, D + 2), dtype=torch.float32).pin_memory() for _ in range(2)] if (gather and not nccl) else None
-        gathered = None
-        if gather and rank == 0:
-            gathered = [[torch.empty((n, D + 2), device=dev if nccl else "cpu", dtype=torch.float32) for _ in range(world)] for _ in range(NB)]
-        pending = [None] * NB
         env.reset_device(None, obs.data_ptr())
-
-        # RCCL's gather kernel cannot share a SIMD with a step-kernel wave (one wave per SIMD, ~460 registers), so a gather issued
-        # right behind step t delays the start of step t+1 by its own duration.  It is therefore issued one step LATE, from a
-        # side stream that waits only for step t's event: by then step t+1 occupies the device and the gather runs in its tail,
-        # on the SIMDs whose waves have already finished.
-        side = torch.cuda.Stream(device=dev) if nccl else None
-        step_done = [torch.cuda.Event() for _ in range(NB)] if nccl else None
-        late = [None]                               # index of the step whose rows still have to be sent
-
-        def send(j):
-            b = j % NB
-            with torch.cuda.stream(side):
-                side.wait_event(step_done[b])
-                pending[b] = dist.gather(rows[b], gathered[b] if rank == 0 else None, dst=0, async_op=True)
+        last = [None]
 
         def one(i):
-            if not gather:
+            if sh is None:
                 env.step_device(actions[i].data_ptr(), obs.data_ptr(), rew.data_ptr(), done.data_ptr())
-                return
-            b = i % NB
-            if pending[b] is not None:
-                pending[b].wait()                   # (current stream waits: the buffer is free to be rewritten)
-                pending[b] = None
-            env.step_rows_device(actions[i].data_ptr(), rows[b].data_ptr())
-            if nccl:
-                step_done[b].record()
-                if late[0] is not None:
-                    send(late[0])
-                late[0] = i
-            else:                                   # rehearsal: stage through the host
-                stage[b].copy_(rows[b])
-                dist.gather(stage[b], gathered[b] if rank == 0 else None, dst=0)
+            else:
+                r = sh.step(local_actions=actions[i])
+                if r is not None:
+                    last[0] = r
 
         def drain():
-            if nccl and late[0] is not None:
-                send(late[0])
-                late[0] = None
-            for b in range(NB):
-                if pending[b] is not None:
-                    pending[b].wait()
-                    pending[b] = None
+            if sh is not None:
+                r = sh.flush()
+                if r is not None:
+                    last[0] = r
 
         for i in range(warmup):
             one(i)
         drain()
-        finite_warm = bool(torch.isfinite(rows[(warmup - 1) % NB] if (gather and warmup) else obs).all().item()) if warmup else True
+        finite_warm = bool(torch.isfinite(sh.last_local_rows() if (sh is not None and warmup) else obs).all().item()) if warmup else True
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize(dev)
@@ -225,12 +193,12 @@ def main():
         wall = time.perf_counter() - t0
         dev_ms = ev0.elapsed_time(ev1)
         sc, ep, cap = env.counters()
-        last = rows[(warmup + steps - 1) % NB][:, :D] if gather else obs
-        finite = finite_warm and bool(torch.isfinite(last).all().item())      # checked after the warm-up and after the timed steps
-        finite = finite and float(cap.max()) < 1000.0                         # ... and no env ever ended a step non-finite (kernel-side flag)
-        if gather and rank == 0:                    # the gathered block of the last step really holds every rank's rows
-            gl = gathered[(warmup + steps - 1) % NB]
-            finite = finite and all(bool(torch.isfinite(x).all().item()) for x in gl) and bool((gl[0].to(dev) == rows[(warmup + steps - 1) % NB]).all().item())
+        lastrows = sh.last_local_rows()[:, :D] if sh is not None else obs
+        finite = finite_warm and bool(torch.isfinite(lastrows).all().item())      # checked after the warm-up and after the timed steps
+        finite = finite and float(cap.max()) < 1000.0                             # ... and no env ever ended a step non-finite (kernel-side flag)
+        if sh is not None and rank == 0:                # the gathered block of the last step really holds every rank's rows
+            ob_all, rw_all, dn_all = last[0]
+            finite = finite and ob_all.shape[0] == n * world and bool(torch.isfinite(ob_all).all().item()) and bool((ob_all[:n] == sh.last_local_rows()[:, :D]).all().item())
         env.close()
         return wall, dev_ms, float(cap.sum()), finite
 
@@ -242,50 +210,107 @@ def main():
     total_envs = n * world
     value = total_envs * K / wall_max
 
+    def config_label(contacts):
+        """which BASELINE.json config this workload is, if any"""
+        if args.augmented:
+            return "BASELINE configs[4]'s per-GPU shard" if n == 8192 else "augmented models, not a BASELINE size"
+        if task == "move_to_pose" and n == N_ENVS_PER_GPU and contacts:
+            return "BASELINE configs[3]'s per-GPU shard"
+        if task == TASK and n == N_ENVS_PER_GPU:
+            return "BASELINE configs[2]" if contacts else "BASELINE configs[1]"
+        return "not a BASELINE config"
+
     also = None
     if not args.no_also and world == 1:
         w2, d2, _, _ = run(1 - args.contacts, max(50, K // 5), 20, gather=False)
-        also = {"workload": "%s N_envs=%d contacts %s (BASELINE configs[%d])" % (task, n, "off" if args.contacts else "on", 1 if args.contacts else 2),
+        also = {"workload": "%s N_envs=%d contacts %s (%s)" % (task, n, "off" if args.contacts else "on", config_label(1 - args.contacts)),
                 "value": n * max(50, K // 5) / w2, "unit": "env steps/s"}
 
+    host_rate = None
+    if world == 1 and not args.no_host_rate:
+        # the reference-shaped entry point jb_step (host pointers: H2D actions, D2H obs/reward/done, stream sync per step) on the same
+        # workload, for the record next to `value` (which has inputs resident in HBM): the PCIe-inclusive rate
+        import numpy as np
+        env = JitterbugVecEnv(n, task, seed=args.seed, device_id=local_rank, contacts=bool(args.contacts), max_newton=args.max_newton, envs_per_wave=args.envs_per_wave)
+        if args.augmented:
+            env.randomise_models(seed=1000, min_mass_clearance=1e-3, return_params=False)
+        env.reset()
+        rs = np.random.default_rng(0)
+        acts = rs.uniform(-1, 1, size=(64, n)).astype(np.float32)
+        kh = min(K, 300)
+        for i in range(min(W, 50)):
+            env.step(acts[i % 64])
+        t0 = time.perf_counter()
+        for i in range(kh):
+            env.step(acts[i % 64])
+        host_rate = {"value": n * kh / (time.perf_counter() - t0), "unit": "env steps/s", "steps": kh,
+                     "what": "jb_step with host buffers through the Python VecEnv (H2D actions + kernel + D2H obs/reward/done + sync + numpy copies per step)"}
+        env.close()
+
     if rank == 0:
-        # HBM traffic per launch from the rocprofv3 PMC passes of the same workload (FETCH_SIZE + WRITE_SIZE, separate runs;
-        # profiles/r01_pmc_summary.md).  It cannot be collected inside this process, so it is read from the committed summary.
+        # HBM traffic and issue counters per launch come from rocprofv3 PMC passes (separate runs: FETCH_SIZE, WRITE_SIZE, SQ_*), which
+        # cannot be collected inside this process.  They are read from the committed summary ONLY when it was collected on this very
+        # build (sha256 of the library) and this workload; otherwise they are null rather than stale.
+        import hashlib
+        from jitterbug_amd import _lib
+        lib_sha = hashlib.sha256(open(_lib.LIB_PATH, "rb").read()).hexdigest()
         traffic = None
-        issue = None
+        compute = None
+        prof_note = "no PMC summary for this build/workload (tools/collect_profiles.sh + tools/summarise_profiles.py write one)"
         try:
-            raw = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_raw.json")))
-            if n == N_ENVS_PER_GPU and args.contacts and task == TASK and not args.augmented:
+            raw = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_raw.json")))
+            if raw.get("lib_sha256") != lib_sha:
+                prof_note = "profiles/r02_pmc_raw.json was collected on another build of libjitterbug_hip.so: not quoted"
+            elif n == N_ENVS_PER_GPU and args.contacts and task == TASK and not args.augmented and world == 1:
                 traffic = (raw["FETCH_SIZE_KB"] + raw["WRITE_SIZE_KB"]) * 1024.0
                 sq = raw["sq"]
-                issue = {"valu_issue_frac_of_wave_life": sq["SQ_ACTIVE_INST_VALU"] / sq["SQ_WAVE_CYCLES"],
-                         "any_issue_frac_of_wave_life": sq["SQ_ACTIVE_INST_ANY"] / sq["SQ_WAVE_CYCLES"],
-                         "waitcnt_frac_of_wave_life": sq.get("SQ_WAIT_ANY", 0.0) / sq["SQ_WAVE_CYCLES"],
-                         "source": "profiles/r01_pmc_raw.json (rocprofv3 PMC passes of this workload)"}
-        except Exception:
-            pass
-        launch_s = dev_ms * 1e-3 / K                 # average duration of one jb_step_kernel launch, from HIP events on its stream
+                waves = sq["SQ_WAVES"]
+                simds = 1024.0
+                compute = {"bound": "fp32 VALU issue of one wave per SIMD",
+                           "waves_per_launch": waves, "waves_per_simd": waves / simds,
+                           "valu_insts_per_launch": sq["SQ_INSTS_VALU"],
+                           "valu_issue_frac_of_wave_life": sq["SQ_ACTIVE_INST_VALU"] / sq["SQ_WAVE_CYCLES"],
+                           "any_issue_frac_of_wave_life": sq["SQ_ACTIVE_INST_ANY"] / sq["SQ_WAVE_CYCLES"],
+                           "waitcnt_frac_of_wave_life": sq.get("SQ_WAIT_ANY", 0.0) / sq["SQ_WAVE_CYCLES"],
+                           "mean_wave_life_ms": raw.get("mean_wave_life_ms"),
+                           "mean_wave_life_over_launch": raw.get("mean_wave_life_ms") / (raw["kernel_avg_ns"] * 1e-6) if raw.get("mean_wave_life_ms") else None,
+                           # issue slots: a SIMD can issue one wave64 VALU instruction per 2 cycles (two waves resident), a lone wave one per 4
+                           "valu_issue_slot_frac_of_chip": sq["SQ_INSTS_VALU"] * 2.0 / (simds * raw["kernel_avg_ns"] * 1e-9 * raw.get("clock_hz", 2.4e9)),
+                           "source": "profiles/r02_pmc_raw.json (rocprofv3 PMC passes of this build and workload)"}
+                prof_note = "profiles/r02_pmc_raw.json, same build (sha256 %s...)" % lib_sha[:12]
+            else:
+                prof_note = "profiles/r02_pmc_raw.json covers move_from_origin, N=4096, contacts on, 1 GPU only"
+        except Exception as e:
+            prof_note = "no usable profiles/r02_pmc_raw.json (%s)" % type(e).__name__
+        launch_s = dev_ms * 1e-3 / K                 # HIP events on the kernel's stream around the K timed launches
         # 317 B for move_from_origin (D=15); other tasks add 4 B per extra obs entry and the 12 B target read; per-env models add
         # the lane constant table (202 x 4 floats) read once per step
         algo_bytes = ALGO_BYTES_PER_ENV_STEP + 4 * (D - 15) + (12 if task != TASK else 0) + (202 * 4 * 4 if args.augmented else 0)
         achieved = algo_bytes * n / launch_s / 1e9
+        gather_txt = ""
+        if world > 1 or dist is not None:
+            gather_txt = ", %s gather of [N,D+2] rows to rank 0 every step, issued one step late from a side stream, three row buffers (jitterbug_amd.distributed.ShardedJitterbugEnv, pipeline_depth=2)" % ("RCCL" if args.dist_backend == "nccl" else args.dist_backend + " (rehearsal, staged through the host)")
         res = {
             "metric": "env steps/s at N_envs=%d, %s" % (n, task),
             "value": value, "unit": "env steps/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": wall_max * 1e3 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s, N_envs=%d per GPU, %s, 50 substeps/step, in-kernel auto-reset (BASELINE configs[%d])"
-                                   % (task + (", one randomised model per env" if args.augmented else ""), n, "full Newton contact solve" if args.contacts else "contacts off", 2 if args.contacts else 1),
-                       "global_envs": total_envs, "parallelism": "env-sharded x%d%s" % (world, (", %s gather of [N,D+2] rows to rank 0 every step, double-buffered" % ("RCCL" if args.dist_backend == "nccl" else args.dist_backend + " (rehearsal)")) if world > 1 else "")},
+            "config": {"workload": "%s, N_envs=%d per GPU, %s, 50 substeps/step, in-kernel auto-reset (%s)"
+                                   % (task + (", one randomised model per env" if args.augmented else ""), n, "full Newton contact solve" if args.contacts else "contacts off", config_label(args.contacts)),
+                       "global_envs": total_envs, "parallelism": "env-sharded x%d%s" % (world, gather_txt)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic,
-                         "kernel": "jb_step_kernel", "launch_ms": launch_s * 1e3, "algorithmic_bytes_per_launch": algo_bytes * n,
+                         "kernel": "jb_step_kernel", "launch_ms": launch_s * 1e3,
+                         "launch_ms_is": "average jb_step_kernel launch" if dist is None else "average step INCLUDING the stream waits on the row gather (N > 1 path), not the bare kernel",
+                         "algorithmic_bytes_per_launch": algo_bytes * n,
                          "note": "path is fp32-VALU/latency bound, not HBM bound (SURVEY.md §8d): 317 B per env step vs ~1e5-1e6 dependent flops",
-                         "issue": issue},
-            "solver_cap_hits": cap_hits, "finite": finite,
+                         "compute": compute, "profile": prof_note},
+            "solver_cap_hits": cap_hits, "finite": finite, "lib_sha256": lib_sha,
         }
         if also:
             res["also"] = also
+        if host_rate:
+            res["host_buffer_rate"] = host_rate
         if world == 1 and not args.no_cpu_baseline:
             cores = usable_cores()
             res["cpu_baseline"] = cpu_baseline(cores, task)

@@ -74,9 +74,17 @@ def scatter_actions(actions_global, sizes, device, src=0, group=None):
 class ShardedJitterbugEnv:
     """One shard of a global batch per rank.  `local_env_factory(n_local, env_offset)` builds the local stepper
     (default: JitterbugVecEnv on this rank's GPU); it must offer reset()/step(actions) over numpy arrays or the
-    *_device entry points (used when tensors live on the GPU)."""
+    *_device entry points (used when tensors live on the GPU).
 
-    def __init__(self, n_global, task="move_from_origin", seed=0, device=None, local_env_factory=None, group=None, **env_kwargs):
+    pipeline_depth = 1: step() returns this step's gathered results (scatter -> kernel -> gather, blocking in stream order).
+    pipeline_depth = 2: step() returns the PREVIOUS step's results (None on the first call; flush() returns the last): the gather of
+    step t is issued from a side stream after step t+1's kernel has been launched, so the RCCL kernel runs in the tail of step
+    t+1 on SIMDs whose waves have finished instead of delaying its start (the step kernel holds one wave per SIMD, an RCCL kernel
+    cannot co-reside with it), and three row buffers rotate so that no step waits for the gather issued just before it.  This is
+    the path `bench.py --gpus N` times (the reference's own vectorisation, stable-baselines SubprocVecEnv, has the same
+    step_async / step_wait split: benchmarks/benchmark.py:146-171)."""
+
+    def __init__(self, n_global, task="move_from_origin", seed=0, device=None, local_env_factory=None, group=None, pipeline_depth=1, **env_kwargs):
         import torch
         import torch.distributed as dist
         self.group = group
@@ -97,6 +105,33 @@ class ShardedJitterbugEnv:
                                        device_id=self.device.index or 0, **kw)
         self.env = local_env_factory(self.n_local, self.lo)
         self.on_gpu = self.device.type == "cuda"
+        if pipeline_depth not in (1, 2):
+            raise ValueError("pipeline_depth must be 1 or 2")
+        self.depth = int(pipeline_depth)
+        self._device_rows = self.on_gpu and hasattr(self.env, "step_rows_device")
+        self._nccl = self._device_rows and dist.get_backend(group) == "nccl"
+        self._i = 0                      # steps issued
+        self._prev = None                # depth 2 on the blocking paths: the result held back one step
+        if self._device_rows:
+            D2 = self.env.obs_dim + 2
+            nmax = max(self.sizes)
+            # the step kernel writes its n_local rows into a buffer padded to the longest shard (gather needs equal shapes); the
+            # buffers persist, nothing is allocated or concatenated per step
+            self._NB = 3 if (self._nccl and self.depth == 2) else (2 if self.depth == 2 else 1)
+            self._rows = [torch.zeros((nmax, D2), device=self.device, dtype=torch.float32) for _ in range(self._NB)]
+            stage_dev = self.device if self._nccl else "cpu"
+            # rank 0 receives into ONE contiguous block per buffer, [world, nmax, D+2]: with equal shards the result is a view of it
+            self._blocks = [torch.empty((self.world, nmax, D2), device=stage_dev, dtype=torch.float32) for _ in range(self._NB)] if self.rank == 0 else [None] * self._NB
+            self._gathered = [[blk[r] for r in range(self.world)] for blk in self._blocks] if self.rank == 0 else [None] * self._NB
+            self._stage = None if self._nccl else [torch.empty((nmax, D2), dtype=torch.float32).pin_memory() for _ in range(self._NB)]
+            self._pending = [None] * self._NB
+            self._side = torch.cuda.Stream(device=self.device) if (self._nccl and self.depth == 2) else None
+            self._step_done = [torch.cuda.Event() for _ in range(self._NB)] if self._side is not None else None
+            self._late = None            # index of the step whose rows still have to be sent (depth 2)
+
+    def last_local_rows(self):
+        """this rank's packed rows [n_local, D+2] of the last step issued (device path)"""
+        return self._rows[(self._i - 1) % self._NB][:self.n_local]
 
     def _to_tensor(self, a, dtype):
         import torch
@@ -104,24 +139,93 @@ class ShardedJitterbugEnv:
 
     def reset(self):
         import torch
+        self.flush()
         obs = self._to_tensor(self.env.reset(), torch.float32)
         rows = pack_rows(obs, torch.zeros(self.n_local, device=self.device), torch.zeros(self.n_local, device=self.device))
         out = gather_rows(rows, self.sizes, 0, self.group)
         return None if out is None else unpack_rows(out)[0]
 
-    def step(self, actions_global):
-        """Rank 0 passes actions for all N_global envs (other ranks pass None); returns (obs, reward, done) on rank 0."""
+    # ------------------------------------------------------------------ device path
+    def _send(self, j):
+        """issue the gather of step j's rows (buffer j % NB)"""
         import torch
-        a = scatter_actions(actions_global, self.sizes, self.device, 0, self.group)
-        if self.on_gpu and hasattr(self.env, "step_rows_device"):
+        import torch.distributed as dist
+        b = j % self._NB
+        if self._side is not None:
+            with torch.cuda.stream(self._side):
+                self._side.wait_event(self._step_done[b])
+                self._pending[b] = dist.gather(self._rows[b], self._gathered[b] if self.rank == 0 else None, dst=0, group=self.group, async_op=True)
+        elif self._nccl:
+            self._pending[b] = dist.gather(self._rows[b], self._gathered[b] if self.rank == 0 else None, dst=0, group=self.group, async_op=True)
+        else:                                            # gloo rehearsal: staged through pinned host memory, synchronous
+            self._stage[b].copy_(self._rows[b])
+            dist.gather(self._stage[b], self._gathered[b] if self.rank == 0 else None, dst=0, group=self.group)
+
+    def _result(self, j):
+        """rows of step j on rank 0 (after its gather), as (obs, reward, done) views; None elsewhere"""
+        import torch
+        b = j % self._NB
+        if self._pending[b] is not None:
+            self._pending[b].wait()                      # the current stream waits for the gather (stream order, no host sync)
+            self._pending[b] = None
+        if self.rank != 0:
+            return None
+        if min(self.sizes) == max(self.sizes):
+            out = self._blocks[b].view(-1, self._blocks[b].shape[-1])
+        else:
+            out = torch.cat([g[:n] for g, n in zip(self._gathered[b], self.sizes)], 0)
+        return unpack_rows(out if self._nccl else out.to(self.device))
+
+    def _step_device(self, a):
+        import torch
+        i = self._i
+        b = i % self._NB
+        if self._pending[b] is not None:                 # the buffer is rewritten only after the gather that read it
+            self._pending[b].wait()
+            self._pending[b] = None
+        self.env.step_rows_device(a.data_ptr(), self._rows[b].data_ptr())
+        self._i += 1
+        if self.depth == 1:
+            self._send(i)
+            return self._result(i)
+        if self._side is not None:
+            self._step_done[b].record()
+        prev = self._late
+        self._late = i
+        if prev is None:
+            return None
+        self._send(prev)                                 # one step late: it overlaps the kernel just launched
+        return self._result(prev)
+
+    def flush(self):
+        """depth 2: the results of the last step issued (None if there is none pending)"""
+        if not getattr(self, "_device_rows", False):
+            out, self._prev = self._prev, None
+            return out
+        if self.depth == 1 or self._late is None:
+            return None
+        prev, self._late = self._late, None
+        self._send(prev)
+        return self._result(prev)
+
+    def step(self, actions_global=None, local_actions=None):
+        """Rank 0 passes actions for all N_global envs (other ranks pass None) - or every rank passes its own slice as
+        `local_actions` (a float32 tensor on this rank's device: actions already resident where they are consumed).
+        Returns (obs, reward, done) on rank 0 - of this step (depth 1) or of the previous one (depth 2)."""
+        import torch
+        if local_actions is not None:
+            a = local_actions
+        else:
+            a = scatter_actions(actions_global, self.sizes, self.device, 0, self.group)
+        if self._device_rows:
             # device path: scatter -> step kernel writes the packed rows -> gather, nothing leaves HBM on the way
-            a = a.contiguous()
-            rows = torch.empty((self.n_local, self.env.obs_dim + 2), dtype=torch.float32, device=self.device)
-            self.env.step_rows_device(a.data_ptr(), rows.data_ptr())
-            out = gather_rows(rows, self.sizes, 0, self.group)
-            return None if out is None else unpack_rows(out)
+            return self._step_device(a.contiguous())
         res = self.env.step(a.cpu().numpy())
         obs, rew, done = res[0], res[1], res[2]
         rows = pack_rows(self._to_tensor(obs, torch.float32), self._to_tensor(rew, torch.float32), self._to_tensor(done, torch.float32))
         out = gather_rows(rows, self.sizes, 0, self.group)
-        return None if out is None else unpack_rows(out)
+        cur = None if out is None else unpack_rows(out)
+        if self.depth == 1:
+            return cur
+        out, self._prev = self._prev, cur
+        return out

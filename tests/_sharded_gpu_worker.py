@@ -28,6 +28,32 @@ for t in range(6):
         assert np.array_equal(o1, o2) and np.array_equal(r1, r2) and np.array_equal(d1, d2.astype(bool)), "step %d differs" % t
     else:
         assert res is None
+# the pipelined product path (what bench.py --gpus N times): results arrive one call late, bit-identical
+sh2 = ShardedJitterbugEnv(n, task, seed=4, device="cuda:0", pipeline_depth=2)
+sh2.reset()
+whole2 = None
+if rank == 0:
+    whole2 = JitterbugVecEnv(n, task, seed=4)
+    whole2.reset()
+rng = np.random.default_rng(0)
+expected = []
+lo, hi = sh2.lo, sh2.hi
+for t in range(7):
+    acts = rng.uniform(-1, 1, size=n).astype(np.float32)                    # every rank draws the same stream and passes ITS slice
+    res = sh2.step(local_actions=torch.as_tensor(acts[lo:hi], device="cuda:0"))
+    if rank == 0:
+        expected.append(whole2.step(acts))
+        if t == 0:
+            assert res is None
+        else:
+            o2, r2, d2, _ = expected[t - 1]
+            o1, r1, d1 = (x.cpu().numpy() for x in res)
+            assert np.array_equal(o1, o2) and np.array_equal(r1, r2) and np.array_equal(d1, d2.astype(bool)), "pipelined step %d differs" % t
+res = sh2.flush()
+if rank == 0:
+    o2, r2, d2, _ = expected[-1]
+    o1, r1, d1 = (x.cpu().numpy() for x in res)
+    assert np.array_equal(o1, o2) and np.array_equal(r1, r2), "pipelined flush differs"
 dist.barrier()
 if rank == 0:
     print("SHARDED_OK", flush=True)

@@ -29,7 +29,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n_global, steps, q):
+def _worker(rank, world, port, n_global, steps, q, depth=1):
     import torch
     import torch.distributed as dist
     from jitterbug_amd.distributed import ShardedJitterbugEnv
@@ -49,12 +49,19 @@ def _worker(rank, world, port, n_global, steps, q):
         def step(self, a):
             return self.e.step(a)
 
-    env = ShardedJitterbugEnv(n_global, "move_to_pose", seed=4, local_env_factory=lambda n, off: Local(n, off))
+    env = ShardedJitterbugEnv(n_global, "move_to_pose", seed=4, local_env_factory=lambda n, off: Local(n, off), pipeline_depth=depth)
     outs = [env.reset()]
     rng = np.random.default_rng(0)
     for t in range(steps):
         acts = rng.uniform(-1, 1, size=n_global) if rank == 0 else None
-        outs.append(env.step(acts))
+        r = env.step(acts)
+        if depth == 1 or t > 0:                 # depth 2: a call returns the previous step's results
+            outs.append(r)
+        elif rank == 0:
+            assert r is None
+    if depth == 2:
+        outs.append(env.flush())
+        assert env.flush() is None
     if rank == 0:
         q.put((outs[0].numpy(), [(o.numpy(), r.numpy(), d.numpy()) for o, r, d in outs[1:]]))
     dist.barrier()
@@ -62,14 +69,15 @@ def _worker(rank, world, port, n_global, steps, q):
 
 
 @pytest.mark.timeout(300)
-def test_sharded_env_matches_single_process_gloo():
+@pytest.mark.parametrize("depth", [1, 2])
+def test_sharded_env_matches_single_process_gloo(depth):
     import torch.multiprocessing as mp
     from oracle import oracle as O
     n_global, steps, world = 11, 5, 2                     # uneven split: 6 + 5
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n_global, steps, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_global, steps, q, depth)) for r in range(world)]
     for p in procs:
         p.start()
     obs0, outs = q.get(timeout=240)

@@ -7,7 +7,7 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $ROOT/bench.py --steps $STEPS --warmup $WARM --no-cpu-baseline --no-also"
+BENCH="python3 $ROOT/bench.py --steps $STEPS --warmup $WARM --no-cpu-baseline --no-also --no-host-rate"
 echo "[prof] kernel trace + stats"; rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $BENCH > $OUT/stats.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   echo "[prof] pmc $c"; rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_$c -- $BENCH > $OUT/pmc_$c.log 2>&1

@@ -2,7 +2,7 @@
 # one-off PMC pass: tools/pmc_extra.sh "<counters>" tag
 ROOT=$(pwd); OUT=$ROOT/gpurun_out/prof/pmc_$2; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --pmc $1 --output-format csv -d $OUT -- python3 $ROOT/bench.py --steps 200 --warmup 50 --no-cpu-baseline --no-also $EXTRA > $OUT.log 2>&1 || { tail -5 $OUT.log; exit 0; }
+rocprofv3 --kernel-trace --pmc $1 --output-format csv -d $OUT -- python3 $ROOT/bench.py --steps 200 --warmup 50 --no-cpu-baseline --no-also --no-host-rate $EXTRA > $OUT.log 2>&1 || { tail -5 $OUT.log; exit 0; }
 cd $ROOT
 python3 - "$OUT" <<'PY'
 import csv, glob, sys

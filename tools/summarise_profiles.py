@@ -31,5 +31,19 @@ out["sq"] = sq
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     v, _ = counters("pmc_" + c)
     if c in v: out[c + "_KB"] = v[c]
+# which build this is: the summary is only quoted by bench.py for the same library
+import hashlib, subprocess
+lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "jitterbug_amd", "libjitterbug_hip.so")
+out["lib_sha256"] = hashlib.sha256(open(lib, "rb").read()).hexdigest()
+if "SQ_WAVE_CYCLES" in sq and "SQ_WAVES" in sq and "GRBM_GUI_ACTIVE" in sq and out.get("kernel_avg_ns"):
+    out["clock_hz"] = sq["GRBM_GUI_ACTIVE"] / 8.0 / (out["kernel_avg_ns"] * 1e-9)          # effective clock (MI355X_MICROARCH.md: sum over 8 XCDs)
+    out["mean_wave_life_ms"] = sq["SQ_WAVE_CYCLES"] * 4.0 / sq["SQ_WAVES"] / out["clock_hz"] * 1e3   # SQ_WAVE_CYCLES counts quad-cycles
+# the dispatch fields rocprofv3 prints are allocation-granule figures of the ARCH VGPR file only; the code object's own numbers
+# (compiler remarks, tools/kernel_resources.sh) are recorded next to them
+try:
+    rep = subprocess.run([os.path.join(os.path.dirname(os.path.abspath(__file__)), "kernel_resources.sh")], capture_output=True, text=True, timeout=600).stdout
+    out["code_object"] = {l.split()[0][:40]: " ".join(l.split()[1:]) for l in rep.splitlines() if "jb_step_kernel" in l}
+except Exception:
+    pass
 json.dump(out, open(prefix + "_pmc_raw.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
