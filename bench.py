@@ -163,7 +163,7 @@ def main():
             if sh is None:
                 env.step_device(actions[i].data_ptr(), obs.data_ptr(), rew.data_ptr(), done.data_ptr())
             else:
-                r = sh.step(local_actions=actions[i])
+                r = sh.step(local_actions=actions[i])          # a PendingRows handle for step i-1: nothing waits unless asked
                 if r is not None:
                     last[0] = r
 
@@ -197,7 +197,7 @@ def main():
         finite = finite_warm and bool(torch.isfinite(lastrows).all().item())      # checked after the warm-up and after the timed steps
         finite = finite and float(cap.max()) < 1000.0                             # ... and no env ever ended a step non-finite (kernel-side flag)
         if sh is not None and rank == 0:                # the gathered block of the last step really holds every rank's rows
-            ob_all, rw_all, dn_all = last[0]
+            ob_all, rw_all, dn_all = last[0].get()
             finite = finite and ob_all.shape[0] == n * world and bool(torch.isfinite(ob_all).all().item()) and bool((ob_all[:n] == sh.last_local_rows()[:, :D]).all().item())
         env.close()
         return wall, dev_ms, float(cap.sum()), finite

@@ -71,14 +71,29 @@ def scatter_actions(actions_global, sizes, device, src=0, group=None):
     return out[:sizes[rank]].to(final_device)
 
 
+class PendingRows:
+    """Result of a pipelined step (pipeline_depth = 2): `get()` makes the CURRENT stream wait for the gather of that step and returns
+    (obs, reward, done) on rank 0 (None elsewhere).  Nothing waits until the consumer asks: the step kernels launched in the meantime
+    do not queue behind the gather.  The data stay valid until two more steps have been issued."""
+
+    def __init__(self, owner, index=None, value=None):
+        self._owner, self._index, self._value = owner, index, value
+
+    def get(self):
+        if self._index is not None:
+            self._value = self._owner._result(self._index)
+            self._index = None
+        return self._value
+
+
 class ShardedJitterbugEnv:
     """One shard of a global batch per rank.  `local_env_factory(n_local, env_offset)` builds the local stepper
     (default: JitterbugVecEnv on this rank's GPU); it must offer reset()/step(actions) over numpy arrays or the
     *_device entry points (used when tensors live on the GPU).
 
     pipeline_depth = 1: step() returns this step's gathered results (scatter -> kernel -> gather, blocking in stream order).
-    pipeline_depth = 2: step() returns the PREVIOUS step's results (None on the first call; flush() returns the last): the gather of
-    step t is issued from a side stream after step t+1's kernel has been launched, so the RCCL kernel runs in the tail of step
+    pipeline_depth = 2: step() returns a PendingRows handle for the PREVIOUS step's results (None on the first call; flush() returns
+    the last one): `handle.get()` yields (obs, reward, done) when the consumer needs them.  The gather of step t is issued from a side stream after step t+1's kernel has been launched, so the RCCL kernel runs in the tail of step
     t+1 on SIMDs whose waves have finished instead of delaying its start (the step kernel holds one wave per SIMD, an RCCL kernel
     cannot co-reside with it), and three row buffers rotate so that no step waits for the gather issued just before it.  This is
     the path `bench.py --gpus N` times (the reference's own vectorisation, stable-baselines SubprocVecEnv, has the same
@@ -195,23 +210,24 @@ class ShardedJitterbugEnv:
         if prev is None:
             return None
         self._send(prev)                                 # one step late: it overlaps the kernel just launched
-        return self._result(prev)
+        return PendingRows(self, prev)
 
     def flush(self):
         """depth 2: the results of the last step issued (None if there is none pending)"""
         if not getattr(self, "_device_rows", False):
-            out, self._prev = self._prev, None
+            out, self._prev = getattr(self, "_prev", None), None
             return out
         if self.depth == 1 or self._late is None:
             return None
         prev, self._late = self._late, None
         self._send(prev)
-        return self._result(prev)
+        return PendingRows(self, prev)
 
     def step(self, actions_global=None, local_actions=None):
         """Rank 0 passes actions for all N_global envs (other ranks pass None) - or every rank passes its own slice as
         `local_actions` (a float32 tensor on this rank's device: actions already resident where they are consumed).
-        Returns (obs, reward, done) on rank 0 - of this step (depth 1) or of the previous one (depth 2)."""
+        depth 1: returns (obs, reward, done) of this step on rank 0 (None elsewhere).  depth 2: returns a PendingRows handle for the
+        previous step (None on the first call)."""
         import torch
         if local_actions is not None:
             a = local_actions
@@ -227,5 +243,5 @@ class ShardedJitterbugEnv:
         cur = None if out is None else unpack_rows(out)
         if self.depth == 1:
             return cur
-        out, self._prev = self._prev, cur
+        out, self._prev = self._prev, PendingRows(self, value=cur)
         return out

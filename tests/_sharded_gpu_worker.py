@@ -47,12 +47,14 @@ for t in range(7):
             assert res is None
         else:
             o2, r2, d2, _ = expected[t - 1]
-            o1, r1, d1 = (x.cpu().numpy() for x in res)
+            o1, r1, d1 = (x.cpu().numpy() for x in res.get())
             assert np.array_equal(o1, o2) and np.array_equal(r1, r2) and np.array_equal(d1, d2.astype(bool)), "pipelined step %d differs" % t
+    elif res is not None:
+        assert res.get() is None
 res = sh2.flush()
 if rank == 0:
     o2, r2, d2, _ = expected[-1]
-    o1, r1, d1 = (x.cpu().numpy() for x in res)
+    o1, r1, d1 = (x.cpu().numpy() for x in res.get())
     assert np.array_equal(o1, o2) and np.array_equal(r1, r2), "pipelined flush differs"
 dist.barrier()
 if rank == 0:

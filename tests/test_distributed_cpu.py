@@ -55,12 +55,14 @@ def _worker(rank, world, port, n_global, steps, q, depth=1):
     for t in range(steps):
         acts = rng.uniform(-1, 1, size=n_global) if rank == 0 else None
         r = env.step(acts)
-        if depth == 1 or t > 0:                 # depth 2: a call returns the previous step's results
+        if depth == 1:
             outs.append(r)
-        elif rank == 0:
+        elif t > 0:                             # depth 2: a call hands back the previous step's results (a PendingRows handle)
+            outs.append(r.get())
+        else:
             assert r is None
     if depth == 2:
-        outs.append(env.flush())
+        outs.append(env.flush().get())
         assert env.flush() is None
     if rank == 0:
         q.put((outs[0].numpy(), [(o.numpy(), r.numpy(), d.numpy()) for o, r, d in outs[1:]]))
