@@ -15,6 +15,10 @@
 #pragma once
 #include <cmath>
 #include <cstdint>
+#if !defined(__HIPCC__)
+#include <atomic>
+#include <thread>
+#endif
 
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
@@ -74,6 +78,10 @@ JB_D float row_transpose_sum(float v0, float v1, float v2, float v3) {
 JB_D float xor_sum(float x, int off, bool sym2) { return __builtin_bit_cast(float, xor_sum_bits(__builtin_bit_cast(unsigned, x), off, sym2, true)); }
 JB_D unsigned xor_sum_u(unsigned x, int off, bool sym2) { return xor_sum_bits(x, off, sym2, false); }
 JB_D unsigned wave_bcast_u(unsigned x) { return (unsigned)__builtin_amdgcn_readfirstlane((int)x); }   // value of the first active lane
+// Hand-over point between lane groups through the scratch (one group wrote, another reads).  The groups are lanes of ONE wave and
+// LDS operations of a wave complete in program order, so the device needs nothing here; the host emulation (one thread per group)
+// needs a barrier.
+JB_D void wave_sync() {}
 #endif
 
 JB_HD float sel(bool m, float a, float b) { return m ? a : b; }
@@ -191,10 +199,70 @@ template <typename T> inline Quad<T> operator-(const Quad<T>& a) { Quad<T> r; fo
 template <typename T> inline Quad<T> quad_sum(const Quad<T>& x) { return Quad<T>((x.v[0] + x.v[1]) + (x.v[2] + x.v[3])); }
 inline UQuad quad_sum_u(const UQuad& x) { uint32_t s = (x.v[0] + x.v[1]) + (x.v[2] + x.v[3]); return UQuad{{s, s, s, s}}; }
 inline bool any_lane(const Mask4& m) { return m.v[0] || m.v[1] || m.v[2] || m.v[3]; }
-template <typename T> inline Quad<T> row_transpose_sum(const Quad<T>& v0, const Quad<T>&, const Quad<T>&, const Quad<T>&) { return v0; }
-template <typename T> inline Quad<T> xor_sum(const Quad<T>& x, int, bool) { return x; }      // the host harness has one group
-inline UQuad xor_sum_u(const UQuad& x, int, bool) { return x; }
-inline unsigned wave_bcast_u(unsigned x) { return x; }
+// ---- helper groups on the host: one THREAD per group, each running the same source on its own Quad<T> lanes (tests/host_harness.cpp).
+// The cross-group operations of the device (permlane swaps, readfirstlane) become mailbox exchanges between the threads; every one of
+// them is also a barrier, like the lockstep of a wave.  With no wave installed (g_host_wave == nullptr) there is one group and
+// they are identities.
+struct HostWave {
+    int ngrp = 1, gstride = 16;
+    double mbox[4][4][4];           // [group][value][lane]
+    uint32_t umbox[4][4];
+    std::atomic<int> arrived{0}, phase{0};
+    void barrier() {
+        const int ph = phase.load(std::memory_order_acquire);
+        if (arrived.fetch_add(1, std::memory_order_acq_rel) == ngrp - 1) { arrived.store(0, std::memory_order_relaxed); phase.store(ph + 1, std::memory_order_release); }
+        else while (phase.load(std::memory_order_acquire) == ph) std::this_thread::yield();
+    }
+};
+inline thread_local HostWave* g_host_wave = nullptr;
+inline thread_local int g_host_grp = 0;
+inline void wave_sync() { if (g_host_wave) g_host_wave->barrier(); }
+template <typename T> inline Quad<T> host_exchange(const Quad<T>& x, int partner) {
+    HostWave* w = g_host_wave;
+    for (int i = 0; i < 4; i++) w->mbox[g_host_grp][0][i] = (double)x.v[i];
+    w->barrier();
+    Quad<T> r;
+    for (int i = 0; i < 4; i++) r.v[i] = (T)w->mbox[partner][0][i];
+    w->barrier();
+    return r;
+}
+// row g returns the total of v[g] over the four groups, associated (g0 + g2) + (g1 + g3) like the device's permlane swaps
+template <typename T> inline Quad<T> row_transpose_sum(const Quad<T>& v0, const Quad<T>& v1, const Quad<T>& v2, const Quad<T>& v3) {
+    HostWave* w = g_host_wave;
+    if (!w) return v0;
+    const Quad<T>* v[4] = {&v0, &v1, &v2, &v3};
+    for (int k = 0; k < 4; k++) for (int i = 0; i < 4; i++) w->mbox[g_host_grp][k][i] = (double)v[k]->v[i];
+    w->barrier();
+    Quad<T> r;
+    const int g = g_host_grp;
+    for (int i = 0; i < 4; i++) r.v[i] = ((T)w->mbox[0][g][i] + (T)w->mbox[2][g][i]) + ((T)w->mbox[1][g][i] + (T)w->mbox[3][g][i]);
+    w->barrier();
+    return r;
+}
+template <typename T> inline Quad<T> xor_sum(const Quad<T>& x, int off, bool) {
+    if (!g_host_wave) return x;
+    return x + host_exchange(x, g_host_grp ^ (off / g_host_wave->gstride));
+}
+inline UQuad xor_sum_u(const UQuad& x, int off, bool) {
+    HostWave* w = g_host_wave;
+    if (!w) return x;
+    for (int i = 0; i < 4; i++) w->umbox[g_host_grp][i] = x.v[i];
+    w->barrier();
+    UQuad r;
+    const int partner = g_host_grp ^ (off / w->gstride);
+    for (int i = 0; i < 4; i++) r.v[i] = x.v[i] + w->umbox[partner][i];
+    w->barrier();
+    return r;
+}
+inline unsigned wave_bcast_u(unsigned x) {           // the first lane of the wave is a lane of group 0
+    HostWave* w = g_host_wave;
+    if (!w) return x;
+    w->umbox[g_host_grp][0] = x;
+    w->barrier();
+    const unsigned r = w->umbox[0][0];
+    w->barrier();
+    return r;
+}
 inline bool any_lane(bool m) { return m; }
 inline float quad_sum(float x) { return x; }
 inline double quad_sum(double x) { return x; }

@@ -745,6 +745,7 @@ JB_HD void contact_sweep(const LaneModel<V>& m, const LaneScratch<V>& sc, bool x
             static_assert(4 * ROW_F >= 52, "reduction buffer");
 #pragma unroll
             for (int k = 0; k < 13; k++) sc.st(SC_RED + 4 * k + sc.grp, row_transpose_sum(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]));
+            wave_sync();          // every group's 13 totals are in the scratch
             if (sc.grp == 0) {
 #pragma unroll
                 for (int i = 0; i < 52; i++) v[i] = sc.ld(SC_RED + i);
@@ -1136,6 +1137,7 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
                 for (int i = 0; i < 6; i++) sc.st(SC_Y + i, yr[i]);
                 sc.st(SC_Y + 6, yl[0]); sc.st(SC_Y + 7, yl[1]); sc.st(SC_Y + 8, ym);
             }
+            wave_sync();          // the helper groups read the iterate from the scratch
         } else {
             acc_clear(acc);
         }
@@ -1254,6 +1256,7 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
             }
             JB_PROF_ADD(o, 3);
             if (final_pass) break;
+            wave_sync();          // new iterate stored by the main lanes -> read by every group's next sweep
         }
     }
     JB_SCHED_FENCE();

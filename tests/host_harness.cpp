@@ -3,13 +3,19 @@
 // so tests/ can check that math in fp64 and fp32 against the oracle without a GPU.
 // It is never linked into, or loaded by, the product library.
 #include <cstring>
+#include <limits>
+#include <thread>
+#include <vector>
 
 #include "../jitterbug_amd/csrc/jb_model_build.hpp"
 
 using namespace jb;
 
+// NGROUPS = 1: the main lanes alone.  NGROUPS = 4: the wave layout of the 4-envs-per-wave kernel for ONE env - a main group and three
+// helper groups, one host thread each, sharing the scratch and exchanging through jb_lane.hpp's HostWave (group_sum, row_transpose_sum,
+// the rank-one pass on rows other groups built, the broadcast loop decisions): the same code paths the device takes with helper lanes.
 template <typename T>
-static int run(const double* P, double* qpos, double* qvel, double ctrl, int nsub, int contacts, int max_newton, int implicit_damp, double* fail) {
+static int run(const double* P, double* qpos, double* qvel, double ctrl, int nsub, int contacts, int max_newton, int implicit_damp, double* fail, int ngroups = 1, int rank_one = 1) {
     using V = Quad<T>;
     LaneModel<V> m;
     T tab[LM_TABLE];
@@ -31,15 +37,42 @@ static int run(const double* P, double* qpos, double* qvel, double ctrl, int nsu
     s.thd2 = V(T(qvel[7]), T(qvel[9]), T(qvel[11]), T(qvel[13]));
     for (int i = 0; i < 3; i++) { s.wa[i] = V(T(0)); s.wl[i] = V(T(0)); }
     s.wj[0] = s.wj[1] = V(T(0)); s.wm = V(T(0)); s.fail = V(T(0));
-    SimOpts o; o.contacts = contacts; o.max_newton = max_newton; o.implicit_damp = implicit_damp; o.rank_one = 1; o.prof = nullptr; o.hist = nullptr;
+    SimOpts o; o.contacts = contacts; o.max_newton = max_newton; o.implicit_damp = implicit_damp; o.rank_one = rank_one; o.prof = nullptr; o.hist = nullptr;
     V scratch[SC_COUNT];
-    LaneScratch<V> sc; sc.p = scratch; sc.stride = 1; sc.grp = 0; sc.ngrp = 1; sc.gstride = 4;
     normalise_state(s);
-    for (int i = 0; i < nsub; i++) {
-        // poison the scratch: a substep must not read anything it has not written itself (on the device LDS keeps whatever
-        // the previous kernel left there)
-        for (int k = 0; k < SC_COUNT; k++) scratch[k] = V(std::numeric_limits<T>::quiet_NaN());
-        substep<V>(m, sc, s, V(T(ctrl)), o);
+    if (ngroups <= 1) {
+        LaneScratch<V> sc; sc.p = scratch; sc.stride = 1; sc.grp = 0; sc.ngrp = 1; sc.gstride = 4;
+        for (int i = 0; i < nsub; i++) {
+            // poison the scratch: a substep must not read anything it has not written itself (on the device LDS keeps whatever
+            // the previous kernel left there)
+            for (int k = 0; k < SC_COUNT; k++) scratch[k] = V(std::numeric_limits<T>::quiet_NaN());
+            substep<V>(m, sc, s, V(T(ctrl)), o);
+        }
+    } else {
+        HostWave wave;
+        wave.ngrp = ngroups; wave.gstride = 16;            // 16: the lane distance between groups in the 4-envs-per-wave kernel (selects its transposed reduction)
+        auto body = [&](int g) {
+            g_host_wave = &wave; g_host_grp = g;
+            LaneScratch<V> sc; sc.p = scratch; sc.stride = 1; sc.grp = g; sc.ngrp = ngroups; sc.gstride = 16;
+            LaneState<V> hs = s;                            // helper lanes start from a harmless state, like the kernel's
+            LaneState<V>& st = (g == 0) ? s : hs;
+            if (g != 0) {
+                hs.px = hs.py = hs.pz = V(T(0)); hs.qw = V(T(1)); hs.qx = hs.qy = hs.qz = V(T(0)); hs.vx = hs.vy = hs.vz = hs.wx = hs.wy = hs.wz = V(T(0));
+                hs.pz_lo = hs.qw_lo = hs.qx_lo = hs.qy_lo = hs.qz_lo = V(T(0));
+                hs.phi = hs.phid = hs.turns = V(T(0)); hs.th1 = hs.th2 = hs.thd1 = hs.thd2 = V(T(0));
+            }
+            for (int i = 0; i < nsub; i++) {
+                wave.barrier();
+                if (g == 0) for (int k = 0; k < SC_COUNT; k++) scratch[k] = V(std::numeric_limits<T>::quiet_NaN());
+                wave.barrier();
+                substep<V>(m, sc, st, V(T(ctrl)), o);
+            }
+            g_host_wave = nullptr;
+        };
+        std::vector<std::thread> th;
+        for (int g = 1; g < ngroups; g++) th.emplace_back(body, g);
+        body(0);
+        for (auto& t : th) t.join();
     }
     // replicated quantities must agree across the quad
     for (int l = 1; l < 4; l++) if (s.px.v[l] != s.px.v[0] || s.qw.v[l] != s.qw.v[0] || s.wz.v[l] != s.wz.v[0] || s.phid.v[l] != s.phid.v[0]) return -100;
@@ -58,6 +91,12 @@ extern "C" int jbh_step(const double* P, double* qpos, double* qvel, double ctrl
                         int use_float, double* fail) {
     return use_float ? run<float>(P, qpos, qvel, ctrl, nsub, contacts, max_newton, implicit_damp, fail)
                      : run<double>(P, qpos, qvel, ctrl, nsub, contacts, max_newton, implicit_damp, fail);
+}
+// the same with ngroups lane groups (1 or 4) and the rank-one Newton passes on or off
+extern "C" int jbh_step_groups(const double* P, double* qpos, double* qvel, double ctrl, int nsub, int contacts, int max_newton, int use_float, int ngroups, int rank_one, double* fail) {
+    if (ngroups != 1 && ngroups != 4) return -101;
+    return use_float ? run<float>(P, qpos, qvel, ctrl, nsub, contacts, max_newton, 1, fail, ngroups, rank_one)
+                     : run<double>(P, qpos, qvel, ctrl, nsub, contacts, max_newton, 1, fail, ngroups, rank_one);
 }
 extern "C" int jbh_lm_count(void) { return LM_COUNT; }
 // the per-leg constant table (LM_COUNT doubles) for inspection by tests / tools

@@ -109,3 +109,88 @@ def test_randomised_models_fp64_equals_oracle(hstep):
             qh, vh, cap = hstep(q0[0], v0[0], a[0], P=P)
             assert cap == 0
             assert np.abs(qh - q1[0]).max() < 1e-11 and (np.abs(vh - v1[0]) / (1 + np.abs(v1[0]))).max() < 1e-10
+
+
+# ----------------------------------------------------------------------------------------------- helper groups on the host
+@pytest.fixture(scope="module")
+def gstep():
+    """jbh_step_groups: the kernel source with FOUR lane groups (one main + three helper groups, one host thread each, exchanging
+    through mailboxes where the device uses permlane swaps / readfirstlane): group_sum, row_transpose_sum, the slot->group plan, the
+    rank-one pass on rows built by other groups and the broadcast loop decisions run in fp64."""
+    import tests.build_harness as bh
+    lib = C.CDLL(bh.build())
+    dp = C.POINTER(C.c_double)
+    lib.jbh_step_groups.argtypes = [dp, dp, dp, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, dp]
+    P0 = model.default_params()
+
+    def step(q, v, u, nsub=50, groups=4, f32=0, rank_one=1, P=None, maxn=20):
+        P = np.ascontiguousarray(P0 if P is None else P, dtype=np.float64)
+        q, v, fail = q.copy(), v.copy(), np.zeros(1)
+        rc = lib.jbh_step_groups(P.ctypes.data_as(dp), q.ctypes.data_as(dp), v.ctypes.data_as(dp), float(u), nsub, 1, maxn, f32, groups, rank_one, fail.ctypes.data_as(dp))
+        assert rc == 0, rc
+        return q, v, fail[0]
+    return step
+
+
+def _contact_states(params, n, tipped):
+    """states from oracle rollouts: ordinary walking, or robots driven flat out until some lie on their legs (all-geom path)"""
+    env = O.OracleEnv(n, "move_from_origin", params, seed=5, step_limit=10 ** 9)
+    env.reset()
+    rng = np.random.default_rng(2)
+    for t in range(260 if tipped else 30):
+        env.step(np.ones(n) if tipped else rng.uniform(-1, 1, size=n), auto_reset=False)
+    return env
+
+
+def test_helper_groups_fp64_equal_single_group_and_oracle(gstep, params):
+    worst_groups = worst_oracle = 0.0
+    n_multi = 0
+    for tipped in (False, True):
+        env = _contact_states(params, 12, tipped)
+        rng = np.random.default_rng(7)
+        for t in range(6):
+            a = rng.uniform(-1, 1, size=12)
+            q0, v0, _ = env.get_state()
+            env.step(a, auto_reset=False)
+            q1, v1, _ = env.get_state()
+            for i in range(12):
+                d = O.forward_debug(params, q0[i], v0[i], a[i])
+                n_multi += d["ncon"] >= 2                                   # >= 2 live slots: the groups really share the work
+                qg, vg, cap = gstep(q0[i], v0[i], a[i], groups=4)
+                qs, vs, _ = gstep(q0[i], v0[i], a[i], groups=1)
+                assert cap == 0
+                worst_groups = max(worst_groups, np.abs(qg - qs).max(), (np.abs(vg - vs) / (1 + np.abs(vs))).max())
+                worst_oracle = max(worst_oracle, np.abs(qg - q1[i]).max(), (np.abs(vg - v1[i]) / (1 + np.abs(v1[i]))).max())
+        if tipped:
+            q, _, _ = env.get_state()
+            assert ((1 - 2 * (q[:, 4] ** 2 + q[:, 5] ** 2)) < 0.5).any()    # some robots really lie on the floor
+    print("4 groups vs 1 group: %.2e   4 groups vs oracle: %.2e   (%d multi-contact starts)" % (worst_groups, worst_oracle, n_multi))
+    assert n_multi > 40 and worst_groups < 1e-11 and worst_oracle < 1e-10
+
+
+def test_rank_one_passes_fp64_equal_full_passes_with_groups(gstep, params):
+    """Sherman-Morrison on the kept factorisation, reading contact rows that OTHER groups built (the path of round 1's
+    uninitialised-row bug), against full sweeps + refactorisation: same minimiser to round-off."""
+    env = _contact_states(params, 16, tipped=False)
+    rng = np.random.default_rng(9)
+    worst = 0.0
+    for t in range(4):
+        a = rng.uniform(-1, 1, size=16)
+        q0, v0, _ = env.get_state()
+        env.step(a, auto_reset=False)
+        for i in range(16):
+            qa, va, _ = gstep(q0[i], v0[i], a[i], groups=4, rank_one=1)
+            qb, vb, _ = gstep(q0[i], v0[i], a[i], groups=4, rank_one=0)
+            worst = max(worst, np.abs(qa - qb).max(), (np.abs(va - vb) / (1 + np.abs(vb))).max())
+    assert worst < 1e-10, worst
+
+
+def test_helper_groups_fp32_agree_with_single_group_within_rounding(gstep, params):
+    env = _contact_states(params, 8, tipped=False)
+    q0, v0, _ = env.get_state()
+    errs = []
+    for i in range(8):
+        qg, vg, _ = gstep(q0[i], v0[i], 0.3, groups=4, f32=1)
+        qs, vs, _ = gstep(q0[i], v0[i], 0.3, groups=1, f32=1)
+        errs.append(max(np.abs(qg[:7] - qs[:7]).max(), np.abs(vg[:6] - vs[:6]).max() / 35))
+    assert np.median(errs) < 1e-6
