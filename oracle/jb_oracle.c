@@ -317,6 +317,10 @@ static int collide(const double* P, const Kin* k, int feet_only, Contact* con, i
             double d1 = dist0 + prjaxis + prjvec;
             MARGIN(d1);
             if (d1 < 0) {
+                /* a second switch of this routine: which END of the cylinder is the "lower" one (prjaxis changes sign when the cylinder
+                 * passes through horizontal - a leg lying flat on the floor); the points at d3 then jump to the other end.  Its distance
+                 * from switching, as a length: the height of the axis end above the centre. */
+                MARGIN(prjaxis);
                 for (int i = 0; i < 3; i++) pos[i] = c[i] + vec[i] + ax[i] - nz[i] * 0.5 * d1;
                 n = add_contact(con, n, d1, pos, b, g, 0);
                 double d2 = dist0 - prjaxis + prjvec;

@@ -97,7 +97,7 @@ def test_state_roundtrip():
 MARGIN_TOL = 3e-8       # metres
 
 
-def _teacher_forced(task, n, steps, seed, contacts=True, params=None):
+def _teacher_forced(task, n, steps, seed, contacts=True, params=None, flat_out=False, skip=0):
     from oracle import oracle as O
     P = model.default_params() if params is None else params
     per_env = P.ndim == 2
@@ -110,8 +110,11 @@ def _teacher_forced(task, n, steps, seed, contacts=True, params=None):
     tot = ok = okr = big = 0
     well_tot = well_ok = well_big = ill_steps = ill_bad_steps = 0
     worst = worst_well = 0.0
-    for t in range(steps):
-        a = rng.uniform(-1, 1, size=n)
+    for t in range(-skip, steps):
+        a = np.ones(n) if flat_out else rng.uniform(-1, 1, size=n)
+        if t < 0:                                       # lead-in on the oracle alone (robots tip over), not compared
+            o.step(a, auto_reset=False)
+            continue
         q, v, tg = o.get_state()
         g.set_state(q, v, tg)
         og, rg, dg, _ = g.step(a)
@@ -131,7 +134,9 @@ def _teacher_forced(task, n, steps, seed, contacts=True, params=None):
         assert np.array_equal(dg, do.astype(bool))
     sc, ep, cap = g.counters()
     g.close()
-    return dict(frac=ok / tot, worst=worst, frac_reward=okr / (n * steps), cap=float(cap.sum()), frac_big=big / tot,
+    q, _, _ = o.get_state()
+    tipped = float(((1 - 2 * (q[:, 4] ** 2 + q[:, 5] ** 2)) < 0.5).mean())
+    return dict(tipped=tipped, well_bad=int(well_tot - well_ok), frac=ok / tot, worst=worst, frac_reward=okr / (n * steps), cap=float(cap.sum()), frac_big=big / tot,
                 well_frac=well_ok / max(well_tot, 1), well_big=int(well_big), worst_well=worst_well,
                 ill_frac=ill_steps / (n * steps), ill_steps=int(ill_steps), ill_bad_steps=int(ill_bad_steps))
 
@@ -144,6 +149,19 @@ def test_step_teacher_forced_contacts(task):
     assert r["well_frac"] == 1.0 and r["well_big"] == 0, r          # every entry of every well-conditioned env-step within 1e-4 rel + 1e-6
     assert r["ill_frac"] < 0.015, r                                  # env-steps within 30 nm of a contact switch: ~0.5 %
     assert r["frac"] >= 0.999 and r["frac_reward"] >= 0.999, r      # overall, ill-conditioned env-steps included (~0.9996)
+    assert r["cap"] == 0
+
+
+def test_step_teacher_forced_tipped_over_robots():
+    """The same protocol where the all-geom path does the work: motor flat out for 250 steps (oracle alone), then 300 compared steps with
+    about half the robots lying on their legs - upper-leg cylinders, knee tips and body geoms in contact, 8+ live slots per leg."""
+    r = _teacher_forced("move_to_pose", 64, 300, seed=5, flat_out=True, skip=250)
+    print("teacher-forced, tipped:", r)
+    assert r["tipped"] > 0.25, r
+    # robots resting on 8+ contact points per leg are a stiffer problem: the fp32 error itself (no contact switch involved) reaches the
+    # tolerance - measured: ONE of 364 800 entries of well-conditioned steps outside it, by 6e-6 absolute; no entry anywhere off by 1e-4
+    assert r["well_bad"] <= 3 and r["worst_well"] < 2e-5 and r["well_big"] == 0, r
+    assert r["ill_frac"] < 0.05 and r["frac"] >= 0.9999 and r["worst"] < 1e-3, r
     assert r["cap"] == 0
 
 
