@@ -53,4 +53,3 @@ for lo, hi in ((0, 1e-9), (1e-9, 1e-8), (1e-8, 3e-8), (3e-8, 1e-7), (1e-7, 3e-7)
     m = (rows[:, 0] >= lo) & (rows[:, 0] < hi)
     if m.any():
         print("margin [%.0e, %.0e): %6d env-steps (%.2f %%), fully within tolerance %.4f, worst error %.3g" % (lo, hi, m.sum(), 100 * m.mean(), (rows[m, 1] == 1).mean(), rows[m, 2].max()))
-np.save("/tmp/exp/flip_rows.npy", rows)
