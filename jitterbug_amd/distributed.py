@@ -81,6 +81,9 @@ class PendingRows:
 
     def get(self):
         if self._index is not None:
+            if self._owner._i > self._index + self._owner._NB:
+                raise RuntimeError("PendingRows of step %d expired: its row buffers were reused (%d steps issued since; keep at most %d in flight)"
+                                   % (self._index, self._owner._i - self._index - 1, self._owner._NB - 1))
             self._value = self._owner._result(self._index)
             self._index = None
         return self._value

@@ -51,6 +51,18 @@ for t in range(7):
             assert np.array_equal(o1, o2) and np.array_equal(r1, r2) and np.array_equal(d1, d2.astype(bool)), "pipelined step %d differs" % t
     elif res is not None:
         assert res.get() is None
+stale = sh2.step(local_actions=torch.zeros(hi - lo, device="cuda:0"))     # a handle nobody asks for in time
+if rank == 0:
+    expected.append(whole2.step(np.zeros(n, dtype=np.float32)))
+for t in range(4):
+    sh2.step(local_actions=torch.zeros(hi - lo, device="cuda:0"))
+    if rank == 0:
+        expected.append(whole2.step(np.zeros(n, dtype=np.float32)))
+try:
+    stale.get()
+    raise SystemExit("an expired PendingRows handle did not raise")
+except RuntimeError as e:
+    assert "expired" in str(e)
 res = sh2.flush()
 if rank == 0:
     o2, r2, d2, _ = expected[-1]
