@@ -156,6 +156,19 @@ int jb_reward_terms(jb_handle* h, float* terms_out /*[N,4]*/);
 int jb_rollout_policy_device(jb_handle* h, int32_t n_steps, float* d_obs_inout, float* d_rewards, uint8_t* d_done_last);
 /* host-buffer form: starts from the handle's current state; rewards_out [n_steps,N] and obs_out [N,D] are nullable */
 int jb_rollout_policy(jb_handle* h, int32_t n_steps, float* rewards_out, float* obs_out);
+/* Rows between GPUs without Python: one RCCL communicator per handle, RCCL bound at run time (dlopen: no link-time
+ * dependency; a process that already holds an RCCL, e.g. PyTorch-ROCm's, keeps that one).  Rank 0 makes the id, the host distributes
+ * its JB_COMM_ID_BYTES to every rank by its own means, every rank calls jb_comm_init (collective).  jb_gather_rows_device sends this
+ * rank's packed rows [N_local, D+2] (what jb_step_rows_device wrote; N_local equal on every rank) to rank 0, which receives
+ * [n_ranks, N_local, D+2] - grouped ncclSend / ncclRecv: on 8 MI355X seven concurrent single-hop xGMI transfers, no ring.  It is
+ * asynchronous on `stream` (use_stream = 1) or on the handle's stream; issue it from a side stream one step late, like
+ * jitterbug_amd.distributed.ShardedJitterbugEnv does, so that it overlaps the next step kernel instead of delaying it. */
+#define JB_COMM_ID_BYTES 128
+int jb_comm_unique_id(void* id_out /*[JB_COMM_ID_BYTES]*/);
+int jb_comm_init(jb_handle* h, int32_t n_ranks, int32_t rank, const void* id);
+int jb_comm_destroy(jb_handle* h);
+int jb_gather_rows_device(jb_handle* h, const float* d_rows, float* d_all /*rank 0: [n_ranks, N_local, D+2]; others: NULL*/, void* stream, int32_t use_stream);
+
 /* Observation-encoder hook (reference jitterbug.py:760-761 -> encode_obs :927-993): a tiny dense network applied to every
  * observation row on the GPU.  n_layers <= JB_ENC_MAX_LAYERS dense layers; dims[0] must be the task's observation width and
  * every width <= JB_ENC_MAX_WIDTH; acts[l] in JB_ACT_*; weights are the layers' [in][out] matrices concatenated, biases

@@ -8,6 +8,7 @@
 // One launch of jb_step_kernel advances every env by one control step (cfg.substeps physics substeps),
 // then computes reward, done, optional in-kernel episode reset, and the observation row.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <cmath>
 #include <cstdio>
@@ -447,9 +448,56 @@ struct jb_handle {
     EncArgs enc;          // observation encoder (n_layers = 0: none)
     PolicyParams<float> policy;      // keyword arguments of the reference's heuristic policies
     JbNominalSpec* d_spec;           // nominal (uncompiled) model for the randomiser
+    void* comm;                      // RCCL communicator (jb_comm_init), null until asked for
+    int comm_ranks, comm_rank;
     float* d_terms;
     float* d_enc_params; float* d_code;
 };
+
+// ---------------------------------------------------------------------------------------------- RCCL, bound at run time
+// The library has no link-time dependency on RCCL: a host that never calls jb_comm_* never loads it, and a process that already
+// holds an RCCL (PyTorch-ROCm ships its own copy) keeps exactly that one - dlopen finds the loaded image first.
+namespace {
+struct RcclApi {
+    struct IdBlob { char b[128]; };          // ncclUniqueId (NCCL_UNIQUE_ID_BYTES = 128), passed BY VALUE to ncclCommInitRank
+    void* lib = nullptr;
+    int (*GetUniqueId)(void*) = nullptr;
+    int (*CommInitRank)(void**, int, IdBlob, int) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+RcclApi g_rccl;
+int load_rccl() {
+    if (g_rccl.lib) return JB_OK;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void* lib = nullptr;
+    for (const char* n : names) if ((lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;          // an image the process already holds
+    if (!lib) for (const char* n : names) if ((lib = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
+    if (!lib) return fail(JB_E_HIP, std::string("RCCL is not available (librccl.so): ") + (dlerror() ? dlerror() : ""));
+    auto sym = [&](const char* n) { return dlsym(lib, n); };
+    g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))sym("ncclGetUniqueId");
+    g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))sym("ncclCommInitRank");
+    g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))sym("ncclCommDestroy");
+    g_rccl.GroupStart = (decltype(g_rccl.GroupStart))sym("ncclGroupStart");
+    g_rccl.GroupEnd = (decltype(g_rccl.GroupEnd))sym("ncclGroupEnd");
+    g_rccl.Send = (decltype(g_rccl.Send))sym("ncclSend");
+    g_rccl.Recv = (decltype(g_rccl.Recv))sym("ncclRecv");
+    g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))sym("ncclGetErrorString");
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.GroupStart || !g_rccl.GroupEnd || !g_rccl.Send || !g_rccl.Recv)
+        return fail(JB_E_HIP, "librccl.so lacks an expected symbol");
+    g_rccl.lib = lib;
+    return JB_OK;
+}
+#define JB_NCCL(call)                                                                                                      \
+    do {                                                                                                                   \
+        int _r = (call);                                                                                                   \
+        if (_r != 0) return fail(JB_E_HIP, std::string(#call) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(_r) : "RCCL error")); \
+    } while (0)
+}  // namespace
 
 // Every entry point that allocates or launches first makes the handle's device current (a process may hold handles on several
 // GPUs, or switch devices with torch.cuda.set_device after jb_create).
@@ -590,6 +638,7 @@ int jb_destroy(jb_handle* h) {
     if (!h) return JB_OK;
     hipSetDevice(h->cfg.device_id);
     if (h->stream || !h->own_stream) hipStreamSynchronize(h->stream);
+    if (h->comm && g_rccl.CommDestroy) { g_rccl.CommDestroy(h->comm); h->comm = nullptr; }
     void* bufs[] = {h->d_terms, h->d_spec, h->d_root, h->d_leg, h->d_model, h->d_step, h->d_episode, h->d_action, h->d_obs, h->d_reward, h->d_done, h->d_mask, h->d_qpos, h->d_qvel, h->d_target, h->d_wave_stats, h->d_enc_params, h->d_code};
     for (void* b : bufs) if (b) hipFree(b);
     if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
@@ -939,6 +988,49 @@ int jb_model_draw_offsets_host(uint64_t seed, uint64_t env, uint32_t attempt, co
     for (int i = 0; i < 3; i++) { sd.legs[i] = cfg->sd_legs[i]; sd.mass_pos[i] = cfg->sd_mass_pos[i]; }
     sd.core1_density = cfg->sd_core1_density; sd.core2_density = cfg->sd_core2_density; sd.global_density = cfg->sd_global_density; sd.gear = cfg->sd_gear;
     draw_offsets(seed, env, attempt, cfg->flags, sd, offsets_out);
+    return JB_OK;
+}
+
+
+// ---- rows between GPUs without Python: one RCCL communicator per handle (gather of [N_local, D+2] rows to rank 0;
+// on 8 MI355X that is 7 concurrent single-hop xGMI sends, not a ring)
+int jb_comm_unique_id(void* id_out) {
+    if (!id_out) return fail(JB_E_INVALID, "id_out is NULL");
+    int rc = load_rccl();
+    if (rc) return rc;
+    JB_NCCL(g_rccl.GetUniqueId(id_out));
+    return JB_OK;
+}
+int jb_comm_init(jb_handle* h, int32_t n_ranks, int32_t rank, const void* id) {
+    if (!h || !id) return fail(JB_E_INVALID, "handle/id is NULL");
+    if (n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(JB_E_INVALID, "need 0 <= rank < n_ranks");
+    if (h->comm) return fail(JB_E_INVALID, "the handle already has a communicator (jb_comm_destroy first)");
+    JB_ENTER(h);
+    int rc = load_rccl();
+    if (rc) return rc;
+    RcclApi::IdBlob blob;
+    std::memcpy(blob.b, id, sizeof blob.b);
+    JB_NCCL(g_rccl.CommInitRank(&h->comm, n_ranks, blob, rank));
+    h->comm_ranks = n_ranks; h->comm_rank = rank;
+    return JB_OK;
+}
+int jb_comm_destroy(jb_handle* h) {
+    if (!h) return fail(JB_E_INVALID, "handle is NULL");
+    if (h->comm) { JB_ENTER(h); hipStreamSynchronize(h->stream); JB_NCCL(g_rccl.CommDestroy(h->comm)); h->comm = nullptr; }
+    return JB_OK;
+}
+int jb_gather_rows_device(jb_handle* h, const float* d_rows, float* d_all, void* stream, int32_t use_stream) {
+    if (!h || !d_rows) return fail(JB_E_INVALID, "handle/rows is NULL");
+    if (!h->comm) return fail(JB_E_INVALID, "no communicator (jb_comm_init)");
+    if (h->comm_rank == 0 && !d_all) return fail(JB_E_INVALID, "rank 0 needs the receive buffer [n_ranks, N_local, D+2]");
+    JB_ENTER(h);
+    hipStream_t st = use_stream ? (hipStream_t)stream : h->stream;
+    const size_t count = (size_t)h->cfg.n_envs * (size_t)(h->D + 2);
+    JB_NCCL(g_rccl.GroupStart());
+    if (h->comm_rank == 0)
+        for (int r = 0; r < h->comm_ranks; r++) JB_NCCL(g_rccl.Recv(d_all + (size_t)r * count, count, 7 /*ncclFloat*/, r, h->comm, st));
+    JB_NCCL(g_rccl.Send(d_rows, count, 7 /*ncclFloat*/, 0, h->comm, st));
+    JB_NCCL(g_rccl.GroupEnd());
     return JB_OK;
 }
 

@@ -237,3 +237,49 @@ def test_velocity_in_target_frame_uses_the_body_com_sensor():
         differs += abs(oo[16] - (c * v[i, 0] + s * v[i, 1])) > 1e-2
     assert differs > n // 2                                # the COM offset matters at these spin rates
     env.close()
+
+
+def test_c_abi_row_gather_over_rccl_one_rank():
+    """jb_comm_* / jb_gather_rows_device: the rows the step kernel wrote travel through a real RCCL communicator bound by dlopen inside
+    the library (no torch.distributed involved).  The test box has one GPU, so the communicator has one rank: rank 0 sends to itself;
+    the grouped send/recv path, the run-time binding and the side-stream use are what is exercised.  Run in a subprocess so that a
+    communicator never shares a process with torch's own process groups."""
+    import os, subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent('''
+        import ctypes as C, numpy as np, sys
+        sys.path.insert(0, %r)
+        import torch
+        from jitterbug_amd import _lib, model
+        from jitterbug_amd.vec_env import JitterbugVecEnv
+        n, task = 777, "move_to_pose"
+        D = model.OBS_DIM[task]
+        L = _lib.load()
+        env = JitterbugVecEnv(n, task, seed=3)
+        ref = JitterbugVecEnv(n, task, seed=3)
+        env.reset(); ref.reset()
+        uid = (C.c_char * 128)()
+        _lib.check(L.jb_comm_unique_id(uid))
+        _lib.check(L.jb_comm_init(env._h, 1, 0, uid))
+        assert L.jb_comm_init(env._h, 1, 0, uid) == -1                     # one communicator per handle
+        dev = torch.device("cuda", 0)
+        rows = torch.zeros((n, D + 2), device=dev); allrows = torch.zeros((1, n, D + 2), device=dev)
+        side = torch.cuda.Stream(device=dev)
+        g = torch.Generator().manual_seed(0)
+        for t in range(5):
+            a = (torch.rand(n, generator=g) * 2 - 1).to(torch.float32)
+            ad = a.to(dev)
+            env.step_rows_device(ad.data_ptr(), rows.data_ptr()); env.synchronize()
+            _lib.check(L.jb_gather_rows_device(env._h, rows.data_ptr(), allrows.data_ptr(), side.cuda_stream, 1))   # on a side stream
+            side.synchronize()
+            ob, rw, dn, _ = ref.step(a.numpy())
+            r = allrows[0].cpu().numpy()
+            assert np.array_equal(r[:, :D], ob) and np.array_equal(r[:, D], rw) and np.array_equal(r[:, D + 1] > 0.5, dn.astype(bool)), t
+        _lib.check(L.jb_gather_rows_device(env._h, rows.data_ptr(), allrows.data_ptr(), None, 0)); env.synchronize()   # on the handle's stream
+        _lib.check(L.jb_comm_destroy(env._h))
+        assert L.jb_gather_rows_device(env._h, rows.data_ptr(), allrows.data_ptr(), None, 0) == -1                    # no communicator any more
+        env.close(); ref.close()
+        print("CABI_GATHER_OK")
+    ''' % root)
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "CABI_GATHER_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
