@@ -59,6 +59,8 @@ extern "C" {
 typedef struct jb_handle jb_handle;
 
 #define JB_FLAG_NO_RANK_ONE 1   /* diagnostic: every Newton pass is a full sweep + refactorisation (no rank-one passes) */
+#define JB_FLAG_LEAN        2   /* the two-waves-per-SIMD kernel variant (256 registers; state / system / factorisation parked in LDS);
+                                  bit-identical results; experimental, see DESIGN.md */
 
 typedef struct jb_config {
     int32_t  n_envs;        /* N >= 1 */

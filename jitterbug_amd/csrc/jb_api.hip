@@ -36,6 +36,7 @@ struct KArgs {
     int n, task, substeps, step_limit, auto_reset, contacts, max_newton, random_pose, per_env_model;
     int epw;       // environments per wave (= per 64-thread workgroup) of the step kernel
     int rank_one;      // 0: diagnostic, no rank-one Newton passes (jb_config.flags & JB_FLAG_NO_RANK_ONE)
+    int lean;          // 1: the LEAN kernel variant (two waves per SIMD; jb_config.flags & JB_FLAG_LEAN)
     int packed_rows;   // step kernel output: 0 = obs[N,D] + reward[N] + done[N]; 1 = one float row [obs(D) | reward | done] per env
     unsigned long long seed, env_offset;
     float* root; float* leg; const float* lane_model;
@@ -45,7 +46,8 @@ struct KArgs {
 
 // Stage the packed constant table(s) of this workgroup (one wave = a.epw envs) into LDS: one LM_TABLE copy for a
 // shared model, epw copies for per-env models.  Called by all 64 threads before the idle quads retire.
-__device__ __forceinline__ void stage_model(const KArgs& a, float* lds, int lblock, int quad, int leg, LaneModel<float>& m) {
+__device__ __forceinline__ void stage_model(const KArgs& a, float* lds, int lblock, int quad, int leg, LaneModel<float>& m, bool lean = false) {
+    m.c.lean = lean;
     const int tsz = LM_TABLE;
     if (a.per_env_model) {
         const int env0 = lblock * a.epw;
@@ -125,9 +127,9 @@ __device__ __forceinline__ void store_target(const KArgs& a, int env, const EnvC
 // ---------------------------------------------------------------------------------------------- step
 // EPW (envs per wave) is a template parameter so that the scratch stride is a compile-time constant and every LDS access
 // of the substep uses an immediate offset instead of integer address arithmetic.
-template <int EPW>
-__global__ __launch_bounds__(64) void jb_step_kernel(KArgs a, const float* __restrict__ action, float* __restrict__ obs_out,
-                                                     float* __restrict__ reward_out, unsigned char* __restrict__ done_out) {
+template <int EPW, bool LEAN>
+__device__ __forceinline__ void step_body(KArgs a, const float* __restrict__ action, float* __restrict__ obs_out,
+                                          float* __restrict__ reward_out, unsigned char* __restrict__ done_out) {
     // one wave per workgroup; quad q (4 lanes) of the wave owns env blockIdx*epw + q.  Quads beyond epw (a small batch is
     // spread over all SIMDs with partially filled waves) and beyond the batch retire at once: DPP quad sums and the
     // wave ballots only ever involve complete, active quads.
@@ -146,7 +148,8 @@ __global__ __launch_bounds__(64) void jb_step_kernel(KArgs a, const float* __res
     const int lblock = xcd * per + (xcd < rem ? xcd : rem) + (b >> 3);
     const int env = lblock * EPW + quad;
     LaneModel<float> m;
-    stage_model(a, lds + SC_COUNT * 4 * EPW, lblock, quad, leg, m);
+    constexpr int SCN = LEAN ? SC_COUNT_LEAN : SC_COUNT;      // floats of per-lane scratch
+    stage_model(a, lds + SCN * 4 * EPW, lblock, quad, leg, m, LEAN);
     if (grp >= NGRP || env >= a.n) return;       // whole quads (and their mirrors in every group) retire together
     const bool live = true;
     const int lane = env * 4 + leg;
@@ -170,7 +173,7 @@ __global__ __launch_bounds__(64) void jb_step_kernel(KArgs a, const float* __res
     s.st_xtra = 0.f; s.st_sweeps = 0.f; s.st_contact = 0.f; s.st_slots = 0.f; s.st_fast = 0.f;
 #endif
     const float ctrl = action[env];
-    SimOpts o; o.contacts = a.contacts; o.max_newton = a.max_newton; o.implicit_damp = 1; o.rank_one = a.rank_one; o.prof = nullptr; o.hist = nullptr;
+    SimOpts o; o.contacts = a.contacts; o.max_newton = a.max_newton; o.implicit_damp = 1; o.rank_one = a.rank_one; o.lean = LEAN ? 1 : 0; o.prof = nullptr; o.hist = nullptr;
 #ifdef JB_WAVE_STATS
     const unsigned long long rt_start = __builtin_amdgcn_s_memrealtime();
     unsigned long long prof_local[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // accumulated in registers, written once at the end
@@ -178,9 +181,11 @@ __global__ __launch_bounds__(64) void jb_step_kernel(KArgs a, const float* __res
     o.hist = a.wave_stats ? a.wave_stats + (size_t)16 * a.n + (size_t)64 * lblock : nullptr;
 #endif
     normalise_state(s);          // mj_kinematics normalises the free-joint quaternion; phase C keeps it normalised from here on
+    if (LEAN && grp == 0) state_store(scr, s);                   // LEAN: the state lives in the scratch between substeps
 #pragma unroll 1
     for (int k = 0; k < a.substeps; k++) substep<float>(m, scr, s, ctrl, o);
     if (grp != 0) return;                        // helper lanes only take part in the substeps
+    if (LEAN) state_load(scr, s);
 #ifdef JB_WAVE_STATS
     if (threadIdx.x == 0 && a.wave_stats) {
         unsigned long long* ws = a.wave_stats + (size_t)lblock * 16;
@@ -222,6 +227,21 @@ __global__ __launch_bounds__(64) void jb_step_kernel(KArgs a, const float* __res
             if (done_out) done_out[env] = done ? 1 : 0;
         }
     }
+}
+
+template <int EPW>
+__global__ __launch_bounds__(64) void jb_step_kernel(KArgs a, const float* __restrict__ action, float* __restrict__ obs_out,
+                                                     float* __restrict__ reward_out, unsigned char* __restrict__ done_out) {
+    step_body<EPW, false>(a, action, obs_out, reward_out, done_out);
+}
+// The LEAN variant: the same substep with the register budget of TWO waves per SIMD (256 registers per lane).  Model constants are read
+// from LDS where they are used, and the lane state, the joint-space system and the kept factorisation are parked in the lane's
+// scratch between the phases that use them (jb_sim.hpp SimOpts::lean).  Same arithmetic in the same order: results are bit-identical
+// to the one-wave kernel's.  A second resident wave doubles the SIMD's VALU issue rate, which pays when a GPU holds >= 2048 waves.
+template <int EPW>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void jb_step_kernel_lean(KArgs a, const float* __restrict__ action, float* __restrict__ obs_out,
+                                                                                                      float* __restrict__ reward_out, unsigned char* __restrict__ done_out) {
+    step_body<EPW, true>(a, action, obs_out, reward_out, done_out);
 }
 
 // ---------------------------------------------------------------------------------------------- reset / observe
@@ -581,6 +601,7 @@ static int create_impl(jb_handle* h) {      // every failure returns through jb_
     k.n = cfg->n_envs; k.task = cfg->task_id; k.substeps = cfg->substeps; k.step_limit = cfg->step_limit; k.auto_reset = cfg->auto_reset;
     k.contacts = cfg->contacts; k.max_newton = h->cfg.max_newton; k.random_pose = cfg->random_pose; k.per_env_model = 0;
     k.seed = cfg->seed; k.env_offset = cfg->env_offset; k.rank_one = (cfg->flags & JB_FLAG_NO_RANK_ONE) ? 0 : 1;
+    k.lean = (cfg->flags & JB_FLAG_LEAN) ? 1 : 0;
     {   // envs per wave: fill every SIMD of the device before filling the lanes of a wave.  The kernel holds one wave
         // per SIMD (register budget), so the device runs (CUs x 4) waves at a time; LDS (scratch is per active lane)
         // allows 4 resident waves per CU up to 8 envs per wave.
@@ -595,6 +616,7 @@ static int create_impl(jb_handle* h) {      // every failure returns through jb_
         if (epw < 1) epw = 1;
         if (epw > 16) epw = 16;
         while (epw & (epw - 1)) epw++;       // 1, 2, 4, 8 or 16 (the kernel is instantiated for these)
+        if (k.lean) { if (cfg->envs_per_wave <= 0) epw = 2; if (epw > 4) epw = 4; }     // LEAN: 2 envs per wave keep 8 waves per CU within 160 KB of LDS
         k.epw = epw;
     }
     k.root = h->d_root; k.leg = h->d_leg; k.step_count = h->d_step; k.episode = h->d_episode; k.wave_stats = h->d_wave_stats;
@@ -732,16 +754,26 @@ static int launch_step(jb_handle* h, const float* d_action, float* d_obs_out, fl
     JB_ENTER(h);
     h->ka.packed_rows = packed_rows;
     const dim3 grid((unsigned)((h->cfg.n_envs + h->ka.epw - 1) / h->ka.epw));
-    const size_t lds_bytes = ((size_t)SC_COUNT * 4 * h->ka.epw + (size_t)LM_TABLE * (h->ka.per_env_model ? h->ka.epw : 1)) * sizeof(float);
+    const size_t lds_bytes = ((size_t)(h->ka.lean ? SC_COUNT_LEAN : SC_COUNT) * 4 * h->ka.epw + (size_t)LM_TABLE * (h->ka.per_env_model ? h->ka.epw : 1)) * sizeof(float);
 #define JB_LAUNCH_STEP(E) hipLaunchKernelGGL(jb_step_kernel<E>, grid, dim3(64), lds_bytes, h->stream, h->ka, d_action, d_obs_out, d_reward_out, d_done_out)
-    switch (h->ka.epw) {
-    case 1: JB_LAUNCH_STEP(1); break;
-    case 2: JB_LAUNCH_STEP(2); break;
-    case 4: JB_LAUNCH_STEP(4); break;
-    case 8: JB_LAUNCH_STEP(8); break;
-    default: JB_LAUNCH_STEP(16); break;
+#define JB_LAUNCH_LEAN(E) hipLaunchKernelGGL(jb_step_kernel_lean<E>, grid, dim3(64), lds_bytes, h->stream, h->ka, d_action, d_obs_out, d_reward_out, d_done_out)
+    if (h->ka.lean) {
+        switch (h->ka.epw) {
+        case 1: JB_LAUNCH_LEAN(1); break;
+        case 2: JB_LAUNCH_LEAN(2); break;
+        default: JB_LAUNCH_LEAN(4); break;
+        }
+    } else {
+        switch (h->ka.epw) {
+        case 1: JB_LAUNCH_STEP(1); break;
+        case 2: JB_LAUNCH_STEP(2); break;
+        case 4: JB_LAUNCH_STEP(4); break;
+        case 8: JB_LAUNCH_STEP(8); break;
+        default: JB_LAUNCH_STEP(16); break;
+        }
     }
 #undef JB_LAUNCH_STEP
+#undef JB_LAUNCH_LEAN
     JB_HIP(hipGetLastError());
     return JB_OK;
 }

@@ -114,17 +114,20 @@ template <typename V> struct LaneConsts {
     // one wave per SIMD the kernel owns all 512 registers of its lanes, and the allocator parks these long-lived values in
     // the accumulation half, one v_accvgpr_read away - no LDS round trip, no s_waitcnt in the middle of the dynamics.
     V hot[LM_HOT];
+    bool lean = false;              // LEAN kernel variant (two waves per SIMD): nothing is preloaded, every constant is read from LDS where it is used
     V tran0, tran1, tran2, tranm;   // the four per-body-level entries that are picked by a run-time level: kept out of the
                                     // array so that the pick is a select of values, never an indexed access (which would
                                     // force the whole array into scratch memory)
     JB_HD V tran_of(int level) const { return level == 2 ? tran2 : level == 1 ? tran1 : level == 0 ? tran0 : tranm; }
     JB_HD V table(int i) const { return i < LM_INV ? lane_bcast(inv + i, (V*)nullptr) : lane_from4(tab + 4 * (i - LM_INV), (V*)nullptr); }
     JB_HD void preload() {
+        if (!lean) {
 #pragma unroll
-        for (int i = 0; i < LM_HOT; i++) hot[i] = table(i);
+            for (int i = 0; i < LM_HOT; i++) hot[i] = table(i);
+        }
         tran0 = table(LM_TRAN0); tran1 = table(LM_TRAN1); tran2 = table(LM_TRAN2); tranm = table(LM_TRANM);
     }
-    JB_HD V operator[](int i) const { return i < LM_HOT ? hot[i] : table(i); }
+    JB_HD V operator[](int i) const { return (i < LM_HOT && !lean) ? hot[i] : table(i); }
 };
 template <typename V> struct LaneModel { LaneConsts<V> c; };
 template <typename V> JB_HD V ldc(const LaneModel<V>& m, int i) { return m.c[i]; }
@@ -261,7 +264,11 @@ enum SC : int {
                     overflow entry per group, 19 floats each)*/,
     SC_Y = 136 + 12 * 19 /*9: current Newton iterate [yr(6), yl(2), ym], shared with the helper groups*/,
     SC_ST = SC_Y + 9 /*6: w(3), thd1, thd2, phid for the helper groups*/,
-    SC_COUNT = SC_ST + 6
+    SC_COUNT = SC_ST + 6,
+    // LEAN kernel variant only (its scratch is longer): long-lived values that the one-wave-per-SIMD kernel keeps in registers are
+    // parked here between the phases that use them
+    SC_SYS = SC_COUNT /*52: joint-space system*/, SC_FAC = SC_SYS + 52 /*43: kept factorisation*/, SC_LSTATE = SC_FAC + 43 /*36: lane state*/,
+    SC_COUNT_LEAN = SC_LSTATE + 36
 };
 template <typename V> struct LaneScratch {
     V* p;
@@ -827,6 +834,8 @@ struct SimOpts {
     int max_newton;      // cap on Newton iterations per substep
     int implicit_damp;   // 1: MuJoCo Euler implicit joint damping
     int rank_one;        // 1: single-edge changes of the active set are rank-one passes (0: diagnostic, always full passes)
+    int lean = 0;        // 1: LEAN kernel variant - the lane state, the joint-space system and the kept factorisation live in the scratch
+                         //    between the phases that use them (register budget of two waves per SIMD); same arithmetic, same results
     unsigned long long* prof;   // diagnostic builds: per-wave cycle accumulators [phaseA, check sweeps, full sweeps, solves, integrate]
     unsigned long long* hist;   // diagnostic builds: per-wave [0..27] live-slot counts over all-geom substeps, [28..35] rounds histogram, [36..43] same for ordinary substeps
 };
@@ -850,6 +859,54 @@ template <typename V> __device__ inline void stats_hist(const SimOpts& o, const 
 template <typename V> inline void stats_hist(const SimOpts&, const LaneScratch<V>&, const SlotPlan&, bool, bool) {}
 #endif
 #endif
+
+// ---- LEAN variant: park / fetch long-lived values in the lane's scratch (lane-private columns: no hand-over between lanes)
+template <typename V> JB_HD void sys_store(const LaneScratch<V>& sc, const StarSys<V>& y) {
+#pragma unroll
+    for (int i = 0; i < 21; i++) sc.st(SC_SYS + i, y.A[i]);
+#pragma unroll
+    for (int i = 0; i < 6; i++) { sc.st(SC_SYS + 21 + 2 * i, y.B[i][0]); sc.st(SC_SYS + 22 + 2 * i, y.B[i][1]); sc.st(SC_SYS + 36 + i, y.Bm[i]); sc.st(SC_SYS + 43 + i, y.tr[i]); }
+    sc.st(SC_SYS + 33, y.C[0]); sc.st(SC_SYS + 34, y.C[1]); sc.st(SC_SYS + 35, y.C[2]); sc.st(SC_SYS + 42, y.Cm);
+    sc.st(SC_SYS + 49, y.tl[0]); sc.st(SC_SYS + 50, y.tl[1]); sc.st(SC_SYS + 51, y.tm);
+}
+template <typename V> JB_HD void sys_load(const LaneScratch<V>& sc, StarSys<V>& y) {
+#pragma unroll
+    for (int i = 0; i < 21; i++) y.A[i] = sc.ld(SC_SYS + i);
+#pragma unroll
+    for (int i = 0; i < 6; i++) { y.B[i][0] = sc.ld(SC_SYS + 21 + 2 * i); y.B[i][1] = sc.ld(SC_SYS + 22 + 2 * i); y.Bm[i] = sc.ld(SC_SYS + 36 + i); y.tr[i] = sc.ld(SC_SYS + 43 + i); }
+    y.C[0] = sc.ld(SC_SYS + 33); y.C[1] = sc.ld(SC_SYS + 34); y.C[2] = sc.ld(SC_SYS + 35); y.Cm = sc.ld(SC_SYS + 42);
+    y.tl[0] = sc.ld(SC_SYS + 49); y.tl[1] = sc.ld(SC_SYS + 50); y.tm = sc.ld(SC_SYS + 51);
+}
+template <typename V> JB_HD void fac_store(const LaneScratch<V>& sc, const StarFactor<V>& F) {
+#pragma unroll
+    for (int i = 0; i < 21; i++) sc.st(SC_FAC + i, F.S[i]);
+#pragma unroll
+    for (int i = 0; i < 6; i++) { sc.st(SC_FAC + 21 + 2 * i, F.B[i][0]); sc.st(SC_FAC + 22 + 2 * i, F.B[i][1]); sc.st(SC_FAC + 36 + i, F.bm[i]); }
+    sc.st(SC_FAC + 33, F.i11); sc.st(SC_FAC + 34, F.i12); sc.st(SC_FAC + 35, F.i22); sc.st(SC_FAC + 42, F.icm);
+}
+template <typename V> JB_HD void fac_load(const LaneScratch<V>& sc, StarFactor<V>& F) {
+#pragma unroll
+    for (int i = 0; i < 21; i++) F.S[i] = sc.ld(SC_FAC + i);
+#pragma unroll
+    for (int i = 0; i < 6; i++) { F.B[i][0] = sc.ld(SC_FAC + 21 + 2 * i); F.B[i][1] = sc.ld(SC_FAC + 22 + 2 * i); F.bm[i] = sc.ld(SC_FAC + 36 + i); }
+    F.i11 = sc.ld(SC_FAC + 33); F.i12 = sc.ld(SC_FAC + 34); F.i22 = sc.ld(SC_FAC + 35); F.icm = sc.ld(SC_FAC + 42);
+}
+template <typename V> JB_HD void state_store(const LaneScratch<V>& sc, const LaneState<V>& s) {
+    const V v[36] = {s.px, s.py, s.pz, s.qw, s.qx, s.qy, s.qz, s.pz_lo, s.qw_lo, s.qx_lo, s.qy_lo, s.qz_lo, s.vx, s.vy, s.vz, s.wx, s.wy, s.wz,
+                     s.phi, s.phid, s.turns, s.th1, s.th2, s.thd1, s.thd2, s.wa[0], s.wa[1], s.wa[2], s.wl[0], s.wl[1], s.wl[2], s.wj[0], s.wj[1], s.wm, s.fail, V(0)};
+#pragma unroll
+    for (int i = 0; i < 35; i++) sc.st(SC_LSTATE + i, v[i]);
+}
+template <typename V> JB_HD void state_load(const LaneScratch<V>& sc, LaneState<V>& s) {
+    V v[35];
+#pragma unroll
+    for (int i = 0; i < 35; i++) v[i] = sc.ld(SC_LSTATE + i);
+    s.px = v[0]; s.py = v[1]; s.pz = v[2]; s.qw = v[3]; s.qx = v[4]; s.qy = v[5]; s.qz = v[6];
+    s.pz_lo = v[7]; s.qw_lo = v[8]; s.qx_lo = v[9]; s.qy_lo = v[10]; s.qz_lo = v[11];
+    s.vx = v[12]; s.vy = v[13]; s.vz = v[14]; s.wx = v[15]; s.wy = v[16]; s.wz = v[17];
+    s.phi = v[18]; s.phid = v[19]; s.turns = v[20]; s.th1 = v[21]; s.th2 = v[22]; s.thd1 = v[23]; s.thd2 = v[24];
+    s.wa[0] = v[25]; s.wa[1] = v[26]; s.wa[2] = v[27]; s.wl[0] = v[28]; s.wl[1] = v[29]; s.wl[2] = v[30]; s.wj[0] = v[31]; s.wj[1] = v[32]; s.wm = v[33]; s.fail = v[34];
+}
 
 // ---- compensated arithmetic for the position state.  two_sum: s + e == a + b exactly (Knuth); the adds are pinned with
 // vadd_rn so that no optimisation re-associates them.
@@ -1103,6 +1160,7 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
         }
     }
     JB_SCHED_FENCE();
+    if (o.lean && is_main) sys_store(sc, sys);
 
     JB_PROF_ADD(o, 0);
     // the helper groups learn what phase A found (values of the first lane, a main lane)
@@ -1116,6 +1174,7 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
     // Main lanes own the iterate and the solves; every decision that steers the loop is broadcast so that the helper groups
     // follow the same control flow.
     V yr[6], yl[2], ym;
+    V fail_inc = V(0);          // Newton cap hits of this substep (added to the state in phase C)
     {
         NewtonAcc<V> acc;
         StarFactor<V> fac;      // factorisation of the last Newton system (main lanes)
@@ -1171,7 +1230,7 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
                         }
 #endif
                         if (!any_lane(unconverged) || it >= o.max_newton) {
-                            s.fail = s.fail + sel(unconverged, V(1), V(0));
+                            fail_inc = fail_inc + sel(unconverged, V(1), V(0));
                             fin = 1u;
                         } else {
                             // An env whose set differs from the factored one by a single pyramid edge of a leg slot (exact
@@ -1191,6 +1250,7 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
                             full = any_lane(mand(unconverged, mnot(fast_env))) ? 1u : 0u;
                             if (any_lane(fast_env)) {
                                 V fyr[6], fyl[2], fym;
+                                if (o.lean) fac_load(sc, fac);
                                 rank_one_pass<V>(sc, fac, dk, m.c[LM_MU], f_entry, f_is, f_plus, f_tan2, f_on, yr, yl, ym, fyr, fyl, fym);
 #pragma unroll
                                 for (int i = 0; i < 6; i++) yr[i] = sel(fast_env, fyr[i], yr[i]);
@@ -1214,6 +1274,7 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
                     if (is_main) s.st_sweeps = s.st_sweeps + V(1);
 #endif
                 } else if (final_pass && is_main) {
+                    if (o.lean) sys_load(sc, sys);
                     // At the minimiser  H y = tau + sum B^T W ahat,  so the constraint force is  qfrc = M y - tau  and MuJoCo's
                     // Euler step with implicit joint damping solves  (M + h diag(b)) qacc = tau + qfrc = M y,  i.e.
                     //     qacc = y - d,   (M + h diag(b)) d = h diag(b) y        (nonzero only in the leg rows).
@@ -1230,6 +1291,7 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
             if (is_main) {
                 V nyr[6], nyl[2], nym;
                 if (final_pass) {
+                    if (o.lean) sys_load(sc, sys);
                     star_factor<V, false>(sys, acc, hb1, hb2, fac);           // acc holds only right-hand sides here
                     star_subst<V>(fac, acc.rr, sys.tr, sys.tl[0] + acc.rl[0], sys.tl[1] + acc.rl[1], sys.tm + quad_sum(acc.rm), nyr, nyl, nym);
                     JB_PROF_ADD(o, 6);
@@ -1238,7 +1300,9 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
                     yl[0] = sel(env_con, yl[0] - nyl[0], nyl[0]); yl[1] = sel(env_con, yl[1] - nyl[1], nyl[1]); ym = sel(env_con, ym - nym, nym);
                 } else {
                     if (full_pass) {
+                        if (o.lean) sys_load(sc, sys);
                         star_solve<V>(sys, acc, V(0), V(0), fac, nyr, nyl, nym);
+                        if (o.lean) fac_store(sc, fac);
                         JB_PROF_ADD(o, 6);
                         // envs whose active set already repeated keep their (exact) solution, rank-one envs theirs
                         const MK take = mand(unconverged, mnot(fast_env));
@@ -1263,6 +1327,8 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
     if (!is_main) return;
 
     // ================= phase C: integrate
+    if (o.lean) state_load(sc, s);
+    s.fail = s.fail + fail_inc;
     Vec3<V> lin = mul(Rw, v3<V>(yr[3], yr[4], yr[5]));
     s.wa[0] = yr[0]; s.wa[1] = yr[1]; s.wa[2] = yr[2]; s.wl[0] = lin.x; s.wl[1] = lin.y; s.wl[2] = lin.z; s.wj[0] = yl[0]; s.wj[1] = yl[1]; s.wm = ym;
     // mj_advance: velocities, then positions with the new velocities
@@ -1297,6 +1363,7 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
         s.phi = pp - k * V(6.283185307179586);
         s.turns = s.turns + k;
     }
+    if (o.lean) state_store(sc, s);
     JB_PROF_ADD(o, 4);
 }
 
@@ -1315,6 +1382,7 @@ template <typename V>
 JB_HD void substep(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneState<V>& s, const V& ctrl, const SimOpts& o) {
     unsigned xt = 0;          // bit 0: some upper leg may touch the floor, bit 1: some root / motor-body geom may
     Mat3<V> Rw;               // root rotation (main lanes): mj_kinematics normalises the quaternion first
+    if (o.lean && sc.grp == 0) state_load(sc, s);       // LEAN: the state lives in the scratch between substeps
     if (sc.grp == 0) Rw = quat2mat(s.qw, s.qx, s.qy, s.qz);      // the quaternion is kept normalised: normalise_state() once per kernel, phase C after every substep
     if (o.contacts && sc.grp == 0) {
         const Vec3<V> nb = v3<V>(Rw.m[6], Rw.m[7], Rw.m[8]);         // floor normal in root coordinates

@@ -15,12 +15,12 @@ using namespace jb;
 // helper groups, one host thread each, sharing the scratch and exchanging through jb_lane.hpp's HostWave (group_sum, row_transpose_sum,
 // the rank-one pass on rows other groups built, the broadcast loop decisions): the same code paths the device takes with helper lanes.
 template <typename T>
-static int run(const double* P, double* qpos, double* qvel, double ctrl, int nsub, int contacts, int max_newton, int implicit_damp, double* fail, int ngroups = 1, int rank_one = 1) {
+static int run(const double* P, double* qpos, double* qvel, double ctrl, int nsub, int contacts, int max_newton, int implicit_damp, double* fail, int ngroups = 1, int rank_one = 1, int lean = 0) {
     using V = Quad<T>;
     LaneModel<V> m;
     T tab[LM_TABLE];
     { int rc = build_packed_model<T>(P, tab); if (rc) return rc; }
-    m.c.inv = tab; m.c.tab = tab + LM_INV; m.c.preload();
+    m.c.inv = tab; m.c.tab = tab + LM_INV; m.c.lean = lean != 0; m.c.preload();
     LaneState<V> s;
     s.px = V(T(qpos[0])); s.py = V(T(qpos[1])); s.pz = V(T(qpos[2]));
     s.qw = V(T(qpos[3])); s.qx = V(T(qpos[4])); s.qy = V(T(qpos[5])); s.qz = V(T(qpos[6]));
@@ -37,17 +37,20 @@ static int run(const double* P, double* qpos, double* qvel, double ctrl, int nsu
     s.thd2 = V(T(qvel[7]), T(qvel[9]), T(qvel[11]), T(qvel[13]));
     for (int i = 0; i < 3; i++) { s.wa[i] = V(T(0)); s.wl[i] = V(T(0)); }
     s.wj[0] = s.wj[1] = V(T(0)); s.wm = V(T(0)); s.fail = V(T(0));
-    SimOpts o; o.contacts = contacts; o.max_newton = max_newton; o.implicit_damp = implicit_damp; o.rank_one = rank_one; o.prof = nullptr; o.hist = nullptr;
-    V scratch[SC_COUNT];
+    SimOpts o; o.contacts = contacts; o.max_newton = max_newton; o.implicit_damp = implicit_damp; o.rank_one = rank_one; o.lean = lean; o.prof = nullptr; o.hist = nullptr;
+    V scratch[SC_COUNT_LEAN];          // (the LEAN variant parks state / system / factorisation behind the ordinary scratch)
     normalise_state(s);
     if (ngroups <= 1) {
         LaneScratch<V> sc; sc.p = scratch; sc.stride = 1; sc.grp = 0; sc.ngrp = 1; sc.gstride = 4;
+        for (int k = 0; k < SC_COUNT_LEAN; k++) scratch[k] = V(std::numeric_limits<T>::quiet_NaN());
+        if (lean) state_store(sc, s);
         for (int i = 0; i < nsub; i++) {
             // poison the scratch: a substep must not read anything it has not written itself (on the device LDS keeps whatever
-            // the previous kernel left there)
-            for (int k = 0; k < SC_COUNT; k++) scratch[k] = V(std::numeric_limits<T>::quiet_NaN());
+            // the previous kernel left there); in the LEAN variant the parked state is the one thing that carries over
+            for (int k = 0; k < SC_LSTATE; k++) scratch[k] = V(std::numeric_limits<T>::quiet_NaN());
             substep<V>(m, sc, s, V(T(ctrl)), o);
         }
+        if (lean) state_load(sc, s);
     } else {
         HostWave wave;
         wave.ngrp = ngroups; wave.gstride = 16;            // 16: the lane distance between groups in the 4-envs-per-wave kernel (selects its transposed reduction)
@@ -61,12 +64,14 @@ static int run(const double* P, double* qpos, double* qvel, double ctrl, int nsu
                 hs.pz_lo = hs.qw_lo = hs.qx_lo = hs.qy_lo = hs.qz_lo = V(T(0));
                 hs.phi = hs.phid = hs.turns = V(T(0)); hs.th1 = hs.th2 = hs.thd1 = hs.thd2 = V(T(0));
             }
+            if (g == 0) { for (int k = 0; k < SC_COUNT_LEAN; k++) scratch[k] = V(std::numeric_limits<T>::quiet_NaN()); if (lean) state_store(sc, st); }
             for (int i = 0; i < nsub; i++) {
                 wave.barrier();
-                if (g == 0) for (int k = 0; k < SC_COUNT; k++) scratch[k] = V(std::numeric_limits<T>::quiet_NaN());
+                if (g == 0) for (int k = 0; k < SC_LSTATE; k++) scratch[k] = V(std::numeric_limits<T>::quiet_NaN());
                 wave.barrier();
                 substep<V>(m, sc, st, V(T(ctrl)), o);
             }
+            if (g == 0 && lean) state_load(sc, st);
             g_host_wave = nullptr;
         };
         std::vector<std::thread> th;
@@ -97,6 +102,12 @@ extern "C" int jbh_step_groups(const double* P, double* qpos, double* qvel, doub
     if (ngroups != 1 && ngroups != 4) return -101;
     return use_float ? run<float>(P, qpos, qvel, ctrl, nsub, contacts, max_newton, 1, fail, ngroups, rank_one)
                      : run<double>(P, qpos, qvel, ctrl, nsub, contacts, max_newton, 1, fail, ngroups, rank_one);
+}
+// ... and in the LEAN variant (state / system / factorisation parked in the scratch, constants never preloaded)
+extern "C" int jbh_step_lean(const double* P, double* qpos, double* qvel, double ctrl, int nsub, int contacts, int max_newton, int use_float, int ngroups, int rank_one, double* fail) {
+    if (ngroups != 1 && ngroups != 4) return -101;
+    return use_float ? run<float>(P, qpos, qvel, ctrl, nsub, contacts, max_newton, 1, fail, ngroups, rank_one, 1)
+                     : run<double>(P, qpos, qvel, ctrl, nsub, contacts, max_newton, 1, fail, ngroups, rank_one, 1);
 }
 extern "C" int jbh_lm_count(void) { return LM_COUNT; }
 // the per-leg constant table (LM_COUNT doubles) for inspection by tests / tools

@@ -97,12 +97,12 @@ def test_state_roundtrip():
 MARGIN_TOL = 3e-8       # metres
 
 
-def _teacher_forced(task, n, steps, seed, contacts=True, params=None, flat_out=False, skip=0):
+def _teacher_forced(task, n, steps, seed, contacts=True, params=None, flat_out=False, skip=0, flags=0):
     from oracle import oracle as O
     P = model.default_params() if params is None else params
     per_env = P.ndim == 2
     from jitterbug_amd.vec_env import JitterbugVecEnv
-    g = JitterbugVecEnv(n, task, seed=seed, auto_reset=False, contacts=contacts, params=P if per_env else None)
+    g = JitterbugVecEnv(n, task, seed=seed, auto_reset=False, contacts=contacts, params=P if per_env else None, flags=flags)
     okw = dict(opts=O.default_opts(contacts=int(contacts)), per_env_model=per_env)
     o = O.OracleEnv(n, task, P, seed=seed, **okw)
     g.reset(), o.reset()
@@ -163,6 +163,32 @@ def test_step_teacher_forced_tipped_over_robots():
     assert r["well_bad"] <= 3 and r["worst_well"] < 2e-5 and r["well_big"] == 0, r
     assert r["ill_frac"] < 0.05 and r["frac"] >= 0.9999 and r["worst"] < 1e-3, r
     assert r["cap"] == 0
+
+
+def test_lean_kernel_variant_parity():
+    """JB_FLAG_LEAN: the two-waves-per-SIMD variant of the step kernel (231 VGPRs, no spills; state / system / factorisation parked in LDS)
+    under the same protocol, and against the ordinary variant from identical states (the compiler fuses multiply-adds differently in
+    the two kernels, so they agree to rounding, not bit for bit - on the host, without contraction, they are identical)."""
+    from jitterbug_amd.vec_env import JitterbugVecEnv
+    r = _teacher_forced("move_to_pose", 64, 200, seed=7, flags=2)
+    print("teacher-forced, lean kernel:", r)
+    assert r["well_frac"] == 1.0 and r["well_big"] == 0 and r["frac"] >= 0.999 and r["cap"] == 0, r
+    r = _teacher_forced("move_to_pose", 64, 100, seed=5, flat_out=True, skip=250, flags=2)
+    assert r["tipped"] > 0.2 and r["well_bad"] <= 3 and r["worst_well"] < 2e-5 and r["frac"] >= 0.9999, r
+    n = 1024
+    a_env, b_env = JitterbugVecEnv(n, "move_to_pose", seed=6), JitterbugVecEnv(n, "move_to_pose", seed=6, flags=2)
+    a_env.reset(), b_env.reset()
+    rng = np.random.default_rng(2)
+    ok = tot = 0
+    for t in range(40):
+        act = rng.uniform(-1, 1, size=n).astype(np.float32)
+        b_env.set_state(*a_env.get_state())
+        oa, ra, _, _ = a_env.step(act)
+        ob, rb, _, _ = b_env.step(act)
+        good = np.abs(oa - ob) <= 1e-4 * np.abs(ob) + 1e-6
+        ok += good.sum(); tot += good.size
+    assert ok / tot >= 0.999, ok / tot
+    a_env.close(); b_env.close()
 
 
 def test_step_teacher_forced_contacts_off():

@@ -194,3 +194,29 @@ def test_helper_groups_fp32_agree_with_single_group_within_rounding(gstep, param
         qs, vs, _ = gstep(q0[i], v0[i], 0.3, groups=1, f32=1)
         errs.append(max(np.abs(qg[:7] - qs[:7]).max(), np.abs(vg[:6] - vs[:6]).max() / 35))
     assert np.median(errs) < 1e-6
+
+
+def test_lean_variant_is_bit_identical_on_the_host(params):
+    """JB_FLAG_LEAN (the 256-register kernel variant: constants read from LDS, lane state / joint-space system / kept factorisation parked
+    in the scratch between phases) runs the same arithmetic in the same order: fp64 AND fp32 host builds reproduce the ordinary variant
+    bit for bit, with one and with four lane groups, walking and tipped over."""
+    import tests.build_harness as bh
+    lib = C.CDLL(bh.build())
+    dp = C.POINTER(C.c_double)
+    for f in (lib.jbh_step_groups, lib.jbh_step_lean):
+        f.argtypes = [dp, dp, dp, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, dp]
+    P = np.ascontiguousarray(params)
+
+    def run(fn, q, v, groups, f32):
+        q, v, fail = q.copy(), v.copy(), np.zeros(1)
+        assert fn(P.ctypes.data_as(dp), q.ctypes.data_as(dp), v.ctypes.data_as(dp), 0.3, 50, 1, 20, f32, groups, 1, fail.ctypes.data_as(dp)) == 0
+        return q, v
+
+    for tipped in (False, True):
+        env = _contact_states(params, 6, tipped)
+        q0, v0, _ = env.get_state()
+        for i in range(6):
+            for groups in (1, 4):
+                for f32 in (0, 1):
+                    a, b = run(lib.jbh_step_groups, q0[i], v0[i], groups, f32), run(lib.jbh_step_lean, q0[i], v0[i], groups, f32)
+                    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), (tipped, i, groups, f32)
