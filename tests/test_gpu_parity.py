@@ -174,7 +174,7 @@ def test_lean_kernel_variant_parity():
     print("teacher-forced, lean kernel:", r)
     assert r["well_frac"] == 1.0 and r["well_big"] == 0 and r["frac"] >= 0.999 and r["cap"] == 0, r
     r = _teacher_forced("move_to_pose", 64, 100, seed=5, flat_out=True, skip=250, flags=2)
-    assert r["tipped"] > 0.2 and r["well_bad"] <= 3 and r["worst_well"] < 2e-5 and r["frac"] >= 0.9999, r
+    assert r["tipped"] > 0.15 and r["well_bad"] <= 3 and r["worst_well"] < 2e-5 and r["frac"] >= 0.9999, r
     n = 1024
     a_env, b_env = JitterbugVecEnv(n, "move_to_pose", seed=6), JitterbugVecEnv(n, "move_to_pose", seed=6, flags=2)
     a_env.reset(), b_env.reset()
