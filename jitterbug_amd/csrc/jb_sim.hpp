@@ -1174,7 +1174,7 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
     // Main lanes own the iterate and the solves; every decision that steers the loop is broadcast so that the helper groups
     // follow the same control flow.
     V yr[6], yl[2], ym;
-    V fail_inc = V(0);          // Newton cap hits of this substep (added to the state in phase C)
+    V fail_inc = V(0);          // LEAN: Newton cap hits of this substep (the state is parked during the solve; added in phase C)
     {
         NewtonAcc<V> acc;
         StarFactor<V> fac;      // factorisation of the last Newton system (main lanes)
@@ -1230,7 +1230,7 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
                         }
 #endif
                         if (!any_lane(unconverged) || it >= o.max_newton) {
-                            fail_inc = fail_inc + sel(unconverged, V(1), V(0));
+                            if (o.lean) fail_inc = fail_inc + sel(unconverged, V(1), V(0)); else s.fail = s.fail + sel(unconverged, V(1), V(0));
                             fin = 1u;
                         } else {
                             // An env whose set differs from the factored one by a single pyramid edge of a leg slot (exact
@@ -1327,8 +1327,7 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
     if (!is_main) return;
 
     // ================= phase C: integrate
-    if (o.lean) state_load(sc, s);
-    s.fail = s.fail + fail_inc;
+    if (o.lean) { state_load(sc, s); s.fail = s.fail + fail_inc; }
     Vec3<V> lin = mul(Rw, v3<V>(yr[3], yr[4], yr[5]));
     s.wa[0] = yr[0]; s.wa[1] = yr[1]; s.wa[2] = yr[2]; s.wl[0] = lin.x; s.wl[1] = lin.y; s.wl[2] = lin.z; s.wj[0] = yl[0]; s.wj[1] = yl[1]; s.wm = ym;
     // mj_advance: velocities, then positions with the new velocities
