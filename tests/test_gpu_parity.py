@@ -92,7 +92,7 @@ def test_state_roundtrip():
 # implementation, MuJoCo's own included.  The oracle reports how close each env-step came to that (jbo_stats.margin_min: the
 # smallest |distance| of any contact candidate at any of the 50 substep boundaries).  tools/flip_study.py (the kernel source on the
 # host in fp32 vs the oracle) shows every out-of-tolerance env-step has margin < 1e-8 m (10 nm; fp32 resolves the 35 mm body
-# height to 3.7 nm), and none above.  So the protocol asserts the north-star tolerance on EVERY entry of every env-step whose
+# height to 3.7 nm), and none above; tools/oracle_fp32_study.py shows the same for the oracle's own algorithm compiled in fp32.  So the protocol asserts the north-star tolerance on EVERY entry of every env-step whose
 # margin is at least MARGIN_TOL, and separately bounds how many env-steps fall below it and the overall fraction.
 MARGIN_TOL = 3e-8       # metres
 
