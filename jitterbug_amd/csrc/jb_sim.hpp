@@ -1227,6 +1227,15 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
                                 o.hist[44] += 1ull; if (!m_multi) o.hist[45] += 1ull;
                                 o.hist[46] += __builtin_popcountll(m1) / 4; o.hist[47] += __builtin_popcountll(m2) / 4; o.hist[48] += __builtin_popcountll(m3) / 4; o.hist[49] += __builtin_popcountll(m4) / 4;
                             }
+                            // of the multi-flip envs: those whose flips sit in different lanes (at most one per leg) - what a per-lane rank-k pass could take
+                            const unsigned lane_fl = (unsigned)__builtin_popcount(acc.bw0 ^ prev_bw0) + (unsigned)__builtin_popcount(acc.bw1 ^ prev_bw1);
+                            const bool spread = quad_sum_u(lane_fl > 1u ? 1u : 0u) == 0u;
+                            const unsigned long long m_sp = __builtin_amdgcn_ballot_w64(unc && fl > 1u && spread), m_sp2 = __builtin_amdgcn_ballot_w64(unc && fl == 2u && spread);
+                            const unsigned long long m_bad = __builtin_amdgcn_ballot_w64(unc && !spread);
+                            if ((threadIdx.x & 63) == 0 && m_unc) {
+                                o.hist[50] += __builtin_popcountll(m_sp) / 4; o.hist[51] += __builtin_popcountll(m_sp2) / 4;
+                                if (m_multi && !m_bad) o.hist[52] += 1ull;          // a changed-set check that needs a full pass today and would not with per-lane rank-k
+                            }
                         }
 #endif
                         if (!any_lane(unconverged) || it >= o.max_newton) {

@@ -64,3 +64,6 @@ if hist[44] > 0:
     print("checks that found a changed set (ordinary substeps): %d; of those with at most ONE flipped bit in every unconverged env: %.3f" % (hist[44], hist[45] / hist[44]))
     e = hist[46:50].astype(float)
     print("flipped bits per unconverged env [1, 2, 3, 4+]:", (e / max(1.0, e.sum())).round(3))
+    multi = max(1.0, float(e[1:].sum()))
+    print("multi-flip envs whose flips sit in different legs (at most one per lane): %.3f of the multi-flip envs (%.3f of the 2-flip ones); changed-set checks that need a full pass only because of such envs: %.3f of all, %.3f of those needing a full pass"
+          % (hist[50] / multi, hist[51] / max(1.0, float(e[1])), hist[52] / hist[44], hist[52] / max(1.0, float(hist[44] - hist[45]))))
