@@ -70,3 +70,21 @@ def test_task_factories_validate_like_the_reference():
     assert compute_n_substeps(0.01) == 50
     with pytest.raises(ValueError):
         compute_n_substeps(0.00031)
+
+
+def test_host_only_entry_points_validate_arguments(lib):
+    """the device-free helpers of the native model compiler: argument errors come back as JB_E_INVALID with a message, never a crash"""
+    assert lib.jb_default_randomise_config(None) == -1 and b"NULL" in lib.jb_last_error()
+    assert lib.jb_model_compile_host(None, 0, None) == -1
+    assert lib.jb_model_mass_clearance_ok(None, 0.001) == -1
+    assert lib.jb_model_draw_offsets_host(0, 0, 0, None, None) == -1
+    cfg = _lib.RandomiseConfig()
+    assert lib.jb_default_randomise_config(cfg) == 0 and cfg.max_attempts == 64 and cfg.min_mass_clearance == 0.0
+    P = np.zeros(model.NPARAM)
+    assert lib.jb_model_compile_host(None, 0, _lib.ptr(P)) == 0 and lib.jb_model_mass_clearance_ok(_lib.ptr(P), 0.001) == 1
+    # handle-taking entry points refuse a NULL handle before touching any device
+    for call in (lambda: lib.jb_randomise_models(None, cfg, None, None, None, None), lambda: lib.jb_set_policy_params(None, 0.5, 0.3, 0.3),
+                 lambda: lib.jb_reward_terms(None, None), lambda: lib.jb_comm_init(None, 1, 0, None), lambda: lib.jb_comm_destroy(None),
+                 lambda: lib.jb_gather_rows_device(None, None, None, None, 0)):
+        assert call() == -1
+    assert lib.jb_comm_unique_id(None) == -1

@@ -373,6 +373,11 @@ def test_edge_cases_batch_sizes_and_layouts():
     g = JitterbugVecEnv(4)
     with pytest.raises(_lib.JitterbugHipError, match="n_tables"):
         g.set_model_params(np.tile(P, (3, 1)))
+    with pytest.raises(_lib.JitterbugHipError, match="policy parameters"):
+        g.set_policy_params(kick_angle=-1.0)
+    with pytest.raises(_lib.JitterbugHipError, match="max_attempts"):
+        g.randomise_models(seed=1, min_mass_clearance=0.02)      # 20 mm of clearance: no draw can satisfy it -> error, and the handle falls back to the nominal model
+    assert np.isfinite(g.step(np.zeros(4, dtype=np.float32))[0]).all()
     bad = P.copy(); bad[model.P_SOLIMP + 4] = 3.0            # solimp power != 2 is not implemented by the kernel
     with pytest.raises(_lib.JitterbugHipError, match="JB_E_MODEL"):
         g.set_model_params(bad)
