@@ -769,7 +769,8 @@ JB_HD void contact_sweep(const LaneModel<V>& m, const LaneScratch<V>& sc, bool x
     }
 }
 
-// Cylinder vs floor, restating MuJoCo's plane-cylinder routine: up to 4 points.  c: centre, ax: unit axis,
+// Cylinder vs floor, restating MuJoCo's plane-cylinder routine (mjc_PlaneCylinder in MuJoCo's engine_collision_primitive.c - third
+// party, not under /root/reference; the oracle's collide() restates the same routine and cites it likewise): up to 4 points.  c: centre, ax: unit axis,
 // xa: geom x axis (degenerate case), all in root coordinates relative to the root origin; nb: floor normal in
 // root coordinates; pz: world height of the root origin.  Outputs positions (relative to the root origin) and
 // distances; a point is a contact when its mask is set.
