@@ -12,6 +12,11 @@ RCCL every step, inside the timed region.
 
 Inputs (actions) are resident in HBM before the timed region; the timed region is K launches bracketed by
 barrier + torch.cuda.synchronize(); rank 0 prints ONE JSON line.
+
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts ITSELF: the parent spawns
+`python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child process (the counterpart of the reference's
+SubprocVecEnv spawning its workers from one command, benchmarks/benchmark.py:146-171), never imports torch or touches a
+GPU, relays rank 0's JSON line and exits with the child's return code.
 """
 import argparse
 import json
@@ -80,7 +85,39 @@ def cpu_baseline(n_cores, task, budget_s=12.0):
             "sample": "%d envs x %d control steps of %s, fp64 oracle (oracle/jb_oracle.c: Newton contact solve), OpenMP over envs" % (n, steps, TASK)}
 
 
-def main():
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(n_gpus, argv):
+    """Parent of a `--gpus N` run started without torch.distributed.run: spawn the ranks as a CHILD process tree (no exec, no
+    torch import, no HIP call here), pass their stderr through, print rank 0's single JSON line, return the child's rc."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: RCCL across processes needs it on this driver
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for out in child.stdout:
+        if out.startswith("{") and '"metric"' in out:
+            line = out.strip()                                # rank 0's result (only rank 0 prints one)
+        else:
+            sys.stderr.write(out)                             # anything else the ranks print is not the result
+    rc = child.wait()
+    if rc == 0 and line is None:
+        sys.stderr.write("bench.py: the ranks exited cleanly but printed no result line\n")
+        rc = 1
+    if rc == 0:
+        print(line, flush=True)
+    return rc
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
@@ -99,8 +136,11 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the measured path); gloo is a CPU-staged rehearsal of the N>1 control flow")
     ap.add_argument("--task", default=TASK, help="default move_from_origin (the BASELINE metric); move_to_pose is BASELINE configs[3]'s task")
     ap.add_argument("--augmented", action="store_true", help="one randomised model per env (BASELINE configs[4], augment_Jitterbug semantics)")
-    args = ap.parse_args()
+    ap.add_argument("--no-steady", action="store_true", help="skip the steady-state (steps 100-400) and full-episode blocks measured next to the headline")
+    args = ap.parse_args(argv)
     task = args.task
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args.gpus, argv)          # before anything imports torch or initialises HIP in this process
 
     import numpy as np
     import torch
@@ -203,13 +243,31 @@ def main():
         env.close()
         return wall, dev_ms, float(cap.sum()), finite
 
+    def rank_max(x):
+        t = torch.tensor([x], device=dev if args.dist_backend == "nccl" else "cpu", dtype=torch.float64)
+        if dist is not None:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
     wall, dev_ms, cap_hits, finite = run(args.contacts, K, W, gather=(dist is not None))
-    t = torch.tensor([wall], device=dev if args.dist_backend == "nccl" else "cpu", dtype=torch.float64)
-    if dist is not None:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    wall_max = float(t.item())
+    wall_max = rank_max(wall)
     total_envs = n * world
     value = total_envs * K / wall_max
+
+    # Next to the headline window (whatever --steps/--warmup the caller chose: with the driver's 5 + 20 that is steps 5-25 of an
+    # episode, every robot still upright), the same workload in the same process over two fixed windows:
+    #   steady        100 warm-up + 300 timed steps (steps 100-400 of the episode; the window the committed rocprofv3 profile covers)
+    #   full_episode  0 + 1000 steps from the reset, including the in-kernel auto-reset of the last step
+    steady = full_episode = None
+    if not args.no_steady:
+        ws, ds, _, fs = run(args.contacts, 300, 100, gather=(dist is not None))
+        ws = rank_max(ws)
+        steady = {"value": total_envs * 300 / ws, "unit": "env steps/s", "ms_per_step": ws * 1e3 / 300, "launch_ms": ds / 300, "steps": 300, "warmup": 100,
+                  "window": "steps 100-400 of the episode (some robots have tipped over by then; the window of profiles/r03_*)", "finite": fs}
+        if world == 1 and dist is None:
+            wf, df, _, ff = run(args.contacts, 1000, 0, gather=False)
+            full_episode = {"value": total_envs * 1000 / wf, "unit": "env steps/s", "ms_per_step": wf * 1e3 / 1000, "launch_ms": df / 1000, "steps": 1000, "warmup": 0,
+                            "window": "steps 0-1000: one whole episode from the reset, auto-reset included", "finite": ff}
 
     def config_label(contacts):
         """which BASELINE.json config this workload is, if any"""
@@ -257,17 +315,21 @@ def main():
         lib_sha = hashlib.sha256(open(_lib.LIB_PATH, "rb").read()).hexdigest()
         traffic = None
         compute = None
+        PROFILE = "profiles/r03_pmc_raw.json"
         prof_note = "no PMC summary for this build/workload (tools/collect_profiles.sh + tools/summarise_profiles.py write one)"
         try:
-            raw = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_raw.json")))
+            raw = json.load(open(os.path.join(ROOT, PROFILE)))
             if raw.get("lib_sha256") != lib_sha:
-                prof_note = "profiles/r02_pmc_raw.json was collected on another build of libjitterbug_hip.so: not quoted"
+                prof_note = PROFILE + " was collected on another build of libjitterbug_hip.so: not quoted"
             elif n == N_ENVS_PER_GPU and args.contacts and task == TASK and not args.augmented and world == 1:
                 traffic = (raw["FETCH_SIZE_KB"] + raw["WRITE_SIZE_KB"]) * 1024.0
                 sq = raw["sq"]
                 waves = sq["SQ_WAVES"]
                 simds = 1024.0
+                k_s = raw["kernel_avg_ns"] * 1e-9
                 compute = {"bound": "fp32 VALU issue of one wave per SIMD",
+                           "window": "steps 100-400 (bench.py --steps 300 --warmup 100 under rocprofv3: the `steady` block's window, NOT the headline's)",
+                           "kernel_avg_ms": raw["kernel_avg_ns"] * 1e-6,
                            "waves_per_launch": waves, "waves_per_simd": waves / simds,
                            "valu_insts_per_launch": sq["SQ_INSTS_VALU"],
                            "valu_issue_frac_of_wave_life": sq["SQ_ACTIVE_INST_VALU"] / sq["SQ_WAVE_CYCLES"],
@@ -276,13 +338,23 @@ def main():
                            "mean_wave_life_ms": raw.get("mean_wave_life_ms"),
                            "mean_wave_life_over_launch": raw.get("mean_wave_life_ms") / (raw["kernel_avg_ns"] * 1e-6) if raw.get("mean_wave_life_ms") else None,
                            # issue slots: a SIMD can issue one wave64 VALU instruction per 2 cycles (two waves resident), a lone wave one per 4
-                           "valu_issue_slot_frac_of_chip": sq["SQ_INSTS_VALU"] * 2.0 / (simds * raw["kernel_avg_ns"] * 1e-9 * raw.get("clock_hz", 2.4e9)),
-                           "source": "profiles/r02_pmc_raw.json (rocprofv3 PMC passes of this build and workload)"}
-                prof_note = "profiles/r02_pmc_raw.json, same build (sha256 %s...)" % lib_sha[:12]
+                           "valu_issue_slot_frac_of_chip": sq["SQ_INSTS_VALU"] * 2.0 / (simds * k_s * raw.get("clock_hz", 2.4e9)),
+                           "source": PROFILE + " (rocprofv3 PMC passes of this build and workload)"}
+                if all(k in sq for k in ("SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_TRANS_F32")):
+                    # fp32 operations per launch: wave-instructions by type (an FMA counts 2) x the lanes that really executed them
+                    wave_ops = 2.0 * sq["SQ_INSTS_VALU_FMA_F32"] + sq["SQ_INSTS_VALU_ADD_F32"] + sq["SQ_INSTS_VALU_MUL_F32"] + sq["SQ_INSTS_VALU_TRANS_F32"]
+                    lanes = sq["SQ_THREAD_CYCLES_VALU"] / sq["SQ_ACTIVE_INST_VALU"] if sq.get("SQ_THREAD_CYCLES_VALU") and sq.get("SQ_ACTIVE_INST_VALU") else None
+                    compute.update({"fp32_wave_insts_per_launch": {"fma": sq["SQ_INSTS_VALU_FMA_F32"], "add": sq["SQ_INSTS_VALU_ADD_F32"], "mul": sq["SQ_INSTS_VALU_MUL_F32"], "trans": sq["SQ_INSTS_VALU_TRANS_F32"]},
+                                    "mean_active_lanes_per_valu_inst": lanes,
+                                    "fp32_tflops_full_wave": wave_ops * 64.0 / k_s / 1e12,          # rocprof-compute's convention: every instruction counted at 64 lanes
+                                    "fp32_tflops_active_lanes": (wave_ops * lanes / k_s / 1e12) if lanes else None,
+                                    "fp32_peak_tflops": 157.3,
+                                    "fp32_frac_of_peak_active_lanes": (wave_ops * lanes / k_s / 1e12 / 157.3) if lanes else None})
+                prof_note = "%s, same build (sha256 %s...)" % (PROFILE, lib_sha[:12])
             else:
-                prof_note = "profiles/r02_pmc_raw.json covers move_from_origin, N=4096, contacts on, 1 GPU only"
+                prof_note = PROFILE + " covers move_from_origin, N=4096, contacts on, 1 GPU only"
         except Exception as e:
-            prof_note = "no usable profiles/r02_pmc_raw.json (%s)" % type(e).__name__
+            prof_note = "no usable %s (%s)" % (PROFILE, type(e).__name__)
         launch_s = dev_ms * 1e-3 / K                 # HIP events on the kernel's stream around the K timed launches
         # 317 B for move_from_origin (D=15); other tasks add 4 B per extra obs entry and the 12 B target read; per-env models add
         # the lane constant table (202 x 4 floats) read once per step
@@ -302,12 +374,21 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic,
                          "kernel": "jb_step_kernel", "launch_ms": launch_s * 1e3,
+                         "window": "the headline's: steps %d-%d of an episode from the reset (achieved / frac / launch_ms); `steady` below repeats them for steps 100-400, the window of `traffic` and `compute`" % (W, W + K),
+                         "steady": None if steady is None else {"launch_ms": steady["launch_ms"], "achieved": algo_bytes * n / (steady["launch_ms"] * 1e-3) / 1e9,
+                                                                  "frac": algo_bytes * n / (steady["launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "window": "steps 100-400"},
                          "launch_ms_is": "average jb_step_kernel launch" if dist is None else "average step INCLUDING the stream waits on the row gather (N > 1 path), not the bare kernel",
                          "algorithmic_bytes_per_launch": algo_bytes * n,
                          "note": "path is fp32-VALU/latency bound, not HBM bound (SURVEY.md §8d): 317 B per env step vs ~1e5-1e6 dependent flops",
                          "compute": compute, "profile": prof_note},
             "solver_cap_hits": cap_hits, "finite": finite, "lib_sha256": lib_sha,
         }
+        res["window"] = "steps %d-%d of an episode from the reset" % (W, W + K)
+        if steady:
+            res["steady"] = steady
+        if full_episode:
+            res["value_full_episode"] = full_episode["value"]
+            res["full_episode"] = full_episode
         if also:
             res["also"] = also
         if host_rate:
@@ -321,4 +402,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

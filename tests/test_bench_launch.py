@@ -1,0 +1,98 @@
+"""bench.py as the driver starts it: `python bench.py --gpus N` launches its own ranks (the reference's vectorisation spawns its
+workers from one command too: benchmarks/benchmark.py:146-171, SubprocVecEnv), and the line it prints names the BASELINE workload
+and the library it ran."""
+import hashlib
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+_PARENT_PROBE = r'''
+import json, subprocess, sys
+sys.path.insert(0, %(root)r)
+seen = {}
+class FakePopen:
+    def __init__(self, cmd, stdout=None, env=None, text=None, **kw):
+        seen["cmd"] = cmd; seen["env_ipc"] = (env or {}).get("HSA_ENABLE_IPC_MODE_LEGACY")
+        seen["torch_loaded_at_spawn"] = any(m == "torch" or m.startswith("torch.") for m in sys.modules)
+        self.stdout = iter(["some rank chatter\n", json.dumps({"metric": "env steps/s", "n_gpus": 2, "value": 1.0}) + "\n"])
+    def wait(self):
+        return %(rc)d
+subprocess.Popen = FakePopen
+import bench
+rc = bench.main(["--gpus", "2", "--steps", "3", "--warmup", "1", "--dist-backend", "gloo"])
+seen["rc"] = rc
+seen["torch_loaded_after"] = any(m == "torch" or m.startswith("torch.") for m in sys.modules)
+sys.stderr.write("PROBE " + json.dumps(seen) + "\n")
+sys.exit(rc)
+'''
+
+
+def _probe(rc):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, "-c", _PARENT_PROBE % {"root": ROOT, "rc": rc}], capture_output=True, text=True, env=env, timeout=120)
+    seen = json.loads([l for l in p.stderr.splitlines() if l.startswith("PROBE ")][-1][6:])
+    return p, seen
+
+
+def test_gpus_n_parent_spawns_the_ranks_without_touching_torch_or_the_gpu():
+    p, seen = _probe(0)
+    assert p.returncode == 0
+    cmd = seen["cmd"]
+    assert cmd[0] == sys.executable and cmd[1:3] == ["-m", "torch.distributed.run"]
+    assert "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "2"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-9] == os.path.abspath(BENCH) and cmd[-8:] == ["--gpus", "2", "--steps", "3", "--warmup", "1", "--dist-backend", "gloo"]
+    assert seen["torch_loaded_at_spawn"] is False and seen["torch_loaded_after"] is False      # the parent never initialises HIP: it never even imports torch
+    assert seen["env_ipc"] == "0"
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 2                              # exactly rank 0's line, chatter goes to stderr
+    assert "some rank chatter" in p.stderr
+
+
+def test_gpus_n_parent_returns_the_childs_failure_and_prints_no_result():
+    p, seen = _probe(3)
+    assert p.returncode == 3 and seen["rc"] == 3
+    assert p.stdout.strip() == ""
+
+
+def test_no_exec_in_bench():
+    src = open(BENCH).read()
+    assert "os.exec" not in src and "execv" not in src
+
+
+@pytest.mark.gpu
+def test_bench_line_names_the_baseline_workload_and_the_loaded_library():
+    p = subprocess.run([sys.executable, BENCH, "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-also", "--no-host-rate"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert "BASELINE configs[2]" in d["config"]["workload"] and "move_from_origin" in d["config"]["workload"] and "N_envs=4096" in d["config"]["workload"]
+    from jitterbug_amd import _lib
+    assert d["lib_sha256"] == hashlib.sha256(open(_lib.LIB_PATH, "rb").read()).hexdigest()
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["finite"] is True
+    assert d["steady"]["steps"] == 300 and d["steady"]["warmup"] == 100 and d["steady"]["value"] > 0
+    assert d["value_full_episode"] > 0 and d["roofline"]["steady"]["frac"] > 0
+    assert abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / d["roofline"]["peak"]) < 1e-12
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_starts_itself_on_one_gpu_over_gloo():
+    """`python bench.py --gpus 2` (no torch.distributed.run in front) must produce one line with n_gpus 2.  On the
+    one-GPU test box both ranks share device 0 (JB_BENCH_DEVICE) and the rows go over gloo; on an 8-GPU node the same command with the
+    default backend is RCCL over xGMI."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["JB_BENCH_DEVICE"] = "0"
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dist-backend", "gloo", "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-steady"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_envs"] == 8192 and d["finite"] is True and d["scaling"] == "weak"

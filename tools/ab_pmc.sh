@@ -4,7 +4,7 @@
 ROOT=$(pwd)
 for lib in "$@"; do
   OUT=$ROOT/gpurun_out/prof/abpmc_$(basename $lib .so); rm -rf $OUT; mkdir -p $OUT
-  ( cd /tmp && export TMPDIR=/tmp && JITTERBUG_HIP_LIB=$ROOT/$lib rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_ANY --output-format csv -d $OUT -- python3 $ROOT/bench.py --steps 300 --warmup 100 --no-cpu-baseline --no-also --no-host-rate > $OUT.log 2>&1 )
+  ( cd /tmp && export TMPDIR=/tmp && JITTERBUG_HIP_LIB=$ROOT/$lib rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_ANY --output-format csv -d $OUT -- python3 $ROOT/bench.py --steps 300 --warmup 100 --no-cpu-baseline --no-also --no-host-rate --no-steady > $OUT.log 2>&1 )
   python3 - "$OUT" "$lib" <<'PY'
 import csv, glob, sys
 f = glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True)[0]

@@ -5,7 +5,7 @@ SEEDS=$1; shift
 for lib in "$@"; do
   tot=0; k=0; line=""
   for sd in $SEEDS; do
-    JITTERBUG_HIP_LIB=$lib timeout -k 10 200 python bench.py --steps ${STEPS:-400} --warmup 50 --no-cpu-baseline --no-also --no-host-rate --seed $sd > gpurun_out/abs.json || exit 1
+    JITTERBUG_HIP_LIB=$lib timeout -k 10 200 python bench.py --steps ${STEPS:-400} --warmup 50 --no-cpu-baseline --no-also --no-host-rate --no-steady --seed $sd > gpurun_out/abs.json || exit 1
     ms=$(python -c "
 import json, sys
 d = json.loads(open('gpurun_out/abs.json').read().strip().split('\n')[-1])

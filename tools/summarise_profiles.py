@@ -24,7 +24,7 @@ def counters(d):
         if not disp: disp = {x: r.get(x) for x in ("LDS_Block_Size", "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "Workgroup_Size", "Grid_Size") if x in r}
     return {k: acc[k] / n[k] for k in acc}, disp
 sq = {}
-for d in ("pmc_sq1", "pmc_sq2", "pmc_sq3", "pmc_sq4", "pmc_grbm"):
+for d in ("pmc_sq1", "pmc_sq2", "pmc_sq3", "pmc_sq4", "pmc_sq5", "pmc_grbm", "pmc_sq6"):      # sq6 last: its SQ_ACTIVE_INST_VALU pairs with its SQ_THREAD_CYCLES_VALU
     c, disp = counters(d); sq.update(c)
     if disp: out["dispatch"] = disp
 out["sq"] = sq
