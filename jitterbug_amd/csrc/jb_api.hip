@@ -19,6 +19,7 @@
 
 #include "../../include/jitterbug_hip.h"
 #include "jb_default_params.h"
+#include "jb_device_guard.hpp"
 #include "jb_model_build.hpp"
 #include "jb_model_compile.hpp"
 #include "jb_nominal_spec.h"
@@ -519,13 +520,18 @@ int load_rccl() {
     } while (0)
 }  // namespace
 
-// Every entry point that allocates or launches first makes the handle's device current (a process may hold handles on several
-// GPUs, or switch devices with torch.cuda.set_device after jb_create).
-#define JB_ENTER(h)                                                              \
-    do {                                                                         \
-        if (!(h)) return fail(JB_E_INVALID, "handle is NULL");                   \
-        JB_HIP(hipSetDevice((h)->cfg.device_id));                                \
-    } while (0)
+// Every entry point that allocates or launches runs with the handle's device current (a process may hold handles on several
+// GPUs, or switch devices with torch.cuda.set_device after jb_create) and hands the caller's current device back on EVERY return
+// path (jb_device_guard.hpp): torch reads the current device through hipGetDevice, so a switch that leaked out of an entry
+// point would send the caller's next allocation or launch to the wrong GPU.
+struct HipDeviceApi {
+    static int get(int* d) { return hipGetDevice(d) == hipSuccess ? 0 : 1; }
+    static int set(int d) { return hipSetDevice(d) == hipSuccess ? 0 : 1; }
+};
+#define JB_ENTER(h)                                                                                                   \
+    if (!(h)) return fail(JB_E_INVALID, "handle is NULL");                                                            \
+    jb::DeviceGuard<HipDeviceApi> _jb_device_guard;                                                                   \
+    if (_jb_device_guard.enter((h)->cfg.device_id) != 0) return fail(JB_E_HIP, "hipSetDevice(" + std::to_string((h)->cfg.device_id) + ") failed")
 
 static dim3 grid_lanes(int n) { return dim3((unsigned)(((size_t)n * 4 + 63) / 64)); }
 
@@ -637,7 +643,8 @@ int jb_create(const jb_config* cfg, jb_handle** out) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(JB_E_NODEVICE, "no HIP device available (there is no CPU fallback)");
     if (cfg->device_id < 0 || cfg->device_id >= ndev) return fail(JB_E_INVALID, "device_id out of range");
-    JB_HIP(hipSetDevice(cfg->device_id));
+    jb::DeviceGuard<HipDeviceApi> guard;              // the caller's current device is restored on every return path
+    if (guard.enter(cfg->device_id) != 0) return fail(JB_E_HIP, "hipSetDevice(" + std::to_string(cfg->device_id) + ") failed");
     jb_handle* h = new (std::nothrow) jb_handle();
     if (!h) return fail(JB_E_INVALID, "out of host memory");
     std::memset(h, 0, sizeof *h);
@@ -658,7 +665,8 @@ int jb_create(const jb_config* cfg, jb_handle** out) {
 
 int jb_destroy(jb_handle* h) {
     if (!h) return JB_OK;
-    hipSetDevice(h->cfg.device_id);
+    jb::DeviceGuard<HipDeviceApi> guard;
+    guard.enter(h->cfg.device_id);
     if (h->stream || !h->own_stream) hipStreamSynchronize(h->stream);
     if (h->comm && g_rccl.CommDestroy) { g_rccl.CommDestroy(h->comm); h->comm = nullptr; }
     void* bufs[] = {h->d_terms, h->d_spec, h->d_root, h->d_leg, h->d_model, h->d_step, h->d_episode, h->d_action, h->d_obs, h->d_reward, h->d_done, h->d_mask, h->d_qpos, h->d_qvel, h->d_target, h->d_wave_stats, h->d_enc_params, h->d_code};
@@ -965,11 +973,15 @@ int jb_randomise_models(jb_handle* h, const jb_randomise_cfg* cfg, const double*
         JB_HIP(hipMalloc(&h->d_spec, sizeof(JbNominalSpec)));
         JB_HIP(hipMemcpy(h->d_spec, &JB_NOMINAL_SPEC, sizeof(JbNominalSpec), hipMemcpyHostToDevice));
     }
-    { int rc = ensure_model_buffer(h, (int)N); if (rc) return rc; }
+    // The tables are generated into a FRESH buffer and swapped into the handle only after the kernel succeeded: a failure on the
+    // way (the 5 KB x N params_out allocation is the likeliest) leaves the handle on the model it had, never on freed or
+    // half-written tables.
+    float* d_tables = nullptr;
     double *d_off_in = nullptr, *d_par = nullptr, *d_off_out = nullptr; int *d_att = nullptr, *d_status = nullptr;
     int rc = JB_OK, status = 0;
-    auto cleanup = [&]() { if (d_off_in) hipFree(d_off_in); if (d_par) hipFree(d_par); if (d_off_out) hipFree(d_off_out); if (d_att) hipFree(d_att); if (d_status) hipFree(d_status); };
+    auto cleanup = [&]() { if (d_tables) hipFree(d_tables); if (d_off_in) hipFree(d_off_in); if (d_par) hipFree(d_par); if (d_off_out) hipFree(d_off_out); if (d_att) hipFree(d_att); if (d_status) hipFree(d_status); };
 #define JB_TRY(call) do { hipError_t _e = (call); if (_e != hipSuccess) { cleanup(); return fail(JB_E_HIP, std::string(#call) + ": " + hipGetErrorString(_e)); } } while (0)
+    JB_TRY(hipMalloc(&d_tables, N * LM_TABLE * sizeof(float)));
     JB_TRY(hipMalloc(&d_status, sizeof(int)));
     JB_TRY(hipMemset(d_status, 0, sizeof(int)));
     if (offsets_in) { JB_TRY(hipMalloc(&d_off_in, sizeof(double) * N * AO_COUNT)); JB_TRY(hipMemcpy(d_off_in, offsets_in, sizeof(double) * N * AO_COUNT, hipMemcpyHostToDevice)); }
@@ -982,21 +994,25 @@ int jb_randomise_models(jb_handle* h, const jb_randomise_cfg* cfg, const double*
     for (int i = 0; i < 3; i++) { a.sd.legs[i] = cfg->sd_legs[i]; a.sd.mass_pos[i] = cfg->sd_mass_pos[i]; }
     a.sd.core1_density = cfg->sd_core1_density; a.sd.core2_density = cfg->sd_core2_density; a.sd.global_density = cfg->sd_global_density; a.sd.gear = cfg->sd_gear;
     a.min_mass_clearance = cfg->min_mass_clearance;
-    a.spec = h->d_spec; a.offsets_in = d_off_in; a.tables = h->d_model; a.params_out = d_par; a.offsets_out = d_off_out; a.attempts_out = d_att; a.status = d_status;
+    a.spec = h->d_spec; a.offsets_in = d_off_in; a.tables = d_tables; a.params_out = d_par; a.offsets_out = d_off_out; a.attempts_out = d_att; a.status = d_status;
     hipLaunchKernelGGL(jb_randomise_kernel, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, h->stream, a);
     JB_TRY(hipGetLastError());
     JB_TRY(hipStreamSynchronize(h->stream));
     JB_TRY(hipMemcpy(&status, d_status, sizeof(int), hipMemcpyDeviceToHost));
-    if (params_out) JB_TRY(hipMemcpy(params_out, d_par, sizeof(double) * N * JB_NPARAM, hipMemcpyDeviceToHost));
-    if (offsets_out) JB_TRY(hipMemcpy(offsets_out, d_off_out, sizeof(double) * N * AO_COUNT, hipMemcpyDeviceToHost));
-    if (attempts_out) JB_TRY(hipMemcpy(attempts_out, d_att, sizeof(int) * N, hipMemcpyDeviceToHost));
+    if (status == 0) {
+        if (params_out) JB_TRY(hipMemcpy(params_out, d_par, sizeof(double) * N * JB_NPARAM, hipMemcpyDeviceToHost));
+        if (offsets_out) JB_TRY(hipMemcpy(offsets_out, d_off_out, sizeof(double) * N * AO_COUNT, hipMemcpyDeviceToHost));
+        if (attempts_out) JB_TRY(hipMemcpy(attempts_out, d_att, sizeof(int) * N, hipMemcpyDeviceToHost));
+    }
 #undef JB_TRY
-    cleanup();
-    if (status != 0) {
-        // leave the handle on the nominal shared model rather than on partly written tables
-        upload_model(h, JB_DEFAULT_PARAMS, 1);
+    if (status != 0) {      // the handle keeps the model it had
+        cleanup();
         return fail(JB_E_MODEL, status == -30 ? "randomise: no draw cleared min_mass_clearance within max_attempts for some env" : "randomise: a generated model is not supported by the kernel (code " + std::to_string(status) + ")");
     }
+    if (h->d_model) hipFree(h->d_model);          // (the stream is idle: synchronised above)
+    h->d_model = d_tables; h->model_tables = N;
+    d_tables = nullptr;
+    cleanup();
     h->ka.lane_model = h->d_model;
     h->ka.per_env_model = 1;
     return rc;
@@ -1059,10 +1075,12 @@ int jb_gather_rows_device(jb_handle* h, const float* d_rows, float* d_all, void*
     hipStream_t st = use_stream ? (hipStream_t)stream : h->stream;
     const size_t count = (size_t)h->cfg.n_envs * (size_t)(h->D + 2);
     JB_NCCL(g_rccl.GroupStart());
+    int err = 0;              // a failed Send/Recv must not leave the RCCL group open: close it, then report the first error
     if (h->comm_rank == 0)
-        for (int r = 0; r < h->comm_ranks; r++) JB_NCCL(g_rccl.Recv(d_all + (size_t)r * count, count, 7 /*ncclFloat*/, r, h->comm, st));
-    JB_NCCL(g_rccl.Send(d_rows, count, 7 /*ncclFloat*/, 0, h->comm, st));
-    JB_NCCL(g_rccl.GroupEnd());
+        for (int r = 0; r < h->comm_ranks && !err; r++) err = g_rccl.Recv(d_all + (size_t)r * count, count, 7 /*ncclFloat*/, r, h->comm, st);
+    if (!err) err = g_rccl.Send(d_rows, count, 7 /*ncclFloat*/, 0, h->comm, st);
+    const int end = g_rccl.GroupEnd();
+    if (err || end) return fail(JB_E_HIP, std::string("RCCL row gather: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(err ? err : end) : "RCCL error"));
     return JB_OK;
 }
 
