@@ -74,7 +74,7 @@ typedef struct jb_config {
                                   same call and its returned observation is the new episode's first */
     int32_t  max_newton;    /* cap on contact-solver iterations per substep (0 -> default 12) */
     int32_t  use_caller_stream; /* 1: launch on `stream` below even when it is NULL (the legacy default stream) */
-    int32_t  envs_per_wave; /* environments per 64-lane wavefront (4 lanes each): 1..16, 0 = choose so that the batch
+    int32_t  envs_per_wave; /* environments per 64-lane wavefront (4 lanes each): 1, 2, 4 or 8 (larger requests run as 8), 0 = choose so that the batch
                                spreads over all SIMDs of the device (small batches use partially filled waves) */
     int32_t  flags;         /* JB_FLAG_* bits, 0 by default */
     uint64_t seed;          /* RNG key */

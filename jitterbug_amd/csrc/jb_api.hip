@@ -12,6 +12,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -139,7 +140,8 @@ __device__ __forceinline__ void step_body(KArgs a, const float* __restrict__ act
     // its spare lanes as NGRP-1 helper groups: helper lane L + g*4*EPW mirrors main lane L (same env, leg, scratch and
     // constant-table addresses) and takes a share of the live contact slots in every Newton pass (jb_sim.hpp, SlotPlan).
     constexpr int MAIN = 4 * EPW;
-    constexpr int NGRP = EPW >= 16 ? 1 : (EPW == 8 ? 2 : 4);
+    constexpr int NGRP = EPW == 8 ? 2 : 4;
+    static_assert(EPW == 1 || EPW == 2 || EPW == 4 || EPW == 8, "envs per wave");
     const int lane_in_grp = threadIdx.x % MAIN, grp = threadIdx.x / MAIN;
     const int quad = lane_in_grp >> 2, leg = threadIdx.x & 3;
     // XCD-aware workgroup -> env-range map: hardware deals workgroups round-robin over the 8 XCDs (b and b+8 share one),
@@ -171,7 +173,7 @@ __device__ __forceinline__ void step_body(KArgs a, const float* __restrict__ act
         s.wj[0] = s.wj[1] = 0.f; s.wm = 0.f; s.fail = 0.f;
     }
 #ifdef JB_WAVE_STATS
-    s.st_xtra = 0.f; s.st_sweeps = 0.f; s.st_contact = 0.f; s.st_slots = 0.f; s.st_fast = 0.f;
+    s.st_xtra = 0.f; s.st_sweeps = 0.f; s.st_contact = 0.f; s.st_slots = 0.f; s.st_fast = 0.f; s.st_checks = 0.f;
 #endif
     const float ctrl = action[env];
     SimOpts o; o.contacts = a.contacts; o.max_newton = a.max_newton; o.implicit_damp = 1; o.rank_one = a.rank_one; o.lean = LEAN ? 1 : 0; o.prof = nullptr; o.hist = nullptr;
@@ -192,7 +194,7 @@ __device__ __forceinline__ void step_body(KArgs a, const float* __restrict__ act
         unsigned long long* ws = a.wave_stats + (size_t)lblock * 16;
         ws[10] = __builtin_amdgcn_s_memrealtime() - rt_start;
         ws[0] = __builtin_amdgcn_s_memtime() - t_start;
-        for (int i = 0; i < 5; i++) ws[4 + i] = prof_local[i]; ws[1] = (unsigned long long)s.st_xtra; ws[2] = (unsigned long long)s.st_sweeps; ws[3] = (unsigned long long)s.st_contact; ws[11] = (unsigned long long)s.st_slots; ws[15] = (unsigned long long)s.st_fast; ws[12] = prof_local[5]; ws[13] = prof_local[6]; ws[14] = prof_local[7];
+        for (int i = 0; i < 5; i++) ws[4 + i] = prof_local[i]; ws[1] = (unsigned long long)s.st_xtra; ws[2] = (unsigned long long)s.st_sweeps; ws[3] = (unsigned long long)s.st_contact; ws[11] = (unsigned long long)s.st_slots; ws[15] = (unsigned long long)s.st_fast; ws[9] = (unsigned long long)s.st_checks; ws[12] = prof_local[5]; ws[13] = prof_local[6]; ws[14] = prof_local[7];
     }
 #endif
     {   // a control step that ends in a non-finite state is recorded in the failure counter (+1000; Newton cap hits add 1 each)
@@ -520,6 +522,43 @@ int load_rccl() {
     } while (0)
 }  // namespace
 
+// ---------------------------------------------------------------------------------------------- roctx ranges, bound at run time
+// Named ranges around step / reset / gather so that a rocprofv3 --marker-trace timeline of the N > 1 path shows where the row gather
+// sits relative to the step kernel (tracing row).  Like RCCL the library is bound by dlopen: an image the process
+// already holds (the profiler's, or PyTorch's libroctx64) is used as is; otherwise it is loaded only when JB_ROCTX=1 asks for it.
+// Without it the ranges cost one predictable branch.
+namespace {
+struct RoctxApi {
+    int state = 0;          // 0: not looked for yet, 1: bound, -1: unavailable
+    int (*Push)(const char*) = nullptr;
+    int (*Pop)() = nullptr;
+};
+RoctxApi g_roctx;
+void load_roctx() {
+    const char* names[] = {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"};
+    void* lib = nullptr;
+    for (const char* n : names) if ((lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;
+    const char* want = getenv("JB_ROCTX");
+    if (!lib && want && want[0] == '1') for (const char* n : names) if ((lib = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
+    if (lib) {
+        g_roctx.Push = (decltype(g_roctx.Push))dlsym(lib, "roctxRangePushA");
+        g_roctx.Pop = (decltype(g_roctx.Pop))dlsym(lib, "roctxRangePop");
+    }
+    g_roctx.state = (g_roctx.Push && g_roctx.Pop) ? 1 : -1;
+}
+struct RoctxRange {          // RAII: popped on every return path
+    bool on;
+    explicit RoctxRange(const char* name) {
+        if (g_roctx.state == 0) load_roctx();
+        on = g_roctx.state == 1;
+        if (on) g_roctx.Push(name);
+    }
+    ~RoctxRange() { if (on) g_roctx.Pop(); }
+    RoctxRange(const RoctxRange&) = delete;
+    RoctxRange& operator=(const RoctxRange&) = delete;
+};
+}  // namespace
+
 // Every entry point that allocates or launches runs with the handle's device current (a process may hold handles on several
 // GPUs, or switch devices with torch.cuda.set_device after jb_create) and hands the caller's current device back on EVERY return
 // path (jb_device_guard.hpp): torch reads the current device through hipGetDevice, so a switch that leaked out of an entry
@@ -620,8 +659,8 @@ static int create_impl(jb_handle* h) {      // every failure returns through jb_
             if (epw > 4) epw = 4;     // LDS: 4 resident waves per CU need <= 40 KB each
         }
         if (epw < 1) epw = 1;
-        if (epw > 16) epw = 16;
-        while (epw & (epw - 1)) epw++;       // 1, 2, 4, 8 or 16 (the kernel is instantiated for these)
+        if (epw > 8) epw = 8;                // (a 16-env wave would need 97 KB of LDS - one wave per CU - and spilled registers: not instantiated)
+        while (epw & (epw - 1)) epw++;       // 1, 2, 4 or 8 (the kernel is instantiated for these)
         if (k.lean) { if (cfg->envs_per_wave <= 0) epw = 2; if (epw > 4) epw = 4; }     // LEAN: 2 envs per wave keep 8 waves per CU within 160 KB of LDS
         k.epw = epw;
     }
@@ -753,6 +792,7 @@ int jb_synchronize(jb_handle* h) {
 
 int jb_reset_device(jb_handle* h, const uint8_t* d_mask, float* d_obs_out) {
     JB_ENTER(h);
+    RoctxRange range("jb_reset");
     hipLaunchKernelGGL(jb_reset_kernel, grid_lanes(h->cfg.n_envs), dim3(64), 0, h->stream, h->ka, d_mask, d_obs_out);
     JB_HIP(hipGetLastError());
     return JB_OK;
@@ -760,6 +800,7 @@ int jb_reset_device(jb_handle* h, const uint8_t* d_mask, float* d_obs_out) {
 static int launch_step(jb_handle* h, const float* d_action, float* d_obs_out, float* d_reward_out, uint8_t* d_done_out, int packed_rows) {
     if (!h || !d_action) return fail(JB_E_INVALID, "handle/action is NULL");
     JB_ENTER(h);
+    RoctxRange range("jb_step");
     h->ka.packed_rows = packed_rows;
     const dim3 grid((unsigned)((h->cfg.n_envs + h->ka.epw - 1) / h->ka.epw));
     const size_t lds_bytes = ((size_t)(h->ka.lean ? SC_COUNT_LEAN : SC_COUNT) * 4 * h->ka.epw + (size_t)LM_TABLE * (h->ka.per_env_model ? h->ka.epw : 1)) * sizeof(float);
@@ -776,8 +817,7 @@ static int launch_step(jb_handle* h, const float* d_action, float* d_obs_out, fl
         case 1: JB_LAUNCH_STEP(1); break;
         case 2: JB_LAUNCH_STEP(2); break;
         case 4: JB_LAUNCH_STEP(4); break;
-        case 8: JB_LAUNCH_STEP(8); break;
-        default: JB_LAUNCH_STEP(16); break;
+        default: JB_LAUNCH_STEP(8); break;
         }
     }
 #undef JB_LAUNCH_STEP
@@ -812,6 +852,7 @@ int jb_reset(jb_handle* h, const uint8_t* mask, float* obs_out) {
 int jb_step(jb_handle* h, const float* action, float* obs_out, float* reward_out, uint8_t* done_out) {
     if (!h || !action) return fail(JB_E_INVALID, "handle/action is NULL");
     JB_ENTER(h);
+    RoctxRange range("jb_step_host_buffers");
     const size_t N = (size_t)h->cfg.n_envs;
     JB_HIP(hipMemcpyAsync(h->d_action, action, sizeof(float) * N, hipMemcpyHostToDevice, h->stream));
     int rc = jb_step_device(h, h->d_action, h->d_obs, h->d_reward, h->d_done);
@@ -1072,6 +1113,7 @@ int jb_gather_rows_device(jb_handle* h, const float* d_rows, float* d_all, void*
     if (!h->comm) return fail(JB_E_INVALID, "no communicator (jb_comm_init)");
     if (h->comm_rank == 0 && !d_all) return fail(JB_E_INVALID, "rank 0 needs the receive buffer [n_ranks, N_local, D+2]");
     JB_ENTER(h);
+    RoctxRange range("jb_gather_rows");
     hipStream_t st = use_stream ? (hipStream_t)stream : h->stream;
     const size_t count = (size_t)h->cfg.n_envs * (size_t)(h->D + 2);
     JB_NCCL(g_rccl.GroupStart());

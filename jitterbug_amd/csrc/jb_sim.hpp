@@ -243,7 +243,7 @@ template <typename V> struct LaneState {
     V wa[3], wl[3], wj[2], wm;
     V fail;                              // >0: the Newton iteration hit its cap in some substep
 #ifdef JB_WAVE_STATS
-    V st_fast;
+    V st_fast, st_checks;
     V st_xtra, st_sweeps, st_contact, st_slots;    // diagnostic build only: substeps on the rare path, Newton sweeps, substeps with contact, live slots summed over contact substeps
 #endif
 };
@@ -1214,6 +1214,9 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
                     // saw a different record; when nobody's changed, every y is the exact minimiser
                     contact_sweep<V>(m, sc, xtra, plan, 2, dk, acc);
                     JB_PROF_ADD(o, 1);
+#ifdef JB_WAVE_STATS
+                    if (is_main) s.st_checks = s.st_checks + V(1);
+#endif
                     unsigned fin = 0u, full = 1u;
                     if (is_main) {
                         MK changed = mor(mor(neq_u(acc.bw0, prev_bw0), neq_u(acc.bw1, prev_bw1)), neq_u(acc.xh, prev_xh));

@@ -144,6 +144,15 @@ class ShardedJitterbugEnv:
             self._stage = None if self._nccl else [torch.empty((nmax, D2), dtype=torch.float32).pin_memory() for _ in range(self._NB)]
             self._pending = [None] * self._NB
             self._side = torch.cuda.Stream(device=self.device) if (self._nccl and self.depth == 2) else None
+            # The step kernel runs on the ENV's stream (the one captured when it was built, or its own): events are recorded on, and
+            # the gathers ordered against, that stream - not whatever torch stream happens to be current when step() is called.
+            sp = self.env.stream
+            self._env_stream = torch.cuda.ExternalStream(int(sp), device=self.device) if sp else torch.cuda.default_stream(self.device)
+            try:
+                torch.cuda.nvtx.range_push("jb_sharded_env"); torch.cuda.nvtx.range_pop()
+                self._nvtx = True
+            except Exception:
+                self._nvtx = False
             self._step_done = [torch.cuda.Event() for _ in range(self._NB)] if self._side is not None else None
             self._late = None            # index of the step whose rows still have to be sent (depth 2)
 
@@ -169,14 +178,28 @@ class ShardedJitterbugEnv:
         import torch
         import torch.distributed as dist
         b = j % self._NB
+        if self._nccl and self._nvtx:             # a named range on the timeline (torch's nvtx shim is roctx on ROCm): where the gather sits vs jb_step
+            torch.cuda.nvtx.range_push("jb_gather_rows")
+            try:
+                return self._send_impl(j, b)
+            finally:
+                torch.cuda.nvtx.range_pop()
+        return self._send_impl(j, b)
+
+    def _send_impl(self, j, b):
+        import torch
+        import torch.distributed as dist
         if self._side is not None:
             with torch.cuda.stream(self._side):
                 self._side.wait_event(self._step_done[b])
                 self._pending[b] = dist.gather(self._rows[b], self._gathered[b] if self.rank == 0 else None, dst=0, group=self.group, async_op=True)
         elif self._nccl:
-            self._pending[b] = dist.gather(self._rows[b], self._gathered[b] if self.rank == 0 else None, dst=0, group=self.group, async_op=True)
+            with torch.cuda.stream(self._env_stream):       # RCCL orders the collective behind the stream current at issue time
+                self._pending[b] = dist.gather(self._rows[b], self._gathered[b] if self.rank == 0 else None, dst=0, group=self.group, async_op=True)
         else:                                            # gloo rehearsal: staged through pinned host memory, synchronous
-            self._stage[b].copy_(self._rows[b])
+            with torch.cuda.stream(self._env_stream):
+                self._stage[b].copy_(self._rows[b], non_blocking=True)
+            self._env_stream.synchronize()
             dist.gather(self._stage[b], self._gathered[b] if self.rank == 0 else None, dst=0, group=self.group)
 
     def _result(self, j):
@@ -198,16 +221,19 @@ class ShardedJitterbugEnv:
         import torch
         i = self._i
         b = i % self._NB
-        if self._pending[b] is not None:                 # the buffer is rewritten only after the gather that read it
-            self._pending[b].wait()
+        if self._pending[b] is not None:                 # the buffer is rewritten only after the gather that read it:
+            with torch.cuda.stream(self._env_stream):    # the ENV's stream (where the kernel that rewrites it runs) waits for that gather
+                self._pending[b].wait()
             self._pending[b] = None
+        if torch.cuda.current_stream(self.device) != self._env_stream:       # actions produced on another stream: the kernel waits for them
+            self._env_stream.wait_stream(torch.cuda.current_stream(self.device))
         self.env.step_rows_device(a.data_ptr(), self._rows[b].data_ptr())
         self._i += 1
         if self.depth == 1:
             self._send(i)
             return self._result(i)
         if self._side is not None:
-            self._step_done[b].record()
+            self._step_done[b].record(self._env_stream)
         prev = self._late
         self._late = i
         if prev is None:

@@ -26,6 +26,31 @@ def compute_n_substeps(control_timestep, physics_timestep=PHYSICS_TIMESTEP, tol=
     return int(round(n))
 
 
+class LazyInfos(list):
+    """A list of N info dicts whose dicts come into being when an entry is first read (indexing, iteration, slicing)."""
+
+    def __init__(self, n):
+        super().__init__([None] * n)
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(len(self)))]
+        d = super().__getitem__(i)
+        if d is None:
+            d = {}
+            super().__setitem__(i, d)
+        return d
+
+    def __iter__(self):
+        for j in range(len(self)):
+            yield self[j]
+
+    def __eq__(self, other):
+        return list(self) == list(other)
+
+    __hash__ = None
+
+
 class JitterbugVecEnv:
     """N lockstep Jitterbug environments on one GPU."""
 
@@ -68,8 +93,8 @@ class JitterbugVecEnv:
         self._rew = np.zeros(self.num_envs, dtype=np.float32)
         self._done = np.zeros(self.num_envs, dtype=np.uint8)
         self._pending = None
-        self._infos = None
         self._params = None              # host copy of the per-env / shared parameter table(s) when set_model_params was used
+        self._rnd = None                 # randomise_models without fetched tables: what model_params() needs to rebuild one on the host
         self.state_version = 0           # bumped by every call that changes the simulator state (Physics caches on it)
         if params is not None:
             self.set_model_params(params)
@@ -100,14 +125,12 @@ class JitterbugVecEnv:
         return self._obs.copy(), self._rew.copy(), self._done.astype(bool), self._empty_infos()
 
     def _empty_infos(self):
-        """VecEnv `infos`: always a list of N dicts (stable-baselines consumers index infos[i]); the dicts are fresh per call
-        for small batches and one re-used list of empty dicts for large ones (built once: 65 536 dict allocations per step
-        would cost more than the step)."""
+        """VecEnv `infos`: always a list of N dicts (stable-baselines consumers index infos[i] and write keys such as 'episode' or
+        'terminal_observation' into it).  Every step returns its OWN list, so nothing a wrapper writes survives into a later step;
+        for large batches the dicts are made when first touched (65 536 dict allocations per step would cost more than the step)."""
         if self.num_envs <= 64:
             return [{} for _ in range(self.num_envs)]
-        if self._infos is None:
-            self._infos = [{} for _ in range(self.num_envs)]
-        return self._infos
+        return LazyInfos(self.num_envs)
 
     def step_async(self, actions):
         self._pending = actions
@@ -148,6 +171,7 @@ class JitterbugVecEnv:
         assert p.size == n_tables * model.NPARAM
         _lib.check(self._L.jb_set_model_params(self._h, _lib.ptr(p), n_tables))
         self._params = p.reshape(n_tables, model.NPARAM).copy()
+        self._rnd = None
         self.state_version += 1
 
     def randomise_models(self, seed=0, modify_legs=True, modify_mass=True, modify_coreBody1=False, modify_coreBody2=False,
@@ -174,8 +198,13 @@ class JitterbugVecEnv:
         par = np.zeros((n, model.NPARAM)) if return_params else None
         off = np.zeros((n, _lib.NOFFSET)) if return_offsets else None
         att = np.zeros(n, dtype=np.int32)
+        # (a failure raises here and leaves the handle - and self._params - on the model it had: jb_randomise_models swaps the new
+        #  tables in only after the kernel succeeded)
         _lib.check(self._L.jb_randomise_models(self._h, C.byref(cfg), _lib.ptr(off_in), _lib.ptr(par), _lib.ptr(off), _lib.ptr(att)))
         self._params = par
+        # tables not fetched (the default above 8192 envs, 5 KB each): model_params() rebuilds the ones it is asked for on the host
+        # from the same Philox draws (the generator is keyed (seed, global env, attempt) and its compiler has a host twin)
+        self._rnd = None if return_params else dict(cfg=cfg, attempts=att, offsets=off_in, cache={})
         self.state_version += 1
         out = dict(attempts=att)
         if return_params:
@@ -187,7 +216,24 @@ class JitterbugVecEnv:
     def model_params(self, index=0):
         """The parameter table (float64[NPARAM]) env `index` is simulated with."""
         if self._params is None:
-            return model.default_params()
+            rnd = getattr(self, "_rnd", None)
+            if rnd is None:
+                return model.default_params()
+            # per-env models whose tables stayed on the device: the host twin of the device generator, same draws, same compiler
+            index = int(index)
+            if index not in rnd["cache"]:
+                if rnd["offsets"] is not None:
+                    off = np.ascontiguousarray(rnd["offsets"][index], dtype=np.float64)
+                else:
+                    off = np.zeros(_lib.NOFFSET)
+                    _lib.check(self._L.jb_model_draw_offsets_host(C.c_uint64(int(rnd["cfg"].seed)), C.c_uint64(int(self.cfg.env_offset) + index),
+                                                                  C.c_uint32(int(rnd["attempts"][index]) - 1), C.byref(rnd["cfg"]), _lib.ptr(off)))
+                P = np.zeros(model.NPARAM)
+                _lib.check(self._L.jb_model_compile_host(_lib.ptr(off), int(rnd["cfg"].flags), _lib.ptr(P)))
+                if len(rnd["cache"]) > 4096:
+                    rnd["cache"].clear()
+                rnd["cache"][index] = P
+            return rnd["cache"][index]
         return self._params[index if self._params.shape[0] > 1 else 0]
 
     def reward_terms(self):

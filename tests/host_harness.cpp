@@ -112,3 +112,30 @@ extern "C" int jbh_step_lean(const double* P, double* qpos, double* qvel, double
 extern "C" int jbh_lm_count(void) { return LM_COUNT; }
 // the per-leg constant table (LM_COUNT doubles) for inspection by tests / tools
 extern "C" int jbh_lane_table(const double* P, int leg, double* out) { return build_lane_model<double>(P, leg, out); }
+
+// ---- jb_device_guard.hpp against a recording stub of hipGetDevice / hipSetDevice (the library instantiates it with the real ones)
+#include "../jitterbug_amd/csrc/jb_device_guard.hpp"
+namespace {
+struct StubDeviceApi {
+    static int cur, fail_set, n_set, last_set;
+    static int get(int* d) { *d = cur; return 0; }
+    static int set(int d) { n_set++; last_set = d; if (fail_set) return 1; cur = d; return 0; }
+};
+int StubDeviceApi::cur = 0, StubDeviceApi::fail_set = 0, StubDeviceApi::n_set = 0, StubDeviceApi::last_set = -1;
+}
+// One "entry point" on a handle of device `target` while the caller's current device is `cur` (early_return: the entry point fails
+// half way, like a JB_HIP return).  out = [rc of enter, device current INSIDE the entry point, device current AFTER it, hipSetDevice calls]
+extern "C" void jbh_device_guard_probe(int cur, int target, int fail_set, int early_return, int* out) {
+    StubDeviceApi::cur = cur; StubDeviceApi::fail_set = fail_set; StubDeviceApi::n_set = 0; StubDeviceApi::last_set = -1;
+    out[1] = -1;
+    auto entry = [&]() -> int {
+        jb::DeviceGuard<StubDeviceApi> g;
+        const int rc = g.enter(target);
+        if (rc) return rc;
+        out[1] = StubDeviceApi::cur;
+        if (early_return) return -3;
+        return 0;
+    };
+    out[0] = entry();
+    out[2] = StubDeviceApi::cur; out[3] = StubDeviceApi::n_set;
+}

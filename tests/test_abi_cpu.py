@@ -88,3 +88,23 @@ def test_host_only_entry_points_validate_arguments(lib):
                  lambda: lib.jb_gather_rows_device(None, None, None, None, 0)):
         assert call() == -1
     assert lib.jb_comm_unique_id(None) == -1
+
+
+def test_entry_points_hand_the_callers_device_back():
+    """an entry point makes the HANDLE's device current and must restore the caller's on every return path (torch reads
+    the current device through hipGetDevice).  The guard the library instantiates with hipGetDevice / hipSetDevice
+    (csrc/jb_device_guard.hpp) is run here against a recording stub; with two real GPUs tests/test_gpu_surface.py checks the library."""
+    import ctypes as C
+    import tests.build_harness as bh
+    lib = C.CDLL(bh.build())
+    out = (C.c_int * 4)()
+    lib.jbh_device_guard_probe(2, 5, 0, 0, out)          # caller on device 2, handle on 5
+    assert list(out) == [0, 5, 2, 2]                      # ran on 5, back on 2: one switch in, one out
+    lib.jbh_device_guard_probe(2, 5, 0, 1, out)          # the entry point fails half way: still restored
+    assert list(out) == [-3, 5, 2, 2]
+    lib.jbh_device_guard_probe(3, 3, 0, 0, out)          # already current: no hipSetDevice at all
+    assert list(out) == [0, 3, 3, 0]
+    lib.jbh_device_guard_probe(1, 4, 1, 0, out)          # the switch itself fails: error out, nothing to restore
+    assert out[0] != 0 and out[1] == -1 and out[2] == 1 and out[3] == 1
+    src = open(bh.os.path.join(bh.HERE, "..", "jitterbug_amd", "csrc", "jb_api.hip")).read()
+    assert "DeviceGuard<HipDeviceApi>" in src and "JB_HIP(hipSetDevice" not in src      # no entry point switches without the guard

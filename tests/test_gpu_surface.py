@@ -283,3 +283,24 @@ def test_c_abi_row_gather_over_rccl_one_rank():
     ''' % root)
     r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "CABI_GATHER_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
+def test_entry_points_leave_the_callers_current_device_alone():
+    """with a handle on another GPU than the caller's current one, jb_step / jb_observe / ... must hand the caller's device
+    back (torch reads it through hipGetDevice).  Needs two GPUs; on the one-GPU box the guard itself is checked against a stub in
+    tests/test_abi_cpu.py and this test only checks that nothing changes."""
+    import torch
+    from jitterbug_amd.vec_env import JitterbugVecEnv
+    ndev = torch.cuda.device_count()
+    other = 1 if ndev > 1 else 0
+    torch.cuda.set_device(0)
+    env = JitterbugVecEnv(8, "move_from_origin", seed=0, device_id=other)
+    assert torch.cuda.current_device() == 0
+    env.reset(); assert torch.cuda.current_device() == 0
+    env.step(np.zeros(8, dtype=np.float32)); assert torch.cuda.current_device() == 0
+    env.observe(); env.get_state(); env.counters(); env.randomise_models(seed=1)
+    assert torch.cuda.current_device() == 0
+    x = torch.zeros(4, device="cuda")
+    assert x.device.index == 0
+    env.close()
+    assert torch.cuda.current_device() == 0

@@ -170,18 +170,21 @@ def test_helper_groups_fp64_equal_single_group_and_oracle(gstep, params):
 
 def test_rank_one_passes_fp64_equal_full_passes_with_groups(gstep, params):
     """Sherman-Morrison on the kept factorisation, reading contact rows that OTHER groups built (the path of round 1's
-    uninitialised-row bug), against full sweeps + refactorisation: same minimiser to round-off."""
-    env = _contact_states(params, 16, tipped=False)
-    rng = np.random.default_rng(9)
+    uninitialised-row bug), and the rank-one update / downdate of that factorisation after every pass (chains of single-edge
+    changes, several edges per check), against full sweeps + refactorisation: same minimiser to round-off."""
     worst = 0.0
-    for t in range(4):
-        a = rng.uniform(-1, 1, size=16)
-        q0, v0, _ = env.get_state()
-        env.step(a, auto_reset=False)
-        for i in range(16):
-            qa, va, _ = gstep(q0[i], v0[i], a[i], groups=4, rank_one=1)
-            qb, vb, _ = gstep(q0[i], v0[i], a[i], groups=4, rank_one=0)
-            worst = max(worst, np.abs(qa - qb).max(), (np.abs(va - vb) / (1 + np.abs(vb))).max())
+    for tipped in (False, True):          # tipped: legs lying on the floor, 8+ contacts per leg, several edges changing per check (chained passes)
+        env = _contact_states(params, 16, tipped=tipped)
+        rng = np.random.default_rng(9)
+        for t in range(4):
+            a = rng.uniform(-1, 1, size=16)
+            q0, v0, _ = env.get_state()
+            env.step(a, auto_reset=False)
+            for i in range(16):
+                qa, va, ca = gstep(q0[i], v0[i], a[i], groups=4, rank_one=1)
+                qb, vb, _ = gstep(q0[i], v0[i], a[i], groups=4, rank_one=0)
+                assert ca == 0
+                worst = max(worst, np.abs(qa - qb).max(), (np.abs(va - vb) / (1 + np.abs(vb))).max())
     assert worst < 1e-10, worst
 
 

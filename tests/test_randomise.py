@@ -164,3 +164,78 @@ def test_device_randomiser_at_config5_size():
     assert np.array_equal(o3["offsets"][same], o2["offsets"][same])               # first draws that were fine are kept
     assert O.mass_sweep_clearance(o3["params"], 144).min() >= 1e-3 - 1e-5
     e2.close()
+
+
+@pytest.mark.gpu
+def test_config5_shard_8192_device_models_against_the_oracle():
+    """BASELINE configs[4]'s per-GPU shard as it really runs: 8192 envs, one DEVICE-generated model each (re-drawn until the mass can
+    turn), per-env constant tables staged in LDS by 2048 full waves, 200 control steps of the open-loop rollout.  A 64-env subset
+    spread over the batch is held against the oracle every step, from the GPU's own pre-step state (teacher-forced the other way
+    round) and with the tables the device generated (return_params=True); the whole batch must stay physical."""
+    from jitterbug_amd.vec_env import JitterbugVecEnv
+    from oracle import oracle as O
+    n, steps, task = 8192, 200, "move_to_pose"
+    env = JitterbugVecEnv(n, task, seed=3, auto_reset=False)
+    out = env.randomise_models(seed=77, min_mass_clearance=1e-3, return_params=True)
+    P = out["params"]
+    assert P.shape == (n, model.NPARAM) and (out["attempts"] >= 1).all() and (out["attempts"] > 1).any()
+    idx = np.linspace(0, n - 1, 64).astype(int)
+    o = O.OracleEnv(64, task, P[idx], seed=3, per_env_model=True)
+    o.reset()
+    env.reset()
+    rng = np.random.default_rng(12)
+    well_bad = well_tot = ill = tot_ok = tot = 0
+    worst_well = 0.0
+    for t in range(steps):
+        a = rng.uniform(-1, 1, size=n)
+        q, v, tg = env.get_state()
+        og, rg, dg, _ = env.step(a)
+        o.set_state(q[idx], v[idx], tg[idx])
+        oo, ro, do = o.step(a[idx], auto_reset=False)
+        well = o.margins() >= 3e-8
+        err = np.abs(og[idx].astype(np.float64) - oo)
+        w = err <= 1e-4 * np.abs(oo) + 1e-6
+        well_bad += (~w[well]).sum(); well_tot += w[well].size; ill += (~well).sum()
+        tot_ok += w.sum(); tot += w.size
+        if well.any():
+            worst_well = max(worst_well, err[well].max())
+        assert np.abs(rg[idx] - ro).max() < 2e-2
+    print("config-5 shard: well-conditioned entries outside tolerance %d of %d (worst error %.2e), ill-conditioned env-steps %d of %d, all entries within tolerance %.5f"
+          % (well_bad, well_tot, worst_well, ill, 64 * steps, tot_ok / tot))
+    assert well_bad <= 2 and ill < 0.03 * 64 * steps and tot_ok / tot >= 0.999
+    q, v, _ = env.get_state()
+    sc, ep, cap = env.counters()
+    assert np.isfinite(og).all() and np.isfinite(q).all() and np.isfinite(v).all()
+    assert np.abs(np.linalg.norm(q[:, 3:7], axis=1) - 1).max() < 1e-5 and q[:, 2].min() > 0.005 and q[:, 2].max() < 0.08
+    assert (sc == steps).all() and cap.sum() < 0.001 * n * steps          # Newton cap hits: a handful at most
+    env.close()
+
+
+@pytest.mark.gpu
+def test_model_params_of_unfetched_per_env_models_are_rebuilt_not_defaulted():
+    """randomise_models(return_params=False) (the default above 8192 envs) leaves the tables on the device; model_params(i) -
+    what the Physics accessors read (root COM, target height) - must then be env i's OWN table, rebuilt on the host from the same draws,
+    not the nominal model's."""
+    from jitterbug_amd.vec_env import JitterbugVecEnv
+    n = 300
+    a = JitterbugVecEnv(n, "move_to_pose", seed=1, env_offset=5000)
+    b = JitterbugVecEnv(n, "move_to_pose", seed=1, env_offset=5000)
+    ref = a.randomise_models(seed=21, min_mass_clearance=1e-3, return_params=True)
+    out = b.randomise_models(seed=21, min_mass_clearance=1e-3, return_params=False)
+    assert np.array_equal(ref["attempts"], out["attempts"]) and (out["attempts"] > 1).any()
+    nominal = model.default_params()
+    for i in (0, 7, 123, int(np.argmax(out["attempts"])), n - 1):
+        np.testing.assert_allclose(b.model_params(i), ref["params"][i], rtol=1e-9, atol=1e-30)
+        assert np.abs(b.model_params(i) - nominal).max() > 1e-5
+    # a failed call leaves handle and host copy on the model they had
+    with pytest.raises(Exception):
+        a.randomise_models(seed=21, sd_mass_pos=(0.02, 0.02, 0.02), min_mass_clearance=0.05, return_params=True)      # nothing clears 5 cm
+    np.testing.assert_array_equal(a.model_params(3), ref["params"][3])
+    ob = a.reset()
+    for _ in range(2):
+        ob, _, _, _ = a.step(np.zeros(n, dtype=np.float32))
+    ob_b = b.reset()
+    for _ in range(2):
+        ob_b, _, _, _ = b.step(np.zeros(n, dtype=np.float32))
+    assert np.array_equal(ob, ob_b)                                        # still the randomised models, bit for bit
+    a.close(); b.close()
