@@ -174,6 +174,15 @@ static double gjk_distance(const Geom* a, const Geom* b) {
     return d > 0 ? d : 0.0;
 }
 
+/* exact distance of two posed geoms given as (type, centre, rotation, size): for the oracle's contact-activation margin of
+ * its geom-geom candidates (jb_oracle.c) */
+double jbo_posed_geom_distance(int ta, const double* ca, const double* Ra, const double* sa, int tb, const double* cb, const double* Rb, const double* sb) {
+    Geom a, b;
+    a.type = ta; memcpy(a.c, ca, sizeof a.c); memcpy(a.R, Ra, sizeof a.R); memcpy(a.s, sa, sizeof a.s); a.rb = 0;
+    b.type = tb; memcpy(b.c, cb, sizeof b.c); memcpy(b.R, Rb, sizeof b.R); memcpy(b.s, sb, sizeof b.s); b.rb = 0;
+    return gjk_distance(&a, &b);
+}
+
 static int pair_tested(int bi, int bj) { return bi != bj && PARENT_[bi] != bj && PARENT_[bj] != bi; }
 
 /* minimum distance over all geom pairs MuJoCo's filters would let through; pair: the two geom indices (nullable) */

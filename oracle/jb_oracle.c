@@ -54,7 +54,8 @@
 #define NH JB_NHINGE
 #define MAXCON 64
 #define MAXROW (4 * MAXCON)
-#define WARM_SIZE (JB_NGEOM * 16 + JB_NV)   /* pyramid forces by (geom,slot,edge) + last qacc */
+#define WARM_PAIR (JB_NGEOM * 16 + JB_NV)    /* then 4 x 4: pyramid forces of the mass - upper-leg contact of leg l */
+#define WARM_SIZE (JB_NGEOM * 16 + JB_NV + 16)   /* pyramid forces by (geom,slot,edge) + last qacc + the geom-geom contacts */
 
 static const int PARENT[NB] = {-1, 0, 1, 0, 3, 0, 5, 0, 7, 0};
 
@@ -67,6 +68,8 @@ typedef struct {
     int feet_only;       /* 1: only the 4 foot spheres collide                     */
     int solver;          /* 0: dual PGS, 1: primal Newton with exact line search   */
                          /*    (MuJoCo 2.0's default solver; same unique optimum)  */
+    int pair_contacts;   /* 1: the geom-geom pairs that can touch on randomised models - the eccentric-mass ellipsoid against the
+                            upper-leg cylinder of each leg - collide like MuJoCo's mjc_Convex would make them (0: floor only) */
 } jbo_opts;
 
 typedef struct {
@@ -249,7 +252,287 @@ static void chol_solve(const double* L, int n, int ld, double* x) {
 }
 
 /* ------------------------------------------------------------------ collisions */
-typedef struct { double dist, pos[3]; int body, geom, slot; } Contact;
+/* body: the body the contact Jacobian is ADDED for (the plane contacts' only body; geom2's body of a geom-geom contact);
+ * body2: the body it is SUBTRACTED for (-1: the world); n: unit normal, world axes, pointing from geom1 to geom2 (MuJoCo's
+ * convention; +z for the floor); wslot: where the contact's pyramid forces are kept in the warm-start buffer. */
+typedef struct { double dist, pos[3], n[3]; int body, body2, geom, slot, wslot; } Contact;
+
+/* ---- geom-geom narrow phase: Minkowski Portal Refinement ------------------------------------------------------------------
+ * MuJoCo 2.0 sends every pair without a dedicated routine (ellipsoid-cylinder among them) through mjc_Convex, i.e. libccd's
+ * ccdMPRPenetration (G. Snethen's XenoCollide algorithm) with opt.mpr_tolerance = 1e-6 and opt.mpr_iterations = 50, over
+ * MuJoCo's support functions.  Neither library is under /root/reference; what follows restates the published algorithm
+ * (libccd src/mpr.c: discoverPortal / refinePortal / findPenetr / findPos / expandPortal, same tests in the same order)
+ * and MuJoCo's ellipsoid and cylinder support mappings.  Result convention (libccd): translating obj2 by depth * dir separates
+ * the two, i.e. dir points from obj1 to obj2 - MuJoCo copies it into the contact normal - and pos is the mean of the two
+ * witness points interpolated over the final portal. */
+typedef struct { int type; double c[3], R[9], sz[3]; } CGeom;
+typedef struct { double v[3], v1[3], v2[3]; } MSupp;
+#define MPR_EPS 2.220446049250313e-16
+#define MPR_TOL 1e-6
+#define MPR_ITERS 50
+static void cgeom_support(const CGeom* g, const double* d, double* out) {
+    double dl[3], sl[3];
+    matTvec3(dl, g->R, d);
+    if (g->type == JB_GEOM_ELLIPSOID) {
+        double den = sqrt(g->sz[0] * g->sz[0] * dl[0] * dl[0] + g->sz[1] * g->sz[1] * dl[1] * dl[1] + g->sz[2] * g->sz[2] * dl[2] * dl[2]);
+        for (int i = 0; i < 3; i++) sl[i] = den > 1e-15 ? g->sz[i] * g->sz[i] * dl[i] / den : 0.0;
+    } else {        /* cylinder: size = radius, half length; axis = geom z */
+        double nr = sqrt(dl[0] * dl[0] + dl[1] * dl[1]);
+        sl[0] = nr > 1e-15 ? dl[0] / nr * g->sz[0] : 0.0;
+        sl[1] = nr > 1e-15 ? dl[1] / nr * g->sz[0] : 0.0;
+        sl[2] = dl[2] > 0 ? g->sz[1] : (dl[2] < 0 ? -g->sz[1] : 0.0);
+    }
+    matvec3(out, g->R, sl);
+    for (int i = 0; i < 3; i++) out[i] += g->c[i];
+}
+static void mpr_support(const CGeom* a, const CGeom* b, const double* dir, MSupp* s) {
+    double nd[3] = {-dir[0], -dir[1], -dir[2]};
+    cgeom_support(a, dir, s->v1);
+    cgeom_support(b, nd, s->v2);
+    for (int i = 0; i < 3; i++) s->v[i] = s->v1[i] - s->v2[i];
+}
+static int mpr_zero(double x) { return fabs(x) < MPR_EPS; }
+static int mpr_eq(double a, double b) {
+    double ab = fabs(a - b);
+    if (ab < MPR_EPS) return 1;
+    double aa = fabs(a), bb = fabs(b);
+    return ab < MPR_EPS * (bb > aa ? bb : aa);
+}
+static void vnormalize(double* v) { double n = sqrt(dot3(v, v)); for (int i = 0; i < 3; i++) v[i] /= n; }
+static void portal_dir(const MSupp* ps, double* dir) {
+    double a[3], b[3];
+    for (int i = 0; i < 3; i++) { a[i] = ps[2].v[i] - ps[1].v[i]; b[i] = ps[3].v[i] - ps[1].v[i]; }
+    cross3(dir, a, b);
+    vnormalize(dir);
+}
+static double g_mpr_tol = MPR_TOL;     /* (tests vary these to show what MuJoCo's setting leaves unconverged) */
+static int g_mpr_iters = MPR_ITERS;
+static int portal_reach_tolerance(const MSupp* ps, const MSupp* v4, const double* dir) {
+    double dv1 = dot3(ps[1].v, dir), dv2 = dot3(ps[2].v, dir), dv3 = dot3(ps[3].v, dir), dv4 = dot3(v4->v, dir);
+    double d1 = dv4 - dv1, d2 = dv4 - dv2, d3 = dv4 - dv3;
+    double m = d1 < d2 ? d1 : d2;
+    m = m < d3 ? m : d3;
+    return mpr_eq(m, g_mpr_tol) || m < g_mpr_tol;
+}
+static void expand_portal(MSupp* ps, const MSupp* v4) {
+    double v4v0[3];
+    cross3(v4v0, v4->v, ps[0].v);
+    if (dot3(ps[1].v, v4v0) > 0) {
+        if (dot3(ps[2].v, v4v0) > 0) ps[1] = *v4; else ps[3] = *v4;
+    } else {
+        if (dot3(ps[3].v, v4v0) > 0) ps[2] = *v4; else ps[1] = *v4;
+    }
+}
+/* closest point of triangle (a, b, c) to the origin (Ericson, Real-Time Collision Detection 5.1.5): what libccd's
+ * ccdVec3PointTriDist2(origin, ...) returns as witness */
+static void tri_closest_to_origin(const double* a, const double* b, const double* c, double* out) {
+    double ab[3], ac[3], ap[3], bp[3], cp[3];
+    for (int i = 0; i < 3; i++) { ab[i] = b[i] - a[i]; ac[i] = c[i] - a[i]; ap[i] = -a[i]; bp[i] = -b[i]; cp[i] = -c[i]; }
+    double d1 = dot3(ab, ap), d2 = dot3(ac, ap);
+    if (d1 <= 0 && d2 <= 0) { memcpy(out, a, 24); return; }
+    double d3 = dot3(ab, bp), d4 = dot3(ac, bp);
+    if (d3 >= 0 && d4 <= d3) { memcpy(out, b, 24); return; }
+    double vc = d1 * d4 - d3 * d2;
+    if (vc <= 0 && d1 >= 0 && d3 <= 0) { double v = d1 / (d1 - d3); for (int i = 0; i < 3; i++) out[i] = a[i] + v * ab[i]; return; }
+    double d5 = dot3(ab, cp), d6 = dot3(ac, cp);
+    if (d6 >= 0 && d5 <= d6) { memcpy(out, c, 24); return; }
+    double vb = d5 * d2 - d1 * d6;
+    if (vb <= 0 && d2 >= 0 && d6 <= 0) { double w = d2 / (d2 - d6); for (int i = 0; i < 3; i++) out[i] = a[i] + w * ac[i]; return; }
+    double va = d3 * d6 - d5 * d4;
+    if (va <= 0 && (d4 - d3) >= 0 && (d5 - d6) >= 0) {
+        double w = (d4 - d3) / ((d4 - d3) + (d5 - d6));
+        for (int i = 0; i < 3; i++) out[i] = b[i] + w * (c[i] - b[i]);
+        return;
+    }
+    double den = 1.0 / (va + vb + vc), v = vb * den, w = vc * den;
+    for (int i = 0; i < 3; i++) out[i] = a[i] + ab[i] * v + ac[i] * w;
+}
+/* returns 0 with depth / dir / pos when the two geoms intersect, -1 otherwise */
+static int mpr_penetration(const CGeom* o1, const CGeom* o2, double* depth, double* dir_out, double* pos) {
+    MSupp ps[4], v4;
+    double dir[3], va[3], vb[3], dot;
+    /* discoverPortal */
+    memcpy(ps[0].v1, o1->c, 24); memcpy(ps[0].v2, o2->c, 24);
+    for (int i = 0; i < 3; i++) ps[0].v[i] = ps[0].v1[i] - ps[0].v2[i];
+    if (mpr_eq(ps[0].v[0], 0) && mpr_eq(ps[0].v[1], 0) && mpr_eq(ps[0].v[2], 0)) ps[0].v[0] += MPR_EPS * 10;
+    for (int i = 0; i < 3; i++) dir[i] = -ps[0].v[i];
+    vnormalize(dir);
+    mpr_support(o1, o2, dir, &ps[1]);
+    dot = dot3(ps[1].v, dir);
+    if (mpr_zero(dot) || dot < 0) return -1;
+    cross3(dir, ps[0].v, ps[1].v);
+    if (mpr_zero(dot3(dir, dir))) {
+        /* the origin lies on the segment v0-v1 (or on v1): libccd's findPenetrSegment / findPenetrTouch */
+        *depth = sqrt(dot3(ps[1].v, ps[1].v));
+        memcpy(dir_out, ps[1].v, 24);
+        if (*depth > 0) vnormalize(dir_out);
+        for (int i = 0; i < 3; i++) pos[i] = 0.5 * (ps[1].v1[i] + ps[1].v2[i]);
+        return 0;
+    }
+    vnormalize(dir);
+    mpr_support(o1, o2, dir, &ps[2]);
+    dot = dot3(ps[2].v, dir);
+    if (mpr_zero(dot) || dot < 0) return -1;
+    for (int i = 0; i < 3; i++) { va[i] = ps[1].v[i] - ps[0].v[i]; vb[i] = ps[2].v[i] - ps[0].v[i]; }
+    cross3(dir, va, vb);
+    vnormalize(dir);
+    if (dot3(dir, ps[0].v) > 0) { MSupp t = ps[1]; ps[1] = ps[2]; ps[2] = t; for (int i = 0; i < 3; i++) dir[i] = -dir[i]; }
+    for (int guard = 0;; guard++) {
+        if (guard > 100) return -1;
+        mpr_support(o1, o2, dir, &ps[3]);
+        dot = dot3(ps[3].v, dir);
+        if (mpr_zero(dot) || dot < 0) return -1;
+        int cont = 0;
+        cross3(va, ps[1].v, ps[3].v);
+        dot = dot3(va, ps[0].v);
+        if (dot < 0 && !mpr_zero(dot)) { ps[2] = ps[3]; cont = 1; }
+        if (!cont) {
+            cross3(va, ps[3].v, ps[2].v);
+            dot = dot3(va, ps[0].v);
+            if (dot < 0 && !mpr_zero(dot)) { ps[1] = ps[3]; cont = 1; }
+        }
+        if (!cont) break;
+        for (int i = 0; i < 3; i++) { va[i] = ps[1].v[i] - ps[0].v[i]; vb[i] = ps[2].v[i] - ps[0].v[i]; }
+        cross3(dir, va, vb);
+        vnormalize(dir);
+    }
+    /* refinePortal */
+    for (int guard = 0;; guard++) {
+        if (guard > 1000) return -1;
+        portal_dir(ps, dir);
+        dot = dot3(dir, ps[1].v);
+        if (mpr_zero(dot) || dot > 0) break;                      /* the portal encapsules the origin */
+        mpr_support(o1, o2, dir, &v4);
+        dot = dot3(v4.v, dir);
+        if (!(mpr_zero(dot) || dot > 0) || portal_reach_tolerance(ps, &v4, dir)) return -1;
+        expand_portal(ps, &v4);
+    }
+    /* findPenetr */
+    for (int it = 0;; it++) {
+        portal_dir(ps, dir);
+        mpr_support(o1, o2, dir, &v4);
+        if (portal_reach_tolerance(ps, &v4, dir) || it > g_mpr_iters) {
+            double pd[3];
+            tri_closest_to_origin(ps[1].v, ps[2].v, ps[3].v, pd);
+            *depth = sqrt(dot3(pd, pd));
+            if (mpr_zero(pd[0]) && mpr_zero(pd[1]) && mpr_zero(pd[2])) memcpy(pd, dir, 24);
+            vnormalize(pd);
+            memcpy(dir_out, pd, 24);
+            /* findPos: barycentric coordinates of the origin in the tetrahedron (v0, v1, v2, v3) */
+            double b[4], vec[3], sum;
+            portal_dir(ps, dir);
+            cross3(vec, ps[1].v, ps[2].v); b[0] = dot3(vec, ps[3].v);
+            cross3(vec, ps[3].v, ps[2].v); b[1] = dot3(vec, ps[0].v);
+            cross3(vec, ps[0].v, ps[1].v); b[2] = dot3(vec, ps[3].v);
+            cross3(vec, ps[2].v, ps[1].v); b[3] = dot3(vec, ps[0].v);
+            sum = b[0] + b[1] + b[2] + b[3];
+            if (mpr_zero(sum) || sum < 0) {
+                b[0] = 0;
+                cross3(vec, ps[2].v, ps[3].v); b[1] = dot3(vec, dir);
+                cross3(vec, ps[3].v, ps[1].v); b[2] = dot3(vec, dir);
+                cross3(vec, ps[1].v, ps[2].v); b[3] = dot3(vec, dir);
+                sum = b[1] + b[2] + b[3];
+            }
+            double p1[3] = {0, 0, 0}, p2[3] = {0, 0, 0};
+            for (int k2 = 0; k2 < 4; k2++) for (int i = 0; i < 3; i++) { p1[i] += b[k2] * ps[k2].v1[i]; p2[i] += b[k2] * ps[k2].v2[i]; }
+            for (int i = 0; i < 3; i++) pos[i] = 0.5 * (p1[i] + p2[i]) / sum;
+            return 0;
+        }
+        expand_portal(ps, &v4);
+    }
+}
+
+/* ---- the narrow phase the oracle (and the HIP kernel) USE for that pair: the geometric contact --------------------------------
+ * MuJoCo's MPR stops at a portal 1e-6 wide; on this pair (an ellipsoid of ~5 mm against a cylinder of 1.5 mm radius, overlaps of
+ * 0.02-0.2 mm) that leaves the normal undetermined to +-10 degrees and the depth to a few per cent from one configuration to the
+ * next, and the iteration converges too slowly to be run to a reproducible limit (tolerance 1e-10: normal still 4e-3 off,
+ * tests/test_pair_contact.py) - no independent implementation, let alone an fp32 one, can reproduce its output.  What its output
+ * scatters around is the geometric contact of the two bodies, which is what is computed here in closed form + two nested
+ * one-dimensional Newton / secant iterations, smooth in the configuration:
+ *     x* = the point of the cylinder's AXIS SEGMENT with the smallest SIGNED distance sd to the ellipsoid (negative inside it), q* the
+ *     ellipsoid's nearest point to x*,   n = the ellipsoid's outward normal at q*  (mass -> leg),
+ *     dist = sd - r_cyl  (negative: penetration),   pos = midpoint of q* and the cylinder surface point x* - r n.
+ * (An overlap at the very end of the leg is taken against the segment's end point - a rounded end where the cylinder has a
+ * flat cap; the upper legs' ends lie inside the shoulder / knee geometry.) */
+/* nearest point q of the axis-aligned ellipsoid (semi-axes s) to a point y, outside OR inside it: q_i = s_i^2 y_i / (s_i^2 + lam)
+ * with lam the root of F(lam) = sum_i (s_i y_i / (s_i^2 + lam))^2 - 1 in (-min s_i^2, inf): positive outside, negative inside.
+ * F is convex and decreasing there: Newton, kept inside the bracket it has established.  Returns the SIGNED distance
+ * (negative inside) and the outward unit normal at q. */
+static double ellipsoid_nearest(const double* s, const double* y, double* q, double* nrm) {
+    double smin2 = s[0] * s[0];
+    for (int i = 1; i < 3; i++) if (s[i] * s[i] < smin2) smin2 = s[i] * s[i];
+    double F0 = -1;
+    for (int i = 0; i < 3; i++) F0 += (y[i] / s[i]) * (y[i] / s[i]);
+    double lo, hi, lam = 0;                      /* F(lo) > 0 > F(hi) */
+    if (F0 > 0) { lo = 0; hi = INFINITY; } else { lo = -smin2; hi = 0; }
+    for (int it = 0; it < 100; it++) {
+        double F = -1, dF = 0;
+        for (int i = 0; i < 3; i++) { double a = s[i] * s[i] + lam, w = s[i] * y[i] / a; F += w * w; dF -= 2 * w * w / a; }
+        if (F > 0) lo = lam; else hi = lam;
+        double nl = (dF < 0) ? lam - F / dF : lam;
+        if (!(nl > lo && nl < hi)) nl = isinf(hi) ? 2 * lam + smin2 : 0.5 * (lo + hi);
+        if (fabs(nl - lam) <= 1e-16 * (smin2 + fabs(lam))) { lam = nl; break; }
+        lam = nl;
+    }
+    double g[3], gl = 0, d2 = 0;
+    for (int i = 0; i < 3; i++) { q[i] = s[i] * s[i] * y[i] / (s[i] * s[i] + lam); g[i] = q[i] / (s[i] * s[i]); gl += g[i] * g[i]; d2 += (y[i] - q[i]) * (y[i] - q[i]); }
+    gl = sqrt(gl);
+    for (int i = 0; i < 3; i++) nrm[i] = g[i] / gl;                  /* gradient of sum (x_i / s_i)^2 at q */
+    return lam >= 0 ? sqrt(d2) : -sqrt(d2);
+}
+/* returns 1 with dist (<0: penetration), n (ellipsoid -> cylinder), pos, all in world axes */
+static int pair_geometric(const CGeom* e, const CGeom* c, double* dist, double* n, double* pos) {
+    double cl[3], ul[3], d[3], ax[3] = {c->R[2], c->R[5], c->R[8]};
+    for (int i = 0; i < 3; i++) d[i] = c->c[i] - e->c[i];
+    matTvec3(cl, e->R, d);
+    matTvec3(ul, e->R, ax);
+    const double h = c->sz[1];
+    /* f(t) = u . n_out(x(t)) is the derivative of the (convex) signed distance along the axis: monotone, root by safeguarded secant */
+    double ta = -h, tb = h, fa, fb, x[3], q[3], nl[3];
+    for (int i = 0; i < 3; i++) x[i] = cl[i] + ta * ul[i];
+    ellipsoid_nearest(e->sz, x, q, nl);
+    fa = dot3(nl, ul);
+    for (int i = 0; i < 3; i++) x[i] = cl[i] + tb * ul[i];
+    ellipsoid_nearest(e->sz, x, q, nl);
+    fb = dot3(nl, ul);
+    double t;
+    if (fa >= 0) t = ta; else if (fb <= 0) t = tb;
+    else {
+        t = ta - fa * (tb - ta) / (fb - fa);
+        for (int it = 0; it < 200; it++) {
+            for (int i = 0; i < 3; i++) x[i] = cl[i] + t * ul[i];
+            ellipsoid_nearest(e->sz, x, q, nl);
+            double f = dot3(nl, ul);
+            if (f < 0) { ta = t; fa = f; } else { tb = t; fb = f; }
+            if (fabs(f) < 1e-15 || tb - ta < 1e-15) break;
+            double tn = t - f * (tb - ta) / (fb - fa);              /* secant through the bracket ends ... */
+            if (!(tn > ta && tn < tb) || it % 3 == 2) tn = 0.5 * (ta + tb);     /* ... bisection when it leaves the bracket or stalls on one side */
+            t = tn;
+        }
+    }
+    for (int i = 0; i < 3; i++) x[i] = cl[i] + t * ul[i];
+    double sd = ellipsoid_nearest(e->sz, x, q, nl), pl[3];
+    *dist = sd - c->sz[0];
+    for (int i = 0; i < 3; i++) pl[i] = 0.5 * (q[i] + x[i] - c->sz[0] * nl[i]);
+    matvec3(n, e->R, nl);
+    matvec3(pos, e->R, pl);
+    for (int i = 0; i < 3; i++) pos[i] += e->c[i];
+    return 1;
+}
+static void cgeom_world(const double* P, const Kin* k, int g, CGeom* out) {
+    const double* G = P + JB_P_GEOM + g * JB_GEOM_STRIDE;
+    int b = (int)G[JB_G_BODY];
+    out->type = (int)G[JB_G_TYPE];
+    matvec3(out->c, k->R[b], G + JB_G_CENTER);
+    for (int i = 0; i < 3; i++) { out->c[i] += k->t[b][i]; out->sz[i] = G[JB_G_SIZE + i]; }
+    matmul3(out->R, k->R[b], G + JB_G_ROT);
+}
+/* MuJoCo's bounding-sphere radius of a geom (rbound) */
+static double cgeom_rbound(const CGeom* g) {
+    if (g->type == JB_GEOM_ELLIPSOID) { double m = g->sz[0] > g->sz[1] ? g->sz[0] : g->sz[1]; return m > g->sz[2] ? m : g->sz[2]; }
+    return sqrt(g->sz[0] * g->sz[0] + g->sz[1] * g->sz[1]);
+}
+double jbo_posed_geom_distance(int ta, const double* ca, const double* Ra, const double* sa, int tb, const double* cb, const double* Rb, const double* sb);   /* jb_clearance.c: exact GJK distance */
 
 /* All against the floor plane z=0 with normal +z (reference: jitterbug.xml:30).
  * Restates MuJoCo's mjc_PlaneSphere / mjc_PlaneCylinder / mjc_PlaneBox /
@@ -259,10 +542,11 @@ static int add_contact(Contact* c, int n, double dist, const double* pos, int bo
     if (n >= MAXCON) return n;
     c[n].dist = dist; c[n].pos[0] = pos[0]; c[n].pos[1] = pos[1]; c[n].pos[2] = pos[2];
     c[n].body = body; c[n].geom = geom; c[n].slot = slot;
+    c[n].body2 = -1; c[n].n[0] = 0; c[n].n[1] = 0; c[n].n[2] = 1; c[n].wslot = (geom * 4 + slot) * 4;
     return n + 1;
 }
 #define MARGIN(d) do { double _a = fabs(d); if (_a < *margin) *margin = _a; } while (0)
-static int collide(const double* P, const Kin* k, int feet_only, Contact* con, int* overflow, double* margin) {
+static int collide(const double* P, const Kin* k, int feet_only, int pair_contacts, Contact* con, int* overflow, double* margin) {
     static const double nz[3] = {0, 0, 1};
     int n = 0;
     for (int g = 0; g < JB_NGEOM; g++) {
@@ -345,7 +629,42 @@ static int collide(const double* P, const Kin* k, int feet_only, Contact* con, i
         }
         if (n == MAXCON && n0 != n) *overflow = 1;
     }
+    if (pair_contacts && !feet_only) {
+        /* The geom pairs that can touch (on randomised models the eccentric-mass ellipsoid, geom 21 on the motor body,
+         * reaches the upper-leg cylinders; every other pair MuJoCo's filters let through keeps its distance in every regime
+         * measured).  MuJoCo orders a pair by geom type (ellipsoid < cylinder), so geom1 = the ellipsoid and the normal points from
+         * the mass to the leg; bounding spheres first (mj_collideGeoms), then - where MuJoCo runs mjc_Convex = MPR - the geometric
+         * contact MPR's output scatters around (pair_geometric above). */
+        CGeom e, c;
+        cgeom_world(P, k, 21, &e);
+        for (int l = 0; l < JB_NLEG; l++) {
+            int g = 4 + 4 * l;
+            cgeom_world(P, k, g, &c);
+            double d[3] = {c.c[0] - e.c[0], c.c[1] - e.c[1], c.c[2] - e.c[2]};
+            if (sqrt(dot3(d, d)) > cgeom_rbound(&e) + cgeom_rbound(&c)) continue;
+            double dist, dir[3], pos[3];
+            pair_geometric(&e, &c, &dist, dir, pos);
+            MARGIN(dist);
+            if (dist < 0) {
+                if (n < MAXCON) {
+                    con[n].dist = dist; memcpy(con[n].pos, pos, 24); memcpy(con[n].n, dir, 24);
+                    con[n].body = (int)P[JB_P_GEOM + g * JB_GEOM_STRIDE + JB_G_BODY]; con[n].body2 = (int)P[JB_P_GEOM + 21 * JB_GEOM_STRIDE + JB_G_BODY];
+                    con[n].geom = JB_NGEOM + l; con[n].slot = 0; con[n].wslot = WARM_PAIR + 4 * l;
+                    n++;
+                } else *overflow = 1;
+            }
+        }
+    }
     return n;
+}
+
+/* MuJoCo's mju_makeFrame: complete a unit normal x to a right-handed frame (x, y, z) */
+static void make_frame(const double* x, double* y, double* z) {
+    if (x[1] < 0.5 && x[1] > -0.5) { y[0] = 0; y[1] = 1; y[2] = 0; } else { y[0] = 0; y[1] = 0; y[2] = 1; }
+    double d = dot3(x, y);
+    for (int i = 0; i < 3; i++) y[i] -= d * x[i];
+    vnormalize(y);
+    cross3(z, x, y);
 }
 
 /* impedance d(r) (MuJoCo solimp, 5-parameter form) */
@@ -398,7 +717,7 @@ static void substep(const double* P, double* qpos, double* qvel, double ctrl, co
     Contact con[MAXCON];
     int ncon = 0, overflow = 0;
     double margin = INFINITY;
-    if (o->contacts) ncon = collide(P, &k, o->feet_only, con, &overflow, &margin);
+    if (o->contacts) ncon = collide(P, &k, o->feet_only, o->pair_contacts, con, &overflow, &margin);
     if (st && margin < st->margin_min) st->margin_min = margin;
     if (dbg) { dbg->ncon = ncon; dbg->nrow = 0; memcpy(dbg->M, M, sizeof M); memcpy(dbg->bias, bias, sizeof bias); memcpy(dbg->tau, tau, sizeof tau); }
 
@@ -426,9 +745,17 @@ static void substep(const double* P, double* qpos, double* qvel, double ctrl, co
         for (int c = 0; c < ncon; c++) {
             double Jv[NV][3], Jw[NV][3];
             jacobian(&k, con[c].body, con[c].pos, Jv, Jw);
-            /* contact frame: x = normal (0,0,1); MuJoCo mju_makeFrame -> y = (0,1,0), z = x cross y = (-1,0,0) */
+            /* contact frame: x = normal; MuJoCo mju_makeFrame -> for the floor (0,0,1): y = (0,1,0), z = x cross y = (-1,0,0) */
+            double fx[3] = {con[c].n[0], con[c].n[1], con[c].n[2]}, fy[3], fz[3];
+            make_frame(fx, fy, fz);
             double imp = impedance(solimp, con[c].dist);
             double tran = P[JB_P_BODY + con[c].body * JB_BODY_STRIDE + JB_B_INVW_TRAN];   /* + world body: 0 */
+            if (con[c].body2 >= 0) {     /* geom-geom contact: relative motion of the two bodies (jac2 - jac1), both inverse weights */
+                double Jv2[NV][3], Jw2[NV][3];
+                jacobian(&k, con[c].body2, con[c].pos, Jv2, Jw2);
+                for (int d = 0; d < NV; d++) for (int i = 0; i < 3; i++) Jv[d][i] -= Jv2[d][i];
+                tran += P[JB_P_BODY + con[c].body2 * JB_BODY_STRIDE + JB_B_INVW_TRAN];
+            }
             double fr = P[JB_P_FRICTION];
             double dA = tran + fr * fr * tran;
             double R0 = (1 - imp) / imp * dA;
@@ -439,8 +766,8 @@ static void substep(const double* P, double* qpos, double* qvel, double ctrl, co
                 double sgn = (e & 1) ? -1.0 : 1.0;
                 double vel = 0;
                 for (int d = 0; d < NV; d++) {
-                    double jn = Jv[d][2];
-                    double jt = (e < 2) ? Jv[d][1] : -Jv[d][0];
+                    double jn = dot3(Jv[d], fx);
+                    double jt = (e < 2) ? dot3(Jv[d], fy) : dot3(Jv[d], fz);
                     J[r][d] = jn + sgn * mu * jt;
                     vel += J[r][d] * qvel[d];
                 }
@@ -451,7 +778,7 @@ static void substep(const double* P, double* qpos, double* qvel, double ctrl, co
                 double a0 = 0;
                 for (int d = 0; d < NV; d++) a0 += J[r][d] * qacc_s[d];
                 b[r] = a0 - aref[r];
-                f[r] = (warm && o->warmstart) ? warm[(con[c].geom * 4 + con[c].slot) * 4 + e] : 0.0;
+                f[r] = (warm && o->warmstart) ? warm[con[c].wslot + e] : 0.0;
             }
         }
         for (int i = 0; i < nr; i++)
@@ -571,7 +898,8 @@ static void substep(const double* P, double* qpos, double* qvel, double ctrl, co
         for (int d = 0; d < NV; d++) { double s = 0; for (int r = 0; r < nr; r++) s += J[r][d] * f[r]; qfc[d] = s; }
         if (warm) {
             memset(warm, 0, sizeof(double) * JB_NGEOM * 16);
-            for (int c = 0; c < ncon; c++) for (int e = 0; e < 4; e++) warm[(con[c].geom * 4 + con[c].slot) * 4 + e] = f[4 * c + e];
+            memset(warm + WARM_PAIR, 0, sizeof(double) * 16);
+            for (int c = 0; c < ncon; c++) for (int e = 0; e < 4; e++) warm[con[c].wslot + e] = f[4 * c + e];
         }
         if (dbg) {
             dbg->nrow = nr;
@@ -588,6 +916,7 @@ static void substep(const double* P, double* qpos, double* qvel, double ctrl, co
         free(J); free(MJ); free(A); free(b); free(Rr); free(f); free(aref);
     } else if (warm) {
         memset(warm, 0, sizeof(double) * JB_NGEOM * 16);
+        memset(warm + WARM_PAIR, 0, sizeof(double) * 16);
     }
     if (st) { st->ncon_last = ncon; if (ncon > st->ncon_max) st->ncon_max = ncon; if (overflow) st->overflow = 1; }
     if (dbg) memcpy(dbg->qfrc_constraint, qfc, sizeof qfc);
@@ -624,7 +953,7 @@ static void substep(const double* P, double* qpos, double* qvel, double ctrl, co
 
 /* ------------------------------------------------------------------ public: physics */
 void jbo_default_opts(jbo_opts* o) {
-    o->contacts = 1; o->implicit_damp = 1; o->solver_iters = 20000; o->solver_tol = 1e-12; o->warmstart = 1; o->feet_only = 0; o->solver = 1;
+    o->contacts = 1; o->implicit_damp = 1; o->solver_iters = 20000; o->solver_tol = 1e-12; o->warmstart = 1; o->feet_only = 0; o->solver = 1; o->pair_contacts = 0;
 }
 
 /* nsub substeps with constant ctrl (reference: control.Environment.step, 50 substeps) */
@@ -644,7 +973,31 @@ void jbo_forward_debug(const double* P, const double* qpos, const double* qvel, 
     substep(P, q, v, ctrl, o, NULL, NULL, dbg);
 }
 int jbo_debug_size(void) { return (int)sizeof(jbo_debug); }
-int jbo_maxcon(void) { return MAXCON; }
+/* the narrow phase of the mass-ellipsoid / upper-leg-cylinder pair of leg l in one configuration, for the tests:
+ * out = [depth, dir(3) from the ellipsoid to the cylinder, pos(3)]; returns 1 when the two intersect, 0 otherwise (out[0] = GJK gap) */
+int jbo_pair_mpr(const double* P, const double* qpos_in, int leg, double tol, int iters, double* out) {
+    Kin k; double qpos[NQ];
+    memcpy(qpos, qpos_in, sizeof qpos);
+    kinematics(P, qpos, &k);
+    CGeom e, c;
+    cgeom_world(P, &k, 21, &e);
+    cgeom_world(P, &k, 4 + 4 * leg, &c);
+    g_mpr_tol = tol > 0 ? tol : MPR_TOL; g_mpr_iters = iters > 0 ? iters : MPR_ITERS;
+    int hit = mpr_penetration(&e, &c, out, out + 1, out + 4) == 0;
+    g_mpr_tol = MPR_TOL; g_mpr_iters = MPR_ITERS;
+    if (!hit) out[0] = jbo_posed_geom_distance(e.type, e.c, e.R, e.sz, c.type, c.c, c.R, c.sz);
+    return hit;
+}
+/* ... and the geometric contact of the same pair (what collide() uses): out = [dist (<0: penetration), n(3), pos(3)]; 0 if undefined */
+int jbo_pair_geometric(const double* P, const double* qpos_in, int leg, double* out) {
+    Kin k; double qpos[NQ];
+    memcpy(qpos, qpos_in, sizeof qpos);
+    kinematics(P, qpos, &k);
+    CGeom e, c;
+    cgeom_world(P, &k, 21, &e);
+    cgeom_world(P, &k, 4 + 4 * leg, &c);
+    return pair_geometric(&e, &c, out, out + 1, out + 4);
+}
 
 /* total momentum (linear P, angular L about world origin) and energies, for the conservation tests */
 void jbo_momentum_energy(const double* P, const double* qpos_in, const double* qvel, double* out /*[8]: P3 L3 T V*/) {

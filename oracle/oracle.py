@@ -14,7 +14,7 @@ _SO = os.path.join(_HERE, "_build", "libjb_oracle.so")
 
 NQ, NV, NGEOM = 16, 15, 22
 NPARAM = 612
-WARM_SIZE = NGEOM * 16 + NV
+WARM_SIZE = NGEOM * 16 + NV + 16
 MAXCON = 64
 MAXROW = 4 * MAXCON
 TASKS = ("move_from_origin", "face_direction", "move_in_direction", "move_to_position", "move_to_pose")
@@ -48,7 +48,7 @@ def build(force=False):
 
 class Opts(C.Structure):
     _fields_ = [("contacts", C.c_int), ("implicit_damp", C.c_int), ("solver_iters", C.c_int),
-                ("solver_tol", C.c_double), ("warmstart", C.c_int), ("feet_only", C.c_int), ("solver", C.c_int)]
+                ("solver_tol", C.c_double), ("warmstart", C.c_int), ("feet_only", C.c_int), ("solver", C.c_int), ("pair_contacts", C.c_int)]
 
 
 class Stats(C.Structure):
@@ -197,6 +197,25 @@ def reward_terms(P, qpos, qvel, target):
 def tolerance(x, bounds=(0.0, 0.0), margin=0.0, value_at_margin=0.1, sigmoid="gaussian"):
     kind = dict(gaussian=0, cosine=1, linear=2)[sigmoid]
     return lib().jbo_tolerance(float(x), float(bounds[0]), float(bounds[1]), float(margin), float(value_at_margin), kind)
+
+
+def pair_mpr(P, qpos, leg, tol=0.0, iters=0):
+    """MuJoCo's narrow phase (MPR; tol / iters default to MuJoCo's 1e-6 / 50) of (mass ellipsoid, upper cylinder of `leg`):
+    (touching, depth_or_gap, normal[3] ellipsoid -> cylinder, pos[3]).  The oracle's substep does NOT use it, see jb_oracle.c."""
+    out = np.zeros(7)
+    L = lib()
+    L.jbo_pair_mpr.argtypes = [_dp, _dp, C.c_int, C.c_double, C.c_int, _dp]
+    hit = L.jbo_pair_mpr(_p(np.ascontiguousarray(P, dtype=np.float64)), _p(np.ascontiguousarray(qpos, dtype=np.float64)), int(leg), float(tol), int(iters), _p(out))
+    return bool(hit), out[0], out[1:4].copy(), out[4:7].copy()
+
+
+def pair_geometric(P, qpos, leg):
+    """The geometric contact of the same pair, which collide() uses: (defined, dist (<0: penetration), normal[3], pos[3])."""
+    out = np.zeros(7)
+    L = lib()
+    L.jbo_pair_geometric.argtypes = [_dp, _dp, C.c_int, _dp]
+    ok = L.jbo_pair_geometric(_p(np.ascontiguousarray(P, dtype=np.float64)), _p(np.ascontiguousarray(qpos, dtype=np.float64)), int(leg), _p(out))
+    return bool(ok), out[0], out[1:4].copy(), out[4:7].copy()
 
 
 def pair_clearance(P, qpos):
