@@ -193,7 +193,7 @@ def main(argv=None):
             sh = None
             env = JitterbugVecEnv(n, task, seed=args.seed, device_id=local_rank, env_offset=rank * n, stream=torch.cuda.current_stream(dev).cuda_stream, **env_kw)
         if args.augmented:           # BASELINE configs[4]: one randomised model per env, generated on the device (keyed by the global env index)
-            env.randomise_models(seed=1000, min_mass_clearance=1e-3, return_params=False)
+            env.randomise_models(seed=1000, return_params=False)          # every draw of the reference's distribution is kept (robots whose mass touches a leg included: PAIR kernel)
         obs = torch.empty((n, D), device=dev, dtype=torch.float32)
         rew = torch.empty((n,), device=dev, dtype=torch.float32)
         done = torch.empty((n,), device=dev, dtype=torch.uint8)
@@ -292,7 +292,7 @@ def main(argv=None):
         import numpy as np
         env = JitterbugVecEnv(n, task, seed=args.seed, device_id=local_rank, contacts=bool(args.contacts), max_newton=args.max_newton, envs_per_wave=args.envs_per_wave)
         if args.augmented:
-            env.randomise_models(seed=1000, min_mass_clearance=1e-3, return_params=False)
+            env.randomise_models(seed=1000, return_params=False)          # every draw of the reference's distribution is kept (robots whose mass touches a leg included: PAIR kernel)
         env.reset()
         rs = np.random.default_rng(0)
         acts = rs.uniform(-1, 1, size=(64, n)).astype(np.float32)

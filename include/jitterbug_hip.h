@@ -61,6 +61,11 @@ typedef struct jb_handle jb_handle;
 #define JB_FLAG_NO_RANK_ONE 1   /* diagnostic: every Newton pass is a full sweep + refactorisation (no rank-one passes) */
 #define JB_FLAG_LEAN        2   /* the two-waves-per-SIMD kernel variant (256 registers; state / system / factorisation parked in LDS);
                                   bit-identical results; experimental, see DESIGN.md */
+#define JB_FLAG_PAIR        4   /* always run the kernel variant with the geom-geom contact (eccentric-mass ellipsoid against the upper-leg
+                                  cylinders, reference jitterbug.xml:44-107: every jitterbug geom collides).  Without the flag the variant
+                                  is chosen by the model: on for one-model-per-env batches and for a shared table whose mass comes within
+                                  0.5 mm of a leg, off for the nominal model (whose mass clears the legs by 3 mm) */
+#define JB_FLAG_NO_PAIR     8   /* never: floor contacts only (rounds 1-2 behaviour; diagnostic) */
 
 typedef struct jb_config {
     int32_t  n_envs;        /* N >= 1 */

@@ -39,6 +39,7 @@ struct KArgs {
     int epw;       // environments per wave (= per 64-thread workgroup) of the step kernel
     int rank_one;      // 0: diagnostic, no rank-one Newton passes (jb_config.flags & JB_FLAG_NO_RANK_ONE)
     int lean;          // 1: the LEAN kernel variant (two waves per SIMD; jb_config.flags & JB_FLAG_LEAN)
+    int pair;          // 1: the PAIR kernel variant (geom-geom contact mass ellipsoid / upper-leg cylinders; see JB_FLAG_PAIR)
     int packed_rows;   // step kernel output: 0 = obs[N,D] + reward[N] + done[N]; 1 = one float row [obs(D) | reward | done] per env
     unsigned long long seed, env_offset;
     float* root; float* leg; const float* lane_model;
@@ -129,7 +130,7 @@ __device__ __forceinline__ void store_target(const KArgs& a, int env, const EnvC
 // ---------------------------------------------------------------------------------------------- step
 // EPW (envs per wave) is a template parameter so that the scratch stride is a compile-time constant and every LDS access
 // of the substep uses an immediate offset instead of integer address arithmetic.
-template <int EPW, bool LEAN>
+template <int EPW, bool LEAN, bool PAIR = false>
 __device__ __forceinline__ void step_body(KArgs a, const float* __restrict__ action, float* __restrict__ obs_out,
                                           float* __restrict__ reward_out, unsigned char* __restrict__ done_out) {
     // one wave per workgroup; quad q (4 lanes) of the wave owns env blockIdx*epw + q.  Quads beyond epw (a small batch is
@@ -186,7 +187,7 @@ __device__ __forceinline__ void step_body(KArgs a, const float* __restrict__ act
     normalise_state(s);          // mj_kinematics normalises the free-joint quaternion; phase C keeps it normalised from here on
     if (LEAN && grp == 0) state_store(scr, s);                   // LEAN: the state lives in the scratch between substeps
 #pragma unroll 1
-    for (int k = 0; k < a.substeps; k++) substep<float>(m, scr, s, ctrl, o);
+    for (int k = 0; k < a.substeps; k++) substep<float, PAIR>(m, scr, s, ctrl, o);
     if (grp != 0) return;                        // helper lanes only take part in the substeps
     if (LEAN) state_load(scr, s);
 #ifdef JB_WAVE_STATS
@@ -245,6 +246,15 @@ template <int EPW>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void jb_step_kernel_lean(KArgs a, const float* __restrict__ action, float* __restrict__ obs_out,
                                                                                                       float* __restrict__ reward_out, unsigned char* __restrict__ done_out) {
     step_body<EPW, true>(a, action, obs_out, reward_out, done_out);
+}
+
+// The PAIR variant: the same step with the one geom-geom contact randomised models need (jb_sim.hpp pair_narrow / pair_rows_build,
+// the shoulder - motor cross term in the star solve).  A separate instantiation so that the nominal model's kernel stays exactly
+// the code it was; chosen per handle (launch_step).
+template <int EPW>
+__global__ __launch_bounds__(64) void jb_step_kernel_pair(KArgs a, const float* __restrict__ action, float* __restrict__ obs_out,
+                                                          float* __restrict__ reward_out, unsigned char* __restrict__ done_out) {
+    step_body<EPW, false, true>(a, action, obs_out, reward_out, done_out);
 }
 
 // ---------------------------------------------------------------------------------------------- reset / observe
@@ -594,6 +604,8 @@ static int upload_model(jb_handle* h, const double* params, int n_tables) {
     JB_HIP(hipStreamSynchronize(h->stream));
     h->ka.lane_model = h->d_model;
     h->ka.per_env_model = n_tables > 1 ? 1 : 0;
+    // which step kernel: the PAIR variant whenever the model(s) may bring the mass against a leg (see JB_FLAG_PAIR)
+    h->ka.pair = (h->cfg.flags & JB_FLAG_NO_PAIR) ? 0 : ((h->cfg.flags & JB_FLAG_PAIR) || n_tables > 1 || !mass_sweep_clear(params, 5e-4)) ? 1 : 0;
     return JB_OK;
 }
 
@@ -806,7 +818,15 @@ static int launch_step(jb_handle* h, const float* d_action, float* d_obs_out, fl
     const size_t lds_bytes = ((size_t)(h->ka.lean ? SC_COUNT_LEAN : SC_COUNT) * 4 * h->ka.epw + (size_t)LM_TABLE * (h->ka.per_env_model ? h->ka.epw : 1)) * sizeof(float);
 #define JB_LAUNCH_STEP(E) hipLaunchKernelGGL(jb_step_kernel<E>, grid, dim3(64), lds_bytes, h->stream, h->ka, d_action, d_obs_out, d_reward_out, d_done_out)
 #define JB_LAUNCH_LEAN(E) hipLaunchKernelGGL(jb_step_kernel_lean<E>, grid, dim3(64), lds_bytes, h->stream, h->ka, d_action, d_obs_out, d_reward_out, d_done_out)
-    if (h->ka.lean) {
+#define JB_LAUNCH_PAIR(E) hipLaunchKernelGGL(jb_step_kernel_pair<E>, grid, dim3(64), lds_bytes, h->stream, h->ka, d_action, d_obs_out, d_reward_out, d_done_out)
+    if (h->ka.pair && !h->ka.lean) {
+        switch (h->ka.epw) {
+        case 1: JB_LAUNCH_PAIR(1); break;
+        case 2: JB_LAUNCH_PAIR(2); break;
+        case 4: JB_LAUNCH_PAIR(4); break;
+        default: JB_LAUNCH_PAIR(8); break;
+        }
+    } else if (h->ka.lean) {
         switch (h->ka.epw) {
         case 1: JB_LAUNCH_LEAN(1); break;
         case 2: JB_LAUNCH_LEAN(2); break;
@@ -822,6 +842,7 @@ static int launch_step(jb_handle* h, const float* d_action, float* d_obs_out, fl
     }
 #undef JB_LAUNCH_STEP
 #undef JB_LAUNCH_LEAN
+#undef JB_LAUNCH_PAIR
     JB_HIP(hipGetLastError());
     return JB_OK;
 }
@@ -1056,6 +1077,7 @@ int jb_randomise_models(jb_handle* h, const jb_randomise_cfg* cfg, const double*
     cleanup();
     h->ka.lane_model = h->d_model;
     h->ka.per_env_model = 1;
+    h->ka.pair = (h->cfg.flags & JB_FLAG_NO_PAIR) ? 0 : 1;
     return rc;
 }
 // host-only helpers (no GPU): the native compiler / validity check on ONE model - what the device kernel runs per env

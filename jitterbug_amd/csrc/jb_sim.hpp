@@ -86,7 +86,11 @@ enum LM : int {
     LM_XC_EN = LM_XB_EN + 16, LM_XC_C = LM_XC_EN + 1 /*3*/, LM_XC_AX = LM_XC_EN + 4 /*3*/, LM_XC_XA = LM_XC_EN + 7 /*3*/, LM_XC_R = LM_XC_EN + 10, LM_XC_H = LM_XC_EN + 11,
     LM_XE_EN = LM_XC_EN + 12, LM_XE_C = LM_XE_EN + 1 /*3*/, LM_XE_R = LM_XE_EN + 4 /*9*/, LM_XE_S = LM_XE_EN + 13 /*3*/,
     LM_X_ONM = LM_XE_EN + 16 /*1: the lane's cylinder+ellipsoid sit on the motor body*/,
-    LM_COUNT = LM_X_ONM + 4,
+    // the eccentric-mass ellipsoid (motor body) for EVERY lane: its contact with the lane's own upper-leg cylinder (PAIR kernels: the
+    // one geom-geom pair that touches on randomised models)
+    LM_PE_C = LM_X_ONM + 4 /*3: centre*/, LM_PE_R = LM_PE_C + 3 /*9: rotation, columns = semi-axes directions*/, LM_PE_S = LM_PE_R + 9 /*3: semi-axes*/,
+    LM_PE_NEAR = LM_PE_S + 3 /*1: largest semi-axis + cylinder radius + slack: the broad phase (distance of the ellipsoid centre from the leg's axis)*/,
+    LM_COUNT = LM_PE_NEAR + 1,
 
     // Entries [0, LM_INV) (global options, root body, motor body) are the same for the 4 lanes of an env and are stored
     // once; the rest is stored per lane.  Packed table: [LM_INV] then [LM_COUNT - LM_INV][4]  = LM_TABLE floats per env.
@@ -256,15 +260,17 @@ template <typename V> struct LaneState {
 // are kept in registers instead, see LaneConsts / StarSys.)
 enum SC : int {
     SC_DD = 0 /*24: contact-frame directions d_k (3x3), own-leg hinge data e1 a1 e2 a2 (4x3), d_k.u (3)*/,
-    SC_CAND = 24 /*28 contact candidates x 4: position (3, root coords rel. root origin) and effective distance
+    SC_CAND = 24 /*29 contact candidates x 4: position (3, root coords rel. root origin) and effective distance
                    (the real distance when the candidate is a contact, +1 otherwise).  Slots: 0 foot, 1-4 lower-leg
                    cylinder | 5-8 upper cylinder, 9 knee tip | root body: 10-13 lane cylinder, 14 lane ellipsoid,
-                   15-22 lane box vertices | motor body: 23-26 lane cylinder, 27 lane ellipsoid*/,
-    SC_ROWS = 136 /*(ROW_K + 4) x ROW_F: y-independent contact rows of the live slots of this substep (8 cached + one
+                   15-22 lane box vertices | motor body: 23-26 lane cylinder, 27 lane ellipsoid | 28: the mass ellipsoid
+                   against the lane's upper-leg cylinder (the geom-geom pair; PAIR kernels only)*/,
+    SC_ROWS = SC_CAND + 4 * 29 /*(ROW_K + 4) x ROW_F: y-independent contact rows of the live slots of this substep (8 cached + one
                     overflow entry per group, 19 floats each)*/,
-    SC_Y = 136 + 12 * 19 /*9: current Newton iterate [yr(6), yl(2), ym], shared with the helper groups*/,
+    SC_Y = SC_ROWS + 12 * 19 /*9: current Newton iterate [yr(6), yl(2), ym], shared with the helper groups*/,
     SC_ST = SC_Y + 9 /*6: w(3), thd1, thd2, phid for the helper groups*/,
-    SC_COUNT = SC_ST + 6,
+    SC_PD = SC_ST + 6 /*9: contact frame (n, t1, t2) of the pair contact, root coordinates*/,
+    SC_COUNT = SC_PD + 9,
     // LEAN kernel variant only (its scratch is longer): long-lived values that the one-wave-per-SIMD kernel keeps in registers are
     // parked here between the phases that use them
     SC_SYS = SC_COUNT /*52: joint-space system*/, SC_FAC = SC_SYS + 52 /*43: kept factorisation*/, SC_LSTATE = SC_FAC + 43 /*36: lane state*/,
@@ -303,6 +309,7 @@ template <typename V> struct NewtonAcc {
     V A[21];                 // lane-private additive part of the root block
     V B[6][2];               // additive part of the leg coupling
     V C11, C12, C22;
+    V X;                     // PAIR kernels: the own shoulder - motor cross term of the pair contact (mass against the own upper leg)
     V Bm[6], Cm;             // lane-private additive part of the motor branch
     V rr[6], rl[2], rm;      // additive rhs parts
     typename lane_traits<V>::uint bw0, bw1;   // active-set records of the leg slots: 5 bits (4 pyramid edges + valid) each, exact; bw0: slots 0-4, bw1: slots 5-9
@@ -313,12 +320,12 @@ template <typename V> JB_HD void acc_clear(NewtonAcc<V>& acc) {
     for (int i = 0; i < 21; i++) acc.A[i] = V(0);
 #pragma unroll
     for (int i = 0; i < 6; i++) { acc.B[i][0] = V(0); acc.B[i][1] = V(0); acc.Bm[i] = V(0); acc.rr[i] = V(0); }
-    acc.C11 = V(0); acc.C12 = V(0); acc.C22 = V(0); acc.Cm = V(0);
+    acc.C11 = V(0); acc.C12 = V(0); acc.C22 = V(0); acc.Cm = V(0); acc.X = V(0);
     acc.rl[0] = V(0); acc.rl[1] = V(0); acc.rm = V(0);
     acc.bw0 = zero_u<V>(); acc.bw1 = zero_u<V>(); acc.xh = zero_u<V>();
 }
 
-// the 52 additive values of the accumulator as a flat list (and back)
+// the 52 additive values of the accumulator as a flat list (and back); PAIR kernels carry X as value 52 (callers pad to 56)
 template <typename V> JB_HD void acc_pack(const NewtonAcc<V>& a, V* v) {
 #pragma unroll
     for (int i = 0; i < 21; i++) v[i] = a.A[i];
@@ -353,9 +360,14 @@ template <typename V> struct StarFactor {
     V B[6][2];
     V i11, i12, i22;
     V bm[6], icm;
+    V cx0, cx1;     // PAIR kernels: C^-1 [X, 0]^T, the leg block's answer to the shoulder - motor cross term
 };
 // WITH_ACC = false: no contact terms (the final pass): the factorisation of M + hb alone; `acc` is not read.
-template <typename V, bool WITH_ACC = true>
+// PAIR: the pair contact (eccentric mass against the own upper leg) couples the lane's shoulder with the motor, H[shoulder, motor] = X.
+// Eliminating the legs first turns that into a correction of the motor branch, and the rest of the elimination is unchanged:
+//     bm' = bm - sum_legs B C^-1 x,    cm' = cm - sum_legs x^T C^-1 x,    rm' = rm - sum_legs x^T C^-1 r_leg,    x = [X, 0]^T,
+//     y_leg = C^-1 (r_leg - B^T y_root) - (C^-1 x) y_motor.
+template <typename V, bool WITH_ACC = true, bool PAIR = false>
 JB_HD void star_factor(const StarSys<V>& M, const NewtonAcc<V>& acc, const V& hb1, const V& hb2, StarFactor<V>& F) {
 #pragma unroll
     for (int i = 0; i < 6; i++) {
@@ -385,6 +397,13 @@ JB_HD void star_factor(const StarSys<V>& M, const NewtonAcc<V>& acc, const V& hb
         for (int i = 0; i < 6; i++) F.bm[i] = F.bm[i] + quad_sum(acc.Bm[i]);
         cm = cm + quad_sum(acc.Cm);
     }
+    F.cx0 = V(0); F.cx1 = V(0);
+    if (WITH_ACC && PAIR) {
+        F.cx0 = F.i11 * acc.X; F.cx1 = F.i12 * acc.X;
+#pragma unroll
+        for (int i = 0; i < 6; i++) F.bm[i] = F.bm[i] - quad_sum(F.B[i][0] * F.cx0 + F.B[i][1] * F.cx1);
+        cm = cm - quad_sum(acc.X * F.cx0);
+    }
     F.icm = vrcp(cm);
 #pragma unroll
     for (int i = 0; i < 6; i++) {
@@ -411,10 +430,12 @@ JB_HD void star_factor(const StarSys<V>& M, const NewtonAcc<V>& acc, const V& hb
 }
 // H y = rhs with the factorisation above.  rr: lane-private parts of the root rhs (summed over the quad), tr: replicated
 // root rhs (added once), rl0/rl1: own leg rhs, rmt: total motor rhs (replicated).
-template <typename V>
-JB_HD void star_subst(const StarFactor<V>& F, const V (&rr)[6], const V (&tr)[6], const V& rl0, const V& rl1, const V& rmt, V (&yr)[6], V (&yl)[2], V& ym) {
+template <typename V, bool PAIR = false>
+JB_HD void star_subst(const StarFactor<V>& F, const V (&rr)[6], const V (&tr)[6], const V& rl0, const V& rl1, const V& rmt_in, V (&yr)[6], V (&yl)[2], V& ym) {
     const V (&S)[21] = F.S;
     V r[6];
+    V rmt = rmt_in;
+    if (PAIR) rmt = rmt_in - quad_sum(F.cx0 * rl0 + F.cx1 * rl1);
 #pragma unroll
     for (int i = 0; i < 6; i++) {
         V g0 = F.B[i][0] * F.i11 + F.B[i][1] * F.i12, g1 = F.B[i][0] * F.i12 + F.B[i][1] * F.i22;
@@ -443,9 +464,10 @@ JB_HD void star_subst(const StarFactor<V>& F, const V (&rr)[6], const V (&tr)[6]
     V t0 = rl0, t1 = rl1, tmm = rmt;
 #pragma unroll
     for (int i = 0; i < 6; i++) { t0 = t0 - F.B[i][0] * yr[i]; t1 = t1 - F.B[i][1] * yr[i]; tmm = tmm - F.bm[i] * yr[i]; }
+    ym = tmm * F.icm;
     yl[0] = F.i11 * t0 + F.i12 * t1;
     yl[1] = F.i12 * t0 + F.i22 * t1;
-    ym = tmm * F.icm;
+    if (PAIR) { yl[0] = yl[0] - F.cx0 * ym; yl[1] = yl[1] - F.cx1 * ym; }
 }
 // Solve  [A B Bm; B^T C 0; Bm^T 0 Cm] y = rhs  where the matrix is M + the contact terms in `acc` (+ hb1/hb2 on the leg
 // diagonal: implicit joint damping) and rhs = tau + acc.r*.
@@ -453,10 +475,10 @@ JB_HD void star_subst(const StarFactor<V>& F, const V (&rr)[6], const V (&tr)[6]
 //   parts that are summed over the quad;  B, C, tau_leg: lane-private leg branch.
 // The own leg (2x2) and the motor (1x1) are eliminated onto the 6 root dofs; the 6x6 Schur complement is
 // Cholesky-factored redundantly by the 4 lanes.
-template <typename V>
+template <typename V, bool PAIR = false>
 JB_HD void star_solve(const StarSys<V>& M, const NewtonAcc<V>& acc, const V& hb1, const V& hb2, StarFactor<V>& F, V (&yr)[6], V (&yl)[2], V& ym) {
-    star_factor<V>(M, acc, hb1, hb2, F);
-    star_subst<V>(F, acc.rr, M.tr, M.tl[0] + acc.rl[0], M.tl[1] + acc.rl[1], M.tm + quad_sum(acc.rm), yr, yl, ym);
+    star_factor<V, true, PAIR>(M, acc, hb1, hb2, F);
+    star_subst<V, PAIR>(F, acc.rr, M.tr, M.tl[0] + acc.rl[0], M.tl[1] + acc.rl[1], M.tm + quad_sum(acc.rm), yr, yl, ym);
 }
 
 // ----------------------------------------------------------------------------- contacts
@@ -483,13 +505,42 @@ template <typename V> JB_HD V impedance(const LaneModel<V>& m, const V& dist) {
 // Direction data in the scratch (SC_DD): the three contact-frame directions d_k, the own leg's hinge axes / anchors and d_k.u.
 //   J_sh(x,d) = (d x e1).(x - a1) = d.(e1 x (x - a1)),   J_kn(x,d) = d.(e2 x (x - a2)),   J_m(x,d) = d.(em x (x - am)):
 // one cross product per hinge and contact, then a dot product per direction.
-JB_HD constexpr int slot_level(int slot) { return slot < 5 ? 2 : slot < 10 ? 1 : slot < 23 ? 0 : 3; }
+constexpr int NSLOT = 29, SLOT_PAIR = 28;
+// 4: the pair contact - upper leg (shoulder column) against the motor body (motor column), no root columns
+JB_HD constexpr int slot_level(int slot) { return slot < 5 ? 2 : slot < 10 ? 1 : slot < 23 ? 0 : slot < 28 ? 3 : 4; }
 constexpr int ROW_F = 19;            // floats per cached contact: ang[3][3], jsh[3], j7[3], ahat[3], D
 constexpr int ROW_K = 8;             // cached live slots per substep (a leg lying on the floor has 8); further ones use the group's overflow entry and are rebuilt per pass
 static_assert(SC_Y == SC_ROWS + (ROW_K + 4) * ROW_F, "scratch layout: row cache size");
 
+// The pair contact's rows: relative motion of the upper leg (geom2's body: + shoulder column) and the motor body (geom1's: - motor
+// column) at the contact point along the pair's own frame (SC_PD); the root columns cancel and are stored as zeros.
 template <typename V>
+JB_HD void pair_rows_build(const LaneModel<V>& m, const LaneScratch<V>& sc, int entry) {
+    const V thd1 = sc.ld(SC_ST + 3), phid = sc.ld(SC_ST + 5);
+    const Vec3<V> x = sc.ld3(SC_CAND + 4 * SLOT_PAIR);
+    const V dist = sc.ld(SC_CAND + 4 * SLOT_PAIR + 3);
+    const V mu = m.c[LM_MU];
+    const auto valid = lt(dist, V(0));
+    const V imp = impedance(m, dist);
+    const V invD = (V(1) - imp) * ((m.c.tran_of(1) + m.c.tran_of(3)) * ((V(1) + m.c[LM_FR2]) * (V(2) * mu * mu)));
+    const int e0 = SC_ROWS + ROW_F * entry;
+    sc.st(e0 + 18, sel(valid, imp * vrcp(invD), V(0)));
+    const Vec3<V> p1 = cross(sc.ld3(SC_DD + 9), x - sc.ld3(SC_DD + 12));      // e1 x (x - a1)
+    const Vec3<V> pm = cross(ldv3(m, LM_EM), x - ldv3(m, LM_AM));              // em x (x - am)
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const Vec3<V> d = sc.ld3(SC_PD + 3 * k);
+        const V jsh = dot(d, p1), jm = -dot(d, pm);
+        V ah = -m.c[LM_BB] * (jsh * thd1 + jm * phid);
+        if (k == 0) ah = ah - m.c[LM_KK] * imp * dist;
+        sc.st3(e0 + 3 * k, v3<V>(V(0), V(0), V(0)));
+        sc.st(e0 + 9 + k, jsh); sc.st(e0 + 12 + k, jm); sc.st(e0 + 15 + k, ah);
+    }
+}
+
+template <typename V, bool PAIR = false>
 JB_HD void contact_rows_build(const LaneModel<V>& m, const LaneScratch<V>& sc, bool xtra, int slot, int entry) {
+    if (PAIR && slot == SLOT_PAIR) { pair_rows_build<V>(m, sc, entry); return; }
     const Vec3<V> w = sc.ld3(SC_ST);
     const V thd1 = sc.ld(SC_ST + 3), thd2 = sc.ld(SC_ST + 4), phid = sc.ld(SC_ST + 5);
     const int level = slot_level(slot);
@@ -525,12 +576,14 @@ JB_HD void contact_rows_build(const LaneModel<V>& m, const LaneScratch<V>& sc, b
 
 // One cached contact against the iterate y.  mode 0: accumulate the Newton matrix / rhs terms for the active set at y;
 // mode 2: only record the active set (the cheap convergence check).
-template <typename V>
+template <typename V, bool PAIR = false>
 JB_HD void contact_apply(const LaneScratch<V>& sc, const Vec3<V> (&dk)[3], const V& mu, int slot, int entry, bool lane_on, int mode,
                          const V (&yr)[6], const V (&yl)[2], const V& ym, NewtonAcc<V>& acc) {
     using U = typename lane_traits<V>::uint;
     const int level = slot_level(slot);
-    const bool has_sh = (level == 1 || level == 2), has_kn = (level == 2), has_m = (level == 3);
+    const bool is_pair = PAIR && level == 4;
+    const bool has_sh = (level == 1 || level == 2 || is_pair), has_kn = (level == 2), has_m = (level == 3 || is_pair);
+    const V lin = V(is_pair ? 0.0f : 1.0f);        // the pair contact has no root columns (the cached angular part is zero, the shared linear part is masked)
     const int e0 = SC_ROWS + ROW_F * entry;
     V Bj[3][8], rho[3], ahat[3];
     const V D = lane_on ? sc.ld(e0 + 18) : V(0);     // a lane without a slot in this round contributes nothing
@@ -540,6 +593,7 @@ JB_HD void contact_apply(const LaneScratch<V>& sc, const Vec3<V> (&dk)[3], const
         Vec3<V> ang = sc.ld3(e0 + 3 * k);
         Bj[k][0] = ang.x; Bj[k][1] = ang.y; Bj[k][2] = ang.z;
         Bj[k][3] = dk[k].x; Bj[k][4] = dk[k].y; Bj[k][5] = dk[k].z;
+        if (PAIR) { Bj[k][3] = Bj[k][3] * lin; Bj[k][4] = Bj[k][4] * lin; Bj[k][5] = Bj[k][5] * lin; }
         Bj[k][6] = sc.ld(e0 + 9 + k); Bj[k][7] = sc.ld(e0 + 12 + k); ahat[k] = sc.ld(e0 + 15 + k);
     }
 #pragma unroll
@@ -592,6 +646,7 @@ JB_HD void contact_apply(const LaneScratch<V>& sc, const Vec3<V> (&dk)[3], const
             acc.C22 = fma3(acc.C22, Bj[0][7], WB[0][7], Bj[1][7], WB[1][7], Bj[2][7], WB[2][7]);
             acc.rl[1] = fma3(acc.rl[1], Bj[0][7], wa0, Bj[1][7], wa1, Bj[2][7], wa2);
         }
+        if (is_pair) acc.X = fma3(acc.X, Bj[0][6], WB[0][7], Bj[1][6], WB[1][7], Bj[2][6], WB[2][7]);
         if (has_m) {
 #pragma unroll
             for (int i = 0; i < 6; i++) acc.Bm[i] = fma3(acc.Bm[i], Bj[0][7], WB[0][i], Bj[1][7], WB[1][i], Bj[2][7], WB[2][i]);
@@ -608,7 +663,7 @@ JB_HD void contact_apply(const LaneScratch<V>& sc, const Vec3<V> (&dk)[3], const
 // Only the lane whose leg carries the contact has a non-zero e; the leg slots sit on the lower leg (0-4: columns 6 root dofs,
 // shoulder, knee) or the upper leg (5-9: the cached knee column is zero).  entry / is_flip / plus / tan2 / on: flip_decode of
 // this lane's records (cached row of the contact, which edge, switched on or off).
-template <typename V>
+template <typename V, bool PAIR = false>
 JB_HD void rank_one_pass(const LaneScratch<V>& sc, const StarFactor<V>& F, const Vec3<V> (&dk)[3], const V& mu,
                          const typename lane_traits<V>::uint& entry, const typename lane_traits<V>::mask& is_flip, const typename lane_traits<V>::mask& plus,
                          const typename lane_traits<V>::mask& tan2, const typename lane_traits<V>::mask& on,
@@ -631,7 +686,7 @@ JB_HD void rank_one_pass(const LaneScratch<V>& sc, const StarFactor<V>& F, const
     V rr[6], zero6[6], zr[6], zl[2], zm;
 #pragma unroll
     for (int i = 0; i < 6; i++) { rr[i] = e[i]; zero6[i] = V(0); }
-    star_subst<V>(F, rr, zero6, e[6], e[7], V(0), zr, zl, zm);
+    star_subst<V, PAIR>(F, rr, zero6, e[6], e[7], V(0), zr, zl, zm);
     V ety = e[6] * yl[0] + e[7] * yl[1], etz = e[6] * zl[0] + e[7] * zl[1];
 #pragma unroll
     for (int i = 0; i < 6; i++) { ety = ety + e[i] * yr[i]; etz = etz + e[i] * zr[i]; }
@@ -661,14 +716,14 @@ JB_HD constexpr int slot_group(int slot, int ngroups) {
     return ngroups <= 1 ? 0 : slot < 10 ? (ngroups == 4 ? leg4[slot] : leg2[slot]) : ((slot - 10) & (ngroups - 1));
 }
 template <int G, int NG> struct GroupMask {
-    static constexpr unsigned make() { unsigned mk = 0; for (int sl = 0; sl < 28; sl++) if (slot_group(sl, NG) == G) mk |= 1u << sl; return mk; }
+    static constexpr unsigned make() { unsigned mk = 0; for (int sl = 0; sl < NSLOT; sl++) if (slot_group(sl, NG) == G) mk |= 1u << sl; return mk; }
     static constexpr unsigned value = make();
 };
 // compile-time masks, selected by the (per-lane) group index
 JB_HD unsigned group_mask(int g, int ngroups) {
     if (ngroups == 4) return g == 0 ? GroupMask<0, 4>::value : g == 1 ? GroupMask<1, 4>::value : g == 2 ? GroupMask<2, 4>::value : GroupMask<3, 4>::value;
     if (ngroups == 2) return g == 0 ? GroupMask<0, 2>::value : GroupMask<1, 2>::value;
-    return 0x0FFFFFFFu;
+    return 0x1FFFFFFFu;
 }
 
 // How the live slots of a substep are shared out: group g works through the live slots of ITS static subset, one per round.
@@ -704,7 +759,7 @@ JB_HD int plan_entry(const SlotPlan& p, int g, int slot) {
 
 // y-independent rows of the live slots, once per substep (slots beyond the cache use the group's overflow entry and are
 // rebuilt in every pass)
-template <typename V>
+template <typename V, bool PAIR = false>
 JB_HD void contact_rows_build_all(const LaneModel<V>& m, const LaneScratch<V>& sc, bool xtra, const SlotPlan& plan) {
     if (!plan.grouped && sc.grp != 0) return;
     const int g = plan.grouped ? sc.grp : 0;
@@ -713,14 +768,14 @@ JB_HD void contact_rows_build_all(const LaneModel<V>& m, const LaneScratch<V>& s
         const int slot = plan_slot(plan, g, r);
         if (slot >= 0) {
             const int entry = plan_entry(plan, g, slot);
-            if (entry < ROW_K) contact_rows_build<V>(m, sc, xtra, slot, entry);
+            if (entry < ROW_K) contact_rows_build<V, PAIR>(m, sc, xtra, slot, entry);
         }
     }
 }
 
 // every live candidate slot against the iterate y kept in the scratch (SC_Y); with helper groups the partial sums of the
 // groups are combined by cross-lane exchanges so that every group ends with the complete accumulator
-template <typename V>
+template <typename V, bool PAIR = false>
 JB_HD void contact_sweep(const LaneModel<V>& m, const LaneScratch<V>& sc, bool xtra, const SlotPlan& plan, int mode, const Vec3<V> (&dk)[3], NewtonAcc<V>& acc) {
     if (!plan.grouped && sc.grp != 0) return;
     if (mode == 2) { acc.bw0 = zero_u<V>(); acc.bw1 = zero_u<V>(); acc.xh = zero_u<V>(); }      // the check only records the active set
@@ -737,8 +792,8 @@ JB_HD void contact_sweep(const LaneModel<V>& m, const LaneScratch<V>& sc, bool x
         const bool lane_on = mine >= 0;
         const int slot = lane_on ? mine : __builtin_ctz(plan.live);       // idle lanes read some valid entry and contribute nothing
         const int entry = plan_entry(plan, g, slot);
-        if (lane_on && entry >= ROW_K) contact_rows_build<V>(m, sc, xtra, slot, entry);      // beyond the cache: rebuilt per pass
-        contact_apply<V>(sc, dk, mu, slot, entry, lane_on, mode, yr, yl, ym, acc);
+        if (lane_on && entry >= ROW_K) contact_rows_build<V, PAIR>(m, sc, xtra, slot, entry);      // beyond the cache: rebuilt per pass
+        contact_apply<V, PAIR>(sc, dk, mu, slot, entry, lane_on, mode, yr, yl, ym, acc);
     }
     if (plan.grouped) {
         acc.bw0 = group_sum_u<V>(sc, acc.bw0); acc.bw1 = group_sum_u<V>(sc, acc.bw1); acc.xh = group_sum_u<V>(sc, acc.xh);
@@ -746,17 +801,20 @@ JB_HD void contact_sweep(const LaneModel<V>& m, const LaneScratch<V>& sc, bool x
             // Only the main lanes need the totals: reduce four values at a time so that row (= group) g ends with the total
             // of value 4k+g, hand the totals over through the scratch (the overflow row entries are dead here) and let the
             // main lanes read all of them.  Same association as group_sum, a quarter of its instructions.
-            V v[52];
+            constexpr int NQ4 = PAIR ? 14 : 13;       // quadruples of values (PAIR: X rides as value 52, padded with zeros)
+            V v[4 * NQ4];
             acc_pack(acc, v);
+            if (PAIR) { v[52] = acc.X; v[53] = V(0); v[54] = V(0); v[55] = V(0); }
             constexpr int SC_RED = SC_ROWS + ROW_K * ROW_F;
-            static_assert(4 * ROW_F >= 52, "reduction buffer");
+            static_assert(4 * ROW_F >= 4 * NQ4, "reduction buffer");
 #pragma unroll
-            for (int k = 0; k < 13; k++) sc.st(SC_RED + 4 * k + sc.grp, row_transpose_sum(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]));
-            wave_sync();          // every group's 13 totals are in the scratch
+            for (int k = 0; k < NQ4; k++) sc.st(SC_RED + 4 * k + sc.grp, row_transpose_sum(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]));
+            wave_sync();          // every group's totals are in the scratch
             if (sc.grp == 0) {
 #pragma unroll
-                for (int i = 0; i < 52; i++) v[i] = sc.ld(SC_RED + i);
+                for (int i = 0; i < (PAIR ? 53 : 52); i++) v[i] = sc.ld(SC_RED + i);
                 acc_unpack(v, acc);
+                if (PAIR) acc.X = v[52];
             }
         } else if (mode == 0) {
 #pragma unroll
@@ -765,6 +823,7 @@ JB_HD void contact_sweep(const LaneModel<V>& m, const LaneScratch<V>& sc, bool x
             for (int i = 0; i < 6; i++) { acc.B[i][0] = group_sum(sc, acc.B[i][0]); acc.B[i][1] = group_sum(sc, acc.B[i][1]); acc.Bm[i] = group_sum(sc, acc.Bm[i]); acc.rr[i] = group_sum(sc, acc.rr[i]); }
             acc.C11 = group_sum(sc, acc.C11); acc.C12 = group_sum(sc, acc.C12); acc.C22 = group_sum(sc, acc.C22); acc.Cm = group_sum(sc, acc.Cm);
             acc.rl[0] = group_sum(sc, acc.rl[0]); acc.rl[1] = group_sum(sc, acc.rl[1]); acc.rm = group_sum(sc, acc.rm);
+            if (PAIR) acc.X = group_sum(sc, acc.X);
         }
     }
 }
@@ -827,6 +886,89 @@ JB_HD unsigned cand_store_cyl(const LaneScratch<V>& sc, int slot0, const CylCont
 #pragma unroll
     for (int k = 0; k < 4; k++) live |= cand_store(sc, slot0 + k, c.x[k], c.dist[k], mand(c.on[k], gate));
     return live;
+}
+
+// ----------------------------------------------------------------------------- the geom-geom pair: mass ellipsoid against the own upper-leg cylinder
+// The narrow phase both the oracle (oracle/jb_oracle.c pair_geometric, where it is also held against a restatement of MuJoCo's MPR)
+// and this kernel use: x* = the point of the cylinder's axis segment with the smallest SIGNED distance to the ellipsoid, q* its nearest
+// ellipsoid point; normal = the ellipsoid's outward normal at q* (from the mass to the leg), distance = sd - r_cyl, position = the
+// middle of the overlap.  In the ellipsoid's own axes the nearest point of y is q_i = s_i^2 y_i / (s_i^2 + lam) with lam the root of
+//     F(lam) = sum_i s_i^2 y_i^2 / (s_i^2 + lam)^2 - 1        (lam > 0 outside, < 0 inside; F convex and decreasing: Newton),
+// and then y - q = lam g with g_i = y_i / (s_i^2 + lam) (half the gradient at q): signed distance = lam |g|, normal = g / |g|.  Along the
+// axis the signed distance is convex, so its derivative f(t) = u . normal is monotone; its root lies within the largest semi-axis of
+// the ellipsoid centre's own projection on the axis - a bracket from which an Illinois iteration with fixed counts converges.
+// Everything is branch-free with fixed iteration counts: all lanes of a wave walk through it together.
+template <typename V> JB_HD void ell_lambda(const Vec3<V>& s2, const V& lam_min, const Vec3<V>& y, V& lam, int iters) {
+    const V px = s2.x * y.x * y.x, py = s2.y * y.y * y.y, pz = s2.z * y.z * y.z;
+#pragma unroll 1
+    for (int it = 0; it < iters; it++) {
+        const V ix = vrcp(s2.x + lam), iy = vrcp(s2.y + lam), iz = vrcp(s2.z + lam);
+        const V tx = px * ix * ix, ty = py * iy * iy, tz = pz * iz * iz;
+        const V F = (tx + ty + tz) - V(1), dF = V(-2) * (tx * ix + ty * iy + tz * iz);
+        const auto flat = gt(dF, V(-1e-30));                       // (only at the very centre)
+        lam = vmax(lam - F * vrcp(sel(flat, V(-1e-30), dF)), lam_min);
+    }
+}
+template <typename V>
+JB_HD void pair_narrow(const Vec3<V>& ce, const Mat3<V>& Re, const Vec3<V>& sz, const Vec3<V>& cc, const Vec3<V>& ua, const V& rad, const V& half,
+                       V& dist, Vec3<V>& n, Vec3<V>& pos) {
+    const Vec3<V> cl = mulT(Re, cc - ce), ul = mulT(Re, ua);
+    const Vec3<V> s2 = v3<V>(sz.x * sz.x, sz.y * sz.y, sz.z * sz.z);
+    const V lam_min = V(-0.95) * vmin(s2.x, vmin(s2.y, s2.z)), smax = vmax(sz.x, vmax(sz.y, sz.z));
+    V lam = V(0);
+    Vec3<V> x, g;
+    auto eval = [&](const V& t, int iters) -> V {
+        x = cl + ul * t;
+        ell_lambda<V>(s2, lam_min, x, lam, iters);
+        g = v3<V>(x.x * vrcp(s2.x + lam), x.y * vrcp(s2.y + lam), x.z * vrcp(s2.z + lam));
+        return dot(g, ul) * vrsqrt(dot(g, g));
+    };
+    const V t0 = -dot(cl, ul);
+    const V a0 = vmax(t0 - smax, -half), b0 = vmin(vmax(t0 + smax, -half), half);
+    V ta = a0, tb = vmax(b0, a0);
+    V fa = eval(ta, 10);
+    V fb = eval(tb, 8);
+    const auto at_a = mnot(lt(fa, V(0))), at_b = mnot(gt(fb, V(0)));      // the minimiser sits on an end of the bracket (an end of the leg)
+    V tc = tb;
+#pragma unroll 1
+    for (int it = 0; it < 5; it++) {
+        const V den = fb - fa;
+        const auto ok = gt(vabs(den), V(1e-20));
+        tc = sel(ok, tb - fb * (tb - ta) * vrcp(sel(ok, den, V(1))), tb);
+        tc = vmin(vmax(tc, vmin(ta, tb)), vmax(ta, tb));
+        const V fc = eval(tc, 5);
+        // Illinois: keep a bracket; when the same end survives twice, halve its function value
+        const auto opposite = lt(fc * fb, V(0));
+        ta = sel(opposite, tb, ta); fa = sel(opposite, fb, fa * V(0.5));
+        tb = tc; fb = fc;
+    }
+    // Newton on f inside the bracket the Illinois steps leave (quadratic: the normal is wanted to round-off, and it is first order in
+    // the error of t).  With x = q + lam g, g = S^-2 q on the ellipsoid:  q' = A (u - lam' g), A = diag(s^2 / (s^2 + lam)),
+    // lam' = (g.A u) / (g.A g),  g' = S^-2 q',  n' = (g' - n (n.g')) / |g|,  f' = u.n'.
+    const V lo_t = vmin(ta, tb), hi_t = vmax(ta, tb);
+    V fc = fb;
+#pragma unroll 1
+    for (int it = 0; it < 3; it++) {
+        const Vec3<V> A = v3<V>(s2.x * vrcp(s2.x + lam), s2.y * vrcp(s2.y + lam), s2.z * vrcp(s2.z + lam));
+        const Vec3<V> Au = v3<V>(A.x * ul.x, A.y * ul.y, A.z * ul.z), Ag = v3<V>(A.x * g.x, A.y * g.y, A.z * g.z);
+        const V dlam = dot(g, Au) * vrcp(dot(g, Ag));
+        const Vec3<V> dq = Au - Ag * dlam;
+        const Vec3<V> dg = v3<V>(dq.x * vrcp(s2.x), dq.y * vrcp(s2.y), dq.z * vrcp(s2.z));
+        const V gg_ = dot(g, g), ig_ = vrsqrt(gg_);
+        const V ndg = dot(g, dg) * ig_;                                   // n . g'
+        const V df = (dot(ul, dg) - (dot(g, ul) * ig_) * ndg) * ig_;      // u . n'
+        const auto okd = gt(df, V(1e-12));
+        tc = vmin(vmax(tc - fc * vrcp(sel(okd, df, V(1))) * sel(okd, V(1), V(0)), lo_t), hi_t);
+        fc = eval(tc, 5);
+    }
+    tc = sel(at_a, a0, sel(at_b, vmax(b0, a0), tc));
+    (void)eval(tc, 6);
+    const V gg = dot(g, g), ig = vrsqrt(gg);
+    const Vec3<V> nl = g * ig;
+    dist = lam * gg * ig - rad;                                   // signed distance of the axis point = lam |g|
+    const Vec3<V> pl = x - g * (V(0.5) * lam) - nl * (V(0.5) * rad);    // (q + x - r n) / 2 with q = x - lam g
+    n = mul(Re, nl);
+    pos = ce + mul(Re, pl);
 }
 
 // ----------------------------------------------------------------------------- options
@@ -946,7 +1088,7 @@ template <typename V> JB_HD void quat_normalise_comp(V (&h)[4], V (&l)[4]) {
 }
 
 // ----------------------------------------------------------------------------- the substep
-template <typename V>
+template <typename V, bool PAIR = false>
 JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneState<V>& s, const V& ctrl, const SimOpts& o, const bool xtra, const bool xbody, const Mat3<V>& Rw) {
     using MK = typename lane_traits<V>::mask;
     using U = typename lane_traits<V>::uint;
@@ -1063,6 +1205,40 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
                     }
                 }
               }
+            }
+            if (PAIR) {
+                // The geom-geom pair: the eccentric-mass ellipsoid (motor body) against the own upper-leg cylinder.  Broad phase: the
+                // ellipsoid's centre within (largest semi-axis + cylinder radius) of the leg's axis segment; the narrow phase runs for
+                // the whole wave when some lane is that close.
+                const Vec3<V> uc = a1 + mul(R1, ldc3(m, LM_UC_D)), ua = mul(R1, ldc3(m, LM_UC_AX));
+                const Vec3<V> pe = am + mul(Rm, ldc3(m, LM_PE_C) - am);
+                const Vec3<V> dce = pe - uc;
+                const V uh = ldc(m, LM_UC_H), tpr = vmin(vmax(dot(dce, ua), -uh), uh);
+                const Vec3<V> off = dce - ua * tpr;
+                const V nearr = ldc(m, LM_PE_NEAR);
+                const MK near_pair = mand(gt(nearr, V(0)), lt(dot(off, off), nearr * nearr));
+                MK pon = lt(V(1), V(0));
+                V pdist = V(1);
+                Vec3<V> pn = nb, ppos = uc;
+                if (any_lane(near_pair)) {
+                    Mat3<V> Re0;
+#pragma unroll
+                    for (int i = 0; i < 9; i++) Re0.m[i] = ldc(m, LM_PE_R + i);
+                    pair_narrow<V>(pe, mul(Rm, Re0), ldc3(m, LM_PE_S), uc, ua, ldc(m, LM_UC_R), uh, pdist, pn, ppos);
+                    pon = mand(near_pair, lt(pdist, V(0)));
+                    if (any_lane(pon)) {
+                        // contact frame: MuJoCo's mju_makeFrame on the WORLD normal (y = world y unless the normal is within 60 degrees of
+                        // it, then world z), expressed in root coordinates like everything else
+                        const Vec3<V> wy = v3<V>(R.m[3], R.m[4], R.m[5]);
+                        const V ny = dot(pn, wy);
+                        const Vec3<V> ys = sel_v3(lt(vabs(ny), V(0.5)), wy, nb);
+                        Vec3<V> t1 = ys - pn * dot(pn, ys);
+                        t1 = t1 * vrsqrt(vmax(dot(t1, t1), V(1e-30)));
+                        sc.st3(SC_PD, pn); sc.st3(SC_PD + 3, t1); sc.st3(SC_PD + 6, cross(pn, t1));
+                    }
+                }
+                live_slots |= cand_store(sc, SLOT_PAIR, ppos, pdist, pon);
+                any_con = mor(any_con, pon);
             }
             any_contact = any_lane(any_con);
             env_con = neq_u(quad_sum_u(mbit(any_con)), zero_u<V>());
@@ -1187,7 +1363,7 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
         if (any_contact) {
 #pragma unroll
             for (int k = 0; k < 3; k++) dk[k] = sc.ld3(SC_DD + 3 * k);      // contact-frame directions: once per substep, every lane
-            contact_rows_build_all<V>(m, sc, xtra, plan);
+            contact_rows_build_all<V, PAIR>(m, sc, xtra, plan);
             JB_PROF_ADD(o, 5);
             if (is_main) {      // warm start (world linear part rotated into the root frame)
                 Vec3<V> lw = mulT(Rw, v3<V>(s.wl[0], s.wl[1], s.wl[2]));
@@ -1212,7 +1388,7 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
                 if (it > 0) {
                     // cheap pass: only the active set at the new iterate.  The ENV's set changed if any lane of the quad
                     // saw a different record; when nobody's changed, every y is the exact minimiser
-                    contact_sweep<V>(m, sc, xtra, plan, 2, dk, acc);
+                    contact_sweep<V, PAIR>(m, sc, xtra, plan, 2, dk, acc);
                     JB_PROF_ADD(o, 1);
 #ifdef JB_WAVE_STATS
                     if (is_main) s.st_checks = s.st_checks + V(1);
@@ -1264,7 +1440,7 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
                             if (any_lane(fast_env)) {
                                 V fyr[6], fyl[2], fym;
                                 if (o.lean) fac_load(sc, fac);
-                                rank_one_pass<V>(sc, fac, dk, m.c[LM_MU], f_entry, f_is, f_plus, f_tan2, f_on, yr, yl, ym, fyr, fyl, fym);
+                                rank_one_pass<V, PAIR>(sc, fac, dk, m.c[LM_MU], f_entry, f_is, f_plus, f_tan2, f_on, yr, yl, ym, fyr, fyl, fym);
 #pragma unroll
                                 for (int i = 0; i < 6; i++) yr[i] = sel(fast_env, fyr[i], yr[i]);
                                 yl[0] = sel(fast_env, fyl[0], yl[0]); yl[1] = sel(fast_env, fyl[1], yl[1]); ym = sel(fast_env, fym, ym);
@@ -1280,7 +1456,7 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
                 }
                 if (!final_pass && full_pass) {
                     // (reads the iterate of the check from the scratch: rank-one results are stored only after this pass)
-                    contact_sweep<V>(m, sc, xtra, plan, 0, dk, acc);
+                    contact_sweep<V, PAIR>(m, sc, xtra, plan, 0, dk, acc);
                     prev_bw0 = acc.bw0; prev_bw1 = acc.bw1; prev_xh = acc.xh;
                     JB_PROF_ADD(o, 2);
 #ifdef JB_WAVE_STATS
@@ -1314,7 +1490,7 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
                 } else {
                     if (full_pass) {
                         if (o.lean) sys_load(sc, sys);
-                        star_solve<V>(sys, acc, V(0), V(0), fac, nyr, nyl, nym);
+                        star_solve<V, PAIR>(sys, acc, V(0), V(0), fac, nyr, nyl, nym);
                         if (o.lean) fac_store(sc, fac);
                         JB_PROF_ADD(o, 6);
                         // envs whose active set already repeated keep their (exact) solution, rank-one envs theirs
@@ -1390,7 +1566,7 @@ template <typename V> JB_HD void normalise_state(LaneState<V>& s) {
 
 // One physics substep.  A wave-uniform broadphase decides whether only the foot sphere + lower-leg cylinder can
 // touch the floor (common) or every geom of the model has to be tested (rare).
-template <typename V>
+template <typename V, bool PAIR = false>
 JB_HD void substep(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneState<V>& s, const V& ctrl, const SimOpts& o) {
     unsigned xt = 0;          // bit 0: some upper leg may touch the floor, bit 1: some root / motor-body geom may
     Mat3<V> Rw;               // root rotation (main lanes): mj_kinematics normalises the quaternion first
@@ -1424,7 +1600,7 @@ JB_HD void substep(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneState<V>
 #ifdef JB_WAVE_STATS
     if (xtra && sc.grp == 0) s.st_xtra = s.st_xtra + V(1);
 #endif
-    substep_impl<V>(m, sc, s, ctrl, o, xtra, xbody, Rw);
+    substep_impl<V, PAIR>(m, sc, s, ctrl, o, xtra, xbody, Rw);
 }
 
 }  // namespace jb

@@ -186,7 +186,9 @@ double jbo_posed_geom_distance(int ta, const double* ca, const double* Ra, const
 static int pair_tested(int bi, int bj) { return bi != bj && PARENT_[bi] != bj && PARENT_[bj] != bi; }
 
 /* minimum distance over all geom pairs MuJoCo's filters would let through; pair: the two geom indices (nullable) */
-double jbo_pair_clearance(const double* P, const double* qpos, int* pair) {
+/* skip_simulated: leave out the pairs the simulator itself collides since round 3 - the mass ellipsoid (geom 21) against the four
+ * upper-leg cylinders (geoms 4, 8, 12, 16) - so that the minimum is over the pairs it still ignores */
+static double pair_clearance_core(const double* P, const double* qpos, int* pair, int skip_simulated) {
     Geom g[JB_NGEOM];
     geoms_world(P, qpos, g);
     double best = INFINITY;
@@ -194,6 +196,7 @@ double jbo_pair_clearance(const double* P, const double* qpos, int* pair) {
     for (int i = 0; i < JB_NGEOM; i++)
         for (int j = i + 1; j < JB_NGEOM; j++) {
             if (!pair_tested((int)P[JB_P_GEOM + i * JB_GEOM_STRIDE + JB_G_BODY], (int)P[JB_P_GEOM + j * JB_GEOM_STRIDE + JB_G_BODY])) continue;
+            if (skip_simulated && j == 21 && i >= 4 && i < 20 && ((i - 4) & 3) == 0) continue;
             double dc[3] = {g[i].c[0] - g[j].c[0], g[i].c[1] - g[j].c[1], g[i].c[2] - g[j].c[2]};
             if (sqrt(dot_(dc, dc)) - g[i].rb - g[j].rb >= best) continue;              /* bounding spheres cannot beat the minimum */
             double d = gjk_distance(&g[i], &g[j]);
@@ -202,6 +205,7 @@ double jbo_pair_clearance(const double* P, const double* qpos, int* pair) {
     if (pair) { pair[0] = bi; pair[1] = bj; }
     return best;
 }
+double jbo_pair_clearance(const double* P, const double* qpos, int* pair) { return pair_clearance_core(P, qpos, pair, 0); }
 /* the same restricted to pairs with one geom on a body of mask_a and the other on a body of mask_b (bit b = body b) */
 double jbo_pair_clearance_masked(const double* P, const double* qpos, unsigned mask_a, unsigned mask_b) {
     Geom g[JB_NGEOM];
@@ -248,13 +252,16 @@ int jbo_num_tested_pairs(const double* P) {
         n += pair_tested((int)P[JB_P_GEOM + i * JB_GEOM_STRIDE + JB_G_BODY], (int)P[JB_P_GEOM + j * JB_GEOM_STRIDE + JB_G_BODY]);
     return n;
 }
-void jbo_pair_clearance_batch(const double* P, int per_env_model, int n, const double* qpos, double* out, int* pairs, int nthreads) {
+void jbo_pair_clearance_batch2(const double* P, int per_env_model, int n, const double* qpos, double* out, int* pairs, int nthreads, int skip_simulated) {
 #ifdef _OPENMP
     if (nthreads > 0) omp_set_num_threads(nthreads);
 #pragma omp parallel for schedule(static)
 #endif
     for (int i = 0; i < n; i++)
-        out[i] = jbo_pair_clearance(per_env_model ? P + (size_t)i * JB_NPARAM : P, qpos + (size_t)i * JB_NQ, pairs ? pairs + 2 * i : (int*)0);
+        out[i] = pair_clearance_core(per_env_model ? P + (size_t)i * JB_NPARAM : P, qpos + (size_t)i * JB_NQ, pairs ? pairs + 2 * i : (int*)0, skip_simulated);
+}
+void jbo_pair_clearance_batch(const double* P, int per_env_model, int n, const double* qpos, double* out, int* pairs, int nthreads) {
+    jbo_pair_clearance_batch2(P, per_env_model, n, qpos, out, pairs, nthreads, 0);
 }
 /* world pose of a geom, for the tests' independent brute-force check */
 void jbo_geom_world(const double* P, const double* qpos, int gi, double* center, double* R, double* size) {

@@ -953,7 +953,7 @@ static void substep(const double* P, double* qpos, double* qvel, double ctrl, co
 
 /* ------------------------------------------------------------------ public: physics */
 void jbo_default_opts(jbo_opts* o) {
-    o->contacts = 1; o->implicit_damp = 1; o->solver_iters = 20000; o->solver_tol = 1e-12; o->warmstart = 1; o->feet_only = 0; o->solver = 1; o->pair_contacts = 0;
+    o->contacts = 1; o->implicit_damp = 1; o->solver_iters = 20000; o->solver_tol = 1e-12; o->warmstart = 1; o->feet_only = 0; o->solver = 1; o->pair_contacts = 1;
 }
 
 /* nsub substeps with constant ctrl (reference: control.Environment.step, 50 substeps) */

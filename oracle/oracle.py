@@ -218,19 +218,22 @@ def pair_geometric(P, qpos, leg):
     return bool(ok), out[0], out[1:4].copy(), out[4:7].copy()
 
 
-def pair_clearance(P, qpos):
+def pair_clearance(P, qpos, skip_simulated=False):
     """Minimum distance over the geom pairs MuJoCo's filters would test (jb_clearance.c).  qpos [16] -> (distance, (gi, gj));
-    qpos [n,16] -> (distances [n], pairs [n,2]); P may be one table or one per row."""
+    qpos [n,16] -> (distances [n], pairs [n,2]); P may be one table or one per row.  skip_simulated: leave out the pairs the simulator
+    collides itself (mass ellipsoid against the upper-leg cylinders)."""
     P = np.ascontiguousarray(P, dtype=np.float64)
     q = np.ascontiguousarray(qpos, dtype=np.float64)
-    if q.ndim == 1:
-        pair = np.zeros(2, dtype=np.int32)
-        d = lib().jbo_pair_clearance(_p(P), _p(q), pair.ctypes.data)
-        return d, (int(pair[0]), int(pair[1]))
+    one = q.ndim == 1
+    q = np.atleast_2d(q)
     n = q.shape[0]
     out = np.zeros(n)
     pairs = np.zeros((n, 2), dtype=np.int32)
-    lib().jbo_pair_clearance_batch(_p(P), int(P.ndim == 2), n, _p(q), _p(out), pairs.ctypes.data, usable_cores())
+    L = lib()
+    L.jbo_pair_clearance_batch2.argtypes = [_dp, C.c_int, C.c_int, _dp, _dp, C.c_void_p, C.c_int, C.c_int]
+    L.jbo_pair_clearance_batch2(_p(P), int(P.ndim == 2), n, _p(q), _p(out), pairs.ctypes.data, usable_cores(), int(bool(skip_simulated)))
+    if one:
+        return float(out[0]), (int(pairs[0, 0]), int(pairs[0, 1]))
     return out, pairs
 
 

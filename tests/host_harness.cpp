@@ -15,7 +15,7 @@ using namespace jb;
 // helper groups, one host thread each, sharing the scratch and exchanging through jb_lane.hpp's HostWave (group_sum, row_transpose_sum,
 // the rank-one pass on rows other groups built, the broadcast loop decisions): the same code paths the device takes with helper lanes.
 template <typename T>
-static int run(const double* P, double* qpos, double* qvel, double ctrl, int nsub, int contacts, int max_newton, int implicit_damp, double* fail, int ngroups = 1, int rank_one = 1, int lean = 0) {
+static int run(const double* P, double* qpos, double* qvel, double ctrl, int nsub, int contacts, int max_newton, int implicit_damp, double* fail, int ngroups = 1, int rank_one = 1, int lean = 0, int pair = 0) {
     using V = Quad<T>;
     LaneModel<V> m;
     T tab[LM_TABLE];
@@ -48,7 +48,7 @@ static int run(const double* P, double* qpos, double* qvel, double ctrl, int nsu
             // poison the scratch: a substep must not read anything it has not written itself (on the device LDS keeps whatever
             // the previous kernel left there); in the LEAN variant the parked state is the one thing that carries over
             for (int k = 0; k < SC_LSTATE; k++) scratch[k] = V(std::numeric_limits<T>::quiet_NaN());
-            substep<V>(m, sc, s, V(T(ctrl)), o);
+            if (pair) substep<V, true>(m, sc, s, V(T(ctrl)), o); else substep<V>(m, sc, s, V(T(ctrl)), o);
         }
         if (lean) state_load(sc, s);
     } else {
@@ -69,7 +69,7 @@ static int run(const double* P, double* qpos, double* qvel, double ctrl, int nsu
                 wave.barrier();
                 if (g == 0) for (int k = 0; k < SC_LSTATE; k++) scratch[k] = V(std::numeric_limits<T>::quiet_NaN());
                 wave.barrier();
-                substep<V>(m, sc, st, V(T(ctrl)), o);
+                if (pair) substep<V, true>(m, sc, st, V(T(ctrl)), o); else substep<V>(m, sc, st, V(T(ctrl)), o);
             }
             if (g == 0 && lean) state_load(sc, st);
             g_host_wave = nullptr;
@@ -109,6 +109,12 @@ extern "C" int jbh_step_lean(const double* P, double* qpos, double* qvel, double
     return use_float ? run<float>(P, qpos, qvel, ctrl, nsub, contacts, max_newton, 1, fail, ngroups, rank_one, 1)
                      : run<double>(P, qpos, qvel, ctrl, nsub, contacts, max_newton, 1, fail, ngroups, rank_one, 1);
 }
+// ... and with the geom-geom pair contact (mass ellipsoid against the upper-leg cylinders): the PAIR instantiation of the substep
+extern "C" int jbh_step_pair(const double* P, double* qpos, double* qvel, double ctrl, int nsub, int contacts, int max_newton, int use_float, int ngroups, int rank_one, double* fail) {
+    if (ngroups != 1 && ngroups != 4) return -101;
+    return use_float ? run<float>(P, qpos, qvel, ctrl, nsub, contacts, max_newton, 1, fail, ngroups, rank_one, 0, 1)
+                     : run<double>(P, qpos, qvel, ctrl, nsub, contacts, max_newton, 1, fail, ngroups, rank_one, 0, 1);
+}
 extern "C" int jbh_lm_count(void) { return LM_COUNT; }
 // the per-leg constant table (LM_COUNT doubles) for inspection by tests / tools
 extern "C" int jbh_lane_table(const double* P, int leg, double* out) { return build_lane_model<double>(P, leg, out); }
@@ -138,4 +144,19 @@ extern "C" void jbh_device_guard_probe(int cur, int target, int fail_set, int ea
     };
     out[0] = entry();
     out[2] = StubDeviceApi::cur; out[3] = StubDeviceApi::n_set;
+}
+
+// ---- the pair narrow phase of jb_sim.hpp (mass ellipsoid against the upper cylinder of `leg`) on a posed model, fp64 or fp32, for the
+// comparison with the oracle's pair_geometric: inputs are the two geoms in WORLD coordinates, out = [dist, n(3), pos(3)]
+extern "C" void jbh_pair_narrow(const double* ce, const double* Re, const double* sz, const double* cc, const double* ua, double rad, double half, int use_float, double* out) {
+    auto run1 = [&](auto tag) {
+        using T = decltype(tag);
+        Vec3<T> c_e = v3<T>(T(ce[0]), T(ce[1]), T(ce[2])), s_z = v3<T>(T(sz[0]), T(sz[1]), T(sz[2])), c_c = v3<T>(T(cc[0]), T(cc[1]), T(cc[2])), u_a = v3<T>(T(ua[0]), T(ua[1]), T(ua[2]));
+        Mat3<T> R;
+        for (int i = 0; i < 9; i++) R.m[i] = T(Re[i]);
+        T dist; Vec3<T> n, pos;
+        pair_narrow<T>(c_e, R, s_z, c_c, u_a, T(rad), T(half), dist, n, pos);
+        out[0] = dist; out[1] = n.x; out[2] = n.y; out[3] = n.z; out[4] = pos.x; out[5] = pos.y; out[6] = pos.z;
+    };
+    if (use_float) run1(float(0)); else run1(double(0));
 }

@@ -20,13 +20,14 @@ def test_no_geom_pair_ever_touches(regime):
     env = JitterbugVecEnv(n, "move_to_pose", seed=8, time_limit=float("inf"), auto_reset=False)     # one 1000-step rollout, no reset at the end
     if regime == "augmented":
         # config 5: one perturbed model per env, generated on the device (leg ends move by sigma = 3 mm, the motor axis by sigma =
-        # 1.5 / 2 / 1 mm).  The reference's distribution itself produces robots whose eccentric mass cannot turn without hitting a
-        # front leg (nominal clearance 3 mm): 3.6 % of the draws intersect for some motor angle at the rest pose, ~14 % come within
-        # 1 mm.  Those are outside what a floor-only simulator represents (deviations): the generator re-draws them.
-        out = env.randomise_models(seed=11, min_mass_clearance=1e-3)
+        # 1.5 / 2 / 1 mm), EVERY draw kept.  The reference's distribution produces robots whose eccentric mass cannot turn without
+        # hitting a front leg (3.6 % of the draws; ~14 % come within 1 mm): that pair - mass ellipsoid against the upper-leg
+        # cylinders - is simulated since round 3 (PAIR kernel) and is left out of the minimum here; every OTHER pair must stay clear.
+        out = env.randomise_models(seed=11, min_mass_clearance=0.0)
         P = out["params"]
-        print("augmented: %.1f %% of the envs needed a re-draw to clear 1 mm between mass and legs" % (100 * (out["attempts"] > 1).mean()))
-        assert O.mass_sweep_clearance(P[:512], 72).min() >= 1e-3 - 1e-5
+        touching = O.mass_sweep_clearance(P[:1024], 72) <= 1e-9
+        print("augmented: %.1f %% of the drawn robots cannot turn their mass without touching a leg" % (100 * touching.mean()))
+        assert (out["attempts"] == 1).all() and 0.01 < touching.mean() < 0.08
     env.reset()
     rng = np.random.default_rng(5)
     worst, worst_pair, max_hinge = np.inf, None, 0.0
@@ -39,7 +40,7 @@ def test_no_geom_pair_ever_touches(regime):
         env.step(a)
         if t % every == every - 1 or t > steps - 20:
             q, _, _ = env.get_state()
-            d, pairs = O.pair_clearance(P, q)
+            d, pairs = O.pair_clearance(P, q, skip_simulated=(regime == "augmented"))
             i = int(d.argmin())
             if d[i] < worst:
                 worst, worst_pair = float(d[i]), (int(pairs[i, 0]), int(pairs[i, 1]), t, i)

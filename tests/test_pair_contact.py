@@ -164,3 +164,56 @@ def test_nominal_model_is_untouched_by_the_pair_contact(params):
         qa, va = O.step_physics(params, qa, va, u, 50, O.default_opts(pair_contacts=1))
         qb, vb = O.step_physics(params, qb, vb, u, 50, O.default_opts(pair_contacts=0))
     assert np.array_equal(qa, qb) and np.array_equal(va, vb)
+
+
+# ----------------------------------------------------------------------------------------------- the HIP path (PAIR kernel variant)
+@pytest.mark.gpu
+def test_gpu_touching_models_match_the_oracle(touching):
+    """One model per env, every one of them a robot whose mass hits a front leg: the PAIR kernel (chosen automatically for per-env
+    models) against the oracle, teacher-forced, 300 control steps with the motor driven both ways - the north-star tolerance on every
+    entry of every well-conditioned env-step, the mass-leg contact's own activation margin included in the conditioning."""
+    from tests.test_gpu_parity import _teacher_forced
+    P = np.stack([touching[i % len(touching)][0] for i in range(64)])
+    r = _teacher_forced("move_to_pose", 64, 300, seed=4, params=P)
+    print("touching models, uniform actions:", r)
+    assert r["well_bad"] <= 2 and r["well_big"] == 0 and r["frac"] >= 0.999 and r["ill_frac"] < 0.03, r
+    r = _teacher_forced("move_from_origin", 64, 150, seed=5, params=P, flat_out=True)
+    print("touching models, motor flat out:", r)
+    assert r["well_bad"] <= 4 and r["well_big"] == 0 and r["frac"] >= 0.998, r
+
+
+@pytest.mark.gpu
+def test_gpu_pair_contact_is_really_simulated_and_chosen_by_the_model(touching):
+    """(i) the contact acts: with it (default for these models) the motor is held back exactly as in the oracle, without it (JB_FLAG_NO_PAIR)
+    it is not; (ii) a SHARED table whose mass touches selects the PAIR kernel by itself; (iii) on the nominal model the PAIR kernel, forced
+    by JB_FLAG_PAIR, reproduces the ordinary kernel."""
+    from jitterbug_amd.vec_env import JitterbugVecEnv
+    P0, hits = touching[0]
+    n = 8
+    res = {}
+    for name, flags in (("auto", 0), ("off", 8)):
+        g = JitterbugVecEnv(n, "move_from_origin", seed=1, auto_reset=False, random_pose=False, params=P0, flags=flags)
+        g.reset()
+        for t in range(30):
+            g.step(np.full(n, 0.5, dtype=np.float32))
+        q, v, _ = g.get_state()
+        res[name] = q[0, 15]
+        g.close()
+    o = O.OracleEnv(1, "move_from_origin", P0, seed=1, random_pose=False)
+    o.reset()
+    for t in range(30):
+        o.step(np.full(1, 0.5), auto_reset=False)
+    qo, _, _ = o.get_state()
+    print("motor angle after 30 steps: GPU with the contact %.4f, oracle %.4f, GPU without %.4f" % (res["auto"], qo[0, 15], res["off"]))
+    assert abs(res["auto"] - qo[0, 15]) < 2e-3 * abs(qo[0, 15]) and abs(res["off"] - qo[0, 15]) > 0.05
+    # nominal model: the forced PAIR kernel never finds the mass near a leg
+    a = JitterbugVecEnv(64, "move_to_pose", seed=2, flags=4)
+    b = JitterbugVecEnv(64, "move_to_pose", seed=2)
+    oa, ob = a.reset(), b.reset()
+    rng = np.random.default_rng(0)
+    for t in range(40):
+        u = rng.uniform(-1, 1, size=64).astype(np.float32)
+        oa, ra, _, _ = a.step(u); ob, rb, _, _ = b.step(u)
+    print("nominal model, PAIR kernel vs ordinary kernel: max |diff| %.2e (bit-identical: %s)" % (np.abs(oa - ob).max(), np.array_equal(oa, ob)))
+    np.testing.assert_allclose(oa, ob, rtol=2e-4, atol=2e-5)
+    a.close(); b.close()

@@ -168,18 +168,21 @@ def test_device_randomiser_at_config5_size():
 
 @pytest.mark.gpu
 def test_config5_shard_8192_device_models_against_the_oracle():
-    """BASELINE configs[4]'s per-GPU shard as it really runs: 8192 envs, one DEVICE-generated model each (re-drawn until the mass can
-    turn), per-env constant tables staged in LDS by 2048 full waves, 200 control steps of the open-loop rollout.  A 64-env subset
+    """BASELINE configs[4]'s per-GPU shard as it really runs: 8192 envs, one DEVICE-generated model each (every draw kept: 3.6 % of
+    the robots touch a front leg with their eccentric mass, simulated by the PAIR kernel), per-env constant tables staged in LDS by 2048 full waves, 200 control steps of the open-loop rollout.  A 64-env subset
     spread over the batch is held against the oracle every step, from the GPU's own pre-step state (teacher-forced the other way
     round) and with the tables the device generated (return_params=True); the whole batch must stay physical."""
     from jitterbug_amd.vec_env import JitterbugVecEnv
     from oracle import oracle as O
     n, steps, task = 8192, 200, "move_to_pose"
     env = JitterbugVecEnv(n, task, seed=3, auto_reset=False)
-    out = env.randomise_models(seed=77, min_mass_clearance=1e-3, return_params=True)
+    out = env.randomise_models(seed=77, return_params=True)                  # the reference's distribution, every draw kept
     P = out["params"]
-    assert P.shape == (n, model.NPARAM) and (out["attempts"] >= 1).all() and (out["attempts"] > 1).any()
-    idx = np.linspace(0, n - 1, 64).astype(int)
+    assert P.shape == (n, model.NPARAM) and (out["attempts"] == 1).all()
+    touching = np.nonzero(O.mass_sweep_clearance(P[:2048], 72) <= 1e-9)[0]
+    assert len(touching) >= 30                                               # ~3.6 % of the robots cannot turn their mass without touching a leg
+    idx = np.unique(np.concatenate([np.linspace(0, n - 1, 40).astype(int), touching[:24]]))[:64]      # a spread of envs plus robots that touch
+    assert len(idx) == 64
     o = O.OracleEnv(64, task, P[idx], seed=3, per_env_model=True)
     o.reset()
     env.reset()
