@@ -130,9 +130,7 @@ template <typename T> JB_HD int build_lane_model(const double* P, int leg, T* ou
         put3(LM_PE_C, ge + JB_G_CENTER);
         for (int i = 0; i < 9; i++) out[LM_PE_R + i] = T(ge[JB_G_ROT + i]);
         put3(LM_PE_S, ge + JB_G_SIZE);
-        double mx = ge[JB_G_SIZE];
-        for (int i = 1; i < 3; i++) if (ge[JB_G_SIZE + i] > mx) mx = ge[JB_G_SIZE + i];
-        out[LM_PE_NEAR] = T((int)ge[JB_G_TYPE] == JB_GEOM_ELLIPSOID ? mx + gu[JB_G_SIZE] + 2e-4 : -1.0);
+        for (int i = 0; i < 3; i++) out[LM_PE_IS + i] = T((int)ge[JB_G_TYPE] == JB_GEOM_ELLIPSOID ? 1.0 / (ge[JB_G_SIZE + i] + gu[JB_G_SIZE] + 2e-4) : -1.0);
     }
     {   // broadphase boxes (LM_BX): oriented boxes around the lane's root-body geoms; motor-body geoms (lane 3) get one
         // axis-aligned cube centred on the motor axis (invariant under the motor angle).  Unused boxes have negative sizes.

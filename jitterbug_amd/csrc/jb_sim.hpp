@@ -89,8 +89,8 @@ enum LM : int {
     // the eccentric-mass ellipsoid (motor body) for EVERY lane: its contact with the lane's own upper-leg cylinder (PAIR kernels: the
     // one geom-geom pair that touches on randomised models)
     LM_PE_C = LM_X_ONM + 4 /*3: centre*/, LM_PE_R = LM_PE_C + 3 /*9: rotation, columns = semi-axes directions*/, LM_PE_S = LM_PE_R + 9 /*3: semi-axes*/,
-    LM_PE_NEAR = LM_PE_S + 3 /*1: largest semi-axis + cylinder radius + slack: the broad phase (distance of the ellipsoid centre from the leg's axis)*/,
-    LM_COUNT = LM_PE_NEAR + 1,
+    LM_PE_IS = LM_PE_S + 3 /*3: 1 / (semi-axis + cylinder radius + 0.2 mm): the broad phase tests the leg's axis against this inflated ellipsoid; <= 0: no pair*/,
+    LM_COUNT = LM_PE_IS + 3,
 
     // Entries [0, LM_INV) (global options, root body, motor body) are the same for the 4 lanes of an env and are stored
     // once; the rest is stored per lane.  Packed table: [LM_INV] then [LM_COUNT - LM_INV][4]  = LM_TABLE floats per env.
@@ -899,14 +899,17 @@ JB_HD unsigned cand_store_cyl(const LaneScratch<V>& sc, int slot0, const CylCont
 // the ellipsoid centre's own projection on the axis - a bracket from which an Illinois iteration with fixed counts converges.
 // Everything is branch-free with fixed iteration counts: all lanes of a wave walk through it together.
 template <typename V> JB_HD void ell_lambda(const Vec3<V>& s2, const V& lam_min, const Vec3<V>& y, V& lam, int iters) {
+    // Newton on 1 / N(lam) - 1 with N^2 = F + 1 (the "secular equation" form: 1 / N is nearly linear in lam, all the way to the pole at
+    // -min s^2, so the iteration neither crawls away from the pole nor overshoots far past the root as Newton on F itself does for
+    // points inside the ellipsoid):  lam <- lam + (N - 1) N^2 / sum_i p_i / (s_i^2 + lam)^3.
     const V px = s2.x * y.x * y.x, py = s2.y * y.y * y.y, pz = s2.z * y.z * y.z;
 #pragma unroll 1
     for (int it = 0; it < iters; it++) {
         const V ix = vrcp(s2.x + lam), iy = vrcp(s2.y + lam), iz = vrcp(s2.z + lam);
         const V tx = px * ix * ix, ty = py * iy * iy, tz = pz * iz * iz;
-        const V F = (tx + ty + tz) - V(1), dF = V(-2) * (tx * ix + ty * iy + tz * iz);
-        const auto flat = gt(dF, V(-1e-30));                       // (only at the very centre)
-        lam = vmax(lam - F * vrcp(sel(flat, V(-1e-30), dF)), lam_min);
+        const V N2 = vmax(tx + ty + tz, V(1e-30)), S3 = vmax(tx * ix + ty * iy + tz * iz, V(1e-30));
+        const V N = N2 * vrsqrt(N2);
+        lam = vmax(lam + (N - V(1)) * N2 * vrcp(S3), lam_min);
     }
 }
 template <typename V>
@@ -926,8 +929,8 @@ JB_HD void pair_narrow(const Vec3<V>& ce, const Mat3<V>& Re, const Vec3<V>& sz, 
     const V t0 = -dot(cl, ul);
     const V a0 = vmax(t0 - smax, -half), b0 = vmin(vmax(t0 + smax, -half), half);
     V ta = a0, tb = vmax(b0, a0);
-    V fa = eval(ta, 10);
-    V fb = eval(tb, 8);
+    V fa = eval(ta, 8);
+    V fb = eval(tb, 6);
     const auto at_a = mnot(lt(fa, V(0))), at_b = mnot(gt(fb, V(0)));      // the minimiser sits on an end of the bracket (an end of the leg)
     V tc = tb;
 #pragma unroll 1
@@ -936,7 +939,7 @@ JB_HD void pair_narrow(const Vec3<V>& ce, const Mat3<V>& Re, const Vec3<V>& sz, 
         const auto ok = gt(vabs(den), V(1e-20));
         tc = sel(ok, tb - fb * (tb - ta) * vrcp(sel(ok, den, V(1))), tb);
         tc = vmin(vmax(tc, vmin(ta, tb)), vmax(ta, tb));
-        const V fc = eval(tc, 5);
+        const V fc = eval(tc, 4);
         // Illinois: keep a bracket; when the same end survives twice, halve its function value
         const auto opposite = lt(fc * fb, V(0));
         ta = sel(opposite, tb, ta); fa = sel(opposite, fb, fa * V(0.5));
@@ -959,10 +962,10 @@ JB_HD void pair_narrow(const Vec3<V>& ce, const Mat3<V>& Re, const Vec3<V>& sz, 
         const V df = (dot(ul, dg) - (dot(g, ul) * ig_) * ndg) * ig_;      // u . n'
         const auto okd = gt(df, V(1e-12));
         tc = vmin(vmax(tc - fc * vrcp(sel(okd, df, V(1))) * sel(okd, V(1), V(0)), lo_t), hi_t);
-        fc = eval(tc, 5);
+        fc = eval(tc, 4);
     }
     tc = sel(at_a, a0, sel(at_b, vmax(b0, a0), tc));
-    (void)eval(tc, 6);
+    (void)eval(tc, 5);
     const V gg = dot(g, g), ig = vrsqrt(gg);
     const Vec3<V> nl = g * ig;
     dist = lam * gg * ig - rad;                                   // signed distance of the axis point = lam |g|
@@ -1212,19 +1215,24 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
                 // the whole wave when some lane is that close.
                 const Vec3<V> uc = a1 + mul(R1, ldc3(m, LM_UC_D)), ua = mul(R1, ldc3(m, LM_UC_AX));
                 const Vec3<V> pe = am + mul(Rm, ldc3(m, LM_PE_C) - am);
-                const Vec3<V> dce = pe - uc;
-                const V uh = ldc(m, LM_UC_H), tpr = vmin(vmax(dot(dce, ua), -uh), uh);
-                const Vec3<V> off = dce - ua * tpr;
-                const V nearr = ldc(m, LM_PE_NEAR);
-                const MK near_pair = mand(gt(nearr, V(0)), lt(dot(off, off), nearr * nearr));
+                Mat3<V> Re0;
+#pragma unroll
+                for (int i = 0; i < 9; i++) Re0.m[i] = ldc(m, LM_PE_R + i);
+                const Mat3<V> Re = mul(Rm, Re0);
+                const V uh = ldc(m, LM_UC_H);
+                // broad phase, exact for what it tests: does the axis segment enter the ellipsoid with semi-axes s + (r_cyl + 0.2 mm)?  In that
+                // ellipsoid's unit-sphere coordinates the segment is still a segment: its closest point to the origin decides.
+                const Vec3<V> isv = ldc3(m, LM_PE_IS);
+                const Vec3<V> cl = mulT(Re, uc - pe), ul = mulT(Re, ua);
+                const Vec3<V> cs = v3<V>(cl.x * isv.x, cl.y * isv.y, cl.z * isv.z), us = v3<V>(ul.x * isv.x, ul.y * isv.y, ul.z * isv.z);
+                const V tpr = vmin(vmax(-dot(cs, us) * vrcp(dot(us, us)), -uh), uh);
+                const Vec3<V> pcl = cs + us * tpr;
+                const MK near_pair = mand(gt(isv.x, V(0)), lt(dot(pcl, pcl), V(1)));
                 MK pon = lt(V(1), V(0));
                 V pdist = V(1);
                 Vec3<V> pn = nb, ppos = uc;
                 if (any_lane(near_pair)) {
-                    Mat3<V> Re0;
-#pragma unroll
-                    for (int i = 0; i < 9; i++) Re0.m[i] = ldc(m, LM_PE_R + i);
-                    pair_narrow<V>(pe, mul(Rm, Re0), ldc3(m, LM_PE_S), uc, ua, ldc(m, LM_UC_R), uh, pdist, pn, ppos);
+                    pair_narrow<V>(pe, Re, ldc3(m, LM_PE_S), uc, ua, ldc(m, LM_UC_R), uh, pdist, pn, ppos);
                     pon = mand(near_pair, lt(pdist, V(0)));
                     if (any_lane(pon)) {
                         // contact frame: MuJoCo's mju_makeFrame on the WORLD normal (y = world y unless the normal is within 60 degrees of

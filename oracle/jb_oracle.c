@@ -481,7 +481,7 @@ static double ellipsoid_nearest(const double* s, const double* y, double* q, dou
     return lam >= 0 ? sqrt(d2) : -sqrt(d2);
 }
 /* returns 1 with dist (<0: penetration), n (ellipsoid -> cylinder), pos, all in world axes */
-static int pair_geometric(const CGeom* e, const CGeom* c, double* dist, double* n, double* pos) {
+static int pair_geometric_exact(const CGeom* e, const CGeom* c, double* dist, double* n, double* pos) {
     double cl[3], ul[3], d[3], ax[3] = {c->R[2], c->R[5], c->R[8]};
     for (int i = 0; i < 3; i++) d[i] = c->c[i] - e->c[i];
     matTvec3(cl, e->R, d);
@@ -514,6 +514,75 @@ static int pair_geometric(const CGeom* e, const CGeom* c, double* dist, double* 
     double sd = ellipsoid_nearest(e->sz, x, q, nl), pl[3];
     *dist = sd - c->sz[0];
     for (int i = 0; i < 3; i++) pl[i] = 0.5 * (q[i] + x[i] - c->sz[0] * nl[i]);
+    matvec3(n, e->R, nl);
+    matvec3(pos, e->R, pl);
+    for (int i = 0; i < 3; i++) pos[i] += e->c[i];
+    return 1;
+}
+/* The same contact by the FIXED scheme the HIP kernel runs (jb_sim.hpp pair_narrow: all lanes of a wave walk through it together, so its
+ * iteration counts are constants): multiplier by Newton on the secular form 1 / N(lam) - 1, clamped at -0.95 min s^2; axis parameter
+ * from the bracket [t0 - s_max, t0 + s_max] (t0: the ellipsoid centre's projection) by 5 Illinois + 3 Newton steps.  On contacts
+ * shallower than the cylinder radius it agrees with pair_geometric_exact to round-off (tests/test_pair_contact.py); on overlaps so deep
+ * that the leg's axis runs through the mass (a robot that could not exist) both stay finite, and this is the definition. */
+static void ell_lambda_fixed(const double* s2, double lam_min, const double* y, double* lam, int iters) {
+    double p[3] = {s2[0] * y[0] * y[0], s2[1] * y[1] * y[1], s2[2] * y[2] * y[2]};
+    for (int it = 0; it < iters; it++) {
+        double N2 = 0, S3 = 0;
+        for (int i = 0; i < 3; i++) { double ia = 1.0 / (s2[i] + *lam), t = p[i] * ia * ia; N2 += t; S3 += t * ia; }
+        if (N2 < 1e-30) N2 = 1e-30;
+        if (S3 < 1e-30) S3 = 1e-30;
+        double N = sqrt(N2), nl = *lam + (N - 1.0) * N2 / S3;
+        *lam = nl > lam_min ? nl : lam_min;
+    }
+}
+typedef struct { double cl[3], ul[3], s2[3], lam_min, lam, x[3], g[3]; } PairEval;
+static double pair_eval(PairEval* w, double t, int iters) {
+    for (int i = 0; i < 3; i++) w->x[i] = w->cl[i] + t * w->ul[i];
+    ell_lambda_fixed(w->s2, w->lam_min, w->x, &w->lam, iters);
+    for (int i = 0; i < 3; i++) w->g[i] = w->x[i] / (w->s2[i] + w->lam);
+    return dot3(w->g, w->ul) / sqrt(dot3(w->g, w->g));
+}
+static int pair_geometric(const CGeom* e, const CGeom* c, double* dist, double* n, double* pos) {
+    PairEval w;
+    double d[3], ax[3] = {c->R[2], c->R[5], c->R[8]};
+    for (int i = 0; i < 3; i++) { d[i] = c->c[i] - e->c[i]; w.s2[i] = e->sz[i] * e->sz[i]; }
+    matTvec3(w.cl, e->R, d);
+    matTvec3(w.ul, e->R, ax);
+    double smin2 = fmin(w.s2[0], fmin(w.s2[1], w.s2[2])), smax = fmax(e->sz[0], fmax(e->sz[1], e->sz[2]));
+    const double half = c->sz[1], rad = c->sz[0];
+    w.lam_min = -0.95 * smin2; w.lam = 0;
+    double t0 = -dot3(w.cl, w.ul);
+    double a0 = fmax(t0 - smax, -half), b0 = fmin(fmax(t0 + smax, -half), half);
+    double ta = a0, tb = fmax(b0, a0);
+    double fa = pair_eval(&w, ta, 8), fb = pair_eval(&w, tb, 6);
+    int at_a = !(fa < 0), at_b = !(fb > 0);
+    double tc = tb;
+    for (int it = 0; it < 5; it++) {
+        double den = fb - fa;
+        int ok = fabs(den) > 1e-20;
+        tc = ok ? tb - fb * (tb - ta) / den : tb;
+        tc = fmin(fmax(tc, fmin(ta, tb)), fmax(ta, tb));
+        double fc = pair_eval(&w, tc, 4);
+        if (fc * fb < 0) { ta = tb; fa = fb; } else fa *= 0.5;
+        tb = tc; fb = fc;
+    }
+    double lo_t = fmin(ta, tb), hi_t = fmax(ta, tb), fc = fb;
+    for (int it = 0; it < 3; it++) {
+        double A[3], Au[3], Ag[3], dq[3], dg[3];
+        for (int i = 0; i < 3; i++) { A[i] = w.s2[i] / (w.s2[i] + w.lam); Au[i] = A[i] * w.ul[i]; Ag[i] = A[i] * w.g[i]; }
+        double dlam = dot3(w.g, Au) / dot3(w.g, Ag);
+        for (int i = 0; i < 3; i++) { dq[i] = Au[i] - Ag[i] * dlam; dg[i] = dq[i] / w.s2[i]; }
+        double gg = dot3(w.g, w.g), ig = 1.0 / sqrt(gg);
+        double ndg = dot3(w.g, dg) * ig, df = (dot3(w.ul, dg) - (dot3(w.g, w.ul) * ig) * ndg) * ig;
+        if (df > 1e-12) tc = tc - fc / df;
+        tc = fmin(fmax(tc, lo_t), hi_t);
+        fc = pair_eval(&w, tc, 4);
+    }
+    tc = at_a ? a0 : (at_b ? fmax(b0, a0) : tc);
+    (void)pair_eval(&w, tc, 5);
+    double gg = dot3(w.g, w.g), gl = sqrt(gg), nl[3], pl[3];
+    *dist = w.lam * gl - rad;
+    for (int i = 0; i < 3; i++) { nl[i] = w.g[i] / gl; pl[i] = w.x[i] - 0.5 * w.lam * w.g[i] - 0.5 * rad * nl[i]; }
     matvec3(n, e->R, nl);
     matvec3(pos, e->R, pl);
     for (int i = 0; i < 3; i++) pos[i] += e->c[i];
@@ -645,6 +714,10 @@ static int collide(const double* P, const Kin* k, int feet_only, int pair_contac
             double dist, dir[3], pos[3];
             pair_geometric(&e, &c, &dist, dir, pos);
             MARGIN(dist);
+            /* An overlap deeper than the cylinder radius puts the leg's AXIS inside the mass: the nearest-surface point of an interior point
+             * of this flat ellipsoid (3 mm half thickness) is ill-conditioned towards its mid-plane, and no robot could be built that
+             * way - such env-steps count as ill-conditioned for the fp32 comparison (the contact itself is simulated all the same). */
+            if (dist < -c.sz[0]) MARGIN(0.0);
             if (dist < 0) {
                 if (n < MAXCON) {
                     con[n].dist = dist; memcpy(con[n].pos, pos, 24); memcpy(con[n].n, dir, 24);
@@ -989,6 +1062,15 @@ int jbo_pair_mpr(const double* P, const double* qpos_in, int leg, double tol, in
     return hit;
 }
 /* ... and the geometric contact of the same pair (what collide() uses): out = [dist (<0: penetration), n(3), pos(3)]; 0 if undefined */
+int jbo_pair_geometric_exact(const double* P, const double* qpos_in, int leg, double* out) {
+    Kin k; double qpos[NQ];
+    memcpy(qpos, qpos_in, sizeof qpos);
+    kinematics(P, qpos, &k);
+    CGeom e, c;
+    cgeom_world(P, &k, 21, &e);
+    cgeom_world(P, &k, 4 + 4 * leg, &c);
+    return pair_geometric_exact(&e, &c, out, out + 1, out + 4);
+}
 int jbo_pair_geometric(const double* P, const double* qpos_in, int leg, double* out) {
     Kin k; double qpos[NQ];
     memcpy(qpos, qpos_in, sizeof qpos);

@@ -209,12 +209,14 @@ def pair_mpr(P, qpos, leg, tol=0.0, iters=0):
     return bool(hit), out[0], out[1:4].copy(), out[4:7].copy()
 
 
-def pair_geometric(P, qpos, leg):
-    """The geometric contact of the same pair, which collide() uses: (defined, dist (<0: penetration), normal[3], pos[3])."""
+def pair_geometric(P, qpos, leg, exact=False):
+    """The geometric contact of the same pair, which collide() uses: (defined, dist (<0: penetration), normal[3], pos[3]).
+    exact=True: the same contact by bracketed iterations run to convergence instead of the kernel's fixed scheme."""
     out = np.zeros(7)
     L = lib()
-    L.jbo_pair_geometric.argtypes = [_dp, _dp, C.c_int, _dp]
-    ok = L.jbo_pair_geometric(_p(np.ascontiguousarray(P, dtype=np.float64)), _p(np.ascontiguousarray(qpos, dtype=np.float64)), int(leg), _p(out))
+    fn = L.jbo_pair_geometric_exact if exact else L.jbo_pair_geometric
+    fn.argtypes = [_dp, _dp, C.c_int, _dp]
+    ok = fn(_p(np.ascontiguousarray(P, dtype=np.float64)), _p(np.ascontiguousarray(qpos, dtype=np.float64)), int(leg), _p(out))
     return bool(ok), out[0], out[1:4].copy(), out[4:7].copy()
 
 

@@ -32,6 +32,7 @@ def test_no_geom_pair_ever_touches(regime):
     rng = np.random.default_rng(5)
     worst, worst_pair, max_hinge = np.inf, None, 0.0
     tipped = 0.0
+    touched = np.zeros(n, bool)
     for t in range(steps):
         if regime in ("uniform", "augmented"):
             a = rng.uniform(-1, 1, size=n).astype(np.float32)
@@ -41,14 +42,23 @@ def test_no_geom_pair_ever_touches(regime):
         if t % every == every - 1 or t > steps - 20:
             q, _, _ = env.get_state()
             d, pairs = O.pair_clearance(P, q, skip_simulated=(regime == "augmented"))
+            touched |= d <= 0.0
             i = int(d.argmin())
             if d[i] < worst:
                 worst, worst_pair = float(d[i]), (int(pairs[i, 0]), int(pairs[i, 1]), t, i)
             max_hinge = max(max_hinge, float(np.abs(q[:, 7:15]).max()))
             tipped = float(((1 - 2 * (q[:, 4] ** 2 + q[:, 5] ** 2)) < 0.5).mean())
     env.close()
+    n_touch = int(touched.sum())
+    if regime == "augmented":
+        print("augmented: envs in which a pair the simulator does NOT collide touched at some sample: %d of %d" % (n_touch, n))
     print("%s: min pair clearance %.3f mm (geoms %s), max |leg hinge| %.3f rad, tipped over at the end %.1f %%"
           % (regime, worst * 1e3, worst_pair, max_hinge, 100 * tipped))
-    assert worst > 0.0, (worst, worst_pair)
+    if regime == "augmented":
+        # the pairs still left out: on 3000 host draws ONE robot (0.03 %) had its motor-axis thread inside a front upper leg at rest, 0.17 %
+        # had some such pair within 0.3 mm (tools measurement recorded in DESIGN.md 6); over this rollout a handful of envs at most
+        assert n_touch <= 0.002 * n, (n_touch, worst_pair)
+    else:
+        assert worst > 0.0, (worst, worst_pair)
     if regime.startswith("flat_out"):
         assert tipped > 0.1                              # the regime really has robots lying on their legs

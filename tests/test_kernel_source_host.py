@@ -223,3 +223,42 @@ def test_lean_variant_is_bit_identical_on_the_host(params):
                 for f32 in (0, 1):
                     a, b = run(lib.jbh_step_groups, q0[i], v0[i], groups, f32), run(lib.jbh_step_lean, q0[i], v0[i], groups, f32)
                     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), (tipped, i, groups, f32)
+
+
+def test_pair_contact_kernel_source_fp64_equals_oracle():
+    """The PAIR instantiation of the substep (closed-form narrow phase of the mass ellipsoid against the upper-leg cylinders, the pair's own
+    contact frame, rows without root columns, the shoulder - motor cross term folded into the motor branch of the star solve, the 53rd
+    value of the group reduction) on robots whose mass really hits a front leg: fp64 = the oracle's dense formulation to round-off, with
+    one lane group and with four; the fp32 build is within single-precision rounding of it."""
+    import tests.build_harness as bh
+    from jitterbug_amd import augmented_jitterbug as aj
+    lib = C.CDLL(bh.build())
+    dp = C.POINTER(C.c_double)
+    lib.jbh_step_pair.argtypes = [dp, dp, dp, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, dp]
+
+    def step(P, q, v, u, f32=0, groups=1):
+        P = np.ascontiguousarray(P); q = q.copy(); v = v.copy(); fail = np.zeros(1)
+        assert lib.jbh_step_pair(P.ctypes.data_as(dp), q.ctypes.data_as(dp), v.ctypes.data_as(dp), float(u), 50, 1, 20, f32, groups, 1, fail.ctypes.data_as(dp)) == 0
+        assert fail[0] == 0
+        return q, v
+
+    Ps = aj.augmented_params(600, seed=123)
+    bad = np.nonzero(O.mass_sweep_clearance(Ps, 72) <= 1e-9)[0]
+    o = O.default_opts(pair_contacts=1)
+    worst, n_pair, e32 = 0.0, 0, []
+    for i in bad[:5]:
+        P = Ps[i]
+        q, v = model.qpos0(P), np.zeros(model.NV)
+        rng = np.random.default_rng(int(i))
+        for t in range(24):
+            u = rng.uniform(-1, 1)
+            n_pair += int((O.forward_debug(P, q, v, u, o)["con_geom"] >= 22).any())
+            q1, v1 = O.step_physics(P, q, v, u, 50, o)
+            for g in (1, 4):
+                qh, vh = step(P, q, v, u, groups=g)
+                worst = max(worst, np.abs(qh - q1).max(), (np.abs(vh - v1) / (1 + np.abs(v1))).max())
+            qf, vf = step(P, q, v, u, f32=1, groups=4)
+            e32.append(max(np.abs(qf[:7] - q1[:7]).max(), (np.abs(vf[:6] - v1[:6]) / np.array([1, 1, 1, 35, 35, 35])).max(), abs(vf[14] - v1[14]) / 180))
+            q, v = q1, v1
+    print("control steps that start with the mass on a leg: %d; fp64 vs oracle %.2e; fp32 median %.1e max %.1e" % (n_pair, worst, np.median(e32), max(e32)))
+    assert n_pair >= 20 and worst < 2e-9 and np.median(e32) < 1e-6 and max(e32) < 1e-5

