@@ -49,6 +49,10 @@
 #define JB_PROF_ADD(o, i) ((void)0)
 #endif
 
+#ifndef JB_ROW_K
+#define JB_ROW_K 10         // cached contact rows per substep (SC_ROWS); a build parameter for A/B measurements
+#endif
+
 namespace jb {
 
 // ----------------------------------------------------------------------------- lane model table
@@ -267,7 +271,7 @@ enum SC : int {
                    against the lane's upper-leg cylinder (the geom-geom pair; PAIR kernels only)*/,
     SC_ROWS = SC_CAND + 4 * 29 /*(ROW_K + 4) x ROW_F: y-independent contact rows of the live slots of this substep (8 cached + one
                     overflow entry per group, 19 floats each)*/,
-    SC_Y = SC_ROWS + 12 * 19 /*9: current Newton iterate [yr(6), yl(2), ym], shared with the helper groups*/,
+    SC_Y = SC_ROWS + (JB_ROW_K + 4) * 19 /*9: current Newton iterate [yr(6), yl(2), ym], shared with the helper groups*/,
     SC_ST = SC_Y + 9 /*6: w(3), thd1, thd2, phid for the helper groups*/,
     SC_PD = SC_ST + 6 /*9: contact frame (n, t1, t2) of the pair contact, root coordinates*/,
     SC_COUNT = SC_PD + 9,
@@ -509,7 +513,7 @@ constexpr int NSLOT = 29, SLOT_PAIR = 28;
 // 4: the pair contact - upper leg (shoulder column) against the motor body (motor column), no root columns
 JB_HD constexpr int slot_level(int slot) { return slot < 5 ? 2 : slot < 10 ? 1 : slot < 23 ? 0 : slot < 28 ? 3 : 4; }
 constexpr int ROW_F = 19;            // floats per cached contact: ang[3][3], jsh[3], j7[3], ahat[3], D
-constexpr int ROW_K = 8;             // cached live slots per substep (a leg lying on the floor has 8); further ones use the group's overflow entry and are rebuilt per pass
+constexpr int ROW_K = JB_ROW_K;      // cached live slots per substep (a leg lying on the floor has 8-9; 10 measured +1.4 % / +3.4 % (uniform / flat-out actions) over 8); further ones use the group's overflow entry and are rebuilt per pass
 static_assert(SC_Y == SC_ROWS + (ROW_K + 4) * ROW_F, "scratch layout: row cache size");
 
 // The pair contact's rows: relative motion of the upper leg (geom2's body: + shoulder column) and the motor body (geom1's: - motor
