@@ -44,20 +44,21 @@ struct KArgs {
     unsigned long long seed, env_offset;
     float* root; float* leg; const float* lane_model;
     int* step_count; unsigned* episode;
+    float* ovc_buf;    // LEAN variant: per wave, the candidates of the live slots beyond the row cache (global memory: the variant's 20 KB of LDS have no room)
     unsigned long long* wave_stats;   // diagnostic builds (-DJB_WAVE_STATS): [n_waves][4] = cycles, rare-path substeps, Newton sweeps, contact substeps
 };
 
 // Stage the packed constant table(s) of this workgroup (one wave = a.epw envs) into LDS: one LM_TABLE copy for a
 // shared model, epw copies for per-env models.  Called by all 64 threads before the idle quads retire.
-__device__ __forceinline__ void stage_model(const KArgs& a, float* lds, int lblock, int quad, int leg, LaneModel<float>& m, bool lean = false) {
+__device__ __forceinline__ void stage_model(const KArgs& a, float* lds, int lblock, int quad, int leg, LaneModel<float>& m, bool lean = false, bool pair = true) {
     m.c.lean = lean;
-    const int tsz = LM_TABLE;
+    const int tsz = pair ? LM_TABLE : LM_TABLE_BASE, gsz = LM_TABLE;      // staged prefix / table pitch in global memory
     if (a.per_env_model) {
         const int env0 = lblock * a.epw;
         for (int i = threadIdx.x; i < tsz * a.epw; i += blockDim.x) {
             int e = env0 + i / tsz;
             if (e >= a.n) e = a.n - 1;
-            lds[i] = a.lane_model[(size_t)e * tsz + (i % tsz)];
+            lds[i] = a.lane_model[(size_t)e * gsz + (i % tsz)];
         }
         __syncthreads();
         m.c.inv = lds + quad * tsz;
@@ -153,7 +154,8 @@ __device__ __forceinline__ void step_body(KArgs a, const float* __restrict__ act
     const int env = lblock * EPW + quad;
     LaneModel<float> m;
     constexpr int SCN = LEAN ? SC_COUNT_LEAN : SC_COUNT;      // floats of per-lane scratch
-    stage_model(a, lds + SCN * 4 * EPW, lblock, quad, leg, m, LEAN);
+    static_assert(!(LEAN && PAIR), "the LEAN layout has no room for the pair contact");
+    stage_model(a, lds + SCN * 4 * EPW, lblock, quad, leg, m, LEAN, PAIR || !LEAN);
     if (grp >= NGRP || env >= a.n) return;       // whole quads (and their mirrors in every group) retire together
     const bool live = true;
     const int lane = env * 4 + leg;
@@ -161,6 +163,9 @@ __device__ __forceinline__ void step_body(KArgs a, const float* __restrict__ act
     scr.p = lds + lane_in_grp;
     scr.stride = MAIN;
     scr.grp = grp; scr.ngrp = NGRP; scr.gstride = MAIN;
+    if (LEAN) { scr.ovc = a.ovc_buf + (size_t)lblock * (4 * (NSLOT - ROW_K) * MAIN) + lane_in_grp; scr.red_lds = false; }
+    else { scr.ovc = lds + SC_OVC * MAIN + lane_in_grp; scr.red_lds = true; }
+    scr.ovc_stride = MAIN;
 #ifdef JB_WAVE_STATS
     const unsigned long long t_start = __builtin_amdgcn_s_memtime();
 #endif
@@ -471,7 +476,7 @@ struct jb_handle {
     int D;
     hipStream_t stream;
     bool own_stream;
-    float *d_root, *d_leg, *d_model;
+    float *d_root, *d_leg, *d_model, *d_ovc;
     int* d_step; unsigned* d_episode;
     // staging for the host-buffer entry points
     float *d_action, *d_obs, *d_reward; unsigned char *d_done, *d_mask;
@@ -673,7 +678,7 @@ static int create_impl(jb_handle* h) {      // every failure returns through jb_
         if (epw < 1) epw = 1;
         if (epw > 8) epw = 8;                // (a 16-env wave would need 97 KB of LDS - one wave per CU - and spilled registers: not instantiated)
         while (epw & (epw - 1)) epw++;       // 1, 2, 4 or 8 (the kernel is instantiated for these)
-        if (k.lean) { if (cfg->envs_per_wave <= 0) epw = 2; if (epw > 4) epw = 4; }     // LEAN: 2 envs per wave keep 8 waves per CU within 160 KB of LDS
+        if (k.lean) { if (cfg->envs_per_wave <= 0) epw = 4; if (epw > 4) epw = 4; }     // LEAN: 4 envs per wave, 20 KB of LDS each: 8 waves per CU, two per SIMD
         k.epw = epw;
     }
     k.root = h->d_root; k.leg = h->d_leg; k.step_count = h->d_step; k.episode = h->d_episode; k.wave_stats = h->d_wave_stats;
@@ -720,7 +725,7 @@ int jb_destroy(jb_handle* h) {
     guard.enter(h->cfg.device_id);
     if (h->stream || !h->own_stream) hipStreamSynchronize(h->stream);
     if (h->comm && g_rccl.CommDestroy) { g_rccl.CommDestroy(h->comm); h->comm = nullptr; }
-    void* bufs[] = {h->d_terms, h->d_spec, h->d_root, h->d_leg, h->d_model, h->d_step, h->d_episode, h->d_action, h->d_obs, h->d_reward, h->d_done, h->d_mask, h->d_qpos, h->d_qvel, h->d_target, h->d_wave_stats, h->d_enc_params, h->d_code};
+    void* bufs[] = {h->d_ovc, h->d_terms, h->d_spec, h->d_root, h->d_leg, h->d_model, h->d_step, h->d_episode, h->d_action, h->d_obs, h->d_reward, h->d_done, h->d_mask, h->d_qpos, h->d_qvel, h->d_target, h->d_wave_stats, h->d_enc_params, h->d_code};
     for (void* b : bufs) if (b) hipFree(b);
     if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
     delete h;
@@ -815,7 +820,13 @@ static int launch_step(jb_handle* h, const float* d_action, float* d_obs_out, fl
     RoctxRange range("jb_step");
     h->ka.packed_rows = packed_rows;
     const dim3 grid((unsigned)((h->cfg.n_envs + h->ka.epw - 1) / h->ka.epw));
-    const size_t lds_bytes = ((size_t)(h->ka.lean ? SC_COUNT_LEAN : SC_COUNT) * 4 * h->ka.epw + (size_t)LM_TABLE * (h->ka.per_env_model ? h->ka.epw : 1)) * sizeof(float);
+    const bool use_lean = h->ka.lean && !h->ka.pair;
+    const size_t lds_bytes = ((size_t)(use_lean ? SC_COUNT_LEAN : SC_COUNT) * 4 * h->ka.epw + (size_t)(use_lean ? LM_TABLE_BASE : LM_TABLE) * (h->ka.per_env_model ? h->ka.epw : 1)) * sizeof(float);
+    if (use_lean && !h->d_ovc) {      // the LEAN variant's overflow candidates (beyond the row cache): one block per wave
+        const size_t waves = (size_t)grid.x, fl = waves * 4 * (NSLOT - ROW_K) * 4 * h->ka.epw;
+        JB_HIP(hipMalloc(&h->d_ovc, fl * sizeof(float)));
+        h->ka.ovc_buf = h->d_ovc;
+    }
 #define JB_LAUNCH_STEP(E) hipLaunchKernelGGL(jb_step_kernel<E>, grid, dim3(64), lds_bytes, h->stream, h->ka, d_action, d_obs_out, d_reward_out, d_done_out)
 #define JB_LAUNCH_LEAN(E) hipLaunchKernelGGL(jb_step_kernel_lean<E>, grid, dim3(64), lds_bytes, h->stream, h->ka, d_action, d_obs_out, d_reward_out, d_done_out)
 #define JB_LAUNCH_PAIR(E) hipLaunchKernelGGL(jb_step_kernel_pair<E>, grid, dim3(64), lds_bytes, h->stream, h->ka, d_action, d_obs_out, d_reward_out, d_done_out)
@@ -826,7 +837,7 @@ static int launch_step(jb_handle* h, const float* d_action, float* d_obs_out, fl
         case 4: JB_LAUNCH_PAIR(4); break;
         default: JB_LAUNCH_PAIR(8); break;
         }
-    } else if (h->ka.lean) {
+    } else if (use_lean) {
         switch (h->ka.epw) {
         case 1: JB_LAUNCH_LEAN(1); break;
         case 2: JB_LAUNCH_LEAN(2); break;

@@ -50,7 +50,7 @@
 #endif
 
 #ifndef JB_ROW_K
-#define JB_ROW_K 10         // cached contact rows per substep (SC_ROWS); a build parameter for A/B measurements
+#define JB_ROW_K 9          // cached contact rows per substep (SC_ROWS); a build parameter for A/B measurements and for the tests of the beyond-the-cache path
 #endif
 
 namespace jb {
@@ -99,7 +99,8 @@ enum LM : int {
     // Entries [0, LM_INV) (global options, root body, motor body) are the same for the 4 lanes of an env and are stored
     // once; the rest is stored per lane.  Packed table: [LM_INV] then [LM_COUNT - LM_INV][4]  = LM_TABLE floats per env.
     LM_INV = 49,
-    LM_TABLE = LM_INV + 4 * (LM_COUNT - LM_INV)
+    LM_TABLE = LM_INV + 4 * (LM_COUNT - LM_INV),
+    LM_TABLE_BASE = LM_INV + 4 * (LM_PE_C - LM_INV)       // the table without the pair contact's entries (its tail): what the kernels without that contact stage into LDS
 };
 JB_HD constexpr int lm_offset(int i, int leg) { return i < LM_INV ? i : LM_INV + 4 * (i - LM_INV) + leg; }
 
@@ -262,22 +263,31 @@ template <typename V> struct LaneState {
 // this is LDS with element i of lane L at lds[i*stride + L] (conflict free); on the host a plain array.  Helper lanes use
 // the addresses of the main lane they mirror.  (Lane-private long-lived values - model constants, the joint-space system -
 // are kept in registers instead, see LaneConsts / StarSys.)
+constexpr int NSLOT = 29, SLOT_PAIR = 28;
+constexpr int ROW_F = 13;            // floats per cached contact: x(3), w (the candidate's effective distance until the row is built, then the weight D), jsh(3), j7(3), ahat(3)
+constexpr int ROW_K = JB_ROW_K;      // cached live slots per substep: a leg lying on the floor has 8-9 live (10 measured +1.4 % / +3.4 % over 8 for uniform / flat-out actions; 9 is what lets eight
+                                     // LEAN waves share a CU's 160 KB of LDS); the contacts
+                                     // beyond them keep only their candidate (sc.ovc) and their rows are recomputed in registers in every pass
 enum SC : int {
     SC_DD = 0 /*24: contact-frame directions d_k (3x3), own-leg hinge data e1 a1 e2 a2 (4x3), d_k.u (3)*/,
-    SC_CAND = 24 /*29 contact candidates x 4: position (3, root coords rel. root origin) and effective distance
-                   (the real distance when the candidate is a contact, +1 otherwise).  Slots: 0 foot, 1-4 lower-leg
-                   cylinder | 5-8 upper cylinder, 9 knee tip | root body: 10-13 lane cylinder, 14 lane ellipsoid,
-                   15-22 lane box vertices | motor body: 23-26 lane cylinder, 27 lane ellipsoid | 28: the mass ellipsoid
-                   against the lane's upper-leg cylinder (the geom-geom pair; PAIR kernels only)*/,
-    SC_ROWS = SC_CAND + 4 * 29 /*(ROW_K + 4) x ROW_F: y-independent contact rows of the live slots of this substep (8 cached + one
-                    overflow entry per group, 19 floats each)*/,
-    SC_Y = SC_ROWS + (JB_ROW_K + 4) * 19 /*9: current Newton iterate [yr(6), yl(2), ym], shared with the helper groups*/,
+    SC_Y = 24 /*9: current Newton iterate [yr(6), yl(2), ym], shared with the helper groups*/,
     SC_ST = SC_Y + 9 /*6: w(3), thd1, thd2, phid for the helper groups*/,
-    SC_PD = SC_ST + 6 /*9: contact frame (n, t1, t2) of the pair contact, root coordinates*/,
+    SC_ROWS = SC_ST + 6 /*ROW_K x ROW_F: one entry per LIVE candidate slot of this substep, in slot order (entry = rank of the slot among the
+                   live ones).  Phase A writes position (3, root coords rel. root origin) and effective distance (the real distance when the
+                   candidate is a contact, +1 otherwise) of a live slot straight into its entry; the row build adds the y-independent
+                   rest.  Slots: 0 foot, 1-4 lower-leg cylinder | 5-8 upper cylinder, 9 knee tip | root body: 10-13 lane cylinder, 14 lane
+                   ellipsoid, 15-22 lane box vertices | motor body: 23-26 lane cylinder, 27 lane ellipsoid | 28: the mass ellipsoid against
+                   the lane's upper-leg cylinder (the geom-geom pair; PAIR kernels only)*/,
+    SC_VAR = SC_ROWS + ROW_K * ROW_F /*from here on the layout depends on the kernel variant*/,
+    // ---- one wave per SIMD (the ordinary and the PAIR kernels)
+    SC_RED = SC_VAR /*56: hand-over of the group reduction's totals to the main lanes*/,
+    SC_OVC = SC_RED + 56 /*(NSLOT - ROW_K) x 4: candidates of the live slots beyond the row cache (sc.ovc points here)*/,
+    SC_PD = SC_OVC + 4 * (NSLOT - ROW_K) /*9: contact frame (n, t1, t2) of the pair contact, root coordinates*/,
     SC_COUNT = SC_PD + 9,
-    // LEAN kernel variant only (its scratch is longer): long-lived values that the one-wave-per-SIMD kernel keeps in registers are
-    // parked here between the phases that use them
-    SC_SYS = SC_COUNT /*52: joint-space system*/, SC_FAC = SC_SYS + 52 /*43: kept factorisation*/, SC_LSTATE = SC_FAC + 43 /*36: lane state*/,
+    // ---- LEAN kernel variant (two waves per SIMD: 20 KB of LDS per wave): long-lived values that the one-wave-per-SIMD kernel keeps in
+    // registers are parked here between the phases that use them; no reduction hand-over (the totals are combined in registers), the
+    // candidates beyond the row cache live in global memory (sc.ovc)
+    SC_SYS = SC_VAR /*41: joint-space system (the root block without its structural zeros)*/, SC_FAC = SC_SYS + 41 /*43: kept factorisation*/, SC_LSTATE = SC_FAC + 43 /*36: lane state*/,
     SC_COUNT_LEAN = SC_LSTATE + 36
 };
 template <typename V> struct LaneScratch {
@@ -286,6 +296,9 @@ template <typename V> struct LaneScratch {
     // Helper groups: when a wave holds fewer than 16 envs its spare lanes form ngrp-1 helper groups that mirror the main
     // lanes (same env, same leg, same scratch addresses) and take a share of the live contact slots in every pass.
     int grp, ngrp, gstride;   // group of this lane (0 = main), number of groups (1, 2 or 4), lane distance between groups
+    V* ovc;                   // candidates of the live slots beyond the row cache: [i * ovc_stride], LDS (SC_OVC) or, in the LEAN variant, global memory
+    int ovc_stride;
+    bool red_lds;             // the group reduction hands its totals over through SC_RED (false: combined in registers, the LEAN variant has no room for the buffer)
     JB_HD V ld(int i) const { return p[i * stride]; }
     JB_HD void st(int i, const V& v) const { p[i * stride] = v; }
     JB_HD V ldv(const typename lane_traits<V>::uint& i) const { return ld_gather(p, stride, i); }      // per-lane index
@@ -509,56 +522,50 @@ template <typename V> JB_HD V impedance(const LaneModel<V>& m, const V& dist) {
 // Direction data in the scratch (SC_DD): the three contact-frame directions d_k, the own leg's hinge axes / anchors and d_k.u.
 //   J_sh(x,d) = (d x e1).(x - a1) = d.(e1 x (x - a1)),   J_kn(x,d) = d.(e2 x (x - a2)),   J_m(x,d) = d.(em x (x - am)):
 // one cross product per hinge and contact, then a dot product per direction.
-constexpr int NSLOT = 29, SLOT_PAIR = 28;
 // 4: the pair contact - upper leg (shoulder column) against the motor body (motor column), no root columns
 JB_HD constexpr int slot_level(int slot) { return slot < 5 ? 2 : slot < 10 ? 1 : slot < 23 ? 0 : slot < 28 ? 3 : 4; }
-constexpr int ROW_F = 19;            // floats per cached contact: ang[3][3], jsh[3], j7[3], ahat[3], D
-constexpr int ROW_K = JB_ROW_K;      // cached live slots per substep (a leg lying on the floor has 8-9; 10 measured +1.4 % / +3.4 % (uniform / flat-out actions) over 8); further ones use the group's overflow entry and are rebuilt per pass
-static_assert(SC_Y == SC_ROWS + (ROW_K + 4) * ROW_F, "scratch layout: row cache size");
+
+// the y-independent part of one contact: position, weight, the joint columns and reference accelerations of its three directions
+template <typename V> struct RowVals { Vec3<V> x; V D; V jsh[3], j7[3], ah[3]; };
 
 // The pair contact's rows: relative motion of the upper leg (geom2's body: + shoulder column) and the motor body (geom1's: - motor
-// column) at the contact point along the pair's own frame (SC_PD); the root columns cancel and are stored as zeros.
+// column) at the contact point along the pair's own frame (SC_PD); the root columns cancel (contact_apply masks them).
 template <typename V>
-JB_HD void pair_rows_build(const LaneModel<V>& m, const LaneScratch<V>& sc, int entry) {
+JB_HD void pair_row_values(const LaneModel<V>& m, const LaneScratch<V>& sc, const Vec3<V>& x, const V& dist, RowVals<V>& r) {
     const V thd1 = sc.ld(SC_ST + 3), phid = sc.ld(SC_ST + 5);
-    const Vec3<V> x = sc.ld3(SC_CAND + 4 * SLOT_PAIR);
-    const V dist = sc.ld(SC_CAND + 4 * SLOT_PAIR + 3);
     const V mu = m.c[LM_MU];
     const auto valid = lt(dist, V(0));
     const V imp = impedance(m, dist);
     const V invD = (V(1) - imp) * ((m.c.tran_of(1) + m.c.tran_of(3)) * ((V(1) + m.c[LM_FR2]) * (V(2) * mu * mu)));
-    const int e0 = SC_ROWS + ROW_F * entry;
-    sc.st(e0 + 18, sel(valid, imp * vrcp(invD), V(0)));
+    r.x = x;
+    r.D = sel(valid, imp * vrcp(invD), V(0));
     const Vec3<V> p1 = cross(sc.ld3(SC_DD + 9), x - sc.ld3(SC_DD + 12));      // e1 x (x - a1)
     const Vec3<V> pm = cross(ldv3(m, LM_EM), x - ldv3(m, LM_AM));              // em x (x - am)
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         const Vec3<V> d = sc.ld3(SC_PD + 3 * k);
-        const V jsh = dot(d, p1), jm = -dot(d, pm);
-        V ah = -m.c[LM_BB] * (jsh * thd1 + jm * phid);
-        if (k == 0) ah = ah - m.c[LM_KK] * imp * dist;
-        sc.st3(e0 + 3 * k, v3<V>(V(0), V(0), V(0)));
-        sc.st(e0 + 9 + k, jsh); sc.st(e0 + 12 + k, jm); sc.st(e0 + 15 + k, ah);
+        r.jsh[k] = dot(d, p1); r.j7[k] = -dot(d, pm);
+        r.ah[k] = -m.c[LM_BB] * (r.jsh[k] * thd1 + r.j7[k] * phid);
+        if (k == 0) r.ah[k] = r.ah[k] - m.c[LM_KK] * imp * dist;
     }
 }
 
+// position x and effective distance of a candidate -> its row values
 template <typename V, bool PAIR = false>
-JB_HD void contact_rows_build(const LaneModel<V>& m, const LaneScratch<V>& sc, bool xtra, int slot, int entry) {
-    if (PAIR && slot == SLOT_PAIR) { pair_rows_build<V>(m, sc, entry); return; }
+JB_HD void row_values(const LaneModel<V>& m, const LaneScratch<V>& sc, bool xtra, int slot, const Vec3<V>& x, const V& dist, RowVals<V>& r) {
+    if (PAIR && slot == SLOT_PAIR) { pair_row_values<V>(m, sc, x, dist, r); return; }
     const Vec3<V> w = sc.ld3(SC_ST);
     const V thd1 = sc.ld(SC_ST + 3), thd2 = sc.ld(SC_ST + 4), phid = sc.ld(SC_ST + 5);
     const int level = slot_level(slot);
     const V f_sh = V((level == 1 || level == 2) ? 1.0f : 0.0f), f_kn = V(level == 2 ? 1.0f : 0.0f), f_m = V(level == 3 ? 1.0f : 0.0f);
-    const Vec3<V> x = sc.ld3(SC_CAND + 4 * slot);
-    const V dist = sc.ld(SC_CAND + 4 * slot + 3);
     const V tran = m.c.tran_of(level);
     const V mu = m.c[LM_MU];
     const auto valid = lt(dist, V(0));
     V imp = impedance(m, dist);
     // weight of a pyramid edge  D = 1 / (2 mu^2 R),  R = (1 - d)/d * tran * (1 + mu^2)   (MuJoCo's diagApprox regulariser)
     const V invD = (V(1) - imp) * (tran * ((V(1) + m.c[LM_FR2]) * (V(2) * mu * mu)));
-    const int e0 = SC_ROWS + ROW_F * entry;
-    sc.st(e0 + 18, sel(valid, imp * vrcp(invD), V(0)));
+    r.x = x;
+    r.D = sel(valid, imp * vrcp(invD), V(0));
     const V jdot = f_kn * thd2 + f_m * phid;                    // the rate column 7 multiplies
     const Vec3<V> p1 = cross(sc.ld3(SC_DD + 9), x - sc.ld3(SC_DD + 12)), p2 = cross(sc.ld3(SC_DD + 15), x - sc.ld3(SC_DD + 18));
     Vec3<V> pm = v3<V>(V(0), V(0), V(0));
@@ -566,39 +573,56 @@ JB_HD void contact_rows_build(const LaneModel<V>& m, const LaneScratch<V>& sc, b
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         const Vec3<V> d = sc.ld3(SC_DD + 3 * k);
-        Vec3<V> ang = cross(x, d);
+        const Vec3<V> ang = cross(x, d);
         V jsh = f_sh * dot(d, p1);
         V j7 = f_kn * dot(d, p2);
         if (xtra) j7 = j7 + f_m * dot(d, pm);
         V vel = dot(ang, w) + sc.ld(SC_DD + 21 + k) + jsh * thd1 + j7 * jdot;
         V ah = -m.c[LM_BB] * vel;
         if (k == 0) ah = ah - m.c[LM_KK] * imp * dist;
-        sc.st3(e0 + 3 * k, ang);
-        sc.st(e0 + 9 + k, jsh); sc.st(e0 + 12 + k, j7); sc.st(e0 + 15 + k, ah);
+        r.jsh[k] = jsh; r.j7[k] = j7; r.ah[k] = ah;
     }
+}
+// a cached entry: phase A left position and effective distance in it; the build adds the rest (the weight takes the distance's place)
+template <typename V, bool PAIR = false>
+JB_HD void contact_rows_build(const LaneModel<V>& m, const LaneScratch<V>& sc, bool xtra, int slot, int entry) {
+    const int e0 = SC_ROWS + ROW_F * entry;
+    RowVals<V> r;
+    row_values<V, PAIR>(m, sc, xtra, slot, sc.ld3(e0), sc.ld(e0 + 3), r);
+    sc.st(e0 + 3, r.D);
+#pragma unroll
+    for (int k = 0; k < 3; k++) { sc.st(e0 + 4 + k, r.jsh[k]); sc.st(e0 + 7 + k, r.j7[k]); sc.st(e0 + 10 + k, r.ah[k]); }
+}
+template <typename V> JB_HD void row_load(const LaneScratch<V>& sc, int entry, RowVals<V>& r) {
+    const int e0 = SC_ROWS + ROW_F * entry;
+    r.x = sc.ld3(e0); r.D = sc.ld(e0 + 3);
+#pragma unroll
+    for (int k = 0; k < 3; k++) { r.jsh[k] = sc.ld(e0 + 4 + k); r.j7[k] = sc.ld(e0 + 7 + k); r.ah[k] = sc.ld(e0 + 10 + k); }
 }
 
 // One cached contact against the iterate y.  mode 0: accumulate the Newton matrix / rhs terms for the active set at y;
 // mode 2: only record the active set (the cheap convergence check).
 template <typename V, bool PAIR = false>
-JB_HD void contact_apply(const LaneScratch<V>& sc, const Vec3<V> (&dk)[3], const V& mu, int slot, int entry, bool lane_on, int mode,
+JB_HD void contact_apply(const RowVals<V>& rv, const Vec3<V> (&dk)[3], const V& mu, int slot, bool lane_on, int mode,
                          const V (&yr)[6], const V (&yl)[2], const V& ym, NewtonAcc<V>& acc) {
     using U = typename lane_traits<V>::uint;
     const int level = slot_level(slot);
     const bool is_pair = PAIR && level == 4;
     const bool has_sh = (level == 1 || level == 2 || is_pair), has_kn = (level == 2), has_m = (level == 3 || is_pair);
     const V lin = V(is_pair ? 0.0f : 1.0f);        // the pair contact has no root columns (the cached angular part is zero, the shared linear part is masked)
-    const int e0 = SC_ROWS + ROW_F * entry;
     V Bj[3][8], rho[3], ahat[3];
-    const V D = lane_on ? sc.ld(e0 + 18) : V(0);     // a lane without a slot in this round contributes nothing
+    const V D = lane_on ? rv.D : V(0);             // a lane without a slot in this round contributes nothing
     const V y7 = has_kn ? yl[1] : ym;              // levels 0/1 have a zero column 7
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-        Vec3<V> ang = sc.ld3(e0 + 3 * k);
+        const Vec3<V> ang = cross(rv.x, dk[k]);    // (recomputed from the position: 6 instructions against 3 LDS reads and 9 floats of row cache)
         Bj[k][0] = ang.x; Bj[k][1] = ang.y; Bj[k][2] = ang.z;
         Bj[k][3] = dk[k].x; Bj[k][4] = dk[k].y; Bj[k][5] = dk[k].z;
-        if (PAIR) { Bj[k][3] = Bj[k][3] * lin; Bj[k][4] = Bj[k][4] * lin; Bj[k][5] = Bj[k][5] * lin; }
-        Bj[k][6] = sc.ld(e0 + 9 + k); Bj[k][7] = sc.ld(e0 + 12 + k); ahat[k] = sc.ld(e0 + 15 + k);
+        if (PAIR) {
+#pragma unroll
+            for (int i = 0; i < 6; i++) Bj[k][i] = Bj[k][i] * lin;
+        }
+        Bj[k][6] = rv.jsh[k]; Bj[k][7] = rv.j7[k]; ahat[k] = rv.ah[k];
     }
 #pragma unroll
     for (int k = 0; k < 3; k++) {
@@ -676,15 +700,15 @@ JB_HD void rank_one_pass(const LaneScratch<V>& sc, const StarFactor<V>& F, const
     const U e0 = entry * (unsigned)ROW_F + (unsigned)SC_ROWS;
     const V sg = sel(plus, mu, -mu);                    // e = B_n + sg * B_t
     V e[8];
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
-        e[i] = sc.ldv(e0 + (unsigned)i) + sg * sel(tan2, sc.ldv(e0 + (unsigned)(6 + i)), sc.ldv(e0 + (unsigned)(3 + i)));
-    }
-    e[3] = dk[0].x + sg * sel(tan2, dk[2].x, dk[1].x); e[4] = dk[0].y + sg * sel(tan2, dk[2].y, dk[1].y); e[5] = dk[0].z + sg * sel(tan2, dk[2].z, dk[1].z);
-    e[6] = sc.ldv(e0 + 9u) + sg * sel(tan2, sc.ldv(e0 + 11u), sc.ldv(e0 + 10u));
-    e[7] = sc.ldv(e0 + 12u) + sg * sel(tan2, sc.ldv(e0 + 14u), sc.ldv(e0 + 13u));
-    const V ah = sc.ldv(e0 + 15u) + sg * sel(tan2, sc.ldv(e0 + 17u), sc.ldv(e0 + 16u));
-    const V sD = sel(is_flip, sel(on, sc.ldv(e0 + 18u), -sc.ldv(e0 + 18u)), V(0));
+    const Vec3<V> x = v3<V>(sc.ldv(e0), sc.ldv(e0 + 1u), sc.ldv(e0 + 2u));
+    const Vec3<V> dt = v3<V>(dk[0].x + sg * sel(tan2, dk[2].x, dk[1].x), dk[0].y + sg * sel(tan2, dk[2].y, dk[1].y), dk[0].z + sg * sel(tan2, dk[2].z, dk[1].z));
+    const Vec3<V> an = cross(x, dk[0]), at = sel_v3(tan2, cross(x, dk[2]), cross(x, dk[1]));
+    e[0] = an.x + sg * at.x; e[1] = an.y + sg * at.y; e[2] = an.z + sg * at.z;
+    e[3] = dt.x; e[4] = dt.y; e[5] = dt.z;
+    e[6] = sc.ldv(e0 + 4u) + sg * sel(tan2, sc.ldv(e0 + 6u), sc.ldv(e0 + 5u));
+    e[7] = sc.ldv(e0 + 7u) + sg * sel(tan2, sc.ldv(e0 + 9u), sc.ldv(e0 + 8u));
+    const V ah = sc.ldv(e0 + 10u) + sg * sel(tan2, sc.ldv(e0 + 12u), sc.ldv(e0 + 11u));
+    const V sD = sel(is_flip, sel(on, sc.ldv(e0 + 3u), -sc.ldv(e0 + 3u)), V(0));
 #pragma unroll
     for (int i = 0; i < 8; i++) e[i] = sel(is_flip, e[i], V(0));
     V rr[6], zero6[6], zr[6], zl[2], zm;
@@ -752,17 +776,14 @@ template <typename V> JB_HD SlotPlan make_slot_plan(const LaneScratch<V>& sc, un
     p.mine = live_slots & group_mask(p.grouped ? sc.grp : 0, p.ngroups);
     return p;
 }
-// the slot group g takes in round r (or -1), and the row-cache entry of a slot: its rank among the live slots
+// the slot group g takes in round r (or -1), and the rank of a slot among the live ones (= its row-cache entry while below ROW_K)
 JB_HD int plan_slot(const SlotPlan& p, int, int r) {
     return r < __builtin_popcount(p.mine) ? nth_set_bit(p.mine, r) : -1;
 }
-JB_HD int plan_entry(const SlotPlan& p, int g, int slot) {
-    const int rank = __builtin_popcount(p.live & ((1u << slot) - 1u));
-    return rank < ROW_K ? rank : ROW_K + g;
-}
+JB_HD int plan_rank(const SlotPlan& p, int slot) { return __builtin_popcount(p.live & ((1u << slot) - 1u)); }
 
-// y-independent rows of the live slots, once per substep (slots beyond the cache use the group's overflow entry and are
-// rebuilt in every pass)
+// y-independent rows of the live slots, once per substep (slots beyond the cache keep their candidate only; their rows are
+// recomputed in registers in every pass)
 template <typename V, bool PAIR = false>
 JB_HD void contact_rows_build_all(const LaneModel<V>& m, const LaneScratch<V>& sc, bool xtra, const SlotPlan& plan) {
     if (!plan.grouped && sc.grp != 0) return;
@@ -771,7 +792,7 @@ JB_HD void contact_rows_build_all(const LaneModel<V>& m, const LaneScratch<V>& s
     for (int r = 0; r < plan.rounds; r++) {
         const int slot = plan_slot(plan, g, r);
         if (slot >= 0) {
-            const int entry = plan_entry(plan, g, slot);
+            const int entry = plan_rank(plan, slot);
             if (entry < ROW_K) contact_rows_build<V, PAIR>(m, sc, xtra, slot, entry);
         }
     }
@@ -795,13 +816,18 @@ JB_HD void contact_sweep(const LaneModel<V>& m, const LaneScratch<V>& sc, bool x
         const int mine = plan_slot(plan, g, r);
         const bool lane_on = mine >= 0;
         const int slot = lane_on ? mine : __builtin_ctz(plan.live);       // idle lanes read some valid entry and contribute nothing
-        const int entry = plan_entry(plan, g, slot);
-        if (lane_on && entry >= ROW_K) contact_rows_build<V, PAIR>(m, sc, xtra, slot, entry);      // beyond the cache: rebuilt per pass
-        contact_apply<V, PAIR>(sc, dk, mu, slot, entry, lane_on, mode, yr, yl, ym, acc);
+        const int rank = plan_rank(plan, slot);
+        RowVals<V> rv;
+        if (rank < ROW_K) row_load<V>(sc, rank, rv);
+        else {      // beyond the cache: the candidate -> row values, every pass
+            const int c0 = 4 * (rank - ROW_K) * sc.ovc_stride;
+            row_values<V, PAIR>(m, sc, xtra, slot, v3<V>(sc.ovc[c0], sc.ovc[c0 + sc.ovc_stride], sc.ovc[c0 + 2 * sc.ovc_stride]), sc.ovc[c0 + 3 * sc.ovc_stride], rv);
+        }
+        contact_apply<V, PAIR>(rv, dk, mu, slot, lane_on, mode, yr, yl, ym, acc);
     }
     if (plan.grouped) {
         acc.bw0 = group_sum_u<V>(sc, acc.bw0); acc.bw1 = group_sum_u<V>(sc, acc.bw1); acc.xh = group_sum_u<V>(sc, acc.xh);
-        if (mode == 0 && sc.ngrp == 4 && sc.gstride == 16) {
+        if (mode == 0 && sc.ngrp == 4 && sc.gstride == 16 && sc.red_lds) {
             // Only the main lanes need the totals: reduce four values at a time so that row (= group) g ends with the total
             // of value 4k+g, hand the totals over through the scratch (the overflow row entries are dead here) and let the
             // main lanes read all of them.  Same association as group_sum, a quarter of its instructions.
@@ -809,8 +835,7 @@ JB_HD void contact_sweep(const LaneModel<V>& m, const LaneScratch<V>& sc, bool x
             V v[4 * NQ4];
             acc_pack(acc, v);
             if (PAIR) { v[52] = acc.X; v[53] = V(0); v[54] = V(0); v[55] = V(0); }
-            constexpr int SC_RED = SC_ROWS + ROW_K * ROW_F;
-            static_assert(4 * ROW_F >= 4 * NQ4, "reduction buffer");
+            static_assert(4 * NQ4 <= 56, "reduction buffer");
 #pragma unroll
             for (int k = 0; k < NQ4; k++) sc.st(SC_RED + 4 * k + sc.grp, row_transpose_sum(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]));
             wave_sync();          // every group's totals are in the scratch
@@ -878,18 +903,28 @@ JB_HD void cylinder_floor(const Vec3<V>& c, const Vec3<V>& ax_in, const Vec3<V>&
 // store a candidate: position and effective distance (+1 when it is not a contact)
 // Returns the wave-uniform bit "some lane of the wave has a contact in this slot" (shifted to the slot's position):
 // the sweeps of the substep visit only slots whose bit is set.
+// `live_before`: the live bits of the slots BELOW this one (candidates are generated in increasing slot order), so that the slot's
+// entry - its rank among the live slots - is known as it is stored: a slot nobody touches takes no entry at all.
 template <typename V, typename MKT>
-JB_HD unsigned cand_store(const LaneScratch<V>& sc, int slot, const Vec3<V>& x, const V& dist, const MKT& on) {
-    sc.st3(SC_CAND + 4 * slot, x);
-    sc.st(SC_CAND + 4 * slot + 3, sel(on, dist, V(1)));
-    return any_lane(on) ? (1u << slot) : 0u;
+JB_HD unsigned cand_store(const LaneScratch<V>& sc, unsigned live_before, int slot, const Vec3<V>& x, const V& dist, const MKT& on) {
+    if (!any_lane(on)) return 0u;
+    const int rank = __builtin_popcount(live_before & ((1u << slot) - 1u));
+    const V d = sel(on, dist, V(1));
+    if (rank < ROW_K) {
+        const int e0 = SC_ROWS + ROW_F * rank;
+        sc.st3(e0, x); sc.st(e0 + 3, d);
+    } else {
+        const int c0 = 4 * (rank - ROW_K) * sc.ovc_stride;
+        sc.ovc[c0] = x.x; sc.ovc[c0 + sc.ovc_stride] = x.y; sc.ovc[c0 + 2 * sc.ovc_stride] = x.z; sc.ovc[c0 + 3 * sc.ovc_stride] = d;
+    }
+    return 1u << slot;
 }
 template <typename V, typename MKT>
-JB_HD unsigned cand_store_cyl(const LaneScratch<V>& sc, int slot0, const CylContacts<V>& c, const MKT& gate) {
-    unsigned live = 0;
+JB_HD unsigned cand_store_cyl(const LaneScratch<V>& sc, unsigned live_before, int slot0, const CylContacts<V>& c, const MKT& gate) {
+    unsigned live = live_before;
 #pragma unroll
-    for (int k = 0; k < 4; k++) live |= cand_store(sc, slot0 + k, c.x[k], c.dist[k], mand(c.on[k], gate));
-    return live;
+    for (int k = 0; k < 4; k++) live |= cand_store(sc, live, slot0 + k, c.x[k], c.dist[k], mand(c.on[k], gate));
+    return live & ~live_before;
 }
 
 // ----------------------------------------------------------------------------- the geom-geom pair: mass ellipsoid against the own upper-leg cylinder
@@ -1011,21 +1046,28 @@ template <typename V> inline void stats_hist(const SimOpts&, const LaneScratch<V
 #endif
 
 // ---- LEAN variant: park / fetch long-lived values in the lane's scratch (lane-private columns: no hand-over between lanes)
+// (the root block [[J, [h]x], [[h]x^T, m 1]] is parked as its 10 distinct values: J (6), h (3), m)
 template <typename V> JB_HD void sys_store(const LaneScratch<V>& sc, const StarSys<V>& y) {
+    sc.st(SC_SYS + 0, y.A[tri(0, 0)]); sc.st(SC_SYS + 1, y.A[tri(1, 0)]); sc.st(SC_SYS + 2, y.A[tri(1, 1)]);
+    sc.st(SC_SYS + 3, y.A[tri(2, 0)]); sc.st(SC_SYS + 4, y.A[tri(2, 1)]); sc.st(SC_SYS + 5, y.A[tri(2, 2)]);
+    sc.st(SC_SYS + 6, y.A[tri(4, 2)]) /*hx*/; sc.st(SC_SYS + 7, y.A[tri(5, 0)]) /*hy*/; sc.st(SC_SYS + 8, y.A[tri(3, 1)]) /*hz*/; sc.st(SC_SYS + 9, y.A[tri(3, 3)]) /*m*/;
 #pragma unroll
-    for (int i = 0; i < 21; i++) sc.st(SC_SYS + i, y.A[i]);
-#pragma unroll
-    for (int i = 0; i < 6; i++) { sc.st(SC_SYS + 21 + 2 * i, y.B[i][0]); sc.st(SC_SYS + 22 + 2 * i, y.B[i][1]); sc.st(SC_SYS + 36 + i, y.Bm[i]); sc.st(SC_SYS + 43 + i, y.tr[i]); }
-    sc.st(SC_SYS + 33, y.C[0]); sc.st(SC_SYS + 34, y.C[1]); sc.st(SC_SYS + 35, y.C[2]); sc.st(SC_SYS + 42, y.Cm);
-    sc.st(SC_SYS + 49, y.tl[0]); sc.st(SC_SYS + 50, y.tl[1]); sc.st(SC_SYS + 51, y.tm);
+    for (int i = 0; i < 6; i++) { sc.st(SC_SYS + 10 + 2 * i, y.B[i][0]); sc.st(SC_SYS + 11 + 2 * i, y.B[i][1]); sc.st(SC_SYS + 25 + i, y.Bm[i]); sc.st(SC_SYS + 32 + i, y.tr[i]); }
+    sc.st(SC_SYS + 22, y.C[0]); sc.st(SC_SYS + 23, y.C[1]); sc.st(SC_SYS + 24, y.C[2]); sc.st(SC_SYS + 31, y.Cm);
+    sc.st(SC_SYS + 38, y.tl[0]); sc.st(SC_SYS + 39, y.tl[1]); sc.st(SC_SYS + 40, y.tm);
 }
 template <typename V> JB_HD void sys_load(const LaneScratch<V>& sc, StarSys<V>& y) {
+    const V Z = V(0), hx = sc.ld(SC_SYS + 6), hy = sc.ld(SC_SYS + 7), hz = sc.ld(SC_SYS + 8), mt = sc.ld(SC_SYS + 9);
+    y.A[tri(0, 0)] = sc.ld(SC_SYS + 0); y.A[tri(1, 0)] = sc.ld(SC_SYS + 1); y.A[tri(1, 1)] = sc.ld(SC_SYS + 2);
+    y.A[tri(2, 0)] = sc.ld(SC_SYS + 3); y.A[tri(2, 1)] = sc.ld(SC_SYS + 4); y.A[tri(2, 2)] = sc.ld(SC_SYS + 5);
+    y.A[tri(3, 0)] = Z;   y.A[tri(3, 1)] = hz;  y.A[tri(3, 2)] = -hy;
+    y.A[tri(4, 0)] = -hz; y.A[tri(4, 1)] = Z;   y.A[tri(4, 2)] = hx;
+    y.A[tri(5, 0)] = hy;  y.A[tri(5, 1)] = -hx; y.A[tri(5, 2)] = Z;
+    y.A[tri(3, 3)] = mt; y.A[tri(4, 3)] = Z; y.A[tri(4, 4)] = mt; y.A[tri(5, 3)] = Z; y.A[tri(5, 4)] = Z; y.A[tri(5, 5)] = mt;
 #pragma unroll
-    for (int i = 0; i < 21; i++) y.A[i] = sc.ld(SC_SYS + i);
-#pragma unroll
-    for (int i = 0; i < 6; i++) { y.B[i][0] = sc.ld(SC_SYS + 21 + 2 * i); y.B[i][1] = sc.ld(SC_SYS + 22 + 2 * i); y.Bm[i] = sc.ld(SC_SYS + 36 + i); y.tr[i] = sc.ld(SC_SYS + 43 + i); }
-    y.C[0] = sc.ld(SC_SYS + 33); y.C[1] = sc.ld(SC_SYS + 34); y.C[2] = sc.ld(SC_SYS + 35); y.Cm = sc.ld(SC_SYS + 42);
-    y.tl[0] = sc.ld(SC_SYS + 49); y.tl[1] = sc.ld(SC_SYS + 50); y.tm = sc.ld(SC_SYS + 51);
+    for (int i = 0; i < 6; i++) { y.B[i][0] = sc.ld(SC_SYS + 10 + 2 * i); y.B[i][1] = sc.ld(SC_SYS + 11 + 2 * i); y.Bm[i] = sc.ld(SC_SYS + 25 + i); y.tr[i] = sc.ld(SC_SYS + 32 + i); }
+    y.C[0] = sc.ld(SC_SYS + 22); y.C[1] = sc.ld(SC_SYS + 23); y.C[2] = sc.ld(SC_SYS + 24); y.Cm = sc.ld(SC_SYS + 31);
+    y.tl[0] = sc.ld(SC_SYS + 38); y.tl[1] = sc.ld(SC_SYS + 39); y.tm = sc.ld(SC_SYS + 40);
 }
 template <typename V> JB_HD void fac_store(const LaneScratch<V>& sc, const StarFactor<V>& F) {
 #pragma unroll
@@ -1148,21 +1190,21 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
             Vec3<V> foot = a2 + mul(R12, ldv3(m, LM_DFOOT));
             V fdist = (s.pz + dot(foot, nb) - m.c[LM_FOOT_R]) + s.pz_lo;
             MK fon = lt(fdist, V(0));
-            live_slots |= cand_store(sc, 0, foot - nb * (m.c[LM_FOOT_R] + fdist * V(0.5)), fdist, fon);
+            live_slots |= cand_store(sc, live_slots, 0, foot - nb * (m.c[LM_FOOT_R] + fdist * V(0.5)), fdist, fon);
             CylContacts<V> lc;
             MK all_on = lt(V(0), V(1));
             cylinder_floor(a2 + mul(R12, ldv3(m, LM_LC_D)), mul(R12, ldv3(m, LM_LC_AX)), mul(R12, ldv3(m, LM_LC_XA)), m.c[LM_LC_R], m.c[LM_LC_H], nb, s.pz, s.pz_lo, all_on, lc);
-            live_slots |= cand_store_cyl(sc, 1, lc, all_on);
+            live_slots |= cand_store_cyl(sc, live_slots, 1, lc, all_on);
             MK any_con = mor(fon, lc.on[0]);
             if (xtra) {
                 // every remaining geom of the model against the floor
                 CylContacts<V> cy;
                 cylinder_floor(a1 + mul(R1, ldc3(m, LM_UC_D)), mul(R1, ldc3(m, LM_UC_AX)), mul(R1, ldc3(m, LM_UC_XA)), ldc(m, LM_UC_R), ldc(m, LM_UC_H), nb, s.pz, s.pz_lo, all_on, cy);
-                live_slots |= cand_store_cyl(sc, 5, cy, all_on);
+                live_slots |= cand_store_cyl(sc, live_slots, 5, cy, all_on);
                 any_con = mor(any_con, cy.on[0]);
                 Vec3<V> tip = a1 + mul(R1, ldc3(m, LM_DTIP));
                 V tipd = (s.pz + dot(tip, nb) - ldc(m, LM_TIP_R)) + s.pz_lo;
-                live_slots |= cand_store(sc, 9, tip - nb * (ldc(m, LM_TIP_R) + tipd * V(0.5)), tipd, lt(tipd, V(0)));
+                live_slots |= cand_store(sc, live_slots, 9, tip - nb * (ldc(m, LM_TIP_R) + tipd * V(0.5)), tipd, lt(tipd, V(0)));
                 any_con = mor(any_con, lt(tipd, V(0)));
               if (xbody) {
                 // lane cylinder (root body: lane 2 screw1; motor body: lane 3 threadMass)
@@ -1170,9 +1212,11 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
                 Vec3<V> xc_c = ldc3(m, LM_XC_C), xc_ax = ldc3(m, LM_XC_AX), xc_xa = ldc3(m, LM_XC_XA);
                 cylinder_floor(sel_v3(x_onm, am + mul(Rm, xc_c - am), xc_c), sel_v3(x_onm, mul(Rm, xc_ax), xc_ax), sel_v3(x_onm, mul(Rm, xc_xa), xc_xa),
                                ldc(m, LM_XC_R), ldc(m, LM_XC_H), nb, s.pz, s.pz_lo, gt(ldc(m, LM_XC_EN), V(0.5)), cy);
-                live_slots |= cand_store_cyl(sc, 10, cy, mnot(x_onm));
-                live_slots |= cand_store_cyl(sc, 23, cy, x_onm);
+                live_slots |= cand_store_cyl(sc, live_slots, 10, cy, mnot(x_onm));      // (slots in increasing order: 10-13, 14, 15-22, then the motor body's 23-27)
                 any_con = mor(any_con, cy.on[0]);
+                Vec3<V> ellx_m;
+                V elld_m;
+                MK ellon_m;
                 {   // lane ellipsoid: support point in direction -n
                     Mat3<V> Re0, Re;
 #pragma unroll
@@ -1189,8 +1233,8 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
                     V elld = (s.pz + dot(sup, nb)) + s.pz_lo;
                     MK ellon = mand(gt(ldc(m, LM_XE_EN), V(0.5)), lt(elld, V(0)));
                     Vec3<V> ellx = sup - nb * (elld * V(0.5));
-                    live_slots |= cand_store(sc, 14, ellx, elld, mand(ellon, mnot(x_onm)));
-                    live_slots |= cand_store(sc, 27, ellx, elld, mand(ellon, x_onm));
+                    live_slots |= cand_store(sc, live_slots, 14, ellx, elld, mand(ellon, mnot(x_onm)));
+                    ellx_m = ellx; elld_m = elld; ellon_m = mand(ellon, x_onm);
                     any_con = mor(any_con, ellon);
                 }
                 {   // lane box (root body): first 4 penetrating vertices in vertex order
@@ -1207,10 +1251,12 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
                         V d = (s.pz + dot(pnt, nb)) + s.pz_lo;
                         MK on = mand(mand(ben, lt(d, V(0))), lt(cnt, V(3.5)));
                         cnt = cnt + sel(on, V(1), V(0));
-                        live_slots |= cand_store(sc, 15 + vtx, pnt - nb * (d * V(0.5)), d, on);
+                        live_slots |= cand_store(sc, live_slots, 15 + vtx, pnt - nb * (d * V(0.5)), d, on);
                         any_con = mor(any_con, on);
                     }
                 }
+                live_slots |= cand_store_cyl(sc, live_slots, 23, cy, x_onm);
+                live_slots |= cand_store(sc, live_slots, 27, ellx_m, elld_m, ellon_m);
               }
             }
             if (PAIR) {
@@ -1249,7 +1295,7 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
                         sc.st3(SC_PD, pn); sc.st3(SC_PD + 3, t1); sc.st3(SC_PD + 6, cross(pn, t1));
                     }
                 }
-                live_slots |= cand_store(sc, SLOT_PAIR, ppos, pdist, pon);
+                live_slots |= cand_store(sc, live_slots, SLOT_PAIR, ppos, pdist, pon);
                 any_con = mor(any_con, pon);
             }
             any_contact = any_lane(any_con);

@@ -38,16 +38,22 @@ static int run(const double* P, double* qpos, double* qvel, double ctrl, int nsu
     for (int i = 0; i < 3; i++) { s.wa[i] = V(T(0)); s.wl[i] = V(T(0)); }
     s.wj[0] = s.wj[1] = V(T(0)); s.wm = V(T(0)); s.fail = V(T(0));
     SimOpts o; o.contacts = contacts; o.max_newton = max_newton; o.implicit_damp = implicit_damp; o.rank_one = rank_one; o.lean = lean; o.prof = nullptr; o.hist = nullptr;
-    V scratch[SC_COUNT_LEAN];          // (the LEAN variant parks state / system / factorisation behind the ordinary scratch)
+    constexpr int SCMAX = SC_COUNT > SC_COUNT_LEAN ? SC_COUNT : SC_COUNT_LEAN;
+    V scratch[SCMAX];                  // (the LEAN variant parks state / system / factorisation where the ordinary one has its reduction buffer and overflow candidates)
+    V ovcbuf[4 * (NSLOT - ROW_K)];     // LEAN: the candidates beyond the row cache live outside the scratch (global memory on the device)
+    auto set_ovc = [&](LaneScratch<V>& sc) {
+        sc.ovc = lean ? ovcbuf : scratch + SC_OVC; sc.ovc_stride = 1; sc.red_lds = !lean;
+    };
     normalise_state(s);
     if (ngroups <= 1) {
-        LaneScratch<V> sc; sc.p = scratch; sc.stride = 1; sc.grp = 0; sc.ngrp = 1; sc.gstride = 4;
-        for (int k = 0; k < SC_COUNT_LEAN; k++) scratch[k] = V(std::numeric_limits<T>::quiet_NaN());
+        LaneScratch<V> sc; sc.p = scratch; sc.stride = 1; sc.grp = 0; sc.ngrp = 1; sc.gstride = 4; set_ovc(sc);
+        for (int k = 0; k < SCMAX; k++) scratch[k] = V(std::numeric_limits<T>::quiet_NaN());
         if (lean) state_store(sc, s);
         for (int i = 0; i < nsub; i++) {
             // poison the scratch: a substep must not read anything it has not written itself (on the device LDS keeps whatever
             // the previous kernel left there); in the LEAN variant the parked state is the one thing that carries over
-            for (int k = 0; k < SC_LSTATE; k++) scratch[k] = V(std::numeric_limits<T>::quiet_NaN());
+            for (int k = 0; k < (lean ? SC_LSTATE : SCMAX); k++) scratch[k] = V(std::numeric_limits<T>::quiet_NaN());
+            for (auto& c : ovcbuf) c = V(std::numeric_limits<T>::quiet_NaN());
             if (pair) substep<V, true>(m, sc, s, V(T(ctrl)), o); else substep<V>(m, sc, s, V(T(ctrl)), o);
         }
         if (lean) state_load(sc, s);
@@ -56,7 +62,7 @@ static int run(const double* P, double* qpos, double* qvel, double ctrl, int nsu
         wave.ngrp = ngroups; wave.gstride = 16;            // 16: the lane distance between groups in the 4-envs-per-wave kernel (selects its transposed reduction)
         auto body = [&](int g) {
             g_host_wave = &wave; g_host_grp = g;
-            LaneScratch<V> sc; sc.p = scratch; sc.stride = 1; sc.grp = g; sc.ngrp = ngroups; sc.gstride = 16;
+            LaneScratch<V> sc; sc.p = scratch; sc.stride = 1; sc.grp = g; sc.ngrp = ngroups; sc.gstride = 16; set_ovc(sc);
             LaneState<V> hs = s;                            // helper lanes start from a harmless state, like the kernel's
             LaneState<V>& st = (g == 0) ? s : hs;
             if (g != 0) {
@@ -64,10 +70,10 @@ static int run(const double* P, double* qpos, double* qvel, double ctrl, int nsu
                 hs.pz_lo = hs.qw_lo = hs.qx_lo = hs.qy_lo = hs.qz_lo = V(T(0));
                 hs.phi = hs.phid = hs.turns = V(T(0)); hs.th1 = hs.th2 = hs.thd1 = hs.thd2 = V(T(0));
             }
-            if (g == 0) { for (int k = 0; k < SC_COUNT_LEAN; k++) scratch[k] = V(std::numeric_limits<T>::quiet_NaN()); if (lean) state_store(sc, st); }
+            if (g == 0) { for (int k = 0; k < SCMAX; k++) scratch[k] = V(std::numeric_limits<T>::quiet_NaN()); if (lean) state_store(sc, st); }
             for (int i = 0; i < nsub; i++) {
                 wave.barrier();
-                if (g == 0) for (int k = 0; k < SC_LSTATE; k++) scratch[k] = V(std::numeric_limits<T>::quiet_NaN());
+                if (g == 0) { for (int k = 0; k < (lean ? SC_LSTATE : SCMAX); k++) scratch[k] = V(std::numeric_limits<T>::quiet_NaN()); for (auto& c : ovcbuf) c = V(std::numeric_limits<T>::quiet_NaN()); }
                 wave.barrier();
                 if (pair) substep<V, true>(m, sc, st, V(T(ctrl)), o); else substep<V>(m, sc, st, V(T(ctrl)), o);
             }

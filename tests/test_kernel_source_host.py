@@ -262,3 +262,38 @@ def test_pair_contact_kernel_source_fp64_equals_oracle():
             q, v = q1, v1
     print("control steps that start with the mass on a leg: %d; fp64 vs oracle %.2e; fp32 median %.1e max %.1e" % (n_pair, worst, np.median(e32), max(e32)))
     assert n_pair >= 20 and worst < 2e-9 and np.median(e32) < 1e-6 and max(e32) < 1e-5
+
+
+def test_contacts_beyond_the_row_cache_give_the_same_answer(params):
+    """A build with a row cache of TWO contacts (-DJB_ROW_K=2): nearly every contact then goes the beyond-the-cache way - its candidate
+    parked in the overflow store, its rows recomputed in registers in every Newton pass, no rank-one passes on it - in the ordinary and
+    the LEAN layout, with one and four lane groups.  Same minimiser as the oracle (and as the default build) to round-off, walking and
+    lying on the legs."""
+    import tests.build_harness as bh
+    lib = C.CDLL(bh.build(row_k=2))
+    dp = C.POINTER(C.c_double)
+    for f in (lib.jbh_step_groups, lib.jbh_step_lean):
+        f.argtypes = [dp, dp, dp, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, dp]
+    P = np.ascontiguousarray(params)
+
+    def run(fn, q, v, u, groups):
+        q, v, fail = q.copy(), v.copy(), np.zeros(1)
+        assert fn(P.ctypes.data_as(dp), q.ctypes.data_as(dp), v.ctypes.data_as(dp), float(u), 50, 1, 20, 0, groups, 1, fail.ctypes.data_as(dp)) == 0
+        assert fail[0] == 0
+        return q, v
+
+    worst = 0.0
+    for tipped in (False, True):
+        env = _contact_states(params, 8, tipped)
+        rng = np.random.default_rng(3)
+        for t in range(3):
+            a = rng.uniform(-1, 1, size=8)
+            q0, v0, _ = env.get_state()
+            env.step(a, auto_reset=False)
+            q1, v1, _ = env.get_state()
+            for i in range(8):
+                for fn in (lib.jbh_step_groups, lib.jbh_step_lean):
+                    for groups in (1, 4):
+                        qh, vh = run(fn, q0[i], v0[i], a[i], groups)
+                        worst = max(worst, np.abs(qh - q1[i]).max(), (np.abs(vh - v1[i]) / (1 + np.abs(v1[i]))).max())
+    assert worst < 1e-10, worst
