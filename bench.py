@@ -131,7 +131,8 @@ def main(argv=None):
     ap.add_argument("--envs-per-wave", type=int, default=0)
     ap.add_argument("--no-rank-one", action="store_true", help="diagnostic: JB_FLAG_NO_RANK_ONE (every Newton pass is a full pass)")
     ap.add_argument("--no-pair", action="store_true", help="diagnostic: JB_FLAG_NO_PAIR (floor contacts only, also for per-env models: what rounds 1-2 simulated)")
-    ap.add_argument("--lean", action="store_true", help="JB_FLAG_LEAN: the two-waves-per-SIMD kernel variant (256 registers, 2 envs per wave by default)")
+    ap.add_argument("--lean", action="store_true", help="JB_FLAG_LEAN: the two-waves-per-SIMD kernel variant (229 registers, 20 KB of LDS per four-env wave); chosen automatically from 8192 envs per GPU on (shared model), where the GPU holds two waves per SIMD")
+    ap.add_argument("--no-lean", action="store_true", help="never the LEAN variant")
     ap.add_argument("--actions", default="uniform", help="uniform (default, the metric's workload) | const1 (motor flat out: about half the robots tip over - diagnostic)")
     ap.add_argument("--seed", type=int, default=0, help="reset / action stream seed (the committed numbers use 0)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the measured path); gloo is a CPU-staged rehearsal of the N>1 control flow")
@@ -139,6 +140,8 @@ def main(argv=None):
     ap.add_argument("--augmented", action="store_true", help="one randomised model per env (BASELINE configs[4], augment_Jitterbug semantics)")
     ap.add_argument("--no-steady", action="store_true", help="skip the steady-state (steps 100-400) and full-episode blocks measured next to the headline")
     args = ap.parse_args(argv)
+    if not args.no_lean and not args.augmented and args.envs_per_gpu >= 8192:
+        args.lean = True          # >= 2048 four-env waves: two resident per SIMD (every rank of a run makes the same choice: results stay independent of the split)
     task = args.task
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return self_launch(args.gpus, argv)          # before anything imports torch or initialises HIP in this process
@@ -370,7 +373,7 @@ def main(argv=None):
             "ms_per_step": wall_max * 1e3 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s, N_envs=%d per GPU, %s, 50 substeps/step, in-kernel auto-reset (%s)"
-                                   % (task + (", one randomised model per env" if args.augmented else ""), n, "full Newton contact solve" if args.contacts else "contacts off", config_label(args.contacts)),
+                                   % (task + (", one randomised model per env" if args.augmented else ""), n, ("full Newton contact solve" if args.contacts else "contacts off") + (", LEAN kernel variant (two waves per SIMD)" if args.lean else ""), config_label(args.contacts)),
                        "global_envs": total_envs, "parallelism": "env-sharded x%d%s" % (world, gather_txt)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic,

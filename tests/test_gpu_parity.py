@@ -168,8 +168,8 @@ def test_step_teacher_forced_tipped_over_robots():
 
 
 def test_lean_kernel_variant_parity():
-    """JB_FLAG_LEAN: the two-waves-per-SIMD variant of the step kernel (231 VGPRs, no spills; state / system / factorisation parked in LDS)
-    under the same protocol, and against the ordinary variant from identical states (the compiler fuses multiply-adds differently in
+    """JB_FLAG_LEAN: the two-waves-per-SIMD variant of the step kernel (229 VGPRs, no spills; state / system / factorisation parked in LDS,
+    20 KB of LDS per four-env wave) under the same protocol, and against the ordinary variant from identical states (the compiler fuses multiply-adds differently in
     the two kernels, so they agree to rounding, not bit for bit - on the host, without contraction, they are identical)."""
     from jitterbug_amd.vec_env import JitterbugVecEnv
     r = _teacher_forced("move_to_pose", 64, 200, seed=7, flags=2)
@@ -191,6 +191,39 @@ def test_lean_kernel_variant_parity():
         ok += good.sum(); tot += good.size
     assert ok / tot >= 0.999, ok / tot
     a_env.close(); b_env.close()
+
+
+def test_lean_variant_at_two_waves_per_simd_is_split_invariant_and_physical():
+    """The LEAN variant where it pays (>= 8192 envs on a GPU: 2048+ four-env waves, two resident per SIMD, 20 KB of LDS each): 16 384 envs,
+    results bit-identical for any split into LEAN shards (the variant is a per-handle choice - JB_FLAG_LEAN - because its arithmetic is
+    rounded differently from the ordinary kernel's: every shard of a batch must use the same one), deterministic, physical."""
+    from jitterbug_amd.vec_env import JitterbugVecEnv
+    n = 16384
+    rng = np.random.default_rng(1)
+    acts = rng.uniform(-1, 1, size=(8, n)).astype(np.float32)
+
+    def run(parts):
+        outs = []
+        for lo, hi in parts:
+            e = JitterbugVecEnv(hi - lo, "move_to_pose", seed=9, env_offset=lo, flags=2)
+            ob = [e.reset()]
+            for a in acts:
+                o_, r_, d_, _ = e.step(a[lo:hi])
+                ob.append(o_)
+            q, v, _ = e.get_state()
+            sc, ep, cap = e.counters()
+            assert cap.sum() < 10
+            outs.append(np.stack(ob))
+            e.close()
+        return np.concatenate(outs, axis=1)
+
+    whole = run([(0, n)])
+    assert np.array_equal(whole, run([(0, n)]))
+    assert np.array_equal(whole, run([(0, 5000), (5000, 8191), (8191, n)]))
+    assert np.isfinite(whole).all()
+    assert np.abs(np.linalg.norm(whole[-1][:, 3:7], axis=1) - 1).max() < 1e-5
+    z = (whole[-1][:, 2] + 1) / 20
+    assert z.min() > 0.02 and z.max() < 0.06
 
 
 def test_step_teacher_forced_contacts_off():
