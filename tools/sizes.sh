@@ -1,16 +1,22 @@
 #!/bin/bash
-# Throughput of the current build at the other BASELINE sizes / modes (run on the GPU box): tools/sizes.sh > gpurun_out/r02_sizes.txt
+# Throughput of the current build at the other BASELINE sizes / modes (run on the GPU box): tools/sizes.sh > gpurun_out/r03_sizes.txt
+# (bench.py picks the LEAN kernel variant from 8192 envs per GPU on; --no-lean is the ordinary kernel on the same batch)
 run() { python bench.py --steps 300 --warmup 50 --no-cpu-baseline --no-also --no-host-rate --no-steady "$@" 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.read().strip().split('\n')[-1]); print('%-70s %10.0f env-steps/s  %.4f ms/step  finite %s' % (' '.join(sys.argv[1:]) or '(default: move_from_origin N=4096)', d['value'], d['ms_per_step'], d['finite']))" "$@"; }
 run
 run --contacts 0
 run --task move_to_pose
+run --envs-per-gpu 8192 --no-lean
 run --envs-per-gpu 8192
+run --envs-per-gpu 16384 --no-lean
 run --envs-per-gpu 16384
+run --envs-per-gpu 65536 --no-lean
 run --envs-per-gpu 65536
+run --task move_to_pose --envs-per-gpu 32768 --no-lean
 run --task move_to_pose --envs-per-gpu 32768
 run --augmented --envs-per-gpu 8192 --task move_to_pose
+run --augmented --envs-per-gpu 8192 --task move_to_pose --no-pair
 run --augmented --envs-per-gpu 4096
 run --actions const1
 JB_BENCH_FORCE_DIST=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 300 --warmup 50 --no-cpu-baseline --no-also --no-host-rate --no-steady 2>/dev/null | grep '^{' | python -c "
