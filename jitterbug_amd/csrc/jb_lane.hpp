@@ -79,9 +79,10 @@ JB_D float xor_sum(float x, int off, bool sym2) { return __builtin_bit_cast(floa
 JB_D unsigned xor_sum_u(unsigned x, int off, bool sym2) { return xor_sum_bits(x, off, sym2, false); }
 JB_D unsigned wave_bcast_u(unsigned x) { return (unsigned)__builtin_amdgcn_readfirstlane((int)x); }   // value of the first active lane
 // Hand-over point between lane groups through the scratch (one group wrote, another reads).  The groups are lanes of ONE wave and
-// LDS operations of a wave complete in program order, so the device needs nothing here; the host emulation (one thread per group)
-// needs a barrier.
-JB_D void wave_sync() {}
+// LDS operations of a wave complete in program order, so the hardware needs nothing here - but the COMPILER must not move a read of
+// the hand-over across the writes it depends on (it sees one thread and may prove the addresses different once the group is known):
+// a wave barrier is that fence and emits no instruction.  The host emulation (one thread per group) needs a real barrier.
+JB_D void wave_sync() { __builtin_amdgcn_wave_barrier(); }
 #endif
 
 JB_HD float sel(bool m, float a, float b) { return m ? a : b; }
