@@ -140,7 +140,7 @@ def main(argv=None):
     ap.add_argument("--augmented", action="store_true", help="one randomised model per env (BASELINE configs[4], augment_Jitterbug semantics)")
     ap.add_argument("--no-steady", action="store_true", help="skip the steady-state (steps 100-400) and full-episode blocks measured next to the headline")
     args = ap.parse_args(argv)
-    if not args.no_lean and not args.augmented and args.envs_per_gpu >= 8192:
+    if not args.no_lean and args.envs_per_gpu >= 8192:
         args.lean = True          # >= 2048 four-env waves: two resident per SIMD (every rank of a run makes the same choice: results stay independent of the split)
     task = args.task
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

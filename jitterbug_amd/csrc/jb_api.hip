@@ -50,10 +50,32 @@ struct KArgs {
 
 // Stage the packed constant table(s) of this workgroup (one wave = a.epw envs) into LDS: one LM_TABLE copy for a
 // shared model, epw copies for per-env models.  Called by all 64 threads before the idle quads retire.
+template <bool SPLIT = false>
 __device__ __forceinline__ void stage_model(const KArgs& a, float* lds, int lblock, int quad, int leg, LaneModel<float>& m, bool lean = false, bool pair = true) {
     m.c.lean = lean;
+    m.c.split = false;
     const int tsz = pair ? LM_TABLE : LM_TABLE_BASE, gsz = LM_TABLE;      // staged prefix / table pitch in global memory
-    if (a.per_env_model) {
+    if (SPLIT) {
+        // split mode (jb_sim.hpp LaneConsts): per env the hot prefix and the pair contact's entries only; the rest stays in global memory
+        const int env0 = lblock * a.epw, hot = LM_INV + 4 * (LM_HOT - LM_INV), ssz = LM_TABLE_SPLIT;
+        for (int i = threadIdx.x; i < ssz * a.epw; i += blockDim.x) {
+            int e = env0 + i / ssz;
+            if (e >= a.n) e = a.n - 1;
+            const int k = i % ssz;
+            int src = k;
+            if (k >= hot) {
+                const int h2 = (k - hot) >> 2, l = (k - hot) & 3;
+                const int ent = h2 < 11 ? LM_UC_D + h2 : LM_PE_C + (h2 - 11);
+                src = LM_INV + 4 * (ent - LM_INV) + l;
+            }
+            lds[i] = a.lane_model[(size_t)e * gsz + src];
+        }
+        __syncthreads();
+        m.c.inv = lds + quad * ssz;
+        m.c.split = true;
+        const int env = lblock * a.epw + quad;
+        m.c.cold = a.lane_model + (size_t)(env < a.n ? env : a.n - 1) * gsz + LM_INV + leg;
+    } else if (a.per_env_model) {
         const int env0 = lblock * a.epw;
         for (int i = threadIdx.x; i < tsz * a.epw; i += blockDim.x) {
             int e = env0 + i / tsz;
@@ -153,9 +175,8 @@ __device__ __forceinline__ void step_body(KArgs a, const float* __restrict__ act
     const int lblock = xcd * per + (xcd < rem ? xcd : rem) + (b >> 3);
     const int env = lblock * EPW + quad;
     LaneModel<float> m;
-    constexpr int SCN = LEAN ? SC_COUNT_LEAN : SC_COUNT;      // floats of per-lane scratch
-    static_assert(!(LEAN && PAIR), "the LEAN layout has no room for the pair contact");
-    stage_model(a, lds + SCN * 4 * EPW, lblock, quad, leg, m, LEAN, PAIR || !LEAN);
+    constexpr int SCN = LEAN ? (PAIR ? SC_COUNT_LEAN_PAIR : SC_COUNT_LEAN) : SC_COUNT;      // floats of per-lane scratch
+    stage_model<LEAN && PAIR>(a, lds + SCN * 4 * EPW, lblock, quad, leg, m, LEAN, PAIR || !LEAN);      // (LEAN + PAIR is only launched with one model per env: split tables)
     if (grp >= NGRP || env >= a.n) return;       // whole quads (and their mirrors in every group) retire together
     const bool live = true;
     const int lane = env * 4 + leg;
@@ -166,6 +187,7 @@ __device__ __forceinline__ void step_body(KArgs a, const float* __restrict__ act
     if (LEAN) { scr.ovc = a.ovc_buf + (size_t)lblock * (4 * (NSLOT - ROW_K) * MAIN) + lane_in_grp; scr.red_lds = false; }
     else { scr.ovc = lds + SC_OVC * MAIN + lane_in_grp; scr.red_lds = true; }
     scr.ovc_stride = MAIN;
+    scr.pd = LEAN ? SC_PD_LEAN : SC_PD;
 #ifdef JB_WAVE_STATS
     const unsigned long long t_start = __builtin_amdgcn_s_memtime();
 #endif
@@ -260,6 +282,14 @@ template <int EPW>
 __global__ __launch_bounds__(64) void jb_step_kernel_pair(KArgs a, const float* __restrict__ action, float* __restrict__ obs_out,
                                                           float* __restrict__ reward_out, unsigned char* __restrict__ done_out) {
     step_body<EPW, false, true>(a, action, obs_out, reward_out, done_out);
+}
+
+// LEAN + PAIR: one model per env on the two-waves-per-SIMD kernel (BASELINE configs[4]'s 8192-env shard).  Four 3 KB tables per wave do not
+// fit next to the scratch, so only the entries of the common path are staged (LaneConsts split mode): 25 KB per wave, six waves per CU.
+template <int EPW>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void jb_step_kernel_lean_pair(KArgs a, const float* __restrict__ action, float* __restrict__ obs_out,
+                                                                                                           float* __restrict__ reward_out, unsigned char* __restrict__ done_out) {
+    step_body<EPW, true, true>(a, action, obs_out, reward_out, done_out);
 }
 
 // ---------------------------------------------------------------------------------------------- reset / observe
@@ -820,8 +850,11 @@ static int launch_step(jb_handle* h, const float* d_action, float* d_obs_out, fl
     RoctxRange range("jb_step");
     h->ka.packed_rows = packed_rows;
     const dim3 grid((unsigned)((h->cfg.n_envs + h->ka.epw - 1) / h->ka.epw));
-    const bool use_lean = h->ka.lean && !h->ka.pair;
-    const size_t lds_bytes = ((size_t)(use_lean ? SC_COUNT_LEAN : SC_COUNT) * 4 * h->ka.epw + (size_t)(use_lean ? LM_TABLE_BASE : LM_TABLE) * (h->ka.per_env_model ? h->ka.epw : 1)) * sizeof(float);
+    // LEAN: the shared-model kernel without the pair contact, or - one model per env, four envs per wave - the LEAN + PAIR kernel
+    const bool lean_pair = h->ka.lean && h->ka.pair && h->ka.per_env_model && h->ka.epw == 4;
+    const bool use_lean = (h->ka.lean && !h->ka.pair) || lean_pair;
+    const size_t lds_bytes = lean_pair ? ((size_t)SC_COUNT_LEAN_PAIR * 4 * h->ka.epw + (size_t)LM_TABLE_SPLIT * h->ka.epw) * sizeof(float)
+                                       : ((size_t)(use_lean ? SC_COUNT_LEAN : SC_COUNT) * 4 * h->ka.epw + (size_t)(use_lean ? LM_TABLE_BASE : LM_TABLE) * (h->ka.per_env_model ? h->ka.epw : 1)) * sizeof(float);
     if (use_lean && !h->d_ovc) {      // the LEAN variant's overflow candidates (beyond the row cache): one block per wave
         const size_t waves = (size_t)grid.x, fl = waves * 4 * (NSLOT - ROW_K) * 4 * h->ka.epw;
         JB_HIP(hipMalloc(&h->d_ovc, fl * sizeof(float)));
@@ -830,7 +863,9 @@ static int launch_step(jb_handle* h, const float* d_action, float* d_obs_out, fl
 #define JB_LAUNCH_STEP(E) hipLaunchKernelGGL(jb_step_kernel<E>, grid, dim3(64), lds_bytes, h->stream, h->ka, d_action, d_obs_out, d_reward_out, d_done_out)
 #define JB_LAUNCH_LEAN(E) hipLaunchKernelGGL(jb_step_kernel_lean<E>, grid, dim3(64), lds_bytes, h->stream, h->ka, d_action, d_obs_out, d_reward_out, d_done_out)
 #define JB_LAUNCH_PAIR(E) hipLaunchKernelGGL(jb_step_kernel_pair<E>, grid, dim3(64), lds_bytes, h->stream, h->ka, d_action, d_obs_out, d_reward_out, d_done_out)
-    if (h->ka.pair && !h->ka.lean) {
+    if (lean_pair) {
+        hipLaunchKernelGGL(jb_step_kernel_lean_pair<4>, grid, dim3(64), lds_bytes, h->stream, h->ka, d_action, d_obs_out, d_reward_out, d_done_out);
+    } else if (h->ka.pair) {
         switch (h->ka.epw) {
         case 1: JB_LAUNCH_PAIR(1); break;
         case 2: JB_LAUNCH_PAIR(2); break;

@@ -100,7 +100,8 @@ enum LM : int {
     // once; the rest is stored per lane.  Packed table: [LM_INV] then [LM_COUNT - LM_INV][4]  = LM_TABLE floats per env.
     LM_INV = 49,
     LM_TABLE = LM_INV + 4 * (LM_COUNT - LM_INV),
-    LM_TABLE_BASE = LM_INV + 4 * (LM_PE_C - LM_INV)       // the table without the pair contact's entries (its tail): what the kernels without that contact stage into LDS
+    LM_TABLE_BASE = LM_INV + 4 * (LM_PE_C - LM_INV),      // the table without the pair contact's entries (its tail): what the kernels without that contact stage into LDS
+    LM_TABLE_SPLIT = LM_INV + 4 * (LM_HOT - LM_INV + 29)  // split mode: what is staged per env (the hot prefix + the pair contact's 29 entries)
 };
 JB_HD constexpr int lm_offset(int i, int leg) { return i < LM_INV ? i : LM_INV + 4 * (i - LM_INV) + leg; }
 
@@ -128,7 +129,19 @@ template <typename V> struct LaneConsts {
                                     // array so that the pick is a select of values, never an indexed access (which would
                                     // force the whole array into scratch memory)
     JB_HD V tran_of(int level) const { return level == 2 ? tran2 : level == 1 ? tran1 : level == 0 ? tran0 : tranm; }
-    JB_HD V table(int i) const { return i < LM_INV ? lane_bcast(inv + i, (V*)nullptr) : lane_from4(tab + 4 * (i - LM_INV), (V*)nullptr); }
+    // Split mode (LEAN kernel with one model per env): only the entries read on the common path are staged into LDS - the prefix
+    // [0, LM_HOT) and, behind it, the pair contact's (upper-leg cylinder, mass ellipsoid); the rest (all-geom path, broad-phase boxes) is
+    // read from the env's table in global memory where it is used.
+    const typename lane_traits<V>::real* cold = nullptr;
+    bool split = false;
+    static JB_HD constexpr int hot2_index(int i) { return (i >= LM_UC_D && i < LM_UC_D + 11) ? i - LM_UC_D : (i >= LM_PE_C && i < LM_PE_C + 18) ? 11 + i - LM_PE_C : -1; }
+    JB_HD V table(int i) const {
+        if (i < LM_INV) return lane_bcast(inv + i, (V*)nullptr);
+        if (!split || i < LM_HOT) return lane_from4(tab + 4 * (i - LM_INV), (V*)nullptr);
+        const int h2 = hot2_index(i);
+        if (h2 >= 0) return lane_from4(tab + 4 * (LM_HOT - LM_INV + h2), (V*)nullptr);
+        return lane_from4(cold + 4 * (i - LM_INV), (V*)nullptr);
+    }
     JB_HD void preload() {
         if (!lean) {
 #pragma unroll
@@ -288,7 +301,9 @@ enum SC : int {
     // registers are parked here between the phases that use them; no reduction hand-over (the totals are combined in registers), the
     // candidates beyond the row cache live in global memory (sc.ovc)
     SC_SYS = SC_VAR /*41: joint-space system (the root block without its structural zeros)*/, SC_FAC = SC_SYS + 41 /*43: kept factorisation*/, SC_LSTATE = SC_FAC + 43 /*36: lane state*/,
-    SC_COUNT_LEAN = SC_LSTATE + 36
+    SC_COUNT_LEAN = SC_LSTATE + 36,
+    // LEAN + PAIR (one model per env on the two-waves-per-SIMD kernel): the cross term's share of the parked factorisation, the pair's frame
+    SC_CX_LEAN = SC_COUNT_LEAN /*2*/, SC_PD_LEAN = SC_CX_LEAN + 2 /*9*/, SC_COUNT_LEAN_PAIR = SC_PD_LEAN + 9
 };
 template <typename V> struct LaneScratch {
     V* p;
@@ -298,6 +313,7 @@ template <typename V> struct LaneScratch {
     int grp, ngrp, gstride;   // group of this lane (0 = main), number of groups (1, 2 or 4), lane distance between groups
     V* ovc;                   // candidates of the live slots beyond the row cache: [i * ovc_stride], LDS (SC_OVC) or, in the LEAN variant, global memory
     int ovc_stride;
+    int pd;                   // where the pair contact's frame lives (SC_PD, or SC_PD_LEAN in the LEAN layout)
     bool red_lds;             // the group reduction hands its totals over through SC_RED (false: combined in registers, the LEAN variant has no room for the buffer)
     JB_HD V ld(int i) const { return p[i * stride]; }
     JB_HD void st(int i, const V& v) const { p[i * stride] = v; }
@@ -529,7 +545,7 @@ JB_HD constexpr int slot_level(int slot) { return slot < 5 ? 2 : slot < 10 ? 1 :
 template <typename V> struct RowVals { Vec3<V> x; V D; V jsh[3], j7[3], ah[3]; };
 
 // The pair contact's rows: relative motion of the upper leg (geom2's body: + shoulder column) and the motor body (geom1's: - motor
-// column) at the contact point along the pair's own frame (SC_PD); the root columns cancel (contact_apply masks them).
+// column) at the contact point along the pair's own frame (sc.pd); the root columns cancel (contact_apply masks them).
 template <typename V>
 JB_HD void pair_row_values(const LaneModel<V>& m, const LaneScratch<V>& sc, const Vec3<V>& x, const V& dist, RowVals<V>& r) {
     const V thd1 = sc.ld(SC_ST + 3), phid = sc.ld(SC_ST + 5);
@@ -543,7 +559,7 @@ JB_HD void pair_row_values(const LaneModel<V>& m, const LaneScratch<V>& sc, cons
     const Vec3<V> pm = cross(ldv3(m, LM_EM), x - ldv3(m, LM_AM));              // em x (x - am)
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-        const Vec3<V> d = sc.ld3(SC_PD + 3 * k);
+        const Vec3<V> d = sc.ld3(sc.pd + 3 * k);
         r.jsh[k] = dot(d, p1); r.j7[k] = -dot(d, pm);
         r.ah[k] = -m.c[LM_BB] * (r.jsh[k] * thd1 + r.j7[k] * phid);
         if (k == 0) r.ah[k] = r.ah[k] - m.c[LM_KK] * imp * dist;
@@ -1069,6 +1085,8 @@ template <typename V> JB_HD void sys_load(const LaneScratch<V>& sc, StarSys<V>& 
     y.C[0] = sc.ld(SC_SYS + 22); y.C[1] = sc.ld(SC_SYS + 23); y.C[2] = sc.ld(SC_SYS + 24); y.Cm = sc.ld(SC_SYS + 31);
     y.tl[0] = sc.ld(SC_SYS + 38); y.tl[1] = sc.ld(SC_SYS + 39); y.tm = sc.ld(SC_SYS + 40);
 }
+template <typename V> JB_HD void fac_store_cx(const LaneScratch<V>& sc, const StarFactor<V>& F) { sc.st(SC_CX_LEAN, F.cx0); sc.st(SC_CX_LEAN + 1, F.cx1); }
+template <typename V> JB_HD void fac_load_cx(const LaneScratch<V>& sc, StarFactor<V>& F) { F.cx0 = sc.ld(SC_CX_LEAN); F.cx1 = sc.ld(SC_CX_LEAN + 1); }
 template <typename V> JB_HD void fac_store(const LaneScratch<V>& sc, const StarFactor<V>& F) {
 #pragma unroll
     for (int i = 0; i < 21; i++) sc.st(SC_FAC + i, F.S[i]);
@@ -1292,7 +1310,7 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
                         const Vec3<V> ys = sel_v3(lt(vabs(ny), V(0.5)), wy, nb);
                         Vec3<V> t1 = ys - pn * dot(pn, ys);
                         t1 = t1 * vrsqrt(vmax(dot(t1, t1), V(1e-30)));
-                        sc.st3(SC_PD, pn); sc.st3(SC_PD + 3, t1); sc.st3(SC_PD + 6, cross(pn, t1));
+                        sc.st3(sc.pd, pn); sc.st3(sc.pd + 3, t1); sc.st3(sc.pd + 6, cross(pn, t1));
                     }
                 }
                 live_slots |= cand_store(sc, live_slots, SLOT_PAIR, ppos, pdist, pon);
@@ -1497,7 +1515,7 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
                             full = any_lane(mand(unconverged, mnot(fast_env))) ? 1u : 0u;
                             if (any_lane(fast_env)) {
                                 V fyr[6], fyl[2], fym;
-                                if (o.lean) fac_load(sc, fac);
+                                if (o.lean) { fac_load(sc, fac); if (PAIR) fac_load_cx(sc, fac); }
                                 rank_one_pass<V, PAIR>(sc, fac, dk, m.c[LM_MU], f_entry, f_is, f_plus, f_tan2, f_on, yr, yl, ym, fyr, fyl, fym);
 #pragma unroll
                                 for (int i = 0; i < 6; i++) yr[i] = sel(fast_env, fyr[i], yr[i]);
@@ -1549,7 +1567,7 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
                     if (full_pass) {
                         if (o.lean) sys_load(sc, sys);
                         star_solve<V, PAIR>(sys, acc, V(0), V(0), fac, nyr, nyl, nym);
-                        if (o.lean) fac_store(sc, fac);
+                        if (o.lean) { fac_store(sc, fac); if (PAIR) fac_store_cx(sc, fac); }
                         JB_PROF_ADD(o, 6);
                         // envs whose active set already repeated keep their (exact) solution, rank-one envs theirs
                         const MK take = mand(unconverged, mnot(fast_env));

@@ -711,6 +711,18 @@ static int collide(const double* P, const Kin* k, int feet_only, int pair_contac
             cgeom_world(P, k, g, &c);
             double d[3] = {c.c[0] - e.c[0], c.c[1] - e.c[1], c.c[2] - e.c[2]};
             if (sqrt(dot3(d, d)) > cgeom_rbound(&e) + cgeom_rbound(&c)) continue;
+            {   /* a second, tight filter (not MuJoCo's; it only saves this oracle the narrow phase where the answer is "apart by more than
+                 * 0.2 mm"): the cylinder's axis segment against the ellipsoid with semi-axes s + r_cyl + 0.2 mm, in that ellipsoid's unit-sphere
+                 * coordinates - the same test the HIP kernel's broad phase makes */
+                double cl[3], ul[3], ax[3] = {c.R[2], c.R[5], c.R[8]}, cs[3], us[3], p[3];
+                matTvec3(cl, e.R, d);
+                matTvec3(ul, e.R, ax);
+                for (int i = 0; i < 3; i++) { double is = 1.0 / (e.sz[i] + c.sz[0] + 2e-4); cs[i] = cl[i] * is; us[i] = ul[i] * is; }
+                double t = -dot3(cs, us) / dot3(us, us);
+                t = t < -c.sz[1] ? -c.sz[1] : (t > c.sz[1] ? c.sz[1] : t);
+                for (int i = 0; i < 3; i++) p[i] = cs[i] + t * us[i];
+                if (dot3(p, p) >= 1.0) { MARGIN(2e-4); continue; }
+            }
             double dist, dir[3], pos[3];
             pair_geometric(&e, &c, &dist, dir, pos);
             MARGIN(dist);

@@ -38,11 +38,11 @@ static int run(const double* P, double* qpos, double* qvel, double ctrl, int nsu
     for (int i = 0; i < 3; i++) { s.wa[i] = V(T(0)); s.wl[i] = V(T(0)); }
     s.wj[0] = s.wj[1] = V(T(0)); s.wm = V(T(0)); s.fail = V(T(0));
     SimOpts o; o.contacts = contacts; o.max_newton = max_newton; o.implicit_damp = implicit_damp; o.rank_one = rank_one; o.lean = lean; o.prof = nullptr; o.hist = nullptr;
-    constexpr int SCMAX = SC_COUNT > SC_COUNT_LEAN ? SC_COUNT : SC_COUNT_LEAN;
+    constexpr int SCMAX = SC_COUNT > SC_COUNT_LEAN_PAIR ? SC_COUNT : SC_COUNT_LEAN_PAIR;
     V scratch[SCMAX];                  // (the LEAN variant parks state / system / factorisation where the ordinary one has its reduction buffer and overflow candidates)
     V ovcbuf[4 * (NSLOT - ROW_K)];     // LEAN: the candidates beyond the row cache live outside the scratch (global memory on the device)
     auto set_ovc = [&](LaneScratch<V>& sc) {
-        sc.ovc = lean ? ovcbuf : scratch + SC_OVC; sc.ovc_stride = 1; sc.red_lds = !lean;
+        sc.ovc = lean ? ovcbuf : scratch + SC_OVC; sc.ovc_stride = 1; sc.red_lds = !lean; sc.pd = lean ? SC_PD_LEAN : SC_PD;
     };
     normalise_state(s);
     if (ngroups <= 1) {
@@ -120,6 +120,12 @@ extern "C" int jbh_step_pair(const double* P, double* qpos, double* qvel, double
     if (ngroups != 1 && ngroups != 4) return -101;
     return use_float ? run<float>(P, qpos, qvel, ctrl, nsub, contacts, max_newton, 1, fail, ngroups, rank_one, 0, 1)
                      : run<double>(P, qpos, qvel, ctrl, nsub, contacts, max_newton, 1, fail, ngroups, rank_one, 0, 1);
+}
+// ... and PAIR in the LEAN layout (parked state / system / factorisation incl. the cross term's share, pair frame behind them)
+extern "C" int jbh_step_pair_lean(const double* P, double* qpos, double* qvel, double ctrl, int nsub, int contacts, int max_newton, int use_float, int ngroups, int rank_one, double* fail) {
+    if (ngroups != 1 && ngroups != 4) return -101;
+    return use_float ? run<float>(P, qpos, qvel, ctrl, nsub, contacts, max_newton, 1, fail, ngroups, rank_one, 1, 1)
+                     : run<double>(P, qpos, qvel, ctrl, nsub, contacts, max_newton, 1, fail, ngroups, rank_one, 1, 1);
 }
 extern "C" int jbh_lm_count(void) { return LM_COUNT; }
 // the per-leg constant table (LM_COUNT doubles) for inspection by tests / tools

@@ -167,7 +167,8 @@ def test_device_randomiser_at_config5_size():
 
 
 @pytest.mark.gpu
-def test_config5_shard_8192_device_models_against_the_oracle():
+@pytest.mark.parametrize("variant", ["ordinary", "lean"])
+def test_config5_shard_8192_device_models_against_the_oracle(variant):
     """BASELINE configs[4]'s per-GPU shard as it really runs: 8192 envs, one DEVICE-generated model each (every draw kept: 3.6 % of
     the robots touch a front leg with their eccentric mass, simulated by the PAIR kernel), per-env constant tables staged in LDS by 2048 full waves, 200 control steps of the open-loop rollout.  A 64-env subset
     spread over the batch is held against the oracle every step, from the GPU's own pre-step state (teacher-forced the other way
@@ -175,7 +176,9 @@ def test_config5_shard_8192_device_models_against_the_oracle():
     from jitterbug_amd.vec_env import JitterbugVecEnv
     from oracle import oracle as O
     n, steps, task = 8192, 200, "move_to_pose"
-    env = JitterbugVecEnv(n, task, seed=3, auto_reset=False)
+    # variant "lean": JB_FLAG_LEAN - with one model per env that is the LEAN + PAIR kernel (two waves per SIMD, only the common path's
+    # table entries staged in LDS, the rest read from the env's table in global memory)
+    env = JitterbugVecEnv(n, task, seed=3, auto_reset=False, flags=2 if variant == "lean" else 0)
     out = env.randomise_models(seed=77, return_params=True)                  # the reference's distribution, every draw kept
     P = out["params"]
     assert P.shape == (n, model.NPARAM) and (out["attempts"] == 1).all()
