@@ -140,8 +140,11 @@ def main(argv=None):
     ap.add_argument("--augmented", action="store_true", help="one randomised model per env (BASELINE configs[4], augment_Jitterbug semantics)")
     ap.add_argument("--no-steady", action="store_true", help="skip the steady-state (steps 100-400) and full-episode blocks measured next to the headline")
     args = ap.parse_args(argv)
-    if not args.no_lean and args.envs_per_gpu >= 8192:
-        args.lean = True          # >= 2048 four-env waves: two resident per SIMD (every rank of a run makes the same choice: results stay independent of the split)
+    if not args.no_lean and args.envs_per_gpu >= (16384 if args.augmented else 8192):
+        # >= 2048 four-env waves: two resident per SIMD (every rank of a run makes the same choice: results stay independent of the split).
+        # One model per env: the LEAN + PAIR kernel holds six waves per CU (25 KB each), which pays from 16 384 envs per GPU on (measured:
+        # 8192: 4.45 -> 4.48 M, 16 384: 5.55 -> 6.26 M)
+        args.lean = True
     task = args.task
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return self_launch(args.gpus, argv)          # before anything imports torch or initialises HIP in this process
