@@ -192,7 +192,8 @@ __device__ __forceinline__ void step_body(KArgs a, const float* __restrict__ act
     const unsigned long long t_start = __builtin_amdgcn_s_memtime();
 #endif
     LaneState<float> s;
-    if (grp == 0) load_state(a, env, lane, s);
+    constexpr bool OFFLOAD = !LEAN;              // lane group 1 replicates the main lanes (jb_sim.hpp SimOpts::offload)
+    if (grp == 0 || (OFFLOAD && grp == 1)) load_state(a, env, lane, s);
     else {
         s.px = s.py = s.pz = 0.f; s.qw = 1.f; s.qx = s.qy = s.qz = 0.f; s.vx = s.vy = s.vz = s.wx = s.wy = s.wz = 0.f;
         s.pz_lo = s.qw_lo = s.qx_lo = s.qy_lo = s.qz_lo = 0.f;
@@ -204,7 +205,7 @@ __device__ __forceinline__ void step_body(KArgs a, const float* __restrict__ act
     s.st_xtra = 0.f; s.st_sweeps = 0.f; s.st_contact = 0.f; s.st_slots = 0.f; s.st_fast = 0.f; s.st_checks = 0.f;
 #endif
     const float ctrl = action[env];
-    SimOpts o; o.contacts = a.contacts; o.max_newton = a.max_newton; o.implicit_damp = 1; o.rank_one = a.rank_one; o.lean = LEAN ? 1 : 0; o.prof = nullptr; o.hist = nullptr;
+    SimOpts o; o.contacts = a.contacts; o.max_newton = a.max_newton; o.implicit_damp = 1; o.rank_one = a.rank_one; o.lean = LEAN ? 1 : 0; o.offload = OFFLOAD ? 1 : 0; o.prof = nullptr; o.hist = nullptr;
 #ifdef JB_WAVE_STATS
     const unsigned long long rt_start = __builtin_amdgcn_s_memrealtime();
     unsigned long long prof_local[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // accumulated in registers, written once at the end
@@ -213,6 +214,10 @@ __device__ __forceinline__ void step_body(KArgs a, const float* __restrict__ act
 #endif
     normalise_state(s);          // mj_kinematics normalises the free-joint quaternion; phase C keeps it normalised from here on
     if (LEAN && grp == 0) state_store(scr, s);                   // LEAN: the state lives in the scratch between substeps
+    if (OFFLOAD && grp == 0) {
+#pragma unroll
+        for (int i = 0; i < 56; i++) scr.st(SC_ZERO + i, 0.f);
+    }
 #pragma unroll 1
     for (int k = 0; k < a.substeps; k++) substep<float, PAIR>(m, scr, s, ctrl, o);
     if (grp != 0) return;                        // helper lanes only take part in the substeps

@@ -296,7 +296,8 @@ enum SC : int {
     SC_RED = SC_VAR /*56: hand-over of the group reduction's totals to the main lanes*/,
     SC_OVC = SC_RED + 56 /*(NSLOT - ROW_K) x 4: candidates of the live slots beyond the row cache (sc.ovc points here)*/,
     SC_PD = SC_OVC + 4 * (NSLOT - ROW_K) /*9: contact frame (n, t1, t2) of the pair contact, root coordinates*/,
-    SC_COUNT = SC_PD + 9,
+    SC_ZERO = SC_PD + 9 /*56 zeros, written once per kernel: what the replica group reads where the main lanes read the reduction's totals (SimOpts::offload)*/,
+    SC_COUNT = SC_ZERO + 56,
     // ---- LEAN kernel variant (two waves per SIMD: 20 KB of LDS per wave): long-lived values that the one-wave-per-SIMD kernel keeps in
     // registers are parked here between the phases that use them; no reduction hand-over (the totals are combined in registers), the
     // candidates beyond the row cache live in global memory (sc.ovc)
@@ -817,8 +818,11 @@ JB_HD void contact_rows_build_all(const LaneModel<V>& m, const LaneScratch<V>& s
 // every live candidate slot against the iterate y kept in the scratch (SC_Y); with helper groups the partial sums of the
 // groups are combined by cross-lane exchanges so that every group ends with the complete accumulator
 template <typename V, bool PAIR = false>
-JB_HD void contact_sweep(const LaneModel<V>& m, const LaneScratch<V>& sc, bool xtra, const SlotPlan& plan, int mode, const Vec3<V> (&dk)[3], NewtonAcc<V>& acc) {
-    if (!plan.grouped && sc.grp != 0) return;
+JB_HD void contact_sweep(const LaneModel<V>& m, const LaneScratch<V>& sc, bool xtra, const SlotPlan& plan, int mode, const Vec3<V> (&dk)[3], NewtonAcc<V>& acc, const bool zero_g1 = false) {
+    // zero_g1 (SimOpts::offload): group 1 must leave with an all-zero accumulator - it factorises M + h diag(b)
+    // with the instruction stream that factorises the main lanes' Newton system (substep_impl)
+    const bool g1z = zero_g1 && sc.grp == 1;
+    if (!plan.grouped && sc.grp != 0 && !g1z) return;
     if (mode == 2) { acc.bw0 = zero_u<V>(); acc.bw1 = zero_u<V>(); acc.xh = zero_u<V>(); }      // the check only records the active set
     else acc_clear(acc);
     const V mu = m.c[LM_MU];
@@ -830,7 +834,7 @@ JB_HD void contact_sweep(const LaneModel<V>& m, const LaneScratch<V>& sc, bool x
 #pragma unroll 1
     for (int r = 0; r < plan.rounds; r++) {
         const int mine = plan_slot(plan, g, r);
-        const bool lane_on = mine >= 0;
+        const bool lane_on = mine >= 0 && !(g1z && !plan.grouped);       // (no helper groups this substep: group 1 only rides along for its zeros)
         const int slot = lane_on ? mine : __builtin_ctz(plan.live);       // idle lanes read some valid entry and contribute nothing
         const int rank = plan_rank(plan, slot);
         RowVals<V> rv;
@@ -855,9 +859,10 @@ JB_HD void contact_sweep(const LaneModel<V>& m, const LaneScratch<V>& sc, bool x
 #pragma unroll
             for (int k = 0; k < NQ4; k++) sc.st(SC_RED + 4 * k + sc.grp, row_transpose_sum(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]));
             wave_sync();          // every group's totals are in the scratch
-            if (sc.grp == 0) {
+            if (sc.grp == 0 || g1z) {
+                const int src = g1z ? SC_ZERO : SC_RED;        // per lane: the same loads, another base address
 #pragma unroll
-                for (int i = 0; i < (PAIR ? 53 : 52); i++) v[i] = sc.ld(SC_RED + i);
+                for (int i = 0; i < (PAIR ? 53 : 52); i++) v[i] = sc.ld(src + i);
                 acc_unpack(v, acc);
                 if (PAIR) acc.X = v[52];
             }
@@ -869,6 +874,7 @@ JB_HD void contact_sweep(const LaneModel<V>& m, const LaneScratch<V>& sc, bool x
             acc.C11 = group_sum(sc, acc.C11); acc.C12 = group_sum(sc, acc.C12); acc.C22 = group_sum(sc, acc.C22); acc.Cm = group_sum(sc, acc.Cm);
             acc.rl[0] = group_sum(sc, acc.rl[0]); acc.rl[1] = group_sum(sc, acc.rl[1]); acc.rm = group_sum(sc, acc.rm);
             if (PAIR) acc.X = group_sum(sc, acc.X);
+            if (g1z) acc_clear(acc);
         }
     }
 }
@@ -1037,6 +1043,11 @@ struct SimOpts {
     int rank_one;        // 1: single-edge changes of the active set are rank-one passes (0: diagnostic, always full passes)
     int lean = 0;        // 1: LEAN kernel variant - the lane state, the joint-space system and the kept factorisation live in the scratch
                          //    between the phases that use them (register budget of two waves per SIMD); same arithmetic, same results
+    int offload = 0;     // 1 (one-wave-per-SIMD kernels with helper groups): lane group 1 is a full REPLICA of the main lanes - it loads the same state
+                         //    and runs phase A and phase C with them, instruction for instruction, so that it holds the joint-space system too.
+                         //    While the main lanes factorise the first Newton system of a substep, the replica factorises M + h diag(b) with the
+                         //    very same instructions (zero accumulator, hb on its diagonal); the final pass is then a substitution in the replica
+                         //    and a 9-value hand-over instead of a second factorisation on the critical path.  Bit-identical results.
     unsigned long long* prof;   // diagnostic builds: per-wave cycle accumulators [phaseA, check sweeps, full sweeps, solves, integrate]
     unsigned long long* hist;   // diagnostic builds: per-wave [0..27] live-slot counts over all-geom substeps, [28..35] rounds histogram, [36..43] same for ordinary substeps
 };
@@ -1167,8 +1178,10 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
     JB_PROF_T0();
 
     const bool is_main = (sc.grp == 0);
-    StarSys<V> sys;     // written and read by the main lanes only
-    if (is_main) {   // ================= phase A: kinematics, composite inertia, bias forces, contact candidates -> scratch
+    const bool g1 = o.offload && sc.grp == 1;       // the replica group (its LDS stores repeat the main lanes': same address, same value)
+    const bool rep = is_main || g1;
+    StarSys<V> sys;     // written and read by the main lanes (and their replica) only
+    if (rep) {   // ================= phase A: kinematics, composite inertia, bias forces, contact candidates -> scratch
         sc.st3(SC_ST, w); sc.st(SC_ST + 3, s.thd1); sc.st(SC_ST + 4, s.thd2); sc.st(SC_ST + 5, s.phid);      // for the helper groups
         const Mat3<V>& R = Rw;                                       // root rotation of the normalised quaternion (substep())
         Vec3<V> nb = v3<V>(R.m[6], R.m[7], R.m[8]);                 // R^T ez
@@ -1432,7 +1445,7 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
         NewtonAcc<V> acc;
         StarFactor<V> fac;      // factorisation of the last Newton system (main lanes)
         Vec3<V> dk[3];
-        bool final_pass = !any_contact, full_pass = true;
+        bool final_pass = !any_contact;
         MK unconverged = lt(V(0), V(1));
         MK fac_valid = lt(V(1), V(0)), fast_env = lt(V(1), V(0));
         U prev_bw0 = zero_u<V>(), prev_bw1 = zero_u<V>(), prev_xh = zero_u<V>();
@@ -1454,14 +1467,61 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
             acc_clear(acc);
         }
         const V hb1 = o.implicit_damp ? h * m.c[LM_B1] : V(0), hb2 = o.implicit_damp ? h * m.c[LM_B2] : V(0);
+        // offload: the replica leaves every full pass with the factorisation of M + h diag(b).  A wave without any contact makes one turn of the
+        // outer loop too (no sweep, zero accumulator), so that this factorisation always comes from the SAME instructions: an env's bits must
+        // not depend on whether a wave-mate has a contact (two inlined copies of one expression may fuse their multiply-adds differently).
+        const bool have_dfac = o.offload != 0;
 #ifdef JB_WAVE_STATS
         if (is_main && any_contact) { s.st_contact = s.st_contact + V(1); s.st_slots = s.st_slots + V((float)__builtin_popcount(plan.live)); }
         stats_hist(o, sc, plan, xtra, any_contact);
 #endif
+        // Two nested loops.  OUTER: one FULL pass per turn - a sweep over every live slot and a new factorisation, always at the top, so that
+        // the factorisation object has a single definition per turn (a conditional redefinition inside one loop costs a register copy per
+        // value and iteration once the object is live after the loop, as the replica's is).  INNER: checks of the active set at the new
+        // iterate, with rank-one passes while every env that still moves differs from its factorisation by a single pyramid edge.
+        int it = 0;
+        if (any_contact || have_dfac) {
 #pragma unroll 1
-        for (int it = 0;; it++) {
-            if (!final_pass) {
-                if (it > 0) {
+            for (;;) {
+                // ---- full pass (reads the iterate of the last check from the scratch: rank-one results are stored only after this pass)
+                if (any_contact) {
+                    contact_sweep<V, PAIR>(m, sc, xtra, plan, 0, dk, acc, have_dfac);
+                    prev_bw0 = acc.bw0; prev_bw1 = acc.bw1; prev_xh = acc.xh;
+                    JB_PROF_ADD(o, 2);
+#ifdef JB_WAVE_STATS
+                    if (is_main) s.st_sweeps = s.st_sweeps + V(1);
+#endif
+                }
+                if (o.offload || is_main) {
+                    V nyr[6], nyl[2], nym;
+                    if (o.lean) sys_load(sc, sys);
+                    // offload: EVERY lane runs this - the replica on M + h diag(b) (zero accumulator from the sweep, hb on its diagonal), in
+                    // every full pass; the other helper groups on whatever their registers hold (nobody reads their result).  No lane
+                    // predicate on register-only work.
+                    const V hx1 = g1 ? hb1 : V(0), hx2 = g1 ? hb2 : V(0);
+                    star_solve<V, PAIR>(sys, acc, hx1, hx2, fac, nyr, nyl, nym);
+                    if (o.lean) { fac_store(sc, fac); if (PAIR) fac_store_cx(sc, fac); }
+                    JB_PROF_ADD(o, 6);
+                    if (is_main) {
+                        // envs whose active set already repeated keep their (exact) solution, rank-one envs theirs
+                        const MK take = mand(unconverged, mnot(fast_env));
+#pragma unroll
+                        for (int i = 0; i < 6; i++) yr[i] = sel(take, nyr[i], yr[i]);
+                        yl[0] = sel(take, nyl[0], yl[0]); yl[1] = sel(take, nyl[1], yl[1]); ym = sel(take, nym, ym);
+                        fac_valid = mnot(fast_env);         // a rank-one env's factorisation is one edge behind its set
+#pragma unroll
+                        for (int i = 0; i < 6; i++) sc.st(SC_Y + i, yr[i]);
+                        sc.st(SC_Y + 6, yl[0]); sc.st(SC_Y + 7, yl[1]); sc.st(SC_Y + 8, ym);
+                    }
+                }
+                JB_PROF_ADD(o, 3);
+                wave_sync();          // new iterate stored by the main lanes -> read by every group's next sweep
+                if (!any_contact) break;      // (nothing to iterate on: the turn was for the replica's factorisation)
+                // ---- checks (and rank-one passes) until the sets repeat or some env needs a full pass
+                bool full_pass = false;
+#pragma unroll 1
+                for (;;) {
+                    it++;
                     // cheap pass: only the active set at the new iterate.  The ENV's set changed if any lane of the quad
                     // saw a different record; when nobody's changed, every y is the exact minimiser
                     contact_sweep<V, PAIR>(m, sc, xtra, plan, 2, dk, acc);
@@ -1474,25 +1534,25 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
                         MK changed = mor(mor(neq_u(acc.bw0, prev_bw0), neq_u(acc.bw1, prev_bw1)), neq_u(acc.xh, prev_xh));
                         unconverged = neq_u(quad_sum_u(mbit(changed)), zero_u<V>());
 #if defined(JB_WAVE_STATS) && defined(__HIPCC__)
-                        if (o.hist && !xtra) {      // how many active-set bits flipped per unconverged env (ordinary substeps: exact records)
-                            const unsigned fl = quad_sum_u((unsigned)__builtin_popcount(acc.bw0 ^ prev_bw0));
-                            const bool unc = unconverged;
-                            const unsigned long long m_unc = __builtin_amdgcn_ballot_w64(unc), m_multi = __builtin_amdgcn_ballot_w64(unc && fl > 1u);
-                            const unsigned long long m1 = __builtin_amdgcn_ballot_w64(unc && fl == 1u), m2 = __builtin_amdgcn_ballot_w64(unc && fl == 2u), m3 = __builtin_amdgcn_ballot_w64(unc && fl == 3u), m4 = __builtin_amdgcn_ballot_w64(unc && fl >= 4u);
-                            if ((threadIdx.x & 63) == 0 && m_unc) {
-                                o.hist[44] += 1ull; if (!m_multi) o.hist[45] += 1ull;
-                                o.hist[46] += __builtin_popcountll(m1) / 4; o.hist[47] += __builtin_popcountll(m2) / 4; o.hist[48] += __builtin_popcountll(m3) / 4; o.hist[49] += __builtin_popcountll(m4) / 4;
-                            }
-                            // of the multi-flip envs: those whose flips sit in different lanes (at most one per leg) - what a per-lane rank-k pass could take
-                            const unsigned lane_fl = (unsigned)__builtin_popcount(acc.bw0 ^ prev_bw0) + (unsigned)__builtin_popcount(acc.bw1 ^ prev_bw1);
-                            const bool spread = quad_sum_u(lane_fl > 1u ? 1u : 0u) == 0u;
-                            const unsigned long long m_sp = __builtin_amdgcn_ballot_w64(unc && fl > 1u && spread), m_sp2 = __builtin_amdgcn_ballot_w64(unc && fl == 2u && spread);
-                            const unsigned long long m_bad = __builtin_amdgcn_ballot_w64(unc && !spread);
-                            if ((threadIdx.x & 63) == 0 && m_unc) {
-                                o.hist[50] += __builtin_popcountll(m_sp) / 4; o.hist[51] += __builtin_popcountll(m_sp2) / 4;
-                                if (m_multi && !m_bad) o.hist[52] += 1ull;          // a changed-set check that needs a full pass today and would not with per-lane rank-k
-                            }
-                        }
+                                            if (o.hist && !xtra) {      // how many active-set bits flipped per unconverged env (ordinary substeps: exact records)
+                                                const unsigned fl = quad_sum_u((unsigned)__builtin_popcount(acc.bw0 ^ prev_bw0));
+                                                const bool unc = unconverged;
+                                                const unsigned long long m_unc = __builtin_amdgcn_ballot_w64(unc), m_multi = __builtin_amdgcn_ballot_w64(unc && fl > 1u);
+                                                const unsigned long long m1 = __builtin_amdgcn_ballot_w64(unc && fl == 1u), m2 = __builtin_amdgcn_ballot_w64(unc && fl == 2u), m3 = __builtin_amdgcn_ballot_w64(unc && fl == 3u), m4 = __builtin_amdgcn_ballot_w64(unc && fl >= 4u);
+                                                if ((threadIdx.x & 63) == 0 && m_unc) {
+                                                    o.hist[44] += 1ull; if (!m_multi) o.hist[45] += 1ull;
+                                                    o.hist[46] += __builtin_popcountll(m1) / 4; o.hist[47] += __builtin_popcountll(m2) / 4; o.hist[48] += __builtin_popcountll(m3) / 4; o.hist[49] += __builtin_popcountll(m4) / 4;
+                                                }
+                                                // of the multi-flip envs: those whose flips sit in different lanes (at most one per leg) - what a per-lane rank-k pass could take
+                                                const unsigned lane_fl = (unsigned)__builtin_popcount(acc.bw0 ^ prev_bw0) + (unsigned)__builtin_popcount(acc.bw1 ^ prev_bw1);
+                                                const bool spread = quad_sum_u(lane_fl > 1u ? 1u : 0u) == 0u;
+                                                const unsigned long long m_sp = __builtin_amdgcn_ballot_w64(unc && fl > 1u && spread), m_sp2 = __builtin_amdgcn_ballot_w64(unc && fl == 2u && spread);
+                                                const unsigned long long m_bad = __builtin_amdgcn_ballot_w64(unc && !spread);
+                                                if ((threadIdx.x & 63) == 0 && m_unc) {
+                                                    o.hist[50] += __builtin_popcountll(m_sp) / 4; o.hist[51] += __builtin_popcountll(m_sp2) / 4;
+                                                    if (m_multi && !m_bad) o.hist[52] += 1ull;          // a changed-set check that needs a full pass today and would not with per-lane rank-k
+                                                }
+                                            }
 #endif
                         if (!any_lane(unconverged) || it >= o.max_newton) {
                             if (o.lean) fail_inc = fail_inc + sel(unconverged, V(1), V(0)); else s.fail = s.fail + sel(unconverged, V(1), V(0));
@@ -1529,69 +1589,70 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
                     }
                     final_pass = wave_bcast_u(fin) != 0u;
                     full_pass = wave_bcast_u(full) != 0u;
-                }
-                if (!final_pass && full_pass) {
-                    // (reads the iterate of the check from the scratch: rank-one results are stored only after this pass)
-                    contact_sweep<V, PAIR>(m, sc, xtra, plan, 0, dk, acc);
-                    prev_bw0 = acc.bw0; prev_bw1 = acc.bw1; prev_xh = acc.xh;
-                    JB_PROF_ADD(o, 2);
-#ifdef JB_WAVE_STATS
-                    if (is_main) s.st_sweeps = s.st_sweeps + V(1);
-#endif
-                } else if (final_pass && is_main) {
-                    if (o.lean) sys_load(sc, sys);
-                    // At the minimiser  H y = tau + sum B^T W ahat,  so the constraint force is  qfrc = M y - tau  and MuJoCo's
-                    // Euler step with implicit joint damping solves  (M + h diag(b)) qacc = tau + qfrc = M y,  i.e.
-                    //     qacc = y - d,   (M + h diag(b)) d = h diag(b) y        (nonzero only in the leg rows).
-                    // star_solve adds tau itself, so the contact envs cancel it (replicated parts enter the quad sums as 1/4).
-                    // An env without contacts has qfrc = 0 exactly, whatever the rest of its wave is doing: plain solve.
-#pragma unroll
-                    for (int i = 0; i < 6; i++) acc.rr[i] = sel(env_con, V(-0.25) * sys.tr[i], V(0));
-                    acc.rl[0] = sel(env_con, hb1 * yl[0] - sys.tl[0], V(0));
-                    acc.rl[1] = sel(env_con, hb2 * yl[1] - sys.tl[1], V(0));
-                    acc.rm = sel(env_con, V(-0.25) * sys.tm, V(0));
-                }
-            }
-            JB_PROF_ADD(o, 7);
-            if (is_main) {
-                V nyr[6], nyl[2], nym;
-                if (final_pass) {
-                    if (o.lean) sys_load(sc, sys);
-                    star_factor<V, false>(sys, acc, hb1, hb2, fac);           // acc holds only right-hand sides here
-                    star_subst<V>(fac, acc.rr, sys.tr, sys.tl[0] + acc.rl[0], sys.tl[1] + acc.rl[1], sys.tm + quad_sum(acc.rm), nyr, nyl, nym);
-                    JB_PROF_ADD(o, 6);
-#pragma unroll
-                    for (int i = 0; i < 6; i++) yr[i] = sel(env_con, yr[i] - nyr[i], nyr[i]);
-                    yl[0] = sel(env_con, yl[0] - nyl[0], nyl[0]); yl[1] = sel(env_con, yl[1] - nyl[1], nyl[1]); ym = sel(env_con, ym - nym, nym);
-                } else {
-                    if (full_pass) {
-                        if (o.lean) sys_load(sc, sys);
-                        star_solve<V, PAIR>(sys, acc, V(0), V(0), fac, nyr, nyl, nym);
-                        if (o.lean) { fac_store(sc, fac); if (PAIR) fac_store_cx(sc, fac); }
-                        JB_PROF_ADD(o, 6);
-                        // envs whose active set already repeated keep their (exact) solution, rank-one envs theirs
-                        const MK take = mand(unconverged, mnot(fast_env));
-#pragma unroll
-                        for (int i = 0; i < 6; i++) yr[i] = sel(take, nyr[i], yr[i]);
-                        yl[0] = sel(take, nyl[0], yl[0]); yl[1] = sel(take, nyl[1], yl[1]); ym = sel(take, nym, ym);
-                        fac_valid = mnot(fast_env);         // a rank-one env's factorisation is one edge behind its set
-                    } else {
+                    JB_PROF_ADD(o, 7);
+                    if (final_pass || full_pass) break;
+                    if (is_main) {      // rank-one passes only: their iterates go to the scratch for the next check
                         fac_valid = mand(fac_valid, mnot(fast_env));
-                    }
 #pragma unroll
-                    for (int i = 0; i < 6; i++) sc.st(SC_Y + i, yr[i]);
-                    sc.st(SC_Y + 6, yl[0]); sc.st(SC_Y + 7, yl[1]); sc.st(SC_Y + 8, ym);
+                        for (int i = 0; i < 6; i++) sc.st(SC_Y + i, yr[i]);
+                        sc.st(SC_Y + 6, yl[0]); sc.st(SC_Y + 7, yl[1]); sc.st(SC_Y + 8, ym);
+                    }
+                    JB_PROF_ADD(o, 3);
+                    wave_sync();
                 }
+                if (final_pass) break;
             }
-            JB_PROF_ADD(o, 3);
-            if (final_pass) break;
-            wave_sync();          // new iterate stored by the main lanes -> read by every group's next sweep
+        }
+        // ---- the final pass: MuJoCo's Euler step with implicit joint damping.
+        // At the minimiser  H y = tau + sum B^T W ahat,  so the constraint force is  qfrc = M y - tau  and the step solves
+        //     (M + h diag(b)) qacc = tau + qfrc = M y,  i.e.  qacc = y - d,   (M + h diag(b)) d = h diag(b) y        (nonzero only in the leg rows).
+        // star_subst adds tau itself, so the contact envs cancel it (replicated parts enter the quad sums as 1/4).
+        // An env without contacts has qfrc = 0 exactly, whatever the rest of its wave is doing: plain solve.
+        if (have_dfac || rep) {
+            V nyr[6], nyl[2], nym;
+            if (o.lean) sys_load(sc, sys);
+            if (have_dfac) {
+                // Every lane takes the iterate from the scratch (what the main lanes hold in registers) and runs the substitution on whatever
+                // factorisation it holds: the REPLICA's is the one of M + h diag(b), and only its result is handed on.
+#pragma unroll
+                for (int i = 0; i < 6; i++) yr[i] = sc.ld(SC_Y + i);
+                yl[0] = sc.ld(SC_Y + 6); yl[1] = sc.ld(SC_Y + 7); ym = sc.ld(SC_Y + 8);
+            }
+            if (any_contact) {
+#pragma unroll
+                for (int i = 0; i < 6; i++) acc.rr[i] = sel(env_con, V(-0.25) * sys.tr[i], V(0));
+                acc.rl[0] = sel(env_con, hb1 * yl[0] - sys.tl[0], V(0));
+                acc.rl[1] = sel(env_con, hb2 * yl[1] - sys.tl[1], V(0));
+                acc.rm = sel(env_con, V(-0.25) * sys.tm, V(0));
+            }
+            if (!have_dfac) {      // (no replica - the LEAN variant, a single lane group: the main lanes factorise on the spot)
+                StarFactor<V> fd;
+                star_factor<V, false>(sys, acc, hb1, hb2, fd);           // acc holds only right-hand sides here
+                star_subst<V>(fd, acc.rr, sys.tr, sys.tl[0] + acc.rl[0], sys.tl[1] + acc.rl[1], sys.tm + quad_sum(acc.rm), nyr, nyl, nym);
+            } else {
+                star_subst<V>(fac, acc.rr, sys.tr, sys.tl[0] + acc.rl[0], sys.tl[1] + acc.rl[1], sys.tm + quad_sum(acc.rm), nyr, nyl, nym);
+            }
+            JB_PROF_ADD(o, 6);
+            if (have_dfac) {
+                if (g1) {
+#pragma unroll
+                    for (int i = 0; i < 6; i++) sc.st(SC_RED + i, nyr[i]);
+                    sc.st(SC_RED + 6, nyl[0]); sc.st(SC_RED + 7, nyl[1]); sc.st(SC_RED + 8, nym);
+                }
+                wave_sync();
+#pragma unroll
+                for (int i = 0; i < 6; i++) nyr[i] = sc.ld(SC_RED + i);
+                nyl[0] = sc.ld(SC_RED + 6); nyl[1] = sc.ld(SC_RED + 7); nym = sc.ld(SC_RED + 8);
+            }
+#pragma unroll
+            for (int i = 0; i < 6; i++) yr[i] = sel(env_con, yr[i] - nyr[i], nyr[i]);
+            yl[0] = sel(env_con, yl[0] - nyl[0], nyl[0]); yl[1] = sel(env_con, yl[1] - nyl[1], nyl[1]); ym = sel(env_con, ym - nym, nym);
         }
     }
     JB_SCHED_FENCE();
-    if (!is_main) return;
+    if (!rep) return;
 
-    // ================= phase C: integrate
+    // ================= phase C: integrate (the replica too: it starts the next substep from the same state)
     if (o.lean) { state_load(sc, s); s.fail = s.fail + fail_inc; }
     Vec3<V> lin = mul(Rw, v3<V>(yr[3], yr[4], yr[5]));
     s.wa[0] = yr[0]; s.wa[1] = yr[1]; s.wa[2] = yr[2]; s.wl[0] = lin.x; s.wl[1] = lin.y; s.wl[2] = lin.z; s.wj[0] = yl[0]; s.wj[1] = yl[1]; s.wm = ym;
@@ -1647,8 +1708,9 @@ JB_HD void substep(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneState<V>
     unsigned xt = 0;          // bit 0: some upper leg may touch the floor, bit 1: some root / motor-body geom may
     Mat3<V> Rw;               // root rotation (main lanes): mj_kinematics normalises the quaternion first
     if (o.lean && sc.grp == 0) state_load(sc, s);       // LEAN: the state lives in the scratch between substeps
-    if (sc.grp == 0) Rw = quat2mat(s.qw, s.qx, s.qy, s.qz);      // the quaternion is kept normalised: normalise_state() once per kernel, phase C after every substep
-    if (o.contacts && sc.grp == 0) {
+    const bool rep = sc.grp == 0 || (o.offload && sc.grp == 1);      // main lanes and their replica (SimOpts::offload)
+    if (rep) Rw = quat2mat(s.qw, s.qx, s.qy, s.qz);      // the quaternion is kept normalised: normalise_state() once per kernel, phase C after every substep
+    if (o.contacts && rep) {
         const Vec3<V> nb = v3<V>(Rw.m[6], Rw.m[7], Rw.m[8]);         // floor normal in root coordinates
         // upper leg: sphere around the upper cylinder (+ slack for the shoulder angle)
         auto near_leg = mor(lt(s.pz + dot(ldv3(m, LM_BS_LEG_C), nb), m.c[LM_BS_LEG_R]), gt(vabs(s.th1), V(0.3)));

@@ -14,6 +14,8 @@ using namespace jb;
 // NGROUPS = 1: the main lanes alone.  NGROUPS = 4: the wave layout of the 4-envs-per-wave kernel for ONE env - a main group and three
 // helper groups, one host thread each, sharing the scratch and exchanging through jb_lane.hpp's HostWave (group_sum, row_transpose_sum,
 // the rank-one pass on rows other groups built, the broadcast loop decisions): the same code paths the device takes with helper lanes.
+static int g_offload = 1;      // lane group 1 as the main lanes' replica (SimOpts::offload), as the one-wave-per-SIMD kernels run it
+extern "C" void jbh_set_offload(int on) { g_offload = on; }
 template <typename T>
 static int run(const double* P, double* qpos, double* qvel, double ctrl, int nsub, int contacts, int max_newton, int implicit_damp, double* fail, int ngroups = 1, int rank_one = 1, int lean = 0, int pair = 0) {
     using V = Quad<T>;
@@ -37,7 +39,7 @@ static int run(const double* P, double* qpos, double* qvel, double ctrl, int nsu
     s.thd2 = V(T(qvel[7]), T(qvel[9]), T(qvel[11]), T(qvel[13]));
     for (int i = 0; i < 3; i++) { s.wa[i] = V(T(0)); s.wl[i] = V(T(0)); }
     s.wj[0] = s.wj[1] = V(T(0)); s.wm = V(T(0)); s.fail = V(T(0));
-    SimOpts o; o.contacts = contacts; o.max_newton = max_newton; o.implicit_damp = implicit_damp; o.rank_one = rank_one; o.lean = lean; o.prof = nullptr; o.hist = nullptr;
+    SimOpts o; o.contacts = contacts; o.max_newton = max_newton; o.implicit_damp = implicit_damp; o.rank_one = rank_one; o.lean = lean; o.offload = (g_offload && !lean && ngroups >= 2) ? 1 : 0; o.prof = nullptr; o.hist = nullptr;
     constexpr int SCMAX = SC_COUNT > SC_COUNT_LEAN_PAIR ? SC_COUNT : SC_COUNT_LEAN_PAIR;
     V scratch[SCMAX];                  // (the LEAN variant parks state / system / factorisation where the ordinary one has its reduction buffer and overflow candidates)
     V ovcbuf[4 * (NSLOT - ROW_K)];     // LEAN: the candidates beyond the row cache live outside the scratch (global memory on the device)
@@ -65,15 +67,19 @@ static int run(const double* P, double* qpos, double* qvel, double ctrl, int nsu
             LaneScratch<V> sc; sc.p = scratch; sc.stride = 1; sc.grp = g; sc.ngrp = ngroups; sc.gstride = 16; set_ovc(sc);
             LaneState<V> hs = s;                            // helper lanes start from a harmless state, like the kernel's
             LaneState<V>& st = (g == 0) ? s : hs;
-            if (g != 0) {
+            if (g != 0 && !(o.offload && g == 1)) {
                 hs.px = hs.py = hs.pz = V(T(0)); hs.qw = V(T(1)); hs.qx = hs.qy = hs.qz = V(T(0)); hs.vx = hs.vy = hs.vz = hs.wx = hs.wy = hs.wz = V(T(0));
                 hs.pz_lo = hs.qw_lo = hs.qx_lo = hs.qy_lo = hs.qz_lo = V(T(0));
                 hs.phi = hs.phid = hs.turns = V(T(0)); hs.th1 = hs.th2 = hs.thd1 = hs.thd2 = V(T(0));
             }
-            if (g == 0) { for (int k = 0; k < SCMAX; k++) scratch[k] = V(std::numeric_limits<T>::quiet_NaN()); if (lean) state_store(sc, st); }
+            if (g == 0) {
+                for (int k = 0; k < SCMAX; k++) scratch[k] = V(std::numeric_limits<T>::quiet_NaN());
+                if (lean) state_store(sc, st);
+                if (o.offload) for (int k = 0; k < 56; k++) scratch[SC_ZERO + k] = V(T(0));       // written once per kernel on the device
+            }
             for (int i = 0; i < nsub; i++) {
                 wave.barrier();
-                if (g == 0) { for (int k = 0; k < (lean ? SC_LSTATE : SCMAX); k++) scratch[k] = V(std::numeric_limits<T>::quiet_NaN()); for (auto& c : ovcbuf) c = V(std::numeric_limits<T>::quiet_NaN()); }
+                if (g == 0) { for (int k = 0; k < (lean ? SC_LSTATE : o.offload ? SC_ZERO : SCMAX); k++) scratch[k] = V(std::numeric_limits<T>::quiet_NaN()); for (auto& c : ovcbuf) c = V(std::numeric_limits<T>::quiet_NaN()); }
                 wave.barrier();
                 if (pair) substep<V, true>(m, sc, st, V(T(ctrl)), o); else substep<V>(m, sc, st, V(T(ctrl)), o);
             }

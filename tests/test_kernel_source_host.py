@@ -225,6 +225,40 @@ def test_lean_variant_is_bit_identical_on_the_host(params):
                     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), (tipped, i, groups, f32)
 
 
+def test_replica_group_offload_is_bit_identical_on_the_host(params):
+    """SimOpts::offload (the one-wave-per-SIMD kernels): lane group 1 replicates the main lanes, factorises M + h diag(b) with the instruction
+    stream of the first Newton solve and does the final pass as a substitution.  Same arithmetic on the same numbers: fp64 and fp32 host
+    builds reproduce the path without it bit for bit (walking, tipped over, the pair-contact variant)."""
+    import tests.build_harness as bh
+    lib = C.CDLL(bh.build())
+    dp = C.POINTER(C.c_double)
+    for f in (lib.jbh_step_groups, lib.jbh_step_pair):
+        f.argtypes = [dp, dp, dp, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, dp]
+    P = np.ascontiguousarray(params)
+
+    def run(fn, q, v, f32, offload, u):
+        lib.jbh_set_offload(offload)
+        q, v, fail = q.copy(), v.copy(), np.zeros(1)
+        try:
+            assert fn(P.ctypes.data_as(dp), q.ctypes.data_as(dp), v.ctypes.data_as(dp), u, 50, 1, 20, f32, 4, 1, fail.ctypes.data_as(dp)) == 0
+        finally:
+            lib.jbh_set_offload(1)
+        return q, v
+
+    for tipped in (False, True):
+        env = _contact_states(params, 6, tipped)
+        q0, v0, _ = env.get_state()
+        for i in range(6):
+            for f32 in (0, 1):
+                for fn in (lib.jbh_step_groups, lib.jbh_step_pair):
+                    a, b = run(fn, q0[i], v0[i], f32, 1, 0.3), run(fn, q0[i], v0[i], f32, 0, 0.3)
+                    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), (tipped, i, f32)
+    # a robot in free fall (no contact anywhere: the final pass factorises on the spot, in both groups)
+    q = q0[0].copy(); q[2] += 0.05
+    a, b = run(lib.jbh_step_groups, q, v0[0], 0, 1, -0.5), run(lib.jbh_step_groups, q, v0[0], 0, 0, -0.5)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
 def test_pair_contact_kernel_source_fp64_equals_oracle():
     """The PAIR instantiation of the substep (closed-form narrow phase of the mass ellipsoid against the upper-leg cylinders, the pair's own
     contact frame, rows without root columns, the shoulder - motor cross term folded into the motor branch of the star solve, the 53rd
