@@ -130,6 +130,7 @@ def main(argv=None):
     ap.add_argument("--max-newton", type=int, default=12)
     ap.add_argument("--envs-per-wave", type=int, default=0)
     ap.add_argument("--no-rank-one", action="store_true", help="diagnostic: JB_FLAG_NO_RANK_ONE (every Newton pass is a full pass)")
+    ap.add_argument("--no-spread", action="store_true", help="diagnostic: JB_FLAG_NO_SPREAD (contact sweeps never in spread mode)")
     ap.add_argument("--no-pair", action="store_true", help="diagnostic: JB_FLAG_NO_PAIR (floor contacts only, also for per-env models: what rounds 1-2 simulated)")
     ap.add_argument("--lean", action="store_true", help="JB_FLAG_LEAN: the two-waves-per-SIMD kernel variant (229 registers, 20 KB of LDS per four-env wave); chosen automatically from 8192 envs per GPU on (shared model), where the GPU holds two waves per SIMD")
     ap.add_argument("--no-lean", action="store_true", help="never the LEAN variant")
@@ -187,7 +188,7 @@ def main(argv=None):
         actions = torch.rand((steps + warmup, n), generator=g, device=dev, dtype=torch.float32) * 2 - 1
         if args.actions == "const1":
             actions.fill_(1.0)
-        env_kw = dict(contacts=bool(contacts), max_newton=args.max_newton, envs_per_wave=args.envs_per_wave, flags=(1 if args.no_rank_one else 0) | (2 if args.lean else 0) | (8 if args.no_pair else 0))
+        env_kw = dict(contacts=bool(contacts), max_newton=args.max_newton, envs_per_wave=args.envs_per_wave, flags=(1 if args.no_rank_one else 0) | (2 if args.lean else 0) | (8 if args.no_pair else 0) | (16 if args.no_spread else 0))
         if gather:
             # N > 1: the PRODUCT's sharded env (jitterbug_amd/distributed.py), pipelined: the step kernel writes packed rows
             # [obs | reward | done] itself and rank 0 gathers them every step over RCCL, one step late from a side stream, three row

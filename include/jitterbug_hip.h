@@ -66,6 +66,8 @@ typedef struct jb_handle jb_handle;
                                   is chosen by the model: on for one-model-per-env batches and for a shared table whose mass comes within
                                   0.5 mm of a leg, off for the nominal model (whose mass clears the legs by 3 mm) */
 #define JB_FLAG_NO_PAIR     8   /* never: floor contacts only (rounds 1-2 behaviour; diagnostic) */
+#define JB_FLAG_NO_SPREAD   16  /* diagnostic: contact sweeps never in spread mode (a robot lying on a leg keeps its 8-9 contacts on that leg's four
+                                   lanes, two or three rounds per sweep) */
 
 typedef struct jb_config {
     int32_t  n_envs;        /* N >= 1 */

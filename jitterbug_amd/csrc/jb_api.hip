@@ -38,6 +38,7 @@ struct KArgs {
     int n, task, substeps, step_limit, auto_reset, contacts, max_newton, random_pose, per_env_model;
     int epw;       // environments per wave (= per 64-thread workgroup) of the step kernel
     int rank_one;      // 0: diagnostic, no rank-one Newton passes (jb_config.flags & JB_FLAG_NO_RANK_ONE)
+    int spread;        // 0: diagnostic, no spread sweeps (JB_FLAG_NO_SPREAD)
     int lean;          // 1: the LEAN kernel variant (two waves per SIMD; jb_config.flags & JB_FLAG_LEAN)
     int pair;          // 1: the PAIR kernel variant (geom-geom contact mass ellipsoid / upper-leg cylinders; see JB_FLAG_PAIR)
     int packed_rows;   // step kernel output: 0 = obs[N,D] + reward[N] + done[N]; 1 = one float row [obs(D) | reward | done] per env
@@ -205,7 +206,7 @@ __device__ __forceinline__ void step_body(KArgs a, const float* __restrict__ act
     s.st_xtra = 0.f; s.st_sweeps = 0.f; s.st_contact = 0.f; s.st_slots = 0.f; s.st_fast = 0.f; s.st_checks = 0.f;
 #endif
     const float ctrl = action[env];
-    SimOpts o; o.contacts = a.contacts; o.max_newton = a.max_newton; o.implicit_damp = 1; o.rank_one = a.rank_one; o.lean = LEAN ? 1 : 0; o.offload = OFFLOAD ? 1 : 0; o.prof = nullptr; o.hist = nullptr;
+    SimOpts o; o.contacts = a.contacts; o.max_newton = a.max_newton; o.implicit_damp = 1; o.rank_one = a.rank_one; o.lean = LEAN ? 1 : 0; o.offload = OFFLOAD ? 1 : 0; o.spread = a.spread; o.prof = nullptr; o.hist = nullptr;
 #ifdef JB_WAVE_STATS
     const unsigned long long rt_start = __builtin_amdgcn_s_memrealtime();
     unsigned long long prof_local[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // accumulated in registers, written once at the end
@@ -697,7 +698,7 @@ static int create_impl(jb_handle* h) {      // every failure returns through jb_
     KArgs& k = h->ka;
     k.n = cfg->n_envs; k.task = cfg->task_id; k.substeps = cfg->substeps; k.step_limit = cfg->step_limit; k.auto_reset = cfg->auto_reset;
     k.contacts = cfg->contacts; k.max_newton = h->cfg.max_newton; k.random_pose = cfg->random_pose; k.per_env_model = 0;
-    k.seed = cfg->seed; k.env_offset = cfg->env_offset; k.rank_one = (cfg->flags & JB_FLAG_NO_RANK_ONE) ? 0 : 1;
+    k.seed = cfg->seed; k.env_offset = cfg->env_offset; k.rank_one = (cfg->flags & JB_FLAG_NO_RANK_ONE) ? 0 : 1; k.spread = (cfg->flags & JB_FLAG_NO_SPREAD) ? 0 : 1;
     k.lean = (cfg->flags & JB_FLAG_LEAN) ? 1 : 0;
     {   // envs per wave: fill every SIMD of the device before filling the lanes of a wave.  The kernel holds one wave
         // per SIMD (register budget), so the device runs (CUs x 4) waves at a time; LDS (scratch is per active lane)

@@ -83,6 +83,20 @@ JB_D unsigned wave_bcast_u(unsigned x) { return (unsigned)__builtin_amdgcn_readf
 // the hand-over across the writes it depends on (it sees one thread and may prove the addresses different once the group is known):
 // a wave barrier is that fence and emits no instruction.  The host emulation (one thread per group) needs a real barrier.
 JB_D void wave_sync() { __builtin_amdgcn_wave_barrier(); }
+// ---- quad-level exchanges for the spread contact sweeps (jb_sim.hpp): a lane may work on a contact of ANOTHER leg of its env
+// quad_rot<K>: the value of lane (l + K) & 3 of the quad; quad_bcast_u: the value of lane j of the quad (DPP quad_perm, one instruction)
+template <int K> JB_D float quad_rot(float x) {
+    constexpr int ctrl = K == 1 ? 0x39 : K == 2 ? 0x4E : 0x93;      // quad_perm [1,2,3,0] / [2,3,0,1] / [3,0,1,2]
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), ctrl, 0xF, 0xF, false));
+}
+template <int K> JB_D unsigned quad_rot_u(unsigned x) {
+    constexpr int ctrl = K == 1 ? 0x39 : K == 2 ? 0x4E : 0x93;
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, ctrl, 0xF, 0xF, false);
+}
+template <int J> JB_D unsigned quad_bcast_u(unsigned x) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, J * 0x55, 0xF, 0xF, false); }
+JB_D unsigned quad_lane_id(const float*) { return threadIdx.x & 3u; }
+// element idx of the scratch column of lane `src` of the own quad (`me`: the own position in the quad)
+JB_D float ld_leg(const float* p, int stride, unsigned idx, unsigned src, unsigned me) { return p[(int)(idx * (unsigned)stride) + (int)src - (int)me]; }
 #endif
 
 JB_HD float sel(bool m, float a, float b) { return m ? a : b; }
@@ -101,6 +115,13 @@ JB_HD unsigned xor_u(unsigned a, unsigned b) { return a ^ b; }
 JB_HD bool eq_u(unsigned a, unsigned b) { return a == b; }
 JB_HD bool lt_u(unsigned a, unsigned b) { return a < b; }
 JB_HD unsigned or_u(unsigned a, unsigned b) { return a | b; }
+JB_HD unsigned and_u(unsigned a, unsigned b) { return a & b; }
+JB_HD unsigned sub_u(unsigned a, unsigned b) { return a - b; }
+JB_HD unsigned shl_u(unsigned a, unsigned s) { return a << s; }
+JB_HD unsigned ctz_u(unsigned a) { return a ? (unsigned)__builtin_ctz(a) : 0u; }
+JB_HD unsigned clear_low_u(unsigned a) { return a & (a - 1u); }
+JB_HD float utov(unsigned a, const float*) { return (float)a; }
+JB_HD double utov(unsigned a, const double*) { return (double)a; }
 // The single flipped bit of an active-set record (5 bits per slot: pyramid edges n+t1, n-t1, n+t2, n-t2, valid): which cached
 // row it belongs to (entry = rank of the slot among the live slots) and which edge it is.  A lane without a flipped bit gets
 // is_flip = false and entry 0.
@@ -279,6 +300,20 @@ inline UQuad popc_u(const UQuad& a) { UQuad r; for (int i = 0; i < 4; i++) r.v[i
 inline UQuad xor_u(const UQuad& a, const UQuad& b) { UQuad r; for (int i = 0; i < 4; i++) r.v[i] = a.v[i] ^ b.v[i]; return r; }
 inline Mask4 lt_u(const UQuad& a, uint32_t b) { Mask4 r; for (int i = 0; i < 4; i++) r.v[i] = a.v[i] < b; return r; }
 inline UQuad or_u(const UQuad& a, const UQuad& b) { UQuad r; for (int i = 0; i < 4; i++) r.v[i] = a.v[i] | b.v[i]; return r; }
+inline UQuad and_u(const UQuad& a, const UQuad& b) { UQuad r; for (int i = 0; i < 4; i++) r.v[i] = a.v[i] & b.v[i]; return r; }
+inline UQuad and_u(const UQuad& a, uint32_t b) { UQuad r; for (int i = 0; i < 4; i++) r.v[i] = a.v[i] & b; return r; }
+inline UQuad sub_u(const UQuad& a, const UQuad& b) { UQuad r; for (int i = 0; i < 4; i++) r.v[i] = a.v[i] - b.v[i]; return r; }
+inline UQuad shl_u(const UQuad& a, const UQuad& s) { UQuad r; for (int i = 0; i < 4; i++) r.v[i] = a.v[i] << s.v[i]; return r; }
+inline UQuad ctz_u(const UQuad& a) { UQuad r; for (int i = 0; i < 4; i++) r.v[i] = a.v[i] ? (uint32_t)__builtin_ctz(a.v[i]) : 0u; return r; }
+inline UQuad clear_low_u(const UQuad& a) { UQuad r; for (int i = 0; i < 4; i++) r.v[i] = a.v[i] & (a.v[i] - 1u); return r; }
+inline Mask4 lt_u(const UQuad& a, const UQuad& b) { Mask4 r; for (int i = 0; i < 4; i++) r.v[i] = a.v[i] < b.v[i]; return r; }
+inline Mask4 eq_u(const UQuad& a, uint32_t b) { Mask4 r; for (int i = 0; i < 4; i++) r.v[i] = a.v[i] == b; return r; }
+template <typename T> inline Quad<T> utov(const UQuad& a, const Quad<T>*) { Quad<T> r; for (int i = 0; i < 4; i++) r.v[i] = (T)a.v[i]; return r; }
+template <int K, typename T> inline Quad<T> quad_rot(const Quad<T>& x) { Quad<T> r; for (int i = 0; i < 4; i++) r.v[i] = x.v[(i + K) & 3]; return r; }
+template <int K> inline UQuad quad_rot_u(const UQuad& x) { UQuad r; for (int i = 0; i < 4; i++) r.v[i] = x.v[(i + K) & 3]; return r; }
+template <int J> inline UQuad quad_bcast_u(const UQuad& x) { return UQuad{{x.v[J], x.v[J], x.v[J], x.v[J]}}; }
+template <typename T> inline UQuad quad_lane_id(const Quad<T>*) { return UQuad{{0u, 1u, 2u, 3u}}; }
+template <typename T> inline Quad<T> ld_leg(const Quad<T>* p, int stride, const UQuad& idx, const UQuad& src, const UQuad&) { Quad<T> r; for (int i = 0; i < 4; i++) r.v[i] = p[idx.v[i] * stride].v[src.v[i]]; return r; }
 inline Mask4 eq_u(const UQuad& a, const UQuad& b) { Mask4 r; for (int i = 0; i < 4; i++) r.v[i] = a.v[i] == b.v[i]; return r; }
 inline void flip_decode(const UQuad& diff0, const UQuad& diff1, const UQuad& rec0, const UQuad& rec1, unsigned live, UQuad& entry, Mask4& is_flip, Mask4& plus, Mask4& tan2, Mask4& on) {
     for (int i = 0; i < 4; i++) flip_decode(diff0.v[i], diff1.v[i], rec0.v[i], rec1.v[i], live, entry.v[i], is_flip.v[i], plus.v[i], tan2.v[i], on.v[i]);

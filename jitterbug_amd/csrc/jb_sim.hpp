@@ -285,7 +285,8 @@ enum SC : int {
     SC_DD = 0 /*24: contact-frame directions d_k (3x3), own-leg hinge data e1 a1 e2 a2 (4x3), d_k.u (3)*/,
     SC_Y = 24 /*9: current Newton iterate [yr(6), yl(2), ym], shared with the helper groups*/,
     SC_ST = SC_Y + 9 /*6: w(3), thd1, thd2, phid for the helper groups*/,
-    SC_ROWS = SC_ST + 6 /*ROW_K x ROW_F: one entry per LIVE candidate slot of this substep, in slot order (entry = rank of the slot among the
+    SC_OWN = SC_ST + 6 /*1: bitmask of the leg slots (0-9) in which THIS lane's leg has a contact, as a number (spread sweeps)*/,
+    SC_ROWS = SC_OWN + 1 /*ROW_K x ROW_F: one entry per LIVE candidate slot of this substep, in slot order (entry = rank of the slot among the
                    live ones).  Phase A writes position (3, root coords rel. root origin) and effective distance (the real distance when the
                    candidate is a contact, +1 otherwise) of a live slot straight into its entry; the row build adds the y-independent
                    rest.  Slots: 0 foot, 1-4 lower-leg cylinder | 5-8 upper cylinder, 9 knee tip | root body: 10-13 lane cylinder, 14 lane
@@ -701,6 +702,149 @@ JB_HD void contact_apply(const RowVals<V>& rv, const Vec3<V> (&dk)[3], const V& 
     }
 }
 
+// ----------------------------------------------------------------------------- spread sweeps
+// A robot lying on a leg has 8-9 live slots in ONE leg: in a sweep of the ordinary kind the four lanes of that leg (one per lane group)
+// work through two or three slots each, one per round, while the twelve lanes of the other legs have next to nothing to do.  When a
+// wave's plan has more than one round, the LEG slots (0-9, cached rows) are swept in spread mode instead: inside every lane group the
+// four lanes of an env share out the group's slots of ALL FOUR legs - a lane keeps the first contact of its own leg and a lane whose
+// own leg has none adopts a further contact of another leg of its env.  What a lane accumulates for the root block is summed over the
+// quad anyway; what it accumulates for a leg block (and the active-set record) is routed to the lane of that leg by a quad-level
+// segmented sum.  The assignment is a function of the env's own contacts only, and an env that never has two contacts in one lane
+// keeps the very bits of the ordinary sweep (every item stays in the lane and group it had, the routed sums add zeros): results remain
+// independent of an env's wave-mates.
+template <typename V> struct SpreadItem {
+    typename lane_traits<V>::uint src, slot;      // leg (position in the quad) and slot of the contact this lane works on
+    typename lane_traits<V>::mask valid;
+    typename lane_traits<V>::mask more;           // the env has contacts left for a further round
+};
+// round r of the assignment.  own: this lane's live leg slots; mg: the slots (live, cached, of this lane's group) that are spread.
+template <typename V>
+JB_HD SpreadItem<V> spread_assign(const typename lane_traits<V>::uint& own, unsigned mg, int round) {
+    using U = typename lane_traits<V>::uint;
+    using MK = typename lane_traits<V>::mask;
+    const U me = quad_lane_id((const V*)nullptr);
+    const U Z = zero_u<V>();
+    U mk[4], c[4], e[4];
+    mk[0] = and_u(quad_bcast_u<0>(own), mg); mk[1] = and_u(quad_bcast_u<1>(own), mg); mk[2] = and_u(quad_bcast_u<2>(own), mg); mk[3] = and_u(quad_bcast_u<3>(own), mg);
+    U F = Z, f = Z, T = Z;        // free lanes of the quad, free lanes below this one, contacts beyond a leg's first
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        c[j] = popc_u(mk[j]);
+        const MK fr = eq_u(c[j], 0u);
+        e[j] = selu(fr, Z, sub_u(c[j], Z + 1u));
+        F = F + mbit(fr);
+        f = f + mbit(mand(fr, lt_u(Z + (unsigned)j, me)));
+        T = T + e[j];
+    }
+    const MK me0 = eq_u(me, 0u), me1 = eq_u(me, 1u), me2 = eq_u(me, 2u);
+    const U c_me = selu(me0, c[0], selu(me1, c[1], selu(me2, c[2], c[3])));
+    const MK own_first = mand(neq_u(c_me, Z), round == 0 ? lt(V(0), V(1)) : lt(V(1), V(0)));
+    // the overflow contact this lane would take: round 0 - the free lanes in order; later rounds - every lane
+    const U o = round == 0 ? f : F + (unsigned)(4 * (round - 1)) + me;
+    const MK has_over = mand(lt_u(o, T), mnot(own_first));
+    U src = me, k = Z, base = Z;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const MK take = mand(mand(has_over, mnot(lt_u(o, base))), lt_u(o, base + e[j]));
+        src = selu(take, Z + (unsigned)j, src);
+        k = selu(take, sub_u(o, base) + 1u, k);
+        base = base + e[j];
+    }
+    const U msrc = selu(eq_u(src, 0u), mk[0], selu(eq_u(src, 1u), mk[1], selu(eq_u(src, 2u), mk[2], mk[3])));
+    const U t1 = clear_low_u(msrc), t2 = clear_low_u(t1), t3 = clear_low_u(t2), t4 = clear_low_u(t3);
+    const U tk = selu(eq_u(k, 0u), msrc, selu(eq_u(k, 1u), t1, selu(eq_u(k, 2u), t2, selu(eq_u(k, 3u), t3, t4))));
+    SpreadItem<V> it;
+    it.valid = mor(own_first, has_over);
+    it.src = selu(it.valid, src, me);
+    it.slot = ctz_u(tk);
+    it.more = lt_u(F + (unsigned)(4 * round), T);
+    return it;
+}
+// sum over the quad of the values whose tag names this lane: out[l] = sum_j [tag_j == l] t_j, associated ((own + next) + second next) + third
+template <typename V> JB_HD V quad_seg_sum(const V& t, const V& m0, const V& m1, const V& m2, const V& m3) {
+    V r = t * m0;
+    r = r + quad_rot<1>(t) * m1;
+    r = r + quad_rot<2>(t) * m2;
+    return r + quad_rot<3>(t) * m3;
+}
+template <typename V> JB_HD typename lane_traits<V>::uint quad_seg_sum_u(const typename lane_traits<V>::uint& t, const typename lane_traits<V>::mask& k0, const typename lane_traits<V>::mask& k1,
+                                                                         const typename lane_traits<V>::mask& k2, const typename lane_traits<V>::mask& k3) {
+    const auto Z = zero_u<V>();
+    return selu(k0, t, Z) + selu(k1, quad_rot_u<1>(t), Z) + selu(k2, quad_rot_u<2>(t), Z) + selu(k3, quad_rot_u<3>(t), Z);
+}
+
+// One cached contact of a LEG slot (0-9) of leg `it.src` of this lane's env against the iterate (spread sweeps).  The arithmetic of
+// contact_apply for a lower-leg slot: an upper-leg slot's cached knee column is zero, so its extra terms add zeros.  yl: the joint part
+// of the iterate of leg it.src.
+template <typename V>
+JB_HD void contact_apply_leg(const RowVals<V>& rv, const Vec3<V> (&dk)[3], const V& mu, const SpreadItem<V>& it, int mode,
+                             const V (&yr)[6], const V (&yl)[2], NewtonAcc<V>& acc) {
+    using U = typename lane_traits<V>::uint;
+    using MK = typename lane_traits<V>::mask;
+    V Bj[3][8], rho[3], ahat[3];
+    const V D = sel(it.valid, rv.D, V(0));
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const Vec3<V> ang = cross(rv.x, dk[k]);
+        Bj[k][0] = ang.x; Bj[k][1] = ang.y; Bj[k][2] = ang.z;
+        Bj[k][3] = dk[k].x; Bj[k][4] = dk[k].y; Bj[k][5] = dk[k].z;
+        Bj[k][6] = rv.jsh[k]; Bj[k][7] = rv.j7[k]; ahat[k] = rv.ah[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        V t = Bj[k][0] * yr[0] - ahat[k];
+        t = t + Bj[k][1] * yr[1]; t = t + Bj[k][2] * yr[2]; t = t + Bj[k][3] * yr[3]; t = t + Bj[k][4] * yr[4]; t = t + Bj[k][5] * yr[5];
+        t = t + Bj[k][6] * yl[0];
+        rho[k] = t + Bj[k][7] * yl[1];
+    }
+    const MK valid = gt(D, V(0));
+    V mr1 = mu * rho[1], mr2 = mu * rho[2];
+    auto a1 = lt(rho[0] + mr1, V(0)), a2 = lt(rho[0] - mr1, V(0)), a3 = lt(rho[0] + mr2, V(0)), a4 = lt(rho[0] - mr2, V(0));
+    // whose leg is it?  tags of the quad's four lanes against this lane's position
+    const U me = quad_lane_id((const V*)nullptr);
+    const MK k0 = eq_u(it.src, me), k1 = eq_u(quad_rot_u<1>(it.src), me), k2 = eq_u(quad_rot_u<2>(it.src), me), k3 = eq_u(quad_rot_u<3>(it.src), me);
+    {   // the record goes to the lane of the contact's leg
+        const U bits = selu(valid, mbit(a1) + mbit(a2) * 2u + mbit(a3) * 4u + mbit(a4) * 8u + 16u, zero_u<V>());
+        const MK low = lt_u(it.slot, 5u);
+        const U sh = selu(low, it.slot, sub_u(it.slot, zero_u<V>() + 5u)) * 5u;
+        const U w = shl_u(bits, sh);
+        acc.bw0 = acc.bw0 + quad_seg_sum_u<V>(selu(low, w, zero_u<V>()), k0, k1, k2, k3);
+        acc.bw1 = acc.bw1 + quad_seg_sum_u<V>(selu(low, zero_u<V>(), w), k0, k1, k2, k3);
+    }
+    if (mode == 2) return;
+    V f1 = sel(a1, V(1), V(0)), f2 = sel(a2, V(1), V(0)), f3 = sel(a3, V(1), V(0)), f4 = sel(a4, V(1), V(0));
+    V Wnn = D * (f1 + f2 + f3 + f4), Wn1 = D * mu * (f1 - f2), Wn2 = D * mu * (f3 - f4), W11 = D * mu * mu * (f1 + f2), W22 = D * mu * mu * (f3 + f4);
+    V wa0 = Wnn * ahat[0] + Wn1 * ahat[1] + Wn2 * ahat[2];
+    V wa1 = Wn1 * ahat[0] + W11 * ahat[1];
+    V wa2 = Wn2 * ahat[0] + W22 * ahat[2];
+    V WB[3][8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        WB[0][i] = Wnn * Bj[0][i] + Wn1 * Bj[1][i] + Wn2 * Bj[2][i];
+        WB[1][i] = Wn1 * Bj[0][i] + W11 * Bj[1][i];
+        WB[2][i] = Wn2 * Bj[0][i] + W22 * Bj[2][i];
+    }
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+#pragma unroll
+        for (int j = 0; j <= i; j++) acc.A[tri(i, j)] = fma3(acc.A[tri(i, j)], Bj[0][i], WB[0][j], Bj[1][i], WB[1][j], Bj[2][i], WB[2][j]);
+        acc.rr[i] = fma3(acc.rr[i], Bj[0][i], wa0, Bj[1][i], wa1, Bj[2][i], wa2);
+    }
+    // the leg block of leg it.src: computed here, added in the lane of that leg
+    const V m0 = sel(k0, V(1), V(0)), m1 = sel(k1, V(1), V(0)), m2 = sel(k2, V(1), V(0)), m3 = sel(k3, V(1), V(0));
+    const V Z = V(0);
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        acc.B[i][0] = acc.B[i][0] + quad_seg_sum(fma3(Z, Bj[0][6], WB[0][i], Bj[1][6], WB[1][i], Bj[2][6], WB[2][i]), m0, m1, m2, m3);
+        acc.B[i][1] = acc.B[i][1] + quad_seg_sum(fma3(Z, Bj[0][7], WB[0][i], Bj[1][7], WB[1][i], Bj[2][7], WB[2][i]), m0, m1, m2, m3);
+    }
+    acc.C11 = acc.C11 + quad_seg_sum(fma3(Z, Bj[0][6], WB[0][6], Bj[1][6], WB[1][6], Bj[2][6], WB[2][6]), m0, m1, m2, m3);
+    acc.C12 = acc.C12 + quad_seg_sum(fma3(Z, Bj[0][6], WB[0][7], Bj[1][6], WB[1][7], Bj[2][6], WB[2][7]), m0, m1, m2, m3);
+    acc.C22 = acc.C22 + quad_seg_sum(fma3(Z, Bj[0][7], WB[0][7], Bj[1][7], WB[1][7], Bj[2][7], WB[2][7]), m0, m1, m2, m3);
+    acc.rl[0] = acc.rl[0] + quad_seg_sum(fma3(Z, Bj[0][6], wa0, Bj[1][6], wa1, Bj[2][6], wa2), m0, m1, m2, m3);
+    acc.rl[1] = acc.rl[1] + quad_seg_sum(fma3(Z, Bj[0][7], wa0, Bj[1][7], wa1, Bj[2][7], wa2), m0, m1, m2, m3);
+}
+
 // Rank-one Newton pass.  The active set at y differs from the factored one by ONE pyramid edge e of one cached contact of
 // this env's legs (weight D, reference acceleration a): H' = H + s D e e^T, rhs' = rhs + s D a e with s = +1 (edge switched on) or
 // -1 (off), hence by Sherman-Morrison
@@ -799,6 +943,36 @@ JB_HD int plan_slot(const SlotPlan& p, int, int r) {
 }
 JB_HD int plan_rank(const SlotPlan& p, int slot) { return __builtin_popcount(p.live & ((1u << slot) - 1u)); }
 
+// The spread part of a substep's plan (see "spread sweeps" above): which slots are spread, this lane's share, and what is left for the
+// ordinary loop (body slots, a leg slot beyond the row cache).
+template <typename V> struct SpreadPlan {
+    bool on = false;
+    unsigned slots = 0;          // wave-uniform: the live leg slots with a cached row
+    unsigned mg = 0;             // ... of this lane's group
+    typename lane_traits<V>::uint own;       // this lane's live leg slots
+    SpreadItem<V> item0;         // round 0 of the assignment (later rounds are rare and recomputed)
+    unsigned rest_mine = 0;      // the ordinary loop's slots of this lane's group, and its rounds
+    int rest_rounds = 0;
+};
+template <typename V> JB_HD SpreadPlan<V> make_spread_plan(const LaneScratch<V>& sc, const SlotPlan& plan, bool enabled) {
+    SpreadPlan<V> sp;
+    if (!enabled || !plan.grouped || plan.rounds < 2) return sp;
+    unsigned t = plan.live & 0x3FFu;
+    while (__builtin_popcount(t) > ROW_K) t &= ~(1u << (31 - __builtin_clz(t)));      // (ranks follow the slot order: the leg slots come first)
+    if (!t) return sp;
+    sp.on = true;
+    sp.slots = t;
+    sp.mg = group_mask(sc.grp, plan.ngroups) & t;
+    sp.own = vtou(sc.ld(SC_OWN));
+    sp.item0 = spread_assign<V>(sp.own, sp.mg, 0);
+    sp.rest_mine = plan.mine & ~t;
+    for (int g = 0; g < plan.ngroups; g++) {
+        const int c = __builtin_popcount(plan.live & ~t & group_mask(g, plan.ngroups));
+        sp.rest_rounds = c > sp.rest_rounds ? c : sp.rest_rounds;
+    }
+    return sp;
+}
+
 // y-independent rows of the live slots, once per substep (slots beyond the cache keep their candidate only; their rows are
 // recomputed in registers in every pass)
 template <typename V, bool PAIR = false>
@@ -818,7 +992,7 @@ JB_HD void contact_rows_build_all(const LaneModel<V>& m, const LaneScratch<V>& s
 // every live candidate slot against the iterate y kept in the scratch (SC_Y); with helper groups the partial sums of the
 // groups are combined by cross-lane exchanges so that every group ends with the complete accumulator
 template <typename V, bool PAIR = false>
-JB_HD void contact_sweep(const LaneModel<V>& m, const LaneScratch<V>& sc, bool xtra, const SlotPlan& plan, int mode, const Vec3<V> (&dk)[3], NewtonAcc<V>& acc, const bool zero_g1 = false) {
+JB_HD void contact_sweep(const LaneModel<V>& m, const LaneScratch<V>& sc, bool xtra, const SlotPlan& plan, const SpreadPlan<V>& sp, int mode, const Vec3<V> (&dk)[3], NewtonAcc<V>& acc, const bool zero_g1 = false) {
     // zero_g1 (SimOpts::offload): group 1 must leave with an all-zero accumulator - it factorises M + h diag(b)
     // with the instruction stream that factorises the main lanes' Newton system (substep_impl)
     const bool g1z = zero_g1 && sc.grp == 1;
@@ -831,9 +1005,35 @@ JB_HD void contact_sweep(const LaneModel<V>& m, const LaneScratch<V>& sc, bool x
     for (int i = 0; i < 6; i++) yr[i] = sc.ld(SC_Y + i);
     yl[0] = sc.ld(SC_Y + 6); yl[1] = sc.ld(SC_Y + 7); ym = sc.ld(SC_Y + 8);
     const int g = plan.grouped ? sc.grp : 0;
+    unsigned rest_mine = plan.mine;
+    int rest_rounds = plan.rounds;
+    if (sp.on) {
+        // spread rounds over the leg slots (normally one): every lane of the quad works on a contact of its env, whichever leg it sits on
+        using U = typename lane_traits<V>::uint;
+        const U me = quad_lane_id((const V*)nullptr);
 #pragma unroll 1
-    for (int r = 0; r < plan.rounds; r++) {
-        const int mine = plan_slot(plan, g, r);
+        for (int r = 0;; r++) {
+            const SpreadItem<V> it = r == 0 ? sp.item0 : spread_assign<V>(sp.own, sp.mg, r);
+            const U below = sub_u(shl_u(zero_u<V>() + 1u, it.slot), zero_u<V>() + 1u);
+            const U e0 = popc_u(and_u(below, zero_u<V>() + plan.live)) * (unsigned)ROW_F + (unsigned)SC_ROWS;      // the slot's cached row: entry = rank among the live slots
+            RowVals<V> rv;
+            rv.x = v3<V>(ld_leg(sc.p, sc.stride, e0, it.src, me), ld_leg(sc.p, sc.stride, e0 + 1u, it.src, me), ld_leg(sc.p, sc.stride, e0 + 2u, it.src, me));
+            rv.D = ld_leg(sc.p, sc.stride, e0 + 3u, it.src, me);
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                rv.jsh[k] = ld_leg(sc.p, sc.stride, e0 + (unsigned)(4 + k), it.src, me); rv.j7[k] = ld_leg(sc.p, sc.stride, e0 + (unsigned)(7 + k), it.src, me);
+                rv.ah[k] = ld_leg(sc.p, sc.stride, e0 + (unsigned)(10 + k), it.src, me);
+            }
+            V yls[2];
+            yls[0] = ld_leg(sc.p, sc.stride, zero_u<V>() + (unsigned)(SC_Y + 6), it.src, me); yls[1] = ld_leg(sc.p, sc.stride, zero_u<V>() + (unsigned)(SC_Y + 7), it.src, me);
+            contact_apply_leg<V>(rv, dk, mu, it, mode, yr, yls, acc);
+            if (!any_lane(it.more)) break;
+        }
+        rest_mine = sp.rest_mine; rest_rounds = sp.rest_rounds;
+    }
+#pragma unroll 1
+    for (int r = 0; r < rest_rounds; r++) {
+        const int mine = r < __builtin_popcount(rest_mine) ? nth_set_bit(rest_mine, r) : -1;
         const bool lane_on = mine >= 0 && !(g1z && !plan.grouped);       // (no helper groups this substep: group 1 only rides along for its zeros)
         const int slot = lane_on ? mine : __builtin_ctz(plan.live);       // idle lanes read some valid entry and contribute nothing
         const int rank = plan_rank(plan, slot);
@@ -928,8 +1128,9 @@ JB_HD void cylinder_floor(const Vec3<V>& c, const Vec3<V>& ax_in, const Vec3<V>&
 // `live_before`: the live bits of the slots BELOW this one (candidates are generated in increasing slot order), so that the slot's
 // entry - its rank among the live slots - is known as it is stored: a slot nobody touches takes no entry at all.
 template <typename V, typename MKT>
-JB_HD unsigned cand_store(const LaneScratch<V>& sc, unsigned live_before, int slot, const Vec3<V>& x, const V& dist, const MKT& on) {
+JB_HD unsigned cand_store(const LaneScratch<V>& sc, unsigned live_before, int slot, const Vec3<V>& x, const V& dist, const MKT& on, typename lane_traits<V>::uint* own = nullptr) {
     if (!any_lane(on)) return 0u;
+    if (own) *own = *own + selu(on, zero_u<V>() + (1u << slot), zero_u<V>());      // leg slots: which of them are contacts of THIS lane's leg
     const int rank = __builtin_popcount(live_before & ((1u << slot) - 1u));
     const V d = sel(on, dist, V(1));
     if (rank < ROW_K) {
@@ -942,10 +1143,10 @@ JB_HD unsigned cand_store(const LaneScratch<V>& sc, unsigned live_before, int sl
     return 1u << slot;
 }
 template <typename V, typename MKT>
-JB_HD unsigned cand_store_cyl(const LaneScratch<V>& sc, unsigned live_before, int slot0, const CylContacts<V>& c, const MKT& gate) {
+JB_HD unsigned cand_store_cyl(const LaneScratch<V>& sc, unsigned live_before, int slot0, const CylContacts<V>& c, const MKT& gate, typename lane_traits<V>::uint* own = nullptr) {
     unsigned live = live_before;
 #pragma unroll
-    for (int k = 0; k < 4; k++) live |= cand_store(sc, live, slot0 + k, c.x[k], c.dist[k], mand(c.on[k], gate));
+    for (int k = 0; k < 4; k++) live |= cand_store(sc, live, slot0 + k, c.x[k], c.dist[k], mand(c.on[k], gate), own);
     return live & ~live_before;
 }
 
@@ -1048,6 +1249,8 @@ struct SimOpts {
                          //    While the main lanes factorise the first Newton system of a substep, the replica factorises M + h diag(b) with the
                          //    very same instructions (zero accumulator, hb on its diagonal); the final pass is then a substitution in the replica
                          //    and a 9-value hand-over instead of a second factorisation on the critical path.  Bit-identical results.
+    int spread = 1;      // 1: a plan with more than one round sweeps the leg slots in spread mode (lanes of idle legs adopt contacts of a leg that has
+                         //    several: "spread sweeps" below); 0: diagnostic, the ordinary sweep only
     unsigned long long* prof;   // diagnostic builds: per-wave cycle accumulators [phaseA, check sweeps, full sweeps, solves, integrate]
     unsigned long long* hist;   // diagnostic builds: per-wave [0..27] live-slot counts over all-geom substeps, [28..35] rounds histogram, [36..43] same for ordinary substeps
 };
@@ -1218,24 +1421,25 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
         // ---- contact candidates and contact-frame direction data (before the heavy dynamics, while the
         //      kinematic quantities are still live)
         if (o.contacts) {
+            U own = zero_u<V>();            // the leg slots in which this lane's leg has a contact
             Vec3<V> foot = a2 + mul(R12, ldv3(m, LM_DFOOT));
             V fdist = (s.pz + dot(foot, nb) - m.c[LM_FOOT_R]) + s.pz_lo;
             MK fon = lt(fdist, V(0));
-            live_slots |= cand_store(sc, live_slots, 0, foot - nb * (m.c[LM_FOOT_R] + fdist * V(0.5)), fdist, fon);
+            live_slots |= cand_store(sc, live_slots, 0, foot - nb * (m.c[LM_FOOT_R] + fdist * V(0.5)), fdist, fon, &own);
             CylContacts<V> lc;
             MK all_on = lt(V(0), V(1));
             cylinder_floor(a2 + mul(R12, ldv3(m, LM_LC_D)), mul(R12, ldv3(m, LM_LC_AX)), mul(R12, ldv3(m, LM_LC_XA)), m.c[LM_LC_R], m.c[LM_LC_H], nb, s.pz, s.pz_lo, all_on, lc);
-            live_slots |= cand_store_cyl(sc, live_slots, 1, lc, all_on);
+            live_slots |= cand_store_cyl(sc, live_slots, 1, lc, all_on, &own);
             MK any_con = mor(fon, lc.on[0]);
             if (xtra) {
                 // every remaining geom of the model against the floor
                 CylContacts<V> cy;
                 cylinder_floor(a1 + mul(R1, ldc3(m, LM_UC_D)), mul(R1, ldc3(m, LM_UC_AX)), mul(R1, ldc3(m, LM_UC_XA)), ldc(m, LM_UC_R), ldc(m, LM_UC_H), nb, s.pz, s.pz_lo, all_on, cy);
-                live_slots |= cand_store_cyl(sc, live_slots, 5, cy, all_on);
+                live_slots |= cand_store_cyl(sc, live_slots, 5, cy, all_on, &own);
                 any_con = mor(any_con, cy.on[0]);
                 Vec3<V> tip = a1 + mul(R1, ldc3(m, LM_DTIP));
                 V tipd = (s.pz + dot(tip, nb) - ldc(m, LM_TIP_R)) + s.pz_lo;
-                live_slots |= cand_store(sc, live_slots, 9, tip - nb * (ldc(m, LM_TIP_R) + tipd * V(0.5)), tipd, lt(tipd, V(0)));
+                live_slots |= cand_store(sc, live_slots, 9, tip - nb * (ldc(m, LM_TIP_R) + tipd * V(0.5)), tipd, lt(tipd, V(0)), &own);
                 any_con = mor(any_con, lt(tipd, V(0)));
               if (xbody) {
                 // lane cylinder (root body: lane 2 screw1; motor body: lane 3 threadMass)
@@ -1331,6 +1535,7 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
             }
             any_contact = any_lane(any_con);
             env_con = neq_u(quad_sum_u(mbit(any_con)), zero_u<V>());
+            if (any_contact) sc.st(SC_OWN, utov(own, (const V*)nullptr));
             if (any_contact) {
                 // direction data for the contact frame (n, t1, t2) = R^T (ez, ey, -ex)
 #pragma unroll
@@ -1433,6 +1638,7 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
     any_contact = wave_bcast_u(any_contact ? 1u : 0u) != 0u;
     live_slots = wave_bcast_u(live_slots);
     const SlotPlan plan = make_slot_plan(sc, live_slots);
+    const SpreadPlan<V> spl = make_spread_plan<V>(sc, plan, o.spread != 0 && any_contact);
 
     // ================= phase B: contact solve (primal Newton on the active set) and final acceleration, ONE loop:
     //   while the active set changes:  H(active set at y) y' = tau + contact rhs          (M without damping)
@@ -1485,7 +1691,7 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
             for (;;) {
                 // ---- full pass (reads the iterate of the last check from the scratch: rank-one results are stored only after this pass)
                 if (any_contact) {
-                    contact_sweep<V, PAIR>(m, sc, xtra, plan, 0, dk, acc, have_dfac);
+                    contact_sweep<V, PAIR>(m, sc, xtra, plan, spl, 0, dk, acc, have_dfac);
                     prev_bw0 = acc.bw0; prev_bw1 = acc.bw1; prev_xh = acc.xh;
                     JB_PROF_ADD(o, 2);
 #ifdef JB_WAVE_STATS
@@ -1524,7 +1730,7 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
                     it++;
                     // cheap pass: only the active set at the new iterate.  The ENV's set changed if any lane of the quad
                     // saw a different record; when nobody's changed, every y is the exact minimiser
-                    contact_sweep<V, PAIR>(m, sc, xtra, plan, 2, dk, acc);
+                    contact_sweep<V, PAIR>(m, sc, xtra, plan, spl, 2, dk, acc);
                     JB_PROF_ADD(o, 1);
 #ifdef JB_WAVE_STATS
                     if (is_main) s.st_checks = s.st_checks + V(1);

@@ -16,6 +16,8 @@ using namespace jb;
 // the rank-one pass on rows other groups built, the broadcast loop decisions): the same code paths the device takes with helper lanes.
 static int g_offload = 1;      // lane group 1 as the main lanes' replica (SimOpts::offload), as the one-wave-per-SIMD kernels run it
 extern "C" void jbh_set_offload(int on) { g_offload = on; }
+static int g_spread = 1;       // spread contact sweeps (SimOpts::spread)
+extern "C" void jbh_set_spread(int on) { g_spread = on; }
 template <typename T>
 static int run(const double* P, double* qpos, double* qvel, double ctrl, int nsub, int contacts, int max_newton, int implicit_damp, double* fail, int ngroups = 1, int rank_one = 1, int lean = 0, int pair = 0) {
     using V = Quad<T>;
@@ -40,6 +42,7 @@ static int run(const double* P, double* qpos, double* qvel, double ctrl, int nsu
     for (int i = 0; i < 3; i++) { s.wa[i] = V(T(0)); s.wl[i] = V(T(0)); }
     s.wj[0] = s.wj[1] = V(T(0)); s.wm = V(T(0)); s.fail = V(T(0));
     SimOpts o; o.contacts = contacts; o.max_newton = max_newton; o.implicit_damp = implicit_damp; o.rank_one = rank_one; o.lean = lean; o.offload = (g_offload && !lean && ngroups >= 2) ? 1 : 0; o.prof = nullptr; o.hist = nullptr;
+    o.spread = g_spread;
     constexpr int SCMAX = SC_COUNT > SC_COUNT_LEAN_PAIR ? SC_COUNT : SC_COUNT_LEAN_PAIR;
     V scratch[SCMAX];                  // (the LEAN variant parks state / system / factorisation where the ordinary one has its reduction buffer and overflow candidates)
     V ovcbuf[4 * (NSLOT - ROW_K)];     // LEAN: the candidates beyond the row cache live outside the scratch (global memory on the device)

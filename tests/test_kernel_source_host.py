@@ -259,6 +259,63 @@ def test_replica_group_offload_is_bit_identical_on_the_host(params):
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
 
 
+def _lying_states(params, n):
+    """robots dropped at random attitudes and left to settle: they end up lying on legs and body, 8 contacts or so each"""
+    env = O.OracleEnv(n, "move_from_origin", params, seed=5, step_limit=10 ** 9)
+    env.reset()
+    q, v, _ = env.get_state()
+    rng = np.random.default_rng(3)
+    quat = rng.normal(size=(n, 4))
+    q[:, 3:7] = quat / np.linalg.norm(quat, axis=1, keepdims=True)
+    q[:, 2] = 0.06
+    v[:] = 0
+    env.set_state(q, v)
+    for _ in range(150):
+        env.step(np.zeros(n), auto_reset=False)
+    return env
+
+
+def test_spread_sweeps_fp64_equal_oracle_on_lying_robots(params):
+    """Spread contact sweeps (a plan with more than one round: the lanes of idle legs adopt contacts of a leg that has several, leg-block sums
+    and active-set records routed to the owning lane): the fp64 host build with four lane groups reproduces the oracle on robots lying on
+    the floor, with the spread mode on and off; the two differ in bits (another order of summation), so the spread path really ran."""
+    import tests.build_harness as bh
+    lib = C.CDLL(bh.build())
+    dp = C.POINTER(C.c_double)
+    lib.jbh_step_groups.argtypes = [dp, dp, dp, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, dp]
+    P = np.ascontiguousarray(params)
+
+    def run(q, v, u, spread, rank_one=1):
+        lib.jbh_set_spread(spread)
+        q, v, fail = q.copy(), v.copy(), np.zeros(1)
+        try:
+            assert lib.jbh_step_groups(P.ctypes.data_as(dp), q.ctypes.data_as(dp), v.ctypes.data_as(dp), float(u), 50, 1, 20, 0, 4, rank_one, fail.ctypes.data_as(dp)) == 0
+        finally:
+            lib.jbh_set_spread(1)
+        assert fail[0] == 0
+        return q, v
+
+    n = 16
+    env = _lying_states(params, n)
+    ncon = []
+    worst = {1: 0.0, 0: 0.0}
+    n_diff = 0
+    rng = np.random.default_rng(11)
+    for t in range(3):
+        q0, v0, _ = env.get_state()
+        u = rng.uniform(-1, 1, size=n)
+        ncon += [O.forward_debug(params, q0[i], v0[i], u[i])["ncon"] for i in range(n)]
+        env.step(u, auto_reset=False)
+        q1, v1, _ = env.get_state()
+        for i in range(n):
+            res = {sp: run(q0[i], v0[i], u[i], sp) for sp in (1, 0)}
+            for sp, (q, v) in res.items():
+                worst[sp] = max(worst[sp], np.abs(q - q1[i]).max(), (np.abs(v - v1[i]) / (1 + np.abs(v1[i]))).max())
+            n_diff += not (np.array_equal(res[1][0], res[0][0]) and np.array_equal(res[1][1], res[0][1]))
+    print("lying robots: contacts %d-%d, spread vs oracle %.2e, ordinary vs oracle %.2e, %d of %d differ in bits" % (min(ncon), max(ncon), worst[1], worst[0], n_diff, 3 * n))
+    assert max(ncon) >= 8 and worst[1] < 1e-10 and worst[0] < 1e-10 and n_diff >= 5
+
+
 def test_pair_contact_kernel_source_fp64_equals_oracle():
     """The PAIR instantiation of the substep (closed-form narrow phase of the mass ellipsoid against the upper-leg cylinders, the pair's own
     contact frame, rows without root columns, the shoulder - motor cross term folded into the motor branch of the star solve, the 53rd
