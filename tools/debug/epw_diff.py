@@ -7,12 +7,15 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 rng = np.random.default_rng(0)
 acts = rng.uniform(-1, 1, size=(steps, n)).astype(np.float32)
+if len(sys.argv) > 3 and sys.argv[3] == "const":
+    acts[:] = 1.0          # motor flat out: most robots tip over and lie on a leg (spread sweeps)
 res = {}
 for epw in (1, 2, 4, 8):
     e = JitterbugVecEnv(n, "move_from_origin", seed=5, envs_per_wave=epw)
     ob = [e.reset()]
     for a in acts:
         ob.append(e.step(a)[0])
+    ob = ob[-50:]
     res[epw] = np.stack(ob)
     e.close()
 for epw in (1, 2, 8):
