@@ -97,6 +97,13 @@ template <int J> JB_D unsigned quad_bcast_u(unsigned x) { return (unsigned)__bui
 JB_D unsigned quad_lane_id(const float*) { return threadIdx.x & 3u; }
 // element idx of the scratch column of lane `src` of the own quad (`me`: the own position in the quad)
 JB_D float ld_leg(const float* p, int stride, unsigned idx, unsigned src, unsigned me) { return p[(int)(idx * (unsigned)stride) + (int)src - (int)me]; }
+JB_D void st_leg(float* p, int stride, unsigned idx, unsigned src, unsigned me, float v, bool on) { if (on) p[(int)(idx * (unsigned)stride) + (int)src - (int)me] = v; }
+// the value lane `src` of the quad holds
+JB_D float quad_pick(float x, unsigned src) {
+    auto bc = [&](int ctrl) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), ctrl, 0xF, 0xF, false)); };
+    const float x0 = bc(0x00), x1 = bc(0x55), x2 = bc(0xAA), x3 = bc(0xFF);
+    return src == 0u ? x0 : src == 1u ? x1 : src == 2u ? x2 : x3;
+}
 #endif
 
 JB_HD float sel(bool m, float a, float b) { return m ? a : b; }
@@ -313,6 +320,8 @@ template <int K, typename T> inline Quad<T> quad_rot(const Quad<T>& x) { Quad<T>
 template <int K> inline UQuad quad_rot_u(const UQuad& x) { UQuad r; for (int i = 0; i < 4; i++) r.v[i] = x.v[(i + K) & 3]; return r; }
 template <int J> inline UQuad quad_bcast_u(const UQuad& x) { return UQuad{{x.v[J], x.v[J], x.v[J], x.v[J]}}; }
 template <typename T> inline UQuad quad_lane_id(const Quad<T>*) { return UQuad{{0u, 1u, 2u, 3u}}; }
+template <typename T> inline void st_leg(Quad<T>* p, int stride, const UQuad& idx, const UQuad& src, const UQuad&, const Quad<T>& v, const Mask4& on) { for (int i = 0; i < 4; i++) if (on.v[i]) p[idx.v[i] * stride].v[src.v[i]] = v.v[i]; }
+template <typename T> inline Quad<T> quad_pick(const Quad<T>& x, const UQuad& src) { Quad<T> r; for (int i = 0; i < 4; i++) r.v[i] = x.v[src.v[i]]; return r; }
 template <typename T> inline Quad<T> ld_leg(const Quad<T>* p, int stride, const UQuad& idx, const UQuad& src, const UQuad&) { Quad<T> r; for (int i = 0; i < 4; i++) r.v[i] = p[idx.v[i] * stride].v[src.v[i]]; return r; }
 inline Mask4 eq_u(const UQuad& a, const UQuad& b) { Mask4 r; for (int i = 0; i < 4; i++) r.v[i] = a.v[i] == b.v[i]; return r; }
 inline void flip_decode(const UQuad& diff0, const UQuad& diff1, const UQuad& rec0, const UQuad& rec1, unsigned live, UQuad& entry, Mask4& is_flip, Mask4& plus, Mask4& tan2, Mask4& on) {

@@ -788,7 +788,9 @@ JB_HD void contact_apply_leg(const RowVals<V>& rv, const Vec3<V> (&dk)[3], const
         const Vec3<V> ang = cross(rv.x, dk[k]);
         Bj[k][0] = ang.x; Bj[k][1] = ang.y; Bj[k][2] = ang.z;
         Bj[k][3] = dk[k].x; Bj[k][4] = dk[k].y; Bj[k][5] = dk[k].z;
-        Bj[k][6] = rv.jsh[k]; Bj[k][7] = rv.j7[k]; ahat[k] = rv.ah[k];
+        // (a lane without a contact this round reads the first live slot's entry of its own leg: position and distance are there, the
+        //  rest of a row is only built for contacts - selects, not a zero weight, keep whatever the entry holds out of the sums)
+        Bj[k][6] = sel(it.valid, rv.jsh[k], V(0)); Bj[k][7] = sel(it.valid, rv.j7[k], V(0)); ahat[k] = sel(it.valid, rv.ah[k], V(0));
     }
 #pragma unroll
     for (int k = 0; k < 3; k++) {
@@ -973,15 +975,66 @@ template <typename V> JB_HD SpreadPlan<V> make_spread_plan(const LaneScratch<V>&
     return sp;
 }
 
+// The rows of the spread slots, built the way they are swept: every lane builds the row of the contact it was dealt (round by round),
+// reading the hinge data of that contact's leg from the leg's own LDS column and writing the row there.  Rows of (leg, slot) pairs
+// without a contact are not built at all (nobody sums them: contact_apply_leg, rank_one_pass).  Same arithmetic as row_values for a
+// leg slot (level 1 or 2 by the lane's slot).
+template <typename V>
+JB_HD void contact_rows_build_spread(const LaneModel<V>& m, const LaneScratch<V>& sc, const SlotPlan& plan, const SpreadPlan<V>& sp) {
+    using U = typename lane_traits<V>::uint;
+    using MK = typename lane_traits<V>::mask;
+    const U me = quad_lane_id((const V*)nullptr);
+    const Vec3<V> w = sc.ld3(SC_ST);
+    const V mu = m.c[LM_MU];
+#pragma unroll 1
+    for (int r = 0;; r++) {
+        const SpreadItem<V> it = r == 0 ? sp.item0 : spread_assign<V>(sp.own, sp.mg, r);
+        const U below = sub_u(shl_u(zero_u<V>() + 1u, it.slot), zero_u<V>() + 1u);
+        const U e0 = popc_u(and_u(below, zero_u<V>() + plan.live)) * (unsigned)ROW_F + (unsigned)SC_ROWS;
+        const Vec3<V> x = v3<V>(ld_leg(sc.p, sc.stride, e0, it.src, me), ld_leg(sc.p, sc.stride, e0 + 1u, it.src, me), ld_leg(sc.p, sc.stride, e0 + 2u, it.src, me));
+        const V dist = ld_leg(sc.p, sc.stride, e0 + 3u, it.src, me);
+        auto ldl = [&](int i) { return ld_leg(sc.p, sc.stride, zero_u<V>() + (unsigned)i, it.src, me); };
+        const V thd1 = ldl(SC_ST + 3), thd2 = ldl(SC_ST + 4);
+        const Vec3<V> e1 = v3<V>(ldl(SC_DD + 9), ldl(SC_DD + 10), ldl(SC_DD + 11)), a1 = v3<V>(ldl(SC_DD + 12), ldl(SC_DD + 13), ldl(SC_DD + 14));
+        const Vec3<V> e2 = v3<V>(ldl(SC_DD + 15), ldl(SC_DD + 16), ldl(SC_DD + 17)), a2 = v3<V>(ldl(SC_DD + 18), ldl(SC_DD + 19), ldl(SC_DD + 20));
+        const MK lvl2 = lt_u(it.slot, 5u);
+        const V f_sh = V(1), f_kn = sel(lvl2, V(1), V(0));
+        const V tran = sel(lvl2, quad_pick(m.c.tran2, it.src), quad_pick(m.c.tran1, it.src));
+        const MK valid = lt(dist, V(0));
+        const V imp = impedance(m, dist);
+        const V invD = (V(1) - imp) * (tran * ((V(1) + m.c[LM_FR2]) * (V(2) * mu * mu)));
+        const V D = sel(valid, imp * vrcp(invD), V(0));
+        const V jdot = f_kn * thd2;
+        const Vec3<V> p1 = cross(e1, x - a1), p2 = cross(e2, x - a2);
+        st_leg(sc.p, sc.stride, e0 + 3u, it.src, me, D, it.valid);
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const Vec3<V> d = sc.ld3(SC_DD + 3 * k);
+            const Vec3<V> ang = cross(x, d);
+            const V jsh = f_sh * dot(d, p1);
+            const V j7 = f_kn * dot(d, p2);
+            const V vel = dot(ang, w) + sc.ld(SC_DD + 21 + k) + jsh * thd1 + j7 * jdot;
+            V ah = -m.c[LM_BB] * vel;
+            if (k == 0) ah = ah - m.c[LM_KK] * imp * dist;
+            st_leg(sc.p, sc.stride, e0 + (unsigned)(4 + k), it.src, me, jsh, it.valid);
+            st_leg(sc.p, sc.stride, e0 + (unsigned)(7 + k), it.src, me, j7, it.valid);
+            st_leg(sc.p, sc.stride, e0 + (unsigned)(10 + k), it.src, me, ah, it.valid);
+        }
+        if (!any_lane(it.more)) break;
+    }
+}
+
 // y-independent rows of the live slots, once per substep (slots beyond the cache keep their candidate only; their rows are
 // recomputed in registers in every pass)
 template <typename V, bool PAIR = false>
-JB_HD void contact_rows_build_all(const LaneModel<V>& m, const LaneScratch<V>& sc, bool xtra, const SlotPlan& plan) {
+JB_HD void contact_rows_build_all(const LaneModel<V>& m, const LaneScratch<V>& sc, bool xtra, const SlotPlan& plan, const SpreadPlan<V>& sp) {
     if (!plan.grouped && sc.grp != 0) return;
-    const int g = plan.grouped ? sc.grp : 0;
+    unsigned mine = plan.mine;
+    int rounds = plan.rounds;
+    if (sp.on) { contact_rows_build_spread<V>(m, sc, plan, sp); mine = sp.rest_mine; rounds = sp.rest_rounds; }
 #pragma unroll 1
-    for (int r = 0; r < plan.rounds; r++) {
-        const int slot = plan_slot(plan, g, r);
+    for (int r = 0; r < rounds; r++) {
+        const int slot = r < __builtin_popcount(mine) ? nth_set_bit(mine, r) : -1;
         if (slot >= 0) {
             const int entry = plan_rank(plan, slot);
             if (entry < ROW_K) contact_rows_build<V, PAIR>(m, sc, xtra, slot, entry);
@@ -1035,7 +1088,7 @@ JB_HD void contact_sweep(const LaneModel<V>& m, const LaneScratch<V>& sc, bool x
     for (int r = 0; r < rest_rounds; r++) {
         const int mine = r < __builtin_popcount(rest_mine) ? nth_set_bit(rest_mine, r) : -1;
         const bool lane_on = mine >= 0 && !(g1z && !plan.grouped);       // (no helper groups this substep: group 1 only rides along for its zeros)
-        const int slot = lane_on ? mine : __builtin_ctz(plan.live);       // idle lanes read some valid entry and contribute nothing
+        const int slot = lane_on ? mine : __builtin_ctz(sp.on ? (plan.live & ~sp.slots) : plan.live);       // idle lanes read some BUILT entry (spread mode: one of this loop's) and contribute nothing
         const int rank = plan_rank(plan, slot);
         RowVals<V> rv;
         if (rank < ROW_K) row_load<V>(sc, rank, rv);
@@ -1658,7 +1711,7 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
         if (any_contact) {
 #pragma unroll
             for (int k = 0; k < 3; k++) dk[k] = sc.ld3(SC_DD + 3 * k);      // contact-frame directions: once per substep, every lane
-            contact_rows_build_all<V, PAIR>(m, sc, xtra, plan);
+            contact_rows_build_all<V, PAIR>(m, sc, xtra, plan, spl);
             JB_PROF_ADD(o, 5);
             if (is_main) {      // warm start (world linear part rotated into the root frame)
                 Vec3<V> lw = mulT(Rw, v3<V>(s.wl[0], s.wl[1], s.wl[2]));
