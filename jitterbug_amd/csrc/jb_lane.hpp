@@ -100,8 +100,9 @@ JB_D float ld_leg(const float* p, int stride, unsigned idx, unsigned src, unsign
 JB_D void st_leg(float* p, int stride, unsigned idx, unsigned src, unsigned me, float v, bool on) { if (on) p[(int)(idx * (unsigned)stride) + (int)src - (int)me] = v; }
 // the value lane `src` of the quad holds
 JB_D float quad_pick(float x, unsigned src) {
-    auto bc = [&](int ctrl) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), ctrl, 0xF, 0xF, false)); };
-    const float x0 = bc(0x00), x1 = bc(0x55), x2 = bc(0xAA), x3 = bc(0xFF);
+    const int xi = __builtin_bit_cast(int, x);
+    const float x0 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, xi, 0x00, 0xF, 0xF, false)), x1 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, xi, 0x55, 0xF, 0xF, false));
+    const float x2 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, xi, 0xAA, 0xF, 0xF, false)), x3 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, xi, 0xFF, 0xF, 0xF, false));
     return src == 0u ? x0 : src == 1u ? x1 : src == 2u ? x2 : x3;
 }
 #endif

@@ -1160,6 +1160,13 @@ JB_HD void cylinder_floor(const Vec3<V>& c, const Vec3<V>& ax_in, const Vec3<V>&
     V prjaxis = prj * half;
     V d1 = dist0 + prjaxis + prjvec;
     auto on1 = mand(enabled, lt(d1, V(0)));
+    if (!any_lane(on1)) {
+        // the first point is the cylinder's lowest: when no lane of the wave has it below the floor there is no contact at all, and the
+        // other points' positions (a cross product, a reciprocal square root, four position sums) need not be worked out - the usual case
+#pragma unroll
+        for (int k = 0; k < 4; k++) { out.dist[k] = V(1); out.on[k] = on1; out.x[k] = c; }
+        return;
+    }
     out.dist[0] = d1; out.on[0] = on1;
     out.x[0] = c + vec + axh - nb * (d1 * V(0.5));
     V d2 = dist0 - prjaxis + prjvec;
