@@ -387,4 +387,15 @@ def test_contacts_beyond_the_row_cache_give_the_same_answer(params):
                     for groups in (1, 4):
                         qh, vh = run(fn, q0[i], v0[i], a[i], groups)
                         worst = max(worst, np.abs(qh - q1[i]).max(), (np.abs(vh - v1[i]) / (1 + np.abs(v1[i]))).max())
+    # ... and robots lying on the floor (8 contacts or so): with four lane groups the TWO cached leg slots are swept in spread mode, the
+    # other six go through the ordinary loop with their rows recomputed per pass - the mixed path of a plan that overflows the cache
+    env = _lying_states(params, 8)
+    q0, v0, _ = env.get_state()
+    a = np.linspace(-1, 1, 8)
+    env.step(a, auto_reset=False)
+    q1, v1, _ = env.get_state()
+    for i in range(8):
+        for fn in (lib.jbh_step_groups, lib.jbh_step_lean):
+            qh, vh = run(fn, q0[i], v0[i], a[i], 4)
+            worst = max(worst, np.abs(qh - q1[i]).max(), (np.abs(vh - v1[i]) / (1 + np.abs(v1[i]))).max())
     assert worst < 1e-10, worst
