@@ -64,10 +64,10 @@ static int run(const double* P, double* qpos, double* qvel, double ctrl, int nsu
         if (lean) state_load(sc, s);
     } else {
         HostWave wave;
-        wave.ngrp = ngroups; wave.gstride = 16;            // 16: the lane distance between groups in the 4-envs-per-wave kernel (selects its transposed reduction)
+        wave.ngrp = ngroups; wave.gstride = ngroups == 2 ? 32 : 16;            // 16: the lane distance between groups in the 4-envs-per-wave kernel (selects its transposed reduction); 32: the 8-envs-per-wave kernel's two groups
         auto body = [&](int g) {
             g_host_wave = &wave; g_host_grp = g;
-            LaneScratch<V> sc; sc.p = scratch; sc.stride = 1; sc.grp = g; sc.ngrp = ngroups; sc.gstride = 16; set_ovc(sc);
+            LaneScratch<V> sc; sc.p = scratch; sc.stride = 1; sc.grp = g; sc.ngrp = ngroups; sc.gstride = ngroups == 2 ? 32 : 16; set_ovc(sc);
             LaneState<V> hs = s;                            // helper lanes start from a harmless state, like the kernel's
             LaneState<V>& st = (g == 0) ? s : hs;
             if (g != 0 && !(o.offload && g == 1)) {
@@ -114,25 +114,25 @@ extern "C" int jbh_step(const double* P, double* qpos, double* qvel, double ctrl
 }
 // the same with ngroups lane groups (1 or 4) and the rank-one Newton passes on or off
 extern "C" int jbh_step_groups(const double* P, double* qpos, double* qvel, double ctrl, int nsub, int contacts, int max_newton, int use_float, int ngroups, int rank_one, double* fail) {
-    if (ngroups != 1 && ngroups != 4) return -101;
+    if (ngroups != 1 && ngroups != 2 && ngroups != 4) return -101;
     return use_float ? run<float>(P, qpos, qvel, ctrl, nsub, contacts, max_newton, 1, fail, ngroups, rank_one)
                      : run<double>(P, qpos, qvel, ctrl, nsub, contacts, max_newton, 1, fail, ngroups, rank_one);
 }
 // ... and in the LEAN variant (state / system / factorisation parked in the scratch, constants never preloaded)
 extern "C" int jbh_step_lean(const double* P, double* qpos, double* qvel, double ctrl, int nsub, int contacts, int max_newton, int use_float, int ngroups, int rank_one, double* fail) {
-    if (ngroups != 1 && ngroups != 4) return -101;
+    if (ngroups != 1 && ngroups != 2 && ngroups != 4) return -101;
     return use_float ? run<float>(P, qpos, qvel, ctrl, nsub, contacts, max_newton, 1, fail, ngroups, rank_one, 1)
                      : run<double>(P, qpos, qvel, ctrl, nsub, contacts, max_newton, 1, fail, ngroups, rank_one, 1);
 }
 // ... and with the geom-geom pair contact (mass ellipsoid against the upper-leg cylinders): the PAIR instantiation of the substep
 extern "C" int jbh_step_pair(const double* P, double* qpos, double* qvel, double ctrl, int nsub, int contacts, int max_newton, int use_float, int ngroups, int rank_one, double* fail) {
-    if (ngroups != 1 && ngroups != 4) return -101;
+    if (ngroups != 1 && ngroups != 2 && ngroups != 4) return -101;
     return use_float ? run<float>(P, qpos, qvel, ctrl, nsub, contacts, max_newton, 1, fail, ngroups, rank_one, 0, 1)
                      : run<double>(P, qpos, qvel, ctrl, nsub, contacts, max_newton, 1, fail, ngroups, rank_one, 0, 1);
 }
 // ... and PAIR in the LEAN layout (parked state / system / factorisation incl. the cross term's share, pair frame behind them)
 extern "C" int jbh_step_pair_lean(const double* P, double* qpos, double* qvel, double ctrl, int nsub, int contacts, int max_newton, int use_float, int ngroups, int rank_one, double* fail) {
-    if (ngroups != 1 && ngroups != 4) return -101;
+    if (ngroups != 1 && ngroups != 2 && ngroups != 4) return -101;
     return use_float ? run<float>(P, qpos, qvel, ctrl, nsub, contacts, max_newton, 1, fail, ngroups, rank_one, 1, 1)
                      : run<double>(P, qpos, qvel, ctrl, nsub, contacts, max_newton, 1, fail, ngroups, rank_one, 1, 1);
 }

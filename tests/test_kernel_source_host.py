@@ -285,11 +285,11 @@ def test_spread_sweeps_fp64_equal_oracle_on_lying_robots(params):
     lib.jbh_step_groups.argtypes = [dp, dp, dp, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, dp]
     P = np.ascontiguousarray(params)
 
-    def run(q, v, u, spread, rank_one=1):
+    def run(q, v, u, spread, rank_one=1, groups=4):
         lib.jbh_set_spread(spread)
         q, v, fail = q.copy(), v.copy(), np.zeros(1)
         try:
-            assert lib.jbh_step_groups(P.ctypes.data_as(dp), q.ctypes.data_as(dp), v.ctypes.data_as(dp), float(u), 50, 1, 20, 0, 4, rank_one, fail.ctypes.data_as(dp)) == 0
+            assert lib.jbh_step_groups(P.ctypes.data_as(dp), q.ctypes.data_as(dp), v.ctypes.data_as(dp), float(u), 50, 1, 20, 0, groups, rank_one, fail.ctypes.data_as(dp)) == 0
         finally:
             lib.jbh_set_spread(1)
         assert fail[0] == 0
@@ -312,6 +312,9 @@ def test_spread_sweeps_fp64_equal_oracle_on_lying_robots(params):
             for sp, (q, v) in res.items():
                 worst[sp] = max(worst[sp], np.abs(q - q1[i]).max(), (np.abs(v - v1[i]) / (1 + np.abs(v1[i]))).max())
             n_diff += not (np.array_equal(res[1][0], res[0][0]) and np.array_equal(res[1][1], res[0][1]))
+            if t == 0:          # the two-group layout of the 8-envs-per-wave kernel (five leg slots per group: up to four spread rounds' worth of overflow)
+                q, v = run(q0[i], v0[i], u[i], 1, groups=2)
+                worst[1] = max(worst[1], np.abs(q - q1[i]).max(), (np.abs(v - v1[i]) / (1 + np.abs(v1[i]))).max())
     print("lying robots: contacts %d-%d, spread vs oracle %.2e, ordinary vs oracle %.2e, %d of %d differ in bits" % (min(ncon), max(ncon), worst[1], worst[0], n_diff, 3 * n))
     assert max(ncon) >= 8 and worst[1] < 1e-10 and worst[0] < 1e-10 and n_diff >= 5
 
