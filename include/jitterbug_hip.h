@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define JB_ABI_VERSION 2
+#define JB_ABI_VERSION 3
 
 #define JB_OK            0
 #define JB_E_INVALID    -1   /* bad argument */
@@ -59,8 +59,13 @@ extern "C" {
 typedef struct jb_handle jb_handle;
 
 #define JB_FLAG_NO_RANK_ONE 1   /* diagnostic: every Newton pass is a full sweep + refactorisation (no rank-one passes) */
-#define JB_FLAG_LEAN        2   /* the two-waves-per-SIMD kernel variant (256 registers; state / system / factorisation parked in LDS);
-                                  bit-identical results; experimental, see DESIGN.md */
+#define JB_FLAG_LEAN        2   /* the two-waves-per-SIMD kernel variant (<= 256 registers and 20 KB of LDS per four-env wave; state / system /
+                                  factorisation parked in LDS).  It agrees with the ordinary kernel to fp32 rounding, NOT bit for bit (the
+                                  compiler fuses multiply-adds differently in the two instantiations): give every shard of one batch the
+                                  same flag.  Pays when a GPU holds >= 2048 four-env waves (8192 envs; one model per env: 16 384), see
+                                  jitterbug_amd.variants / DESIGN.md 4.  A combination it cannot run (a model that needs the pair contact
+                                  unless that is one model per env at 4 envs per wave) is refused with JB_E_INVALID, never run silently as
+                                  the ordinary kernel; jb_kernel_variant() reports what a handle launches */
 #define JB_FLAG_PAIR        4   /* always run the kernel variant with the geom-geom contact (eccentric-mass ellipsoid against the upper-leg
                                   cylinders, reference jitterbug.xml:44-107: every jitterbug geom collides).  Without the flag the variant
                                   is chosen by the model: on for one-model-per-env batches and for a shared table whose mass comes within
@@ -116,8 +121,9 @@ int jb_set_model_params(jb_handle* h, const double* params, int32_t n_tables);
  *   params_out  (host, [N, JB_NPARAM],  nullable): the compiled parameter tables (5 KB per env: ask only when needed)
  *   offsets_out (host, [N, JB_NOFFSET], nullable), attempts_out (host, [N], nullable)
  * cfg.min_mass_clearance > 0 re-draws (attempt 1, 2, ...) any model whose eccentric mass cannot turn at the rest pose without
- * coming within that distance of a leg: the reference's sigmas produce such robots in 3.6 % of the draws, MuJoCo would simulate a
- * mass-leg contact there and this simulator collides with the floor only (deviations).  0 keeps every draw. */
+ * coming within that distance of a leg: the reference's sigmas produce such robots in 3.6 % of the draws.  MuJoCo simulates a
+ * mass-leg contact there and so does this simulator (the PAIR kernel variant, chosen automatically for one-model-per-env
+ * batches), so the default 0 keeps every draw; a positive margin is for callers who want buildable robots only. */
 #define JB_NOFFSET 31   /* [global density, coreBody1 density, coreBody2 density | 4 legs x (upper far end xyz, foot end xyz) | motor xyz | gear] */
 #define JB_RND_LEGS 1
 #define JB_RND_MASS 2
@@ -165,6 +171,21 @@ int jb_reward_terms(jb_handle* h, float* terms_out /*[N,4]*/);
 int jb_rollout_policy_device(jb_handle* h, int32_t n_steps, float* d_obs_inout, float* d_rewards, uint8_t* d_done_last);
 /* host-buffer form: starts from the handle's current state; rewards_out [n_steps,N] and obs_out [N,D] are nullable */
 int jb_rollout_policy(jb_handle* h, int32_t n_steps, float* rewards_out, float* obs_out);
+/* K control steps in ONE kernel launch (SURVEY.md 3.3 "one kernel launch per control step or per K control steps", 8(f)1 "policies fused
+ * ahead of the step kernel"; the loops it serves: benchmarks/evaluate_policy.py:29-33, the async step_async / step_wait split of
+ * benchmarks/benchmark.py:146-171).  Every wave keeps its environments' state in registers / LDS across the K steps and never waits for
+ * another wave, so the launch lasts as long as its slowest wave's SUM over the steps, not the sum of every step's slowest wave.
+ *   d_actions   [K, N] action tape (step k applies row k), or NULL: the handle's heuristic policy (jb_set_policy_params) evaluated in the
+ *               kernel on the observation the lanes just produced (step 0: on the current state's observation)
+ *   d_rows_out  [K, N, D+2] nullable: the packed rows [obs | reward | done] of every step (what jb_step_rows_device writes per step)
+ *   d_rewards   [K, N] nullable; d_obs_last [N, D] nullable; d_done_last [N] nullable: per-step rewards, the last step's observations
+ *               and done flags.  Rows and these three exclude each other.
+ * jb_step_device / jb_step_rows_device ARE this kernel with K = 1: K single-step calls and one K-step call give bit-identical
+ * states, rows and rewards (tests/test_gpu_rollout.py), in-kernel auto-reset included. */
+int jb_step_many_device(jb_handle* h, int32_t n_steps, const float* d_actions, float* d_rows_out, float* d_rewards, float* d_obs_last, uint8_t* d_done_last);
+/* seconds each wave of the LAST step launch was alive (one wave = jb_envs_per_wave envs), out[0 .. min(n_waves, max_waves)); returns the
+ * number of waves.  Mean against maximum is the load imbalance of the launch (roofline). */
+int jb_wave_clocks(jb_handle* h, double* out, int32_t max_waves);
 /* Rows between GPUs without Python: one RCCL communicator per handle, RCCL bound at run time (dlopen: no link-time
  * dependency; a process that already holds an RCCL, e.g. PyTorch-ROCm's, keeps that one).  Rank 0 makes the id, the host distributes
  * its JB_COMM_ID_BYTES to every rank by its own means, every rank calls jb_comm_init (collective).  jb_gather_rows_device sends this
@@ -204,6 +225,13 @@ void* jb_stream(jb_handle* h);                 /* the hipStream_t the handle lau
 /* queries */
 int jb_obs_dim(int32_t task_id);               /* 15/16/19/18/19, or JB_E_INVALID */
 int jb_num_envs(jb_handle* h);
+/* the step kernel a handle launches (it depends on the flags, the model and envs_per_wave; see JB_FLAG_LEAN / JB_FLAG_PAIR) */
+#define JB_VARIANT_ORDINARY  0   /* one wave per SIMD, floor contacts */
+#define JB_VARIANT_PAIR      1   /* one wave per SIMD, floor contacts + the mass / upper-leg geom-geom contact */
+#define JB_VARIANT_LEAN      2   /* two waves per SIMD, floor contacts */
+#define JB_VARIANT_LEAN_PAIR 3   /* two waves per SIMD, one model per env (split tables), floor + pair contact */
+int jb_kernel_variant(jb_handle* h);
+int jb_envs_per_wave(jb_handle* h);
 int jb_device_count(void);
 int jb_abi_version(void);
 const double* jb_default_model_params(void);   /* the compiled nominal model, JB_NPARAM doubles */

@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libjitterbug_hip.so")
 SOURCES = ["jb_api.hip"]
-DEPS = ["jb_api.hip", "jb_sim.hpp", "jb_task.hpp", "jb_lane.hpp", "jb_model_build.hpp", "jb_model_compile.hpp", "jb_model_compile_types.h", "jb_nominal_spec.h", "jb_default_params.h", "jb_device_guard.hpp",
+DEPS = ["jb_api.hip", "jb_sim.hpp", "jb_step.hpp", "jb_task.hpp", "jb_lane.hpp", "jb_model_build.hpp", "jb_model_compile.hpp", "jb_model_compile_types.h", "jb_nominal_spec.h", "jb_default_params.h", "jb_device_guard.hpp",
         os.path.join("..", "..", "include", "jitterbug_hip.h"), os.path.join("..", "..", "include", "jitterbug_model.h")]
 # -fno-slp-vectorize: the SLP vectoriser turns the small fixed-size linear algebra into v_pk_fma_f32 fed by hundreds of
 # register-shuffling v_mov (a third of the contact loop); scalar v_fma code is ~10 % shorter and has no such moves.

@@ -25,6 +25,7 @@
 #include "jb_model_compile.hpp"
 #include "jb_nominal_spec.h"
 #include "jb_sim.hpp"
+#include "jb_step.hpp"
 #include "jb_task.hpp"
 
 using namespace jb;
@@ -47,6 +48,22 @@ struct KArgs {
     int* step_count; unsigned* episode;
     float* ovc_buf;    // LEAN variant: per wave, the candidates of the live slots beyond the row cache (global memory: the variant's 20 KB of LDS have no room)
     unsigned long long* wave_stats;   // diagnostic builds (-DJB_WAVE_STATS): [n_waves][4] = cycles, rare-path substeps, Newton sweeps, contact substeps
+};
+
+// What one launch of a step kernel reads and writes besides the state: K control steps in ONE launch (jb_step_many_device; K = 1 is the
+// ordinary step - the same kernel, hence the same machine code and the same bits).  A wave owns its environments for all K steps:
+// state, step counter, episode and target stay in registers (LEAN: LDS) between the control steps, and no wave waits for another.
+struct StepIO {
+    int n_steps;                   // K >= 1
+    int use_policy;                // 1: the action of every step is the handle's heuristic policy, evaluated in the kernel on the observation the lanes just produced
+    const float* actions;          // use_policy = 0: action tape [K, N] (step k reads row k)
+    const float* obs_in;           // use_policy = 1, nullable: [N, D] current observation rows for step 0 (NULL: observed from the state in the kernel)
+    float* obs_out;                // nullable: obs [.., N, D], or packed rows [.., N, D+2] when KArgs::packed_rows
+    float* reward_out;             // nullable [.., N]   (not packed rows)
+    unsigned char* done_out;       // nullable [.., N]   (not packed rows)
+    int every_step;                // bit 0 / 1 / 2: obs (rows) / reward / done blocks are written for EVERY step ([K, ...] buffers); clear: only the last step's
+    PolicyParams<float> pp;
+    unsigned long long* wave_clock;      // nullable [n_waves]: how long each wave lived in this launch (s_memrealtime ticks, 100 MHz): the imbalance a fused rollout removes
 };
 
 // Stage the packed constant table(s) of this workgroup (one wave = a.epw envs) into LDS: one LM_TABLE copy for a
@@ -123,11 +140,15 @@ __device__ __forceinline__ void store_state(const KArgs& a, int env, int lane, i
 #pragma unroll
     for (int f = 0; f < 5; f++) if ((f & 3) == leg) r[(RF_LO + f) * N] = los[f];
 }
-__device__ __forceinline__ void core_from_state(const KArgs& a, int env, const LaneState<float>& s, const float (&c0)[3], EnvCore<float>& e) {
+__device__ __forceinline__ void core_from_state(const LaneState<float>& s, const float (&c0)[3], const float (&tgt)[3], EnvCore<float>& e) {
     e.cx = c0[0]; e.cy = c0[1]; e.cz = c0[2];
     e.px = s.px; e.py = s.py; e.pz = s.pz; e.qw = s.qw; e.qx = s.qx; e.qy = s.qy; e.qz = s.qz;
     e.vx = s.vx; e.vy = s.vy; e.vz = s.vz; e.wx = s.wx; e.wy = s.wy; e.wz = s.wz; e.phi = s.phi; e.phid = s.phid;
-    e.tx = a.root[(RF_TGT + 0) * a.n + env]; e.ty = a.root[(RF_TGT + 1) * a.n + env]; e.tpsi = a.root[(RF_TGT + 2) * a.n + env];
+    e.tx = tgt[0]; e.ty = tgt[1]; e.tpsi = tgt[2];
+}
+__device__ __forceinline__ void core_from_state(const KArgs& a, int env, const LaneState<float>& s, const float (&c0)[3], EnvCore<float>& e) {
+    const float tgt[3] = {a.root[(RF_TGT + 0) * a.n + env], a.root[(RF_TGT + 1) * a.n + env], a.root[(RF_TGT + 2) * a.n + env]};
+    core_from_state(s, c0, tgt, e);
 }
 __device__ __forceinline__ void state_from_reset(const EnvCore<float>& e, LaneState<float>& s) {
     s.px = e.px; s.py = e.py; s.pz = e.pz; s.qw = e.qw; s.qx = e.qx; s.qy = e.qy; s.qz = e.qz;
@@ -152,11 +173,23 @@ __device__ __forceinline__ void store_target(const KArgs& a, int env, const EnvC
 }
 
 // ---------------------------------------------------------------------------------------------- step
+// The step kernels' arguments (KArgs, StepIO) live in the kernarg segment.  What the control-step epilogue needs of them (output
+// pointers, task options, RNG keys: ~60 scalar registers) must not stay in scalar registers across the 50 substeps - the substep loop
+// needs them all, and what does not fit is spilled to VGPR lanes and read back with v_readlane inside the hot loop.  The epilogue
+// therefore reads its arguments where it uses them, through a pointer to the kernarg segment that the optimiser cannot see through
+// (so the loads cannot be hoisted above the substep loop): a handful of s_load per control step.
+typedef const __attribute__((address_space(4))) KArgs* KArgsC;
+typedef const __attribute__((address_space(4))) StepIO* StepIOC;
+constexpr unsigned STEPIO_KERNARG_OFFSET = (unsigned)((sizeof(KArgs) + alignof(StepIO) - 1) / alignof(StepIO) * alignof(StepIO));
+__device__ __forceinline__ const __attribute__((address_space(4))) char* kernarg_base() {
+    const __attribute__((address_space(4))) char* p = (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return p;
+}
 // EPW (envs per wave) is a template parameter so that the scratch stride is a compile-time constant and every LDS access
 // of the substep uses an immediate offset instead of integer address arithmetic.
 template <int EPW, bool LEAN, bool PAIR = false>
-__device__ __forceinline__ void step_body(KArgs a, const float* __restrict__ action, float* __restrict__ obs_out,
-                                          float* __restrict__ reward_out, unsigned char* __restrict__ done_out) {
+__device__ __forceinline__ void step_body(KArgs a, StepIO io) {
     // one wave per workgroup; quad q (4 lanes) of the wave owns env blockIdx*epw + q.  Quads beyond epw (a small batch is
     // spread over all SIMDs with partially filled waves) and beyond the batch retire at once: DPP quad sums and the
     // wave ballots only ever involve complete, active quads.
@@ -175,11 +208,11 @@ __device__ __forceinline__ void step_body(KArgs a, const float* __restrict__ act
     const int nb = (int)gridDim.x, b = (int)blockIdx.x, xcd = b & 7, per = nb >> 3, rem = nb & 7;
     const int lblock = xcd * per + (xcd < rem ? xcd : rem) + (b >> 3);
     const int env = lblock * EPW + quad;
+    const unsigned long long clock0 = __builtin_amdgcn_s_memrealtime();
     LaneModel<float> m;
     constexpr int SCN = LEAN ? (PAIR ? SC_COUNT_LEAN_PAIR : SC_COUNT_LEAN) : SC_COUNT;      // floats of per-lane scratch
     stage_model<LEAN && PAIR>(a, lds + SCN * 4 * EPW, lblock, quad, leg, m, LEAN, PAIR || !LEAN);      // (LEAN + PAIR is only launched with one model per env: split tables)
     if (grp >= NGRP || env >= a.n) return;       // whole quads (and their mirrors in every group) retire together
-    const bool live = true;
     const int lane = env * 4 + leg;
     LaneScratch<float> scr;
     scr.p = lds + lane_in_grp;
@@ -194,7 +227,10 @@ __device__ __forceinline__ void step_body(KArgs a, const float* __restrict__ act
 #endif
     LaneState<float> s;
     constexpr bool OFFLOAD = !LEAN;              // lane group 1 replicates the main lanes (jb_sim.hpp SimOpts::offload)
-    if (grp == 0 || (OFFLOAD && grp == 1)) load_state(a, env, lane, s);
+    // the lanes that hold an env's state: the main lanes and their replica.  Both run everything below that changes the state
+    // (substeps, failure flag, episode reset) with the very same instructions; only the main lanes write to memory.
+    const bool rep = grp == 0 || (OFFLOAD && grp == 1);
+    if (rep) load_state(a, env, lane, s);
     else {
         s.px = s.py = s.pz = 0.f; s.qw = 1.f; s.qx = s.qy = s.qz = 0.f; s.vx = s.vy = s.vz = s.wx = s.wy = s.wz = 0.f;
         s.pz_lo = s.qw_lo = s.qx_lo = s.qy_lo = s.qz_lo = 0.f;
@@ -205,7 +241,6 @@ __device__ __forceinline__ void step_body(KArgs a, const float* __restrict__ act
 #ifdef JB_WAVE_STATS
     s.st_xtra = 0.f; s.st_sweeps = 0.f; s.st_contact = 0.f; s.st_slots = 0.f; s.st_fast = 0.f; s.st_checks = 0.f;
 #endif
-    const float ctrl = action[env];
     SimOpts o; o.contacts = a.contacts; o.max_newton = a.max_newton; o.implicit_damp = 1; o.rank_one = a.rank_one; o.lean = LEAN ? 1 : 0; o.offload = OFFLOAD ? 1 : 0; o.spread = a.spread; o.prof = nullptr; o.hist = nullptr;
 #ifdef JB_WAVE_STATS
     const unsigned long long rt_start = __builtin_amdgcn_s_memrealtime();
@@ -213,16 +248,88 @@ __device__ __forceinline__ void step_body(KArgs a, const float* __restrict__ act
     o.prof = prof_local;
     o.hist = a.wave_stats ? a.wave_stats + (size_t)16 * a.n + (size_t)64 * lblock : nullptr;
 #endif
-    normalise_state(s);          // mj_kinematics normalises the free-joint quaternion; phase C keeps it normalised from here on
-    if (LEAN && grp == 0) state_store(scr, s);                   // LEAN: the state lives in the scratch between substeps
     if (OFFLOAD && grp == 0) {
 #pragma unroll
         for (int i = 0; i < 56; i++) scr.st(SC_ZERO + i, 0.f);
     }
+    // per-env bookkeeping that a K-step launch carries in registers: step counter, episode number, target
+    EpisodeRegs<float> er;
+    er.step_count = a.step_count[env];
+    er.episode = a.episode[env];
+    er.tgt[0] = a.root[(RF_TGT + 0) * a.n + env]; er.tgt[1] = a.root[(RF_TGT + 1) * a.n + env]; er.tgt[2] = a.root[(RF_TGT + 2) * a.n + env];
+    const int n_substeps = a.substeps;
+    float ctrl_next = 0.f;           // use_policy: the action of the NEXT step, computed right after the observation it reads
+    if (io.use_policy && rep) {      // the observation the first action is computed from: the caller's row, or the state observed here
+        const int D = obs_dim(a.task);
+        float obs0[19];
+#pragma unroll
+        for (int j = 0; j < 19; j++) obs0[j] = 0.f;
+        if (io.obs_in) {
+#pragma unroll
+            for (int j = 0; j < 19; j++) if (j < D) obs0[j] = io.obs_in[(size_t)env * D + j];
+        } else {
+            EnvCore<float> e0;
+            core_from_lane_state<float>(m, s, er.tgt, e0);
+            observe<float>(a.task, e0, m.c[LM_TARGET_Z], obs0, 1);
+        }
+        ctrl_next = heuristic_policy<float>(a.task, obs0, 1, io.pp);
+    }
+    // (from here on the arguments are read through kernarg_base(): see above)
+    int k = 0;
 #pragma unroll 1
-    for (int k = 0; k < a.substeps; k++) substep<float, PAIR>(m, scr, s, ctrl, o);
-    if (grp != 0) return;                        // helper lanes only take part in the substeps
-    if (LEAN) state_load(scr, s);
+    for (;;) {
+        float ctrl = ctrl_next;
+        {
+            const auto kb = kernarg_base();
+            const KArgsC ka = (KArgsC)kb;
+            const StepIOC ic = (StepIOC)(kb + STEPIO_KERNARG_OFFSET);
+            if (rep && !ic->use_policy) ctrl = ic->actions[(size_t)k * ka->n + env];
+        }
+        if (rep) normalise_state(s);          // mj_kinematics normalises the free-joint quaternion; phase C keeps it normalised from here on
+        if (LEAN && grp == 0) state_store(scr, s);                   // LEAN: the state lives in the scratch between substeps
+#pragma unroll 1
+        for (int i = 0; i < n_substeps; i++) substep<float, PAIR>(m, scr, s, ctrl, o);
+        const auto kb = kernarg_base();
+        const KArgsC ka = (KArgsC)kb;
+        const StepIOC ic = (StepIOC)(kb + STEPIO_KERNARG_OFFSET);
+        const bool last = k == ic->n_steps - 1;
+        k++;
+        if (!rep) { if (last) break; continue; }      // helper lanes only take part in the substeps
+        if (LEAN) state_load(scr, s);
+        const int task = ka->task, N = ka->n, D = obs_dim(task), packed = ka->packed_rows, W = packed ? D + 2 : D;
+        TaskOpts topt;
+        topt.task = task; topt.step_limit = ka->step_limit; topt.auto_reset = ka->auto_reset; topt.random_pose = ka->random_pose;
+        topt.seed = ka->seed; topt.env_global = ka->env_offset + (unsigned long long)env;
+        float obs[19], rew;
+        bool done;
+        control_step_tail<float>(topt, m, s, er, obs, rew, done);          // jb_step.hpp: failure flag, reward, time limit, in-place reset, observation
+        if (ic->use_policy) {
+            PolicyParams<float> pp;
+            pp.kick_angle = ic->pp.kick_angle; pp.speed = ic->pp.speed; pp.angle_threshold = ic->pp.angle_threshold;
+            ctrl_next = heuristic_policy<float>(task, obs, 1, pp);
+        }
+        if (grp == 0) {                       // the replica holds the new state and the next action too; only the main lanes write
+            const int every = ic->every_step, kk = k - 1;
+            float* const obs_out = ic->obs_out;
+            if (obs_out && (last || (every & 1))) {
+                float* row = obs_out + ((every & 1) ? (size_t)kk * (size_t)N * W : (size_t)0) + (size_t)env * W;
+#pragma unroll
+                for (int j = 0; j < 19; j++) if ((j & 3) == leg && j < D) row[j] = obs[j];
+                if (packed && leg == 0) { row[D] = rew; row[D + 1] = done ? 1.f : 0.f; }
+            }
+            if (leg == 0 && !packed) {
+                float* const reward_out = ic->reward_out;
+                unsigned char* const done_out = ic->done_out;
+                if (reward_out && (last || (every & 2))) reward_out[((every & 2) ? (size_t)kk * (size_t)N : (size_t)0) + env] = rew;
+                if (done_out && (last || (every & 4))) done_out[((every & 4) ? (size_t)kk * (size_t)N : (size_t)0) + env] = done ? 1 : 0;
+            }
+        }
+        if (last) break;
+    }
+    if (grp != 0) return;
+    const auto kb = kernarg_base();
+    const KArgsC ka = (KArgsC)kb;
+    const StepIOC ic = (StepIOC)(kb + STEPIO_KERNARG_OFFSET);
 #ifdef JB_WAVE_STATS
     if (threadIdx.x == 0 && a.wave_stats) {
         unsigned long long* ws = a.wave_stats + (size_t)lblock * 16;
@@ -231,71 +338,46 @@ __device__ __forceinline__ void step_body(KArgs a, const float* __restrict__ act
         for (int i = 0; i < 5; i++) ws[4 + i] = prof_local[i]; ws[1] = (unsigned long long)s.st_xtra; ws[2] = (unsigned long long)s.st_sweeps; ws[3] = (unsigned long long)s.st_contact; ws[11] = (unsigned long long)s.st_slots; ws[15] = (unsigned long long)s.st_fast; ws[9] = (unsigned long long)s.st_checks; ws[12] = prof_local[5]; ws[13] = prof_local[6]; ws[14] = prof_local[7];
     }
 #endif
-    {   // a control step that ends in a non-finite state is recorded in the failure counter (+1000; Newton cap hits add 1 each)
-        const float chk = s.px + s.py + s.pz + s.qw + s.qx + s.qy + s.qz + s.vx + s.vy + s.vz + s.wx + s.wy + s.wz + s.phi + s.phid + s.th1 + s.th2 + s.thd1 + s.thd2;
-        const unsigned bad = quad_sum_u(fabsf(chk) < 1e30f ? 0u : 1u);
-        if (bad) s.fail += 1000.f;
-    }
-    // (trailing mj_step1: derived quantities use the normalised quaternion - phase C leaves hi + lo normalised to ~1e-14)
-    int sc = a.step_count[env] + 1;
-    EnvCore<float> e;
-    const float c0[3] = {m.c[LM_C0], m.c[LM_C0 + 1], m.c[LM_C0 + 2]};
-    core_from_state(a, env, s, c0, e);
-    const float target_z = m.c[LM_TARGET_Z];
-    const float rew = reward<float>(a.task, e, target_z);
-    const bool done = sc >= a.step_limit;
-    if (done && a.auto_reset) {
-        unsigned ep = a.episode[env];
-        episode_reset<float>(a.task, a.random_pose, a.seed, a.env_offset + (unsigned long long)env, ep, m.c[LM_ROOT_Z0], e);
-        state_from_reset(e, s);
-        sc = 0;
-        if (live && leg == 0) { a.episode[env] = ep + 1; store_target(a, env, e); }
-    }
-    if (!live) return;
-    const int D = obs_dim(a.task);
-    write_obs(a, env, leg, e, target_z, obs_out, a.packed_rows ? D + 2 : 0);
-    store_state(a, env, lane, leg, s);
-    if (leg == 0) {
-        a.step_count[env] = sc;
-        if (a.packed_rows) {
-            if (obs_out) { obs_out[(size_t)env * (D + 2) + D] = rew; obs_out[(size_t)env * (D + 2) + D + 1] = done ? 1.f : 0.f; }
-        } else {
-            if (reward_out) reward_out[env] = rew;
-            if (done_out) done_out[env] = done ? 1 : 0;
+    {
+        KArgs af;                 // the fields store_state reads
+        af.n = ka->n; af.root = ka->root; af.leg = ka->leg;
+        store_state(af, env, lane, leg, s);
+        if (leg == 0) {
+            ka->step_count[env] = er.step_count;
+            ka->episode[env] = er.episode;
+            af.root[(RF_TGT + 0) * af.n + env] = er.tgt[0]; af.root[(RF_TGT + 1) * af.n + env] = er.tgt[1]; af.root[(RF_TGT + 2) * af.n + env] = er.tgt[2];
         }
     }
+    unsigned long long* const wc = ic->wave_clock;
+    if (threadIdx.x == 0 && wc) wc[lblock] = __builtin_amdgcn_s_memrealtime() - clock0;
 }
 
 template <int EPW>
-__global__ __launch_bounds__(64) void jb_step_kernel(KArgs a, const float* __restrict__ action, float* __restrict__ obs_out,
-                                                     float* __restrict__ reward_out, unsigned char* __restrict__ done_out) {
-    step_body<EPW, false>(a, action, obs_out, reward_out, done_out);
+__global__ __launch_bounds__(64) void jb_step_kernel(KArgs a, StepIO io) {
+    step_body<EPW, false>(a, io);
 }
 // The LEAN variant: the same substep with the register budget of TWO waves per SIMD (256 registers per lane).  Model constants are read
 // from LDS where they are used, and the lane state, the joint-space system and the kept factorisation are parked in the lane's
 // scratch between the phases that use them (jb_sim.hpp SimOpts::lean).  Same arithmetic in the same order: results are bit-identical
 // to the one-wave kernel's.  A second resident wave doubles the SIMD's VALU issue rate, which pays when a GPU holds >= 2048 waves.
 template <int EPW>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void jb_step_kernel_lean(KArgs a, const float* __restrict__ action, float* __restrict__ obs_out,
-                                                                                                      float* __restrict__ reward_out, unsigned char* __restrict__ done_out) {
-    step_body<EPW, true>(a, action, obs_out, reward_out, done_out);
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void jb_step_kernel_lean(KArgs a, StepIO io) {
+    step_body<EPW, true>(a, io);
 }
 
 // The PAIR variant: the same step with the one geom-geom contact randomised models need (jb_sim.hpp pair_narrow / pair_rows_build,
 // the shoulder - motor cross term in the star solve).  A separate instantiation so that the nominal model's kernel stays exactly
 // the code it was; chosen per handle (launch_step).
 template <int EPW>
-__global__ __launch_bounds__(64) void jb_step_kernel_pair(KArgs a, const float* __restrict__ action, float* __restrict__ obs_out,
-                                                          float* __restrict__ reward_out, unsigned char* __restrict__ done_out) {
-    step_body<EPW, false, true>(a, action, obs_out, reward_out, done_out);
+__global__ __launch_bounds__(64) void jb_step_kernel_pair(KArgs a, StepIO io) {
+    step_body<EPW, false, true>(a, io);
 }
 
 // LEAN + PAIR: one model per env on the two-waves-per-SIMD kernel (BASELINE configs[4]'s 8192-env shard).  Four 3 KB tables per wave do not
 // fit next to the scratch, so only the entries of the common path are staged (LaneConsts split mode): 25 KB per wave, six waves per CU.
 template <int EPW>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void jb_step_kernel_lean_pair(KArgs a, const float* __restrict__ action, float* __restrict__ obs_out,
-                                                                                                           float* __restrict__ reward_out, unsigned char* __restrict__ done_out) {
-    step_body<EPW, true, true>(a, action, obs_out, reward_out, done_out);
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void jb_step_kernel_lean_pair(KArgs a, StepIO io) {
+    step_body<EPW, true, true>(a, io);
 }
 
 // ---------------------------------------------------------------------------------------------- reset / observe
@@ -518,6 +600,7 @@ struct jb_handle {
     float *d_action, *d_obs, *d_reward; unsigned char *d_done, *d_mask;
     double *d_qpos, *d_qvel, *d_target;
     unsigned long long* d_wave_stats;
+    unsigned long long* d_wave_clock;
     size_t model_tables;
     EncArgs enc;          // observation encoder (n_layers = 0: none)
     PolicyParams<float> policy;      // keyword arguments of the reference's heuristic policies
@@ -634,19 +717,43 @@ static int ensure_model_buffer(jb_handle* h, int n_tables) {
     }
     return JB_OK;
 }
+// Which step kernel a handle runs.  JB_FLAG_LEAN is honoured where a LEAN instantiation exists: a shared model without the pair contact
+// (envs per wave 1, 2 or 4), or one model per env at four envs per wave (LEAN + PAIR, split tables).  Anything else that asks for LEAN is
+// refused (JB_E_INVALID) at the call that creates the combination - never silently run as the ordinary kernel.
+static int kernel_variant(const jb_handle* h) {
+    const bool lean_pair = h->ka.lean && h->ka.pair && h->ka.per_env_model && h->ka.epw == 4;
+    if (lean_pair) return JB_VARIANT_LEAN_PAIR;
+    if (h->ka.pair) return JB_VARIANT_PAIR;
+    if (h->ka.lean) return JB_VARIANT_LEAN;
+    return JB_VARIANT_ORDINARY;
+}
+static int check_variant(const jb_handle* h) {
+    if (h->ka.lean && h->ka.pair && !(h->ka.per_env_model && h->ka.epw == 4))
+        return fail(JB_E_INVALID, "JB_FLAG_LEAN cannot be honoured: the pair-contact kernel has a two-waves-per-SIMD form only for one model per env at 4 envs per wave "
+                                  "(this handle: " + std::string(h->ka.per_env_model ? "one model per env" : "a shared model that needs the pair contact") + ", " + std::to_string(h->ka.epw) +
+                                  " envs per wave); drop JB_FLAG_LEAN, or add JB_FLAG_NO_PAIR for floor contacts only");
+    return JB_OK;
+}
 static int upload_model(jb_handle* h, const double* params, int n_tables) {
     std::vector<float> host((size_t)n_tables * LM_TABLE);
     for (int t = 0; t < n_tables; t++) {
         int rc = build_packed_model<float>(params + (size_t)t * JB_NPARAM, host.data() + (size_t)t * LM_TABLE);
         if (rc) return fail(JB_E_MODEL, "parameter table " + std::to_string(t) + " not supported by the kernel (code " + std::to_string(rc) + ")");
     }
+    // which step kernel: the PAIR variant whenever the model(s) may bring the mass against a leg (see JB_FLAG_PAIR)
+    const int pair = (h->cfg.flags & JB_FLAG_NO_PAIR) ? 0 : ((h->cfg.flags & JB_FLAG_PAIR) || n_tables > 1 || !mass_sweep_clear(params, 5e-4)) ? 1 : 0;
+    {   // a model that JB_FLAG_LEAN cannot run is refused BEFORE anything changes (the handle keeps the model it had)
+        jb_handle probe = *h;
+        probe.ka.pair = pair; probe.ka.per_env_model = n_tables > 1 ? 1 : 0;
+        int rc = check_variant(&probe);
+        if (rc) return rc;
+    }
     { int rc = ensure_model_buffer(h, n_tables); if (rc) return rc; }
     JB_HIP(hipMemcpyAsync(h->d_model, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
     JB_HIP(hipStreamSynchronize(h->stream));
     h->ka.lane_model = h->d_model;
     h->ka.per_env_model = n_tables > 1 ? 1 : 0;
-    // which step kernel: the PAIR variant whenever the model(s) may bring the mass against a leg (see JB_FLAG_PAIR)
-    h->ka.pair = (h->cfg.flags & JB_FLAG_NO_PAIR) ? 0 : ((h->cfg.flags & JB_FLAG_PAIR) || n_tables > 1 || !mass_sweep_clear(params, 5e-4)) ? 1 : 0;
+    h->ka.pair = pair;
     return JB_OK;
 }
 
@@ -761,7 +868,7 @@ int jb_destroy(jb_handle* h) {
     guard.enter(h->cfg.device_id);
     if (h->stream || !h->own_stream) hipStreamSynchronize(h->stream);
     if (h->comm && g_rccl.CommDestroy) { g_rccl.CommDestroy(h->comm); h->comm = nullptr; }
-    void* bufs[] = {h->d_ovc, h->d_terms, h->d_spec, h->d_root, h->d_leg, h->d_model, h->d_step, h->d_episode, h->d_action, h->d_obs, h->d_reward, h->d_done, h->d_mask, h->d_qpos, h->d_qvel, h->d_target, h->d_wave_stats, h->d_enc_params, h->d_code};
+    void* bufs[] = {h->d_wave_clock, h->d_ovc, h->d_terms, h->d_spec, h->d_root, h->d_leg, h->d_model, h->d_step, h->d_episode, h->d_action, h->d_obs, h->d_reward, h->d_done, h->d_mask, h->d_qpos, h->d_qvel, h->d_target, h->d_wave_stats, h->d_enc_params, h->d_code};
     for (void* b : bufs) if (b) hipFree(b);
     if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
     delete h;
@@ -850,15 +957,23 @@ int jb_reset_device(jb_handle* h, const uint8_t* d_mask, float* d_obs_out) {
     JB_HIP(hipGetLastError());
     return JB_OK;
 }
-static int launch_step(jb_handle* h, const float* d_action, float* d_obs_out, float* d_reward_out, uint8_t* d_done_out, int packed_rows) {
-    if (!h || !d_action) return fail(JB_E_INVALID, "handle/action is NULL");
+static int launch_step(jb_handle* h, StepIO io, int packed_rows) {
+    if (!h) return fail(JB_E_INVALID, "handle is NULL");
+    if (io.n_steps < 1) return fail(JB_E_INVALID, "n_steps must be >= 1");
+    if (!io.use_policy && !io.actions) return fail(JB_E_INVALID, "action buffer is NULL");
     JB_ENTER(h);
-    RoctxRange range("jb_step");
+    { int rc = check_variant(h); if (rc) return rc; }
+    RoctxRange range(io.n_steps > 1 ? "jb_step_many" : "jb_step");
     h->ka.packed_rows = packed_rows;
+    io.pp = h->policy;
     const dim3 grid((unsigned)((h->cfg.n_envs + h->ka.epw - 1) / h->ka.epw));
-    // LEAN: the shared-model kernel without the pair contact, or - one model per env, four envs per wave - the LEAN + PAIR kernel
-    const bool lean_pair = h->ka.lean && h->ka.pair && h->ka.per_env_model && h->ka.epw == 4;
-    const bool use_lean = (h->ka.lean && !h->ka.pair) || lean_pair;
+    if (!h->d_wave_clock) {
+        JB_HIP(hipMalloc(&h->d_wave_clock, sizeof(unsigned long long) * (size_t)h->cfg.n_envs));      // (>= the number of waves for any envs-per-wave)
+        JB_HIP(hipMemsetAsync(h->d_wave_clock, 0, sizeof(unsigned long long) * (size_t)h->cfg.n_envs, h->stream));
+    }
+    io.wave_clock = h->d_wave_clock;
+    const int variant = kernel_variant(h);
+    const bool lean_pair = variant == JB_VARIANT_LEAN_PAIR, use_lean = lean_pair || variant == JB_VARIANT_LEAN;
     const size_t lds_bytes = lean_pair ? ((size_t)SC_COUNT_LEAN_PAIR * 4 * h->ka.epw + (size_t)LM_TABLE_SPLIT * h->ka.epw) * sizeof(float)
                                        : ((size_t)(use_lean ? SC_COUNT_LEAN : SC_COUNT) * 4 * h->ka.epw + (size_t)(use_lean ? LM_TABLE_BASE : LM_TABLE) * (h->ka.per_env_model ? h->ka.epw : 1)) * sizeof(float);
     if (use_lean && !h->d_ovc) {      // the LEAN variant's overflow candidates (beyond the row cache): one block per wave
@@ -866,12 +981,12 @@ static int launch_step(jb_handle* h, const float* d_action, float* d_obs_out, fl
         JB_HIP(hipMalloc(&h->d_ovc, fl * sizeof(float)));
         h->ka.ovc_buf = h->d_ovc;
     }
-#define JB_LAUNCH_STEP(E) hipLaunchKernelGGL(jb_step_kernel<E>, grid, dim3(64), lds_bytes, h->stream, h->ka, d_action, d_obs_out, d_reward_out, d_done_out)
-#define JB_LAUNCH_LEAN(E) hipLaunchKernelGGL(jb_step_kernel_lean<E>, grid, dim3(64), lds_bytes, h->stream, h->ka, d_action, d_obs_out, d_reward_out, d_done_out)
-#define JB_LAUNCH_PAIR(E) hipLaunchKernelGGL(jb_step_kernel_pair<E>, grid, dim3(64), lds_bytes, h->stream, h->ka, d_action, d_obs_out, d_reward_out, d_done_out)
+#define JB_LAUNCH_STEP(E) hipLaunchKernelGGL(jb_step_kernel<E>, grid, dim3(64), lds_bytes, h->stream, h->ka, io)
+#define JB_LAUNCH_LEAN(E) hipLaunchKernelGGL(jb_step_kernel_lean<E>, grid, dim3(64), lds_bytes, h->stream, h->ka, io)
+#define JB_LAUNCH_PAIR(E) hipLaunchKernelGGL(jb_step_kernel_pair<E>, grid, dim3(64), lds_bytes, h->stream, h->ka, io)
     if (lean_pair) {
-        hipLaunchKernelGGL(jb_step_kernel_lean_pair<4>, grid, dim3(64), lds_bytes, h->stream, h->ka, d_action, d_obs_out, d_reward_out, d_done_out);
-    } else if (h->ka.pair) {
+        hipLaunchKernelGGL(jb_step_kernel_lean_pair<4>, grid, dim3(64), lds_bytes, h->stream, h->ka, io);
+    } else if (variant == JB_VARIANT_PAIR) {
         switch (h->ka.epw) {
         case 1: JB_LAUNCH_PAIR(1); break;
         case 2: JB_LAUNCH_PAIR(2); break;
@@ -898,12 +1013,50 @@ static int launch_step(jb_handle* h, const float* d_action, float* d_obs_out, fl
     JB_HIP(hipGetLastError());
     return JB_OK;
 }
+int jb_kernel_variant(jb_handle* h) { return h ? kernel_variant(h) : JB_E_INVALID; }
+int jb_envs_per_wave(jb_handle* h) { return h ? h->ka.epw : JB_E_INVALID; }
 int jb_step_device(jb_handle* h, const float* d_action, float* d_obs_out, float* d_reward_out, uint8_t* d_done_out) {
-    return launch_step(h, d_action, d_obs_out, d_reward_out, d_done_out, 0);
+    if (!d_action) return fail(JB_E_INVALID, "handle/action is NULL");
+    StepIO io = StepIO();
+    io.n_steps = 1; io.actions = d_action; io.obs_out = d_obs_out; io.reward_out = d_reward_out; io.done_out = d_done_out;
+    return launch_step(h, io, 0);
 }
 int jb_step_rows_device(jb_handle* h, const float* d_action, float* d_rows_out) {
+    if (!d_action) return fail(JB_E_INVALID, "handle/action is NULL");
     if (!d_rows_out) return fail(JB_E_INVALID, "rows buffer is NULL");
-    return launch_step(h, d_action, d_rows_out, nullptr, nullptr, 1);
+    StepIO io = StepIO();
+    io.n_steps = 1; io.actions = d_action; io.obs_out = d_rows_out;
+    return launch_step(h, io, 1);
+}
+// K control steps in ONE launch (see StepIO).  d_actions [K, N], or NULL: the handle's heuristic policy, evaluated in the kernel.
+// d_rows_out [K, N, D+2] nullable (packed rows of every step); d_rewards [K, N] nullable; d_obs_last [N, D] / d_done_last [N] nullable:
+// the last step's observations / done flags.  Rows and the separate outputs exclude each other (one output layout per launch).
+int jb_step_many_device(jb_handle* h, int32_t n_steps, const float* d_actions, float* d_rows_out, float* d_rewards, float* d_obs_last, uint8_t* d_done_last) {
+    if (!h) return fail(JB_E_INVALID, "handle is NULL");
+    if (n_steps < 0) return fail(JB_E_INVALID, "n_steps < 0");
+    if (n_steps == 0) return JB_OK;
+    if (d_rows_out && (d_rewards || d_obs_last || d_done_last)) return fail(JB_E_INVALID, "jb_step_many_device: either packed rows [K,N,D+2] or rewards / last observations / last done flags, not both");
+    StepIO io = StepIO();
+    io.n_steps = n_steps; io.use_policy = d_actions ? 0 : 1; io.actions = d_actions;
+    if (d_rows_out) {
+        io.obs_out = d_rows_out; io.every_step = 1;
+        return launch_step(h, io, 1);
+    }
+    io.obs_out = d_obs_last; io.reward_out = d_rewards; io.done_out = d_done_last;
+    io.every_step = 2;
+    return launch_step(h, io, 0);
+}
+// how long each wave of the last step launch lived, in seconds (s_memrealtime, 100 MHz): out[0 .. n_waves); returns the number of waves
+int jb_wave_clocks(jb_handle* h, double* out, int32_t max_waves) {
+    if (!h || !out) return fail(JB_E_INVALID, "handle/out is NULL");
+    JB_ENTER(h);
+    const int waves = (h->cfg.n_envs + h->ka.epw - 1) / h->ka.epw;
+    if (!h->d_wave_clock) return fail(JB_E_INVALID, "no step has been launched yet");
+    JB_HIP(hipStreamSynchronize(h->stream));
+    std::vector<unsigned long long> t((size_t)waves);
+    JB_HIP(hipMemcpy(t.data(), h->d_wave_clock, sizeof(unsigned long long) * (size_t)waves, hipMemcpyDeviceToHost));
+    for (int i = 0; i < waves && i < max_waves; i++) out[i] = (double)t[(size_t)i] * 1e-8;
+    return waves;
 }
 int jb_observe_device(jb_handle* h, float* d_obs_out, float* d_reward_out) {
     JB_ENTER(h);
@@ -955,19 +1108,19 @@ int jb_policy_device(jb_handle* h, const float* d_obs, float* d_action) {
     JB_HIP(hipGetLastError());
     return JB_OK;
 }
-// K control steps of "heuristic policy -> step" chained on the stream with no host round trip (the loop of the reference's
-// benchmarks/evaluate_policy.py:29-33, for every env of the batch at once).  d_rewards (nullable): [K, N] per-step rewards.
+// K control steps of "heuristic policy -> step" (the loop of the reference's benchmarks/evaluate_policy.py:29-33, for every env of the
+// batch at once) in ONE launch: the policy is evaluated in the step kernel on the observation the lanes just produced (step 0: on the
+// caller's rows).  d_rewards (nullable): [K, N] per-step rewards.
 int jb_rollout_policy_device(jb_handle* h, int32_t n_steps, float* d_obs_inout /*[N,D]: current observations in, last out*/,
                              float* d_rewards /*[K,N] nullable*/, uint8_t* d_done_last /*[N] nullable*/) {
     if (!h || !d_obs_inout || n_steps < 0) return fail(JB_E_INVALID, "handle/obs is NULL or n_steps < 0");
-    const size_t N = (size_t)h->cfg.n_envs;
-    for (int k = 0; k < n_steps; k++) {
-        int rc = jb_policy_device(h, d_obs_inout, h->d_action);
-        if (rc) return rc;
-        rc = jb_step_device(h, h->d_action, d_obs_inout, d_rewards ? d_rewards + (size_t)k * N : h->d_reward, d_done_last ? d_done_last : h->d_done);
-        if (rc) return rc;
-    }
-    return JB_OK;
+    if (n_steps == 0) return JB_OK;
+    StepIO io = StepIO();
+    io.n_steps = n_steps; io.use_policy = 1; io.obs_in = d_obs_inout;
+    io.obs_out = d_obs_inout;
+    io.reward_out = d_rewards ? d_rewards : h->d_reward; io.every_step = d_rewards ? 2 : 0;
+    io.done_out = d_done_last ? d_done_last : h->d_done;
+    return launch_step(h, io, 0);
 }
 int jb_rollout_policy(jb_handle* h, int32_t n_steps, float* rewards_out /*[K,N] host, nullable*/, float* obs_out /*[N,D] host, nullable*/) {
     if (!h || n_steps < 0) return fail(JB_E_INVALID, "handle is NULL or n_steps < 0");
@@ -1082,6 +1235,12 @@ int jb_randomise_models(jb_handle* h, const jb_randomise_cfg* cfg, const double*
     if (!h || !cfg) return fail(JB_E_INVALID, "handle/cfg is NULL");
     JB_ENTER(h);
     const size_t N = (size_t)h->cfg.n_envs;
+    {   // one model per env runs the PAIR kernel: refuse up front what JB_FLAG_LEAN cannot run (see check_variant)
+        jb_handle probe = *h;
+        probe.ka.per_env_model = 1; probe.ka.pair = (h->cfg.flags & JB_FLAG_NO_PAIR) ? 0 : 1;
+        int rc0 = check_variant(&probe);
+        if (rc0) return rc0;
+    }
     JB_HIP(hipStreamSynchronize(h->stream));
     if (!h->d_spec) {
         JB_HIP(hipMalloc(&h->d_spec, sizeof(JbNominalSpec)));

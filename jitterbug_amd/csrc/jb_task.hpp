@@ -7,6 +7,16 @@
 #pragma once
 #include "jb_lane.hpp"
 
+// The task layer is inlined into several kernels (reset, observe, step, policy).  Its arithmetic is compiled WITHOUT multiply-add
+// contraction, so that an observation, a reward or a policy decision has the same bits whichever kernel computed it (the compiler
+// fuses a*b+c differently from one inlining context to the next): the in-kernel policy of a fused rollout must see exactly the row
+// a separate jb_policy_device launch would read.
+#if defined(__clang__)
+#define JB_NO_CONTRACT _Pragma("clang fp contract(off)")
+#else
+#define JB_NO_CONTRACT
+#endif
+
 namespace jb {
 
 enum Task : int { TASK_MOVE_FROM_ORIGIN = 0, TASK_FACE_DIRECTION = 1, TASK_MOVE_IN_DIRECTION = 2, TASK_MOVE_TO_POSITION = 3, TASK_MOVE_TO_POSE = 4 };
@@ -40,6 +50,7 @@ template <typename T> struct EnvCore {        // the part of the state the task 
 // Returns the root quaternion and the target; everything else resets to qpos0 / zero (the model constants cx, cy, cz are not touched).
 template <typename T>
 JB_HD void episode_reset(int task, int random_pose, uint64_t seed, uint64_t env, uint32_t episode, T root_z0, EnvCore<T>& e) {
+    JB_NO_CONTRACT
     uint32_t r0[4], r1[4];
     philox4x32(seed, env, episode, 0u, r0);
     philox4x32(seed, env, episode, 1u, r1);
@@ -65,6 +76,7 @@ JB_HD void episode_reset(int task, int random_pose, uint64_t seed, uint64_t env,
 }
 
 template <typename T> JB_HD T wrap_pi(T a) {             // (-pi, pi]   reference jitterbug.py:235-238, 313-316
+    JB_NO_CONTRACT
     const T PI = T(3.141592653589793), TWO_PI = T(6.283185307179586);
     T k = vfloor((PI - a) / TWO_PI);                     // a + 2 pi k in (-pi, pi]
     a = a + k * TWO_PI;
@@ -79,6 +91,7 @@ JB_HD double vexp(double x) { return exp(x); }
 
 // relative yaw from the Jitterbug heading to the target  (reference :192-208, 262-273, 305-317)
 template <typename T> JB_HD T angle_to_target(const EnvCore<T>& e) {
+    JB_NO_CONTRACT
     T R00 = e.qw * e.qw + e.qx * e.qx - e.qy * e.qy - e.qz * e.qz;
     T R10 = T(2) * (e.qx * e.qy + e.qw * e.qz);
     T yaw = vatan2(R10, R00) - T(1.5707963267948966);
@@ -89,6 +102,7 @@ template <typename T> JB_HD T angle_to_target(const EnvCore<T>& e) {
 }
 // target position in the Jitterbug frame  R^T (t - p)   (reference :275-290)
 template <typename T> JB_HD void target_in_body(const EnvCore<T>& e, T target_z, T (&o)[3]) {
+    JB_NO_CONTRACT
     T dx = e.tx - e.px, dy = e.ty - e.py, dz = target_z - e.pz;
     T w = e.qw, x = e.qx, y = e.qy, z = e.qz;
     T R00 = w * w + x * x - y * y - z * z, R01 = T(2) * (x * y - w * z), R02 = T(2) * (x * z + w * y);
@@ -102,6 +116,7 @@ template <typename T> JB_HD void target_in_body(const EnvCore<T>& e, T target_z,
 // mjOBJ_BODY object at the body's INERTIAL frame (xipos: the root body's own centre of mass), world axes - only "xbody" means
 // the joint frame.  So the sensor reads  v + R (w_body x c0),  not qvel[0:3].
 template <typename T> JB_HD void framelinvel(const EnvCore<T>& e, T (&o)[3]) {
+    JB_NO_CONTRACT
     T lx = e.wy * e.cz - e.wz * e.cy, ly = e.wz * e.cx - e.wx * e.cz, lz = e.wx * e.cy - e.wy * e.cx;
     T w = e.qw, x = e.qx, y = e.qy, z = e.qz;
     o[0] = e.vx + (w * w + x * x - y * y - z * z) * lx + T(2) * (x * y - w * z) * ly + T(2) * (x * z + w * y) * lz;
@@ -110,6 +125,7 @@ template <typename T> JB_HD void framelinvel(const EnvCore<T>& e, T (&o)[3]) {
 }
 // Jitterbug linear velocity (the sensor above) in the target frame   (reference :292-303)
 template <typename T> JB_HD void vel_in_target(const EnvCore<T>& e, T (&o)[3]) {
+    JB_NO_CONTRACT
     T c = vcos(e.tpsi), s = vsin(e.tpsi);
     T v[3];
     framelinvel(e, v);
@@ -118,6 +134,7 @@ template <typename T> JB_HD void vel_in_target(const EnvCore<T>& e, T (&o)[3]) {
 
 // reference jitterbug.py:673-763: 15 common entries then the task's extras, in dict order; _norm :668-671
 template <typename T> JB_HD void observe(int task, const EnvCore<T>& e, T target_z, T* obs, int stride) {
+    JB_NO_CONTRACT
     const T PI = T(3.141592653589793);
     obs[0 * stride] = e.px * T(0.5); obs[1 * stride] = e.py * T(0.5); obs[2 * stride] = e.pz * T(20) - T(1);
     obs[3 * stride] = e.qw; obs[4 * stride] = e.qx; obs[5 * stride] = e.qy; obs[6 * stride] = e.qz;
@@ -150,6 +167,7 @@ template <typename T> JB_HD void observe(int task, const EnvCore<T>& e, T target
 // the four reward terms on their own (reference :840-889: heading_reward, velocity_reward, position_reward, upright_reward),
 // out = [P, H, V, U]; reward() below combines the ones its task uses
 template <typename T> JB_HD void reward_terms(const EnvCore<T>& e, T target_z, T (&out)[4]) {
+    JB_NO_CONTRACT
     const T LN01 = T(-2.302585092994046);
     T Rzz = e.qw * e.qw - e.qx * e.qx - e.qy * e.qy + e.qz * e.qz;
     T du = vabs(T(1) - Rzz) * T(2);
@@ -165,6 +183,7 @@ template <typename T> JB_HD void reward_terms(const EnvCore<T>& e, T target_z, T
     out[2] = (v >= T(0.1)) ? T(1) : ((T(0.1) - v) * T(10) < T(1) ? T(1) - (T(0.1) - v) * T(10) : T(0));
 }
 template <typename T> JB_HD T reward(int task, const EnvCore<T>& e, T target_z) {
+    JB_NO_CONTRACT
     const T LN01 = T(-2.302585092994046);     // ln 0.1
     T Rzz = e.qw * e.qw - e.qx * e.qx - e.qy * e.qy + e.qz * e.qz;
     T du = vabs(T(1) - Rzz) * T(2);
@@ -199,16 +218,19 @@ template <typename T> JB_HD T reward(int task, const EnvCore<T>& e, T target_z) 
 template <typename T> struct PolicyParams { T kick_angle, speed, angle_threshold; };     // reference keyword arguments :28, :64, :81, :98
 template <typename T> JB_HD PolicyParams<T> default_policy_params() { PolicyParams<T> p; p.kick_angle = T(0.7853981633974483); p.speed = T(0.3); p.angle_threshold = T(0.3490658503988659); return p; }
 template <typename T> JB_HD T policy_face(T angle) {                                  // :6-25
+    JB_NO_CONTRACT
     T v = T(3) * angle / T(3.141592653589793);
     v = v > T(1) ? T(1) : (v < T(-1) ? T(-1) : v);
     return T(0.9) * v;
 }
 template <typename T> JB_HD T policy_forward(T motor_angle, T motor_vel, T offset, const PolicyParams<T>& pp) {  // :28-56
+    JB_NO_CONTRACT
     if (motor_angle < offset - pp.kick_angle) return pp.speed;
     if (motor_angle > offset + pp.kick_angle) return -pp.speed;
     return motor_vel > T(0) ? pp.speed : -pp.speed;
 }
 template <typename T> JB_HD T heuristic_policy(int task, const T* obs, int stride, const PolicyParams<T>& pp) {
+    JB_NO_CONTRACT
     const T PI = T(3.141592653589793), Q = T(0.7853981633974483), H = T(1.5707963267948966), THR = pp.angle_threshold;
     const T ma = obs[13 * stride], mv = obs[14 * stride];
     if (task == TASK_MOVE_FROM_ORIGIN) return policy_forward(ma, mv, T(0), pp);       // :59-61

@@ -320,6 +320,30 @@ class JitterbugVecEnv:
         _lib.check(self._L.jb_rollout_policy_device(self._h, int(n_steps), obs_ptr, rewards_ptr, done_ptr))
         self.state_version += 1
 
+    def step_many_device(self, n_steps, actions_ptr=None, rows_ptr=None, rewards_ptr=None, obs_last_ptr=None, done_last_ptr=None):
+        """n_steps control steps in ONE kernel launch (jb_step_many_device; asynchronous, device pointers).  actions_ptr: an action
+        tape [n_steps, N], or None = the handle's heuristic policy evaluated in the kernel.  rows_ptr [n_steps, N, D+2] (packed rows of
+        every step) OR rewards_ptr [n_steps, N] / obs_last_ptr [N, D] / done_last_ptr [N].  Bit-identical to n_steps single-step calls."""
+        _lib.check(self._L.jb_step_many_device(self._h, int(n_steps), actions_ptr, rows_ptr, rewards_ptr, obs_last_ptr, done_last_ptr))
+        self.state_version += 1
+
+    def wave_clocks(self):
+        """Seconds each wave of the last step launch was alive (its load imbalance: mean against max)."""
+        out = np.zeros(self.num_envs, dtype=np.float64)
+        n = int(self._L.jb_wave_clocks(self._h, _lib.ptr(out), self.num_envs))
+        if n < 0:
+            _lib.check(n)
+        return out[:n]
+
+    @property
+    def kernel_variant(self):
+        """'ordinary' | 'pair' | 'lean' | 'lean_pair': the step kernel this handle launches (jb_kernel_variant)."""
+        return _lib.VARIANT_NAMES[int(self._L.jb_kernel_variant(self._h))]
+
+    @property
+    def envs_per_wave(self):
+        return int(self._L.jb_envs_per_wave(self._h))
+
     def synchronize(self):
         _lib.check(self._L.jb_synchronize(self._h))
 
