@@ -132,7 +132,7 @@ def main(argv=None):
     ap.add_argument("--no-rank-one", action="store_true", help="diagnostic: JB_FLAG_NO_RANK_ONE (every Newton pass is a full pass)")
     ap.add_argument("--no-spread", action="store_true", help="diagnostic: JB_FLAG_NO_SPREAD (contact sweeps never in spread mode)")
     ap.add_argument("--no-pair", action="store_true", help="diagnostic: JB_FLAG_NO_PAIR (floor contacts only, also for per-env models: what rounds 1-2 simulated)")
-    ap.add_argument("--lean", action="store_true", help="JB_FLAG_LEAN: the two-waves-per-SIMD kernel variant (229 registers, 20 KB of LDS per four-env wave); chosen automatically from 8192 envs per GPU on (shared model), where the GPU holds two waves per SIMD")
+    ap.add_argument("--lean", action="store_true", help="force the two-waves-per-SIMD kernel variant (JB_FLAG_LEAN); by default the product picks it from the per-GPU batch (jitterbug_amd.variants)")
     ap.add_argument("--no-lean", action="store_true", help="never the LEAN variant")
     ap.add_argument("--actions", default="uniform", help="uniform (default, the metric's workload) | const1 (motor flat out: about half the robots tip over - diagnostic)")
     ap.add_argument("--seed", type=int, default=0, help="reset / action stream seed (the committed numbers use 0)")
@@ -141,19 +141,18 @@ def main(argv=None):
     ap.add_argument("--augmented", action="store_true", help="one randomised model per env (BASELINE configs[4], augment_Jitterbug semantics)")
     ap.add_argument("--no-steady", action="store_true", help="skip the steady-state (steps 100-400) and full-episode blocks measured next to the headline")
     args = ap.parse_args(argv)
-    if not args.no_lean and args.envs_per_gpu >= (16384 if args.augmented else 8192):
-        # >= 2048 four-env waves: two resident per SIMD (every rank of a run makes the same choice: results stay independent of the split).
-        # One model per env: the LEAN + PAIR kernel holds six waves per CU (25 KB each), which pays from 16 384 envs per GPU on (measured:
-        # 8192: 4.45 -> 4.48 M, 16 384: 5.55 -> 6.26 M)
-        args.lean = True
+    # which step kernel: resolved by the PRODUCT (jitterbug_amd.variants - this script holds no threshold of its own); --lean / --no-lean force one
+    variant = "lean" if args.lean else "ordinary" if args.no_lean else "auto"
     task = args.task
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return self_launch(args.gpus, argv)          # before anything imports torch or initialises HIP in this process
 
     import numpy as np
     import torch
-    from jitterbug_amd import model
+    from jitterbug_amd import model, variants
     from jitterbug_amd.vec_env import JitterbugVecEnv
+    args.lean = variants.resolve(variant, args.envs_per_gpu, args.augmented) == "lean"
+    used_variant = []          # what jb_kernel_variant reports for the handles of the timed runs
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -188,7 +187,8 @@ def main(argv=None):
         actions = torch.rand((steps + warmup, n), generator=g, device=dev, dtype=torch.float32) * 2 - 1
         if args.actions == "const1":
             actions.fill_(1.0)
-        env_kw = dict(contacts=bool(contacts), max_newton=args.max_newton, envs_per_wave=args.envs_per_wave, flags=(1 if args.no_rank_one else 0) | (2 if args.lean else 0) | (8 if args.no_pair else 0) | (16 if args.no_spread else 0))
+        env_kw = dict(contacts=bool(contacts), max_newton=args.max_newton, envs_per_wave=args.envs_per_wave, variant=variant, per_env_model=args.augmented,
+                      flags=(1 if args.no_rank_one else 0) | (8 if args.no_pair else 0) | (16 if args.no_spread else 0))
         if gather:
             # N > 1: the PRODUCT's sharded env (jitterbug_amd/distributed.py), pipelined: the step kernel writes packed rows
             # [obs | reward | done] itself and rank 0 gathers them every step over RCCL, one step late from a side stream, three row
@@ -202,6 +202,7 @@ def main(argv=None):
             env = JitterbugVecEnv(n, task, seed=args.seed, device_id=local_rank, env_offset=rank * n, stream=torch.cuda.current_stream(dev).cuda_stream, **env_kw)
         if args.augmented:           # BASELINE configs[4]: one randomised model per env, generated on the device (keyed by the global env index)
             env.randomise_models(seed=1000, return_params=False)          # every draw of the reference's distribution is kept (robots whose mass touches a leg included: PAIR kernel)
+        used_variant.append(env.kernel_variant)
         obs = torch.empty((n, D), device=dev, dtype=torch.float32)
         rew = torch.empty((n,), device=dev, dtype=torch.float32)
         done = torch.empty((n,), device=dev, dtype=torch.uint8)
@@ -276,6 +277,56 @@ def main(argv=None):
             wf, df, _, ff = run(args.contacts, 1000, 0, gather=False)
             full_episode = {"value": total_envs * 1000 / wf, "unit": "env steps/s", "ms_per_step": wf * 1e3 / 1000, "launch_ms": df / 1000, "steps": 1000, "warmup": 0,
                             "window": "steps 0-1000: one whole episode from the reset, auto-reset included", "finite": ff}
+
+    # The fused K-step rollout (jb_step_many_device: one launch of K control steps, every wave keeps its envs for all of them), next to the
+    # per-step numbers above and on the same workload / seed / action tape: K = 1000 (a whole episode in one launch), K = 100 (ten
+    # launches), the in-kernel heuristic policy instead of the tape, and the motor-flat-out tape.  Its bound is the slowest wave's SUM
+    # over the K steps, measured by the kernel itself (jb_wave_clocks: s_memrealtime per wave) and reported against the mean wave.
+    rollout_fused = None
+    if not args.no_steady and world == 1 and dist is None:
+        def fused(k_launch, source, total=1000):
+            g = torch.Generator(device=dev)
+            g.manual_seed(1234 + rank + 7919 * args.seed)
+            tape = torch.rand((total, n), generator=g, device=dev, dtype=torch.float32) * 2 - 1
+            if source == "const1":
+                tape.fill_(1.0)
+            env = JitterbugVecEnv(n, task, seed=args.seed, device_id=local_rank, env_offset=rank * n, stream=torch.cuda.current_stream(dev).cuda_stream,
+                                  contacts=bool(args.contacts), max_newton=args.max_newton, envs_per_wave=args.envs_per_wave, variant=variant, per_env_model=args.augmented,
+                                  flags=(1 if args.no_rank_one else 0) | (8 if args.no_pair else 0) | (16 if args.no_spread else 0))
+            if args.augmented:
+                env.randomise_models(seed=1000, return_params=False)
+            rew = torch.empty((total, n), device=dev, dtype=torch.float32)
+            obs = torch.empty((n, D), device=dev, dtype=torch.float32)
+            done = torch.empty((n,), device=dev, dtype=torch.uint8)
+            env.reset_device(None, obs.data_ptr())
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for k0 in range(0, total, k_launch):
+                env.step_many_device(k_launch, None if source == "policy" else tape[k0:k0 + k_launch].data_ptr(), rewards_ptr=rew[k0:k0 + k_launch].data_ptr(),
+                                     obs_last_ptr=obs.data_ptr(), done_last_ptr=done.data_ptr())
+            torch.cuda.synchronize(dev)
+            wall = time.perf_counter() - t0
+            wc = env.wave_clocks()            # of the last launch
+            sc, ep, cap = env.counters()
+            ok = bool(torch.isfinite(obs).all().item()) and bool(torch.isfinite(rew).all().item()) and float(cap.max()) < 1000.0 and bool(done.all().item())
+            epw = env.envs_per_wave
+            kv = env.kernel_variant
+            env.close()
+            out = {"value": n * total / wall, "unit": "env steps/s", "ms_per_step": wall * 1e3 / total, "launches": total // k_launch, "steps_per_launch": k_launch,
+                   "actions": {"tape": "uniform action tape [K,N] resident in HBM (the headline's actions)", "policy": "heuristic policy evaluated in the kernel (no action buffer)",
+                               "const1": "motor flat out (about half the robots tip over)"}[source],
+                   "window": "steps 0-%d: one whole episode from the reset, auto-reset included" % total, "finite": ok, "kernel_variant": kv}
+            if k_launch == total:
+                simds = 1024.0
+                out["wave_clock"] = {"mean_wave_ms_per_step": 1e3 * float(wc.mean()) / total, "slowest_wave_ms_per_step": 1e3 * float(wc.max()) / total,
+                                     "p99_wave_ms_per_step": 1e3 * float(np.percentile(wc, 99)) / total, "mean_over_slowest": float(wc.mean() / wc.max()),
+                                     "ceiling_mean_wave": epw * min(simds, len(wc)) / (float(wc.mean()) / total),
+                                     "value_over_ceiling": (n * total / wall) / (epw * min(simds, len(wc)) / (float(wc.mean()) / total)),
+                                     "what": "per-wave lifetimes of the launch (s_memrealtime): the launch lasts as long as its slowest wave; `ceiling_mean_wave` = envs per wave / mean wave time x waves in flight - what the launch would reach if no wave were slower than the mean.  A robot that has tipped over stays tipped for the rest of its episode (tools/tip_persistence.py), so the slowest wave is the one whose robot tipped first"}
+            return out
+        rollout_fused = {"k1000": fused(1000, "tape"), "k100": fused(100, "tape"), "k1000_policy": fused(1000, "policy"), "k1000_const1": fused(1000, "const1"),
+                         "per_step_full_episode": None if full_episode is None else full_episode["value"],
+                         "what": "jb_step_many_device: K control steps per launch, bit-identical to K single-step launches (tests/test_gpu_rollout.py); `value` above stays the per-step path"}
 
     def config_label(contacts):
         """which BASELINE.json config this workload is, if any"""
@@ -378,7 +429,7 @@ def main(argv=None):
             "ms_per_step": wall_max * 1e3 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s, N_envs=%d per GPU, %s, 50 substeps/step, in-kernel auto-reset (%s)"
-                                   % (task + (", one randomised model per env" if args.augmented else ""), n, ("full Newton contact solve" if args.contacts else "contacts off") + (", LEAN kernel variant (two waves per SIMD)" if args.lean else ""), config_label(args.contacts)),
+                                   % (task + (", one randomised model per env" if args.augmented else ""), n, ("full Newton contact solve" if args.contacts else "contacts off") + {"ordinary": "", "pair": ", PAIR kernel variant (floor + mass / upper-leg contact)", "lean": ", LEAN kernel variant (two waves per SIMD)", "lean_pair": ", LEAN + PAIR kernel variant (two waves per SIMD, one model per env)"}[used_variant[0]], config_label(args.contacts)),
                        "global_envs": total_envs, "parallelism": "env-sharded x%d%s" % (world, gather_txt)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic,
@@ -390,7 +441,7 @@ def main(argv=None):
                          "algorithmic_bytes_per_launch": algo_bytes * n,
                          "note": "path is fp32-VALU/latency bound, not HBM bound (SURVEY.md §8d): 317 B per env step vs ~1e5-1e6 dependent flops",
                          "compute": compute, "profile": prof_note},
-            "solver_cap_hits": cap_hits, "finite": finite, "lib_sha256": lib_sha,
+            "solver_cap_hits": cap_hits, "finite": finite, "lib_sha256": lib_sha, "src_sha256": _lib.load().jb_source_sha256().decode(), "kernel_variant": used_variant[0],
         }
         res["window"] = "steps %d-%d of an episode from the reset" % (W, W + K)
         if steady:
@@ -398,6 +449,8 @@ def main(argv=None):
         if full_episode:
             res["value_full_episode"] = full_episode["value"]
             res["full_episode"] = full_episode
+        if rollout_fused:
+            res["rollout_fused"] = rollout_fused
         if also:
             res["also"] = also
         if host_rate:

@@ -234,6 +234,7 @@ int jb_kernel_variant(jb_handle* h);
 int jb_envs_per_wave(jb_handle* h);
 int jb_device_count(void);
 int jb_abi_version(void);
+const char* jb_source_sha256(void);            /* sha256 (hex) of the sources this library was built from (jitterbug_amd/build.py) */
 const double* jb_default_model_params(void);   /* the compiled nominal model, JB_NPARAM doubles */
 const char* jb_last_error(void);
 

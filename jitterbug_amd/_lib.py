@@ -15,7 +15,7 @@ ERR_NAMES = {-1: "JB_E_INVALID", -2: "JB_E_NODEVICE", -3: "JB_E_HIP", -4: "JB_E_
 
 EXPORTS = ["jb_default_config", "jb_create", "jb_destroy", "jb_reset", "jb_step", "jb_observe", "jb_get_state", "jb_set_state",
            "jb_get_counters", "jb_set_model_params", "jb_policy", "jb_policy_device", "jb_set_policy_params", "jb_reward_terms", "jb_reward_terms_device", "jb_default_randomise_config", "jb_randomise_models", "jb_model_compile_host", "jb_model_mass_clearance_ok", "jb_model_draw_offsets_host", "jb_comm_unique_id", "jb_comm_init", "jb_comm_destroy", "jb_gather_rows_device", "jb_rollout_policy_device", "jb_rollout_policy", "jb_step_many_device", "jb_wave_clocks", "jb_kernel_variant", "jb_envs_per_wave", "jb_reset_device", "jb_step_device", "jb_step_rows_device", "jb_observe_device", "jb_debug_poison_lds", "jb_set_obs_encoder", "jb_encoded_dim", "jb_encode_device", "jb_encode", "jb_synchronize",
-           "jb_stream", "jb_obs_dim", "jb_num_envs", "jb_device_count", "jb_abi_version", "jb_default_model_params", "jb_last_error"]
+           "jb_stream", "jb_obs_dim", "jb_num_envs", "jb_device_count", "jb_abi_version", "jb_source_sha256", "jb_default_model_params", "jb_last_error"]
 
 
 class JitterbugHipError(RuntimeError):
@@ -68,6 +68,14 @@ def load():
         raise JitterbugHipError(
             "libjitterbug_hip.so is not built (%s). Build it with `python -m jitterbug_amd.build` "
             "(needs hipcc); there is no CPU fallback." % LIB_PATH)
+    if os.environ.get("JITTERBUG_HIP_LIB") is None:
+        # the in-tree library must be the build of the sources next to it (a stale .so beside newer sources is refused, whatever the
+        # file times say); JITTERBUG_HIP_LIB - an A/B build named by hand - is taken as it is
+        from . import build as _build
+        want, have = _build.source_sha256(), _build.embedded_sha256(LIB_PATH)
+        if want is not None and have != want:
+            raise JitterbugHipError("libjitterbug_hip.so was built from other sources (embedded sha256 %s..., sources now %s...): rebuild with "
+                                    "`python -m jitterbug_amd.build`, or name a library explicitly with JITTERBUG_HIP_LIB" % (str(have)[:12], want[:12]))
     _preload_torch_hip_runtime()
     L = C.CDLL(LIB_PATH)
     vp, fp, dp, u8p = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p
@@ -120,6 +128,8 @@ def load():
     L.jb_obs_dim.argtypes = [C.c_int32]
     L.jb_num_envs.argtypes = [vp]
     L.jb_default_model_params.restype = C.POINTER(C.c_double)
+    if hasattr(L, "jb_source_sha256"):
+        L.jb_source_sha256.restype = C.c_char_p
     L.jb_last_error.restype = C.c_char_p
     _lib = L
     return L

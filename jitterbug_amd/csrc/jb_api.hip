@@ -761,6 +761,13 @@ extern "C" {
 
 const char* jb_last_error(void) { return g_err.c_str(); }
 int jb_abi_version(void) { return JB_ABI_VERSION; }
+// sha256 of the sources (csrc/*, include/*, compiler flags) this library was built from; jitterbug_amd/build.py passes it in and reads it
+// back from the file (the tag in front makes it findable without loading the library)
+#ifndef JB_SRC_SHA
+#define JB_SRC_SHA "0000000000000000000000000000000000000000000000000000000000000000"
+#endif
+static const char JB_SRC_TAG[] = "JB_SRC_SHA256=" JB_SRC_SHA;
+const char* jb_source_sha256(void) { return JB_SRC_TAG + 14; }
 const double* jb_default_model_params(void) { return JB_DEFAULT_PARAMS; }
 int jb_obs_dim(int32_t task_id) { return (task_id >= 0 && task_id < JB_NTASK) ? obs_dim(task_id) : JB_E_INVALID; }
 int jb_device_count(void) {

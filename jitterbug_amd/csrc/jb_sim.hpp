@@ -1044,12 +1044,14 @@ JB_HD void contact_rows_build_all(const LaneModel<V>& m, const LaneScratch<V>& s
 
 // every live candidate slot against the iterate y kept in the scratch (SC_Y); with helper groups the partial sums of the
 // groups are combined by cross-lane exchanges so that every group ends with the complete accumulator
+// (returns the number of spread rounds it made: diagnostics only)
 template <typename V, bool PAIR = false>
-JB_HD void contact_sweep(const LaneModel<V>& m, const LaneScratch<V>& sc, bool xtra, const SlotPlan& plan, const SpreadPlan<V>& sp, int mode, const Vec3<V> (&dk)[3], NewtonAcc<V>& acc, const bool zero_g1 = false) {
+JB_HD int contact_sweep(const LaneModel<V>& m, const LaneScratch<V>& sc, bool xtra, const SlotPlan& plan, const SpreadPlan<V>& sp, int mode, const Vec3<V> (&dk)[3], NewtonAcc<V>& acc, const bool zero_g1 = false) {
     // zero_g1 (SimOpts::offload): group 1 must leave with an all-zero accumulator - it factorises M + h diag(b)
     // with the instruction stream that factorises the main lanes' Newton system (substep_impl)
     const bool g1z = zero_g1 && sc.grp == 1;
-    if (!plan.grouped && sc.grp != 0 && !g1z) return;
+    int spread_rounds = 0;
+    if (!plan.grouped && sc.grp != 0 && !g1z) return 0;
     if (mode == 2) { acc.bw0 = zero_u<V>(); acc.bw1 = zero_u<V>(); acc.xh = zero_u<V>(); }      // the check only records the active set
     else acc_clear(acc);
     const V mu = m.c[LM_MU];
@@ -1080,6 +1082,7 @@ JB_HD void contact_sweep(const LaneModel<V>& m, const LaneScratch<V>& sc, bool x
             V yls[2];
             yls[0] = ld_leg(sc.p, sc.stride, zero_u<V>() + (unsigned)(SC_Y + 6), it.src, me); yls[1] = ld_leg(sc.p, sc.stride, zero_u<V>() + (unsigned)(SC_Y + 7), it.src, me);
             contact_apply_leg<V>(rv, dk, mu, it, mode, yr, yls, acc);
+            spread_rounds = r + 1;
             if (!any_lane(it.more)) break;
         }
         rest_mine = sp.rest_mine; rest_rounds = sp.rest_rounds;
@@ -1130,6 +1133,7 @@ JB_HD void contact_sweep(const LaneModel<V>& m, const LaneScratch<V>& sc, bool x
             if (g1z) acc_clear(acc);
         }
     }
+    return spread_rounds + 8 * rest_rounds;
 }
 
 // Cylinder vs floor, restating MuJoCo's plane-cylinder routine (mjc_PlaneCylinder in MuJoCo's engine_collision_primitive.c - third
@@ -1751,11 +1755,18 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
             for (;;) {
                 // ---- full pass (reads the iterate of the last check from the scratch: rank-one results are stored only after this pass)
                 if (any_contact) {
-                    contact_sweep<V, PAIR>(m, sc, xtra, plan, spl, 0, dk, acc, have_dfac);
+                    const int sweep_rounds = contact_sweep<V, PAIR>(m, sc, xtra, plan, spl, 0, dk, acc, have_dfac);
+                    (void)sweep_rounds;
                     prev_bw0 = acc.bw0; prev_bw1 = acc.bw1; prev_xh = acc.xh;
                     JB_PROF_ADD(o, 2);
 #ifdef JB_WAVE_STATS
                     if (is_main) s.st_sweeps = s.st_sweeps + V(1);
+#if defined(__HIPCC__)
+                    if (o.hist && (threadIdx.x & 63) == 0) {      // full sweeps by the rounds they took: [53 + spread rounds (0-3)], [57 + rest rounds (0-3)]
+                        o.hist[53 + ((sweep_rounds & 7) < 3 ? (sweep_rounds & 7) : 3)] += 1ull;
+                        o.hist[57 + ((sweep_rounds >> 3) < 3 ? (sweep_rounds >> 3) : 3)] += 1ull;
+                    }
+#endif
 #endif
                 }
                 if (o.offload || is_main) {

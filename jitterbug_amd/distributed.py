@@ -102,12 +102,16 @@ class ShardedJitterbugEnv:
     the path `bench.py --gpus N` times (the reference's own vectorisation, stable-baselines SubprocVecEnv, has the same
     step_async / step_wait split: benchmarks/benchmark.py:146-171)."""
 
-    def __init__(self, n_global, task="move_from_origin", seed=0, device=None, local_env_factory=None, group=None, pipeline_depth=1, **env_kwargs):
+    def __init__(self, n_global, task="move_from_origin", seed=0, device=None, local_env_factory=None, group=None, pipeline_depth=1, variant="auto", **env_kwargs):
         import torch
         import torch.distributed as dist
+        from . import variants
         self.group = group
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
         self.n_global = int(n_global)
+        # the kernel variant is resolved from the GLOBAL batch and the world size - numbers every rank holds - so that all shards of the batch
+        # run the same kernel (the variants agree to rounding only); a caller that passes flags by hand (variant=None) owns that duty
+        self.variant = None if variant is None else variants.resolve(variant, variants.envs_per_gpu(n_global, self.world), bool(env_kwargs.get("per_env_model", False)))
         self.sizes = [shard_range(n_global, r, self.world)[1] - shard_range(n_global, r, self.world)[0] for r in range(self.world)]
         self.lo, self.hi = shard_range(n_global, self.rank, self.world)
         self.n_local = self.hi - self.lo
@@ -117,6 +121,8 @@ class ShardedJitterbugEnv:
 
             def local_env_factory(n_local, env_offset):
                 kw = dict(env_kwargs)
+                if self.variant is not None:
+                    kw["variant"] = self.variant
                 if self.device.type == "cuda" and "stream" not in kw:       # launch on torch's stream: ordered with the collectives
                     kw["stream"] = torch.cuda.current_stream(self.device).cuda_stream
                 return JitterbugVecEnv(n_local, task, seed=seed, env_offset=env_offset,

@@ -8,7 +8,7 @@ import ctypes as C
 
 import numpy as np
 
-from . import _lib, model
+from . import _lib, model, variants
 
 TASKS = model.TASKS
 DEFAULT_TIME_LIMIT = 10          # reference jitterbug.py:56
@@ -56,7 +56,12 @@ class JitterbugVecEnv:
 
     def __init__(self, n_envs, task="move_from_origin", seed=0, device_id=0, random_pose=True, contacts=True,
                  time_limit=DEFAULT_TIME_LIMIT, control_timestep=DEFAULT_CONTROL_TIMESTEP, auto_reset=True,
-                 env_offset=0, max_newton=12, stream=None, params=None, envs_per_wave=0, flags=0):
+                 env_offset=0, max_newton=12, stream=None, params=None, envs_per_wave=0, flags=0, variant=None, per_env_model=False,
+                 envs_per_gpu=None):
+        """variant: 'auto' | 'ordinary' | 'lean' (jitterbug_amd.variants: 'auto' picks the two-waves-per-SIMD kernel from 8192 envs per
+        GPU on, 16 384 with one model per env); None keeps `flags` as given (JB_FLAG_LEAN = 2 by hand).  per_env_model: the batch will get
+        one model per env (randomise_models / set_model_params with N tables) - 'auto' needs to know at creation.  envs_per_gpu: what
+        'auto' is resolved from when this env is one shard of a larger batch (every shard must make the same choice); default n_envs."""
         if task not in TASKS:
             raise AssertionError("Invalid task {}, options are {}".format(task, list(TASKS)))   # reference jitterbug.py:425
         self._L = _lib.load()
@@ -80,6 +85,8 @@ class JitterbugVecEnv:
         cfg.auto_reset = int(bool(auto_reset))
         cfg.max_newton = int(max_newton)
         cfg.envs_per_wave = int(envs_per_wave)
+        if variant is not None:
+            flags = variants.flags_for(variant, self.num_envs if envs_per_gpu is None else envs_per_gpu, per_env_model, flags)
         cfg.flags = int(flags)
         cfg.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
         cfg.env_offset = int(env_offset)

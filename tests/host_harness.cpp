@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "../jitterbug_amd/csrc/jb_model_build.hpp"
+#include "../jitterbug_amd/csrc/jb_step.hpp"
 
 using namespace jb;
 
@@ -135,6 +136,120 @@ extern "C" int jbh_step_pair_lean(const double* P, double* qpos, double* qvel, d
     if (ngroups != 1 && ngroups != 2 && ngroups != 4) return -101;
     return use_float ? run<float>(P, qpos, qvel, ctrl, nsub, contacts, max_newton, 1, fail, ngroups, rank_one, 1, 1)
                      : run<double>(P, qpos, qvel, ctrl, nsub, contacts, max_newton, 1, fail, ngroups, rank_one, 1, 1);
+}
+// ---- K control steps in ONE call, the loop of the fused rollout kernel (jb_api.hip step_body): the state, the step counter, the episode
+// number and the target stay in the lane variables between the control steps; every step = normalise + nsub substeps +
+// control_step_tail (jb_step.hpp: failure flag, reward, time limit, in-place reset, observation) and, with actions == NULL, the heuristic
+// policy evaluated on the observation just produced.  ngroups = 1 (main lanes) or 4 (main + replica + two helper groups, one thread each).
+// io: qpos/qvel/target in and out; rows_out [K, D+2] = [obs | reward | done]; counters = [step_count, episode] in and out.
+template <typename T>
+static int rollout(const double* P, double* qpos, double* qvel, double* target, int* counters, int K, const double* actions, int task, int nsub, int step_limit, int auto_reset,
+                   int random_pose, unsigned long long seed, unsigned long long env_global, const double* policy_params, int ngroups, double* rows_out) {
+    using V = Quad<T>;
+    LaneModel<V> m;
+    T tab[LM_TABLE];
+    { int rc = build_packed_model<T>(P, tab); if (rc) return rc; }
+    m.c.inv = tab; m.c.tab = tab + LM_INV; m.c.lean = false; m.c.preload();
+    LaneState<V> s0;
+    s0.px = V(T(qpos[0])); s0.py = V(T(qpos[1])); s0.pz = V(T(qpos[2]));
+    s0.qw = V(T(qpos[3])); s0.qx = V(T(qpos[4])); s0.qy = V(T(qpos[5])); s0.qz = V(T(qpos[6]));
+    auto lo = [](double x) { return V(T(x - (double)T(x))); };
+    s0.pz_lo = lo(qpos[2]); s0.qw_lo = lo(qpos[3]); s0.qx_lo = lo(qpos[4]); s0.qy_lo = lo(qpos[5]); s0.qz_lo = lo(qpos[6]);
+    s0.vx = V(T(qvel[0])); s0.vy = V(T(qvel[1])); s0.vz = V(T(qvel[2]));
+    s0.wx = V(T(qvel[3])); s0.wy = V(T(qvel[4])); s0.wz = V(T(qvel[5]));
+    double ph = qpos[15], kk = std::floor((ph + M_PI) / (2 * M_PI));
+    s0.phi = V(T(ph - kk * 2 * M_PI)); s0.turns = V(T(kk)); s0.phid = V(T(qvel[14]));
+    s0.th1 = V(T(qpos[7]), T(qpos[9]), T(qpos[11]), T(qpos[13]));
+    s0.th2 = V(T(qpos[8]), T(qpos[10]), T(qpos[12]), T(qpos[14]));
+    s0.thd1 = V(T(qvel[6]), T(qvel[8]), T(qvel[10]), T(qvel[12]));
+    s0.thd2 = V(T(qvel[7]), T(qvel[9]), T(qvel[11]), T(qvel[13]));
+    for (int i = 0; i < 3; i++) { s0.wa[i] = V(T(0)); s0.wl[i] = V(T(0)); }
+    s0.wj[0] = s0.wj[1] = V(T(0)); s0.wm = V(T(0)); s0.fail = V(T(0));
+    SimOpts o; o.contacts = 1; o.max_newton = 12; o.implicit_damp = 1; o.rank_one = 1; o.lean = 0; o.offload = (g_offload && ngroups >= 2) ? 1 : 0; o.prof = nullptr; o.hist = nullptr;
+    o.spread = g_spread;
+    V scratch[SC_COUNT];
+    const int D = obs_dim(task);
+    TaskOpts topt; topt.task = task; topt.step_limit = step_limit; topt.auto_reset = auto_reset; topt.random_pose = random_pose; topt.seed = seed; topt.env_global = env_global;
+    PolicyParams<T> pp = default_policy_params<T>();
+    if (policy_params) { pp.kick_angle = T(policy_params[0]); pp.speed = T(policy_params[1]); pp.angle_threshold = T(policy_params[2]); }
+    LaneState<V> s_final;
+    EpisodeRegs<T> er_final;
+    HostWave wave;
+    wave.ngrp = ngroups; wave.gstride = 16;
+    auto body = [&](int g) {
+        if (ngroups > 1) { g_host_wave = &wave; g_host_grp = g; }
+        LaneScratch<V> sc; sc.p = scratch; sc.stride = 1; sc.grp = g; sc.ngrp = ngroups; sc.gstride = ngroups > 1 ? 16 : 4;
+        sc.ovc = scratch + SC_OVC; sc.ovc_stride = 1; sc.red_lds = true; sc.pd = SC_PD;
+        const bool rep = g == 0 || (o.offload && g == 1);
+        LaneState<V> s = s0;
+        if (!rep) {
+            s.px = s.py = s.pz = V(T(0)); s.qw = V(T(1)); s.qx = s.qy = s.qz = V(T(0)); s.vx = s.vy = s.vz = s.wx = s.wy = s.wz = V(T(0));
+            s.pz_lo = s.qw_lo = s.qx_lo = s.qy_lo = s.qz_lo = V(T(0));
+            s.phi = s.phid = s.turns = V(T(0)); s.th1 = s.th2 = s.thd1 = s.thd2 = V(T(0));
+        }
+        EpisodeRegs<T> er;
+        er.step_count = counters[0]; er.episode = (uint32_t)counters[1];
+        er.tgt[0] = T(target[0]); er.tgt[1] = T(target[1]); er.tgt[2] = T(target[2]);
+        if (g == 0) {
+            for (int k = 0; k < SC_COUNT; k++) scratch[k] = V(std::numeric_limits<T>::quiet_NaN());
+            if (o.offload) for (int k = 0; k < 56; k++) scratch[SC_ZERO + k] = V(T(0));
+        }
+        T ctrl_next = T(0);
+        if (!actions && rep) {
+            T obs0[19];
+            EnvCore<T> e0;
+            core_from_lane_state<V>(m, s, er.tgt, e0);
+            observe<T>(task, e0, lane0(m.c[LM_TARGET_Z]), obs0, 1);
+            ctrl_next = heuristic_policy<T>(task, obs0, 1, pp);
+        }
+        for (int k = 0; k < K; k++) {
+            T ctrl = ctrl_next;
+            if (actions && rep) ctrl = T(actions[k]);
+            if (rep) normalise_state(s);
+            for (int i = 0; i < nsub; i++) {
+                if (ngroups > 1) wave.barrier();
+                if (g == 0) for (int q = 0; q < (o.offload ? SC_ZERO : SC_COUNT); q++) scratch[q] = V(std::numeric_limits<T>::quiet_NaN());
+                if (ngroups > 1) wave.barrier();
+                substep<V>(m, sc, s, V(ctrl), o);
+            }
+            if (!rep) continue;
+            T obs[19], rew;
+            bool done;
+            control_step_tail<V>(topt, m, s, er, obs, rew, done);
+            if (!actions) ctrl_next = heuristic_policy<T>(task, obs, 1, pp);
+            if (g == 0) {
+                double* row = rows_out + (size_t)k * (D + 2);
+                for (int j = 0; j < D; j++) row[j] = (double)obs[j];
+                row[D] = (double)rew; row[D + 1] = done ? 1.0 : 0.0;
+            }
+        }
+        if (g == 0) { s_final = s; er_final = er; }
+        g_host_wave = nullptr;
+    };
+    if (ngroups <= 1) body(0);
+    else {
+        std::vector<std::thread> th;
+        for (int g = 1; g < ngroups; g++) th.emplace_back(body, g);
+        body(0);
+        for (auto& t : th) t.join();
+    }
+    const LaneState<V>& s = s_final;
+    T nq = std::sqrt(s.qw.v[0] * s.qw.v[0] + s.qx.v[0] * s.qx.v[0] + s.qy.v[0] * s.qy.v[0] + s.qz.v[0] * s.qz.v[0]);
+    qpos[0] = s.px.v[0]; qpos[1] = s.py.v[0]; qpos[2] = (double)s.pz.v[0] + (double)s.pz_lo.v[0];
+    qpos[3] = ((double)s.qw.v[0] + (double)s.qw_lo.v[0]) / nq; qpos[4] = ((double)s.qx.v[0] + (double)s.qx_lo.v[0]) / nq;
+    qpos[5] = ((double)s.qy.v[0] + (double)s.qy_lo.v[0]) / nq; qpos[6] = ((double)s.qz.v[0] + (double)s.qz_lo.v[0]) / nq;
+    qvel[0] = s.vx.v[0]; qvel[1] = s.vy.v[0]; qvel[2] = s.vz.v[0]; qvel[3] = s.wx.v[0]; qvel[4] = s.wy.v[0]; qvel[5] = s.wz.v[0];
+    for (int l = 0; l < 4; l++) { qpos[7 + 2 * l] = s.th1.v[l]; qpos[8 + 2 * l] = s.th2.v[l]; qvel[6 + 2 * l] = s.thd1.v[l]; qvel[7 + 2 * l] = s.thd2.v[l]; }
+    qpos[15] = (double)s.phi.v[0] + 2 * M_PI * (double)s.turns.v[0]; qvel[14] = s.phid.v[0];
+    target[0] = er_final.tgt[0]; target[1] = er_final.tgt[1]; target[2] = er_final.tgt[2];
+    counters[0] = er_final.step_count; counters[1] = (int)er_final.episode;
+    return 0;
+}
+extern "C" int jbh_rollout(const double* P, double* qpos, double* qvel, double* target, int* counters, int K, const double* actions, int task, int nsub, int step_limit,
+                           int auto_reset, int random_pose, unsigned long long seed, unsigned long long env_global, const double* policy_params, int ngroups, int use_float, double* rows_out) {
+    if (ngroups != 1 && ngroups != 4) return -101;
+    return use_float ? rollout<float>(P, qpos, qvel, target, counters, K, actions, task, nsub, step_limit, auto_reset, random_pose, seed, env_global, policy_params, ngroups, rows_out)
+                     : rollout<double>(P, qpos, qvel, target, counters, K, actions, task, nsub, step_limit, auto_reset, random_pose, seed, env_global, policy_params, ngroups, rows_out);
 }
 extern "C" int jbh_lm_count(void) { return LM_COUNT; }
 // the per-leg constant table (LM_COUNT doubles) for inspection by tests / tools

@@ -21,7 +21,7 @@ def lib():
 
 def test_exports_every_declared_symbol(lib):
     hdr = open(os.path.join(ROOT, "include", "jitterbug_hip.h")).read()
-    declared = set(re.findall(r"\b(jb_[a-z_]+)\s*\(", hdr))
+    declared = set(re.findall(r"\b(jb_[a-z_0-9]+)\s*\(", hdr))
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     for sym in declared:
         assert getattr(lib, sym) is not None
@@ -108,3 +108,34 @@ def test_entry_points_hand_the_callers_device_back():
     assert out[0] != 0 and out[1] == -1 and out[2] == 1 and out[3] == 1
     src = open(bh.os.path.join(bh.HERE, "..", "jitterbug_amd", "csrc", "jb_api.hip")).read()
     assert "DeviceGuard<HipDeviceApi>" in src and "JB_HIP(hipSetDevice" not in src      # no entry point switches without the guard
+
+
+def test_build_is_keyed_on_the_source_hash_not_on_file_times(tmp_path):
+    """the library carries the sha256 of the sources it was built from; needs_build() compares that with the sources
+    as they are (a comment edited in a copy of csrc/ makes it true, restoring the text makes it false again - whatever the mtimes), and
+    _lib.load() refuses an in-tree library that was built from other sources."""
+    import shutil
+    from jitterbug_amd import _lib, build as B
+    assert os.path.exists(B.OUT), "library not built"
+    have = B.embedded_sha256(B.OUT)
+    assert have is not None and len(have) == 64
+    assert have == B.source_sha256() and not B.needs_build()
+    assert _lib.load().jb_source_sha256().decode() == have
+    csrc, inc = tmp_path / "csrc", tmp_path / "include"
+    shutil.copytree(B.CSRC, csrc)
+    shutil.copytree(B.INCLUDE, inc)
+    assert B.source_sha256(str(csrc), str(inc)) == have and not B.needs_build(B.OUT, str(csrc), str(inc))       # a copy (new mtimes) is not a change
+    f = csrc / "jb_task.hpp"
+    text = f.read_text()
+    f.write_text(text.replace("// jb_task.hpp", "// jb_task.hpp (edited)", 1))
+    assert B.needs_build(B.OUT, str(csrc), str(inc))
+    f.write_text(text)
+    os.utime(f, (1, 1))                                                                                            # ... and an old mtime does not hide one
+    assert not B.needs_build(B.OUT, str(csrc), str(inc))
+    (inc / "jitterbug_hip.h").write_text((inc / "jitterbug_hip.h").read_text() + "\n/* edited */\n")
+    assert B.needs_build(B.OUT, str(csrc), str(inc))
+    # the loader's guard: same check, against the real tree
+    stale = tmp_path / "libstale.so"
+    data = open(B.OUT, "rb").read()
+    stale.write_bytes(data.replace(b"JB_SRC_SHA256=" + have.encode(), b"JB_SRC_SHA256=" + b"0" * 64))
+    assert B.embedded_sha256(str(stale)) == "0" * 64 and B.needs_build(str(stale))

@@ -80,6 +80,34 @@ def test_bench_line_names_the_baseline_workload_and_the_loaded_library():
     assert d["steady"]["steps"] == 300 and d["steady"]["warmup"] == 100 and d["steady"]["value"] > 0
     assert d["value_full_episode"] > 0 and d["roofline"]["steady"]["frac"] > 0
     assert abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / d["roofline"]["peak"]) < 1e-12
+    # the kernel the line names is the kernel the handle launched (jb_kernel_variant), not a flag the script believed in
+    assert d["kernel_variant"] == "ordinary" and "LEAN" not in d["config"]["workload"]
+    # the fused rollout block next to the per-step headline: same workload, one launch per K steps, bounded by its slowest wave
+    rf = d["rollout_fused"]
+    for key in ("k1000", "k100", "k1000_policy", "k1000_const1"):
+        assert rf[key]["finite"] is True and rf[key]["value"] > 0 and rf[key]["kernel_variant"] == "ordinary"
+    assert rf["k1000"]["launches"] == 1 and rf["k100"]["launches"] == 10
+    wc = rf["k1000"]["wave_clock"]
+    assert 0 < wc["mean_over_slowest"] <= 1 and rf["k1000"]["value"] <= wc["ceiling_mean_wave"] * 1.02
+    assert rf["k1000"]["value"] > 1.1 * d["value_full_episode"]          # what the fused launch is for (measured: 6.3 -> 8.3 M env-steps/s)
+
+
+@pytest.mark.gpu
+def test_bench_resolves_the_kernel_variant_in_the_product_and_reports_the_one_launched():
+    """No threshold lives in bench.py: `variant="auto"` is resolved by jitterbug_amd.variants (8192 envs per GPU -> the two-waves-per-SIMD
+    kernel), and the line reports jb_kernel_variant of the handle that was timed."""
+    src = open(BENCH).read()
+    assert "8192" not in src.split("def main")[1].split("import numpy")[0] and "16384" not in src.split("def main")[1].split("import numpy")[0]
+    p = subprocess.run([sys.executable, BENCH, "--envs-per-gpu", "8192", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-also", "--no-host-rate", "--no-steady"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    assert d["kernel_variant"] == "lean" and "LEAN kernel variant" in d["config"]["workload"] and d["finite"] is True
+    p = subprocess.run([sys.executable, BENCH, "--envs-per-gpu", "8192", "--augmented", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-also", "--no-host-rate", "--no-steady"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    assert d["kernel_variant"] == "pair" and "PAIR kernel variant" in d["config"]["workload"] and d["finite"] is True
 
 
 @pytest.mark.gpu

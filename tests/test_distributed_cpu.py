@@ -98,3 +98,54 @@ def test_sharded_env_matches_single_process_gloo(depth):
         assert np.array_equal(d, rd.astype(bool))
         saw_done |= bool(d.any())
     assert saw_done            # the auto-reset (episode 2 streams) crossed the shard boundary consistently
+
+
+def _variant_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from jitterbug_amd.distributed import ShardedJitterbugEnv
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    class Stub:
+        obs_dim = 15
+
+        def __init__(self, n, off):
+            self.n, self.off = n, off
+
+    out = []
+    for n_global, kw in ((16383, {}), (16383, dict(per_env_model=True)), (16380, {}), (32768, dict(per_env_model=True)), (16383, dict(variant="ordinary"))):
+        env = ShardedJitterbugEnv(n_global, "move_from_origin", local_env_factory=lambda n, off: Stub(n, off), **kw)
+        out.append((n_global, tuple(sorted(kw.items())), env.n_local, env.variant))
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_every_rank_resolves_the_same_kernel_variant_gloo():
+    """variant='auto' is resolved from the GLOBAL batch and the world size, never from a rank's own shard length: with 16 383 envs on two
+    ranks (8192 + 8191) a per-shard rule would run the LEAN kernel on rank 0 and the ordinary one on rank 1 - two roundings in one
+    batch.  (The reference's harness builds its vec env with no knobs: benchmarks/benchmark.py:146-171.)"""
+    import torch.multiprocessing as mp
+    from jitterbug_amd import variants
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_variant_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    r0, r1 = got[0], got[1]
+    assert [x[3] for x in r0] == [x[3] for x in r1] == ["lean", "ordinary", "ordinary", "lean", "ordinary"]
+    assert r0[0][2] == 8192 and r1[0][2] == 8191          # ... although the shards straddle the threshold
+    # the thresholds themselves, in the one place they live
+    assert variants.resolve("auto", 8191) == "ordinary" and variants.resolve("auto", 8192) == "lean"
+    assert variants.resolve("auto", 16383, per_env_model=True) == "ordinary" and variants.resolve("auto", 16384, per_env_model=True) == "lean"
+    assert variants.flags_for("lean", 64, flags=8) == 10 and variants.flags_for("ordinary", 10 ** 6, flags=2 | 16) == 16
+    with pytest.raises(ValueError):
+        variants.resolve("fast", 64)

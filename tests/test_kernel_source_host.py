@@ -402,3 +402,90 @@ def test_contacts_beyond_the_row_cache_give_the_same_answer(params):
             qh, vh = run(fn, q0[i], v0[i], a[i], 4)
             worst = max(worst, np.abs(qh - q1[i]).max(), (np.abs(vh - v1[i]) / (1 + np.abs(v1[i]))).max())
     assert worst < 1e-10, worst
+
+
+# ---------------------------------------------------------------------------------------------- the fused rollout's loop on the host
+@pytest.fixture(scope="module")
+def hrollout():
+    import tests.build_harness as bh
+    lib = C.CDLL(bh.build())
+    dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int)
+    lib.jbh_rollout.argtypes = [dp, dp, dp, dp, ip, C.c_int, dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64, dp, C.c_int, C.c_int, dp]
+    P0 = np.ascontiguousarray(model.default_params(), dtype=np.float64)
+
+    def run(q, v, tgt, counters, K, actions, task, step_limit, seed, env_global, ngroups=1, f32=0, policy_params=None, auto_reset=1):
+        D = model.OBS_DIM[task]
+        q, v, tgt = q.copy(), v.copy(), tgt.copy()
+        cnt = np.array(counters, dtype=np.int32)
+        rows = np.zeros((K, D + 2))
+        a = None if actions is None else np.ascontiguousarray(actions, dtype=np.float64)
+        pp = None if policy_params is None else np.ascontiguousarray(policy_params, dtype=np.float64)
+        rc = lib.jbh_rollout(P0.ctypes.data_as(dp), q.ctypes.data_as(dp), v.ctypes.data_as(dp), tgt.ctypes.data_as(dp), cnt.ctypes.data_as(ip), K,
+                             None if a is None else a.ctypes.data_as(dp), model.TASKS.index(task), 50, step_limit, auto_reset, 1, seed, env_global,
+                             None if pp is None else pp.ctypes.data_as(dp), ngroups, f32, rows.ctypes.data_as(dp))
+        assert rc == 0, rc
+        return rows, q, v, tgt, cnt
+    return run
+
+
+@pytest.mark.parametrize("task", ["move_from_origin", "move_to_pose", "move_in_direction"])
+def test_rollout_loop_fp64_equals_oracle_through_auto_resets(hrollout, params, task):
+    """The K-step loop of the fused rollout kernel (state, step counter, episode and target carried between control steps,
+    jb_step.hpp control_step_tail after every 50 substeps) on the host in fp64 against the oracle stepping one control step at a time:
+    30 steps of an action tape with a 12-step time limit - two in-loop episode resets (new Philox draws, new target)."""
+    seed, env_global, limit, K = 11, 5, 12, 30
+    env = O.OracleEnv(1, task, params, step_limit=limit, seed=seed, env_offset=env_global)
+    env.reset()
+    q, v, t = env.get_state()
+    sc, ep = env.counters()
+    rng = np.random.default_rng(4)
+    tape = rng.uniform(-1, 1, size=K)
+    D = model.OBS_DIM[task]
+    ref = np.zeros((K, D + 2))
+    for k in range(K):
+        ob, rw, dn = env.step(tape[k])
+        ref[k, :D], ref[k, D], ref[k, D + 1] = ob[0], rw[0], dn[0]
+    qo, vo, to = env.get_state()
+    sco, epo = env.counters()
+    rows, qh, vh, th, cnt = hrollout(q[0], v[0], t[0], [sc[0], ep[0]], K, tape, task, limit, seed, env_global)
+    assert ref[:, D + 1].sum() == 2 and np.array_equal(rows[:, D + 1], ref[:, D + 1])
+    np.testing.assert_allclose(rows, ref, rtol=0, atol=2e-8)
+    np.testing.assert_allclose(qh, qo[0], rtol=0, atol=1e-8)
+    np.testing.assert_allclose(th, to[0], rtol=0, atol=1e-12)
+    assert cnt[0] == sco[0] and cnt[1] == epo[0]
+    # the wave layout of the kernel (main + replica + two helper groups: the replica runs the tail too, and must reset with the main lanes)
+    rows4, q4, v4, t4, cnt4 = hrollout(q[0], v[0], t[0], [sc[0], ep[0]], K, tape, task, limit, seed, env_global, ngroups=4)
+    np.testing.assert_allclose(rows4, rows, rtol=0, atol=1e-9)
+    assert np.array_equal(cnt4, cnt)
+    # one K-step call = K one-step calls with the state exported / imported in between (only the contact solver's warm start is lost
+    # at each hand-over: the minimiser is the same to the solver's tolerance)
+    qs, vs, ts, cs = q[0], v[0], t[0], [sc[0], ep[0]]
+    rows1 = np.zeros_like(rows)
+    for k in range(K):
+        r, qs, vs, ts, cs = hrollout(qs, vs, ts, cs, 1, tape[k:k + 1], task, limit, seed, env_global)
+        rows1[k] = r[0]
+    np.testing.assert_allclose(rows1, rows, rtol=0, atol=2e-8)
+
+
+def test_rollout_loop_in_loop_policy_fp64_equals_oracle_with_the_python_policy(hrollout, params):
+    """actions = NULL: the heuristic policy evaluated inside the loop on the observation just produced (what the fused kernel does
+    instead of a jb_policy_kernel launch per step) against the oracle driven by jitterbug_amd.heuristic_policies.policy_batch."""
+    from jitterbug_amd import heuristic_policies as HP
+    kw = dict(kick_angle=0.6, speed=0.8, angle_threshold=0.3)
+    for task in ("move_from_origin", "move_to_position", "move_to_pose"):
+        seed, env_global, limit, K = 2, 9, 15, 25
+        env = O.OracleEnv(1, task, params, step_limit=limit, seed=seed, env_offset=env_global)
+        ob = env.reset()
+        q, v, t = env.get_state()
+        sc, ep = env.counters()
+        D = model.OBS_DIM[task]
+        ref = np.zeros((K, D + 2))
+        acts = []
+        for k in range(K):
+            a = HP.policy_batch(task, ob, **kw)
+            acts.append(float(a[0]))
+            ob, rw, dn = env.step(a)
+            ref[k, :D], ref[k, D], ref[k, D + 1] = ob[0], rw[0], dn[0]
+        rows, *_ = hrollout(q[0], v[0], t[0], [sc[0], ep[0]], K, None, task, limit, seed, env_global, policy_params=[kw["kick_angle"], kw["speed"], kw["angle_threshold"]])
+        assert len(set(np.sign(acts))) == 2 and ref[:, D + 1].sum() == 1          # the policy really switches, and an episode ends inside
+        np.testing.assert_allclose(rows, ref, rtol=0, atol=2e-8)
