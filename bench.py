@@ -94,13 +94,34 @@ def free_port():
 
 def self_launch(n_gpus, argv):
     """Parent of a `--gpus N` run started without torch.distributed.run: spawn the ranks as a CHILD process tree (no exec, no
-    torch import, no HIP call here), pass their stderr through, print rank 0's single JSON line, return the child's rc."""
+    torch import, no HIP call here), pass their stderr through, print rank 0's single JSON line, return the child's rc.
+    A watchdog (JB_BENCH_LAUNCH_TIMEOUT seconds, default 1500) kills the child's whole process group if the ranks neither finish nor
+    fail - a rendezvous or a collective that never completes must not hang the caller; the run then returns 124 and prints no line."""
+    import signal
     import subprocess
+    import threading
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus), "--master-addr", "127.0.0.1",
            "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
     env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: RCCL across processes needs it on this driver
-    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    # What the launcher sets for the ranks, and why (DESIGN.md 5):
+    #   HSA_ENABLE_IPC_MODE_LEGACY=0   dmabuf IPC: the host driver of this pool supports only that, RCCL across processes fails with
+    #                                  hipIpcGetMemHandle: invalid argument otherwise (already exported on the boxes; kept for a bare environment)
+    #   (MASTER_ADDR/PORT, RANK, LOCAL_RANK, WORLD_SIZE come from torch.distributed.run; nothing else is touched)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True, start_new_session=True)
+    limit = float(os.environ.get("JB_BENCH_LAUNCH_TIMEOUT", "1500"))
+    timed_out = []
+
+    def kill_group():
+        timed_out.append(True)
+        try:
+            os.killpg(child.pid, signal.SIGKILL)          # the exact process group this function started (start_new_session), nothing by pattern
+        except (ProcessLookupError, PermissionError, AttributeError):
+            pass
+    watchdog = threading.Timer(limit, kill_group)
+    watchdog.daemon = True
+    if hasattr(child, "pid"):
+        watchdog.start()
     line = None
     for out in child.stdout:
         if out.startswith("{") and '"metric"' in out:
@@ -108,6 +129,10 @@ def self_launch(n_gpus, argv):
         else:
             sys.stderr.write(out)                             # anything else the ranks print is not the result
     rc = child.wait()
+    watchdog.cancel()
+    if timed_out:
+        sys.stderr.write("bench.py: the ranks did not finish within %.0f s (JB_BENCH_LAUNCH_TIMEOUT): killed\n" % limit)
+        return 124
     if rc == 0 and line is None:
         sys.stderr.write("bench.py: the ranks exited cleanly but printed no result line\n")
         rc = 1

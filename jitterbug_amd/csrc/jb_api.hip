@@ -358,8 +358,11 @@ __global__ __launch_bounds__(64) void jb_step_kernel(KArgs a, StepIO io) {
 }
 // The LEAN variant: the same substep with the register budget of TWO waves per SIMD (256 registers per lane).  Model constants are read
 // from LDS where they are used, and the lane state, the joint-space system and the kept factorisation are parked in the lane's
-// scratch between the phases that use them (jb_sim.hpp SimOpts::lean).  Same arithmetic in the same order: results are bit-identical
-// to the one-wave kernel's.  A second resident wave doubles the SIMD's VALU issue rate, which pays when a GPU holds >= 2048 waves.
+// scratch between the phases that use them (jb_sim.hpp SimOpts::lean).  The same algorithm, but NOT the same bits as the one-wave kernel:
+// the damping factorisation comes from star_factor<false> instead of the replica group's star_solve stream, and the compiler fuses
+// multiply-adds differently in the two instantiations - the results agree to fp32 rounding (on the host, without contraction, they are
+// identical).  Every shard of one batch must therefore run the same variant (jitterbug_amd.variants resolves it from the global batch).
+// A second resident wave doubles the SIMD's VALU issue rate, which pays when a GPU holds >= 2048 waves.
 template <int EPW>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void jb_step_kernel_lean(KArgs a, StepIO io) {
     step_body<EPW, true>(a, io);

@@ -82,7 +82,14 @@ JB_D unsigned wave_bcast_u(unsigned x) { return (unsigned)__builtin_amdgcn_readf
 // LDS operations of a wave complete in program order, so the hardware needs nothing here - but the COMPILER must not move a read of
 // the hand-over across the writes it depends on (it sees one thread and may prove the addresses different once the group is known):
 // a wave barrier is that fence and emits no instruction.  The host emulation (one thread per group) needs a real barrier.
-JB_D void wave_sync() { __builtin_amdgcn_wave_barrier(); }
+// The wave barrier alone is a scheduling fence (IntrNoMem + side effects): it stops the machine scheduler, but IR-level passes (GVN / PRE load
+// forwarding) may still move or forward LDS / global accesses across it.  The wavefront-scope release / acquire fences around it are
+// what makes the hand-over a memory ordering point for the optimiser too; at wavefront scope they emit no instruction on gfx9.
+JB_D void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 // ---- quad-level exchanges for the spread contact sweeps (jb_sim.hpp): a lane may work on a contact of ANOTHER leg of its env
 // quad_rot<K>: the value of lane (l + K) & 3 of the quad; quad_bcast_u: the value of lane j of the quad (DPP quad_perm, one instruction)
 template <int K> JB_D float quad_rot(float x) {

@@ -1701,6 +1701,7 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
     // the helper groups learn what phase A found (values of the first lane, a main lane)
     any_contact = wave_bcast_u(any_contact ? 1u : 0u) != 0u;
     live_slots = wave_bcast_u(live_slots);
+    wave_sync();          // phase A's scratch (SC_OWN, SC_ST, SC_DD, the candidate rows: written under `if (rep)`) -> read by every group below
     const SlotPlan plan = make_slot_plan(sc, live_slots);
     const SpreadPlan<V> spl = make_spread_plan<V>(sc, plan, o.spread != 0 && any_contact);
 

@@ -231,8 +231,9 @@ class ShardedJitterbugEnv:
             with torch.cuda.stream(self._env_stream):    # the ENV's stream (where the kernel that rewrites it runs) waits for that gather
                 self._pending[b].wait()
             self._pending[b] = None
-        if torch.cuda.current_stream(self.device) != self._env_stream:       # actions produced on another stream: the kernel waits for them
-            self._env_stream.wait_stream(torch.cuda.current_stream(self.device))
+        cur = torch.cuda.current_stream(self.device)
+        if cur.cuda_stream != self._env_stream.cuda_stream:      # actions produced on another stream: the kernel waits for them.  (RAW handles:
+            self._env_stream.wait_stream(cur)                    # a pool Stream and an ExternalStream never compare equal even when both wrap one hipStream)
         self.env.step_rows_device(a.data_ptr(), self._rows[b].data_ptr())
         self._i += 1
         if self.depth == 1:

@@ -17,7 +17,9 @@ import json, subprocess, sys
 sys.path.insert(0, %(root)r)
 seen = {}
 class FakePopen:
+    pid = 2 ** 22 + 12345          # (no such process: the watchdog is cancelled long before it could fire anyway)
     def __init__(self, cmd, stdout=None, env=None, text=None, **kw):
+        seen["new_session"] = kw.get("start_new_session")
         seen["cmd"] = cmd; seen["env_ipc"] = (env or {}).get("HSA_ENABLE_IPC_MODE_LEGACY")
         seen["torch_loaded_at_spawn"] = any(m == "torch" or m.startswith("torch.") for m in sys.modules)
         self.stdout = iter(["some rank chatter\n", json.dumps({"metric": "env steps/s", "n_gpus": 2, "value": 1.0}) + "\n"])
@@ -49,7 +51,7 @@ def test_gpus_n_parent_spawns_the_ranks_without_touching_torch_or_the_gpu():
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
     assert cmd[-9] == os.path.abspath(BENCH) and cmd[-8:] == ["--gpus", "2", "--steps", "3", "--warmup", "1", "--dist-backend", "gloo"]
     assert seen["torch_loaded_at_spawn"] is False and seen["torch_loaded_after"] is False      # the parent never initialises HIP: it never even imports torch
-    assert seen["env_ipc"] == "0"
+    assert seen["env_ipc"] == "0" and seen["new_session"] is True          # own process group: the watchdog can end exactly these ranks
     lines = [l for l in p.stdout.splitlines() if l.strip()]
     assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 2                              # exactly rank 0's line, chatter goes to stderr
     assert "some rank chatter" in p.stderr
@@ -124,3 +126,49 @@ def test_bench_gpus_2_starts_itself_on_one_gpu_over_gloo():
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["global_envs"] == 8192 and d["finite"] is True and d["scaling"] == "weak"
+
+
+def test_gpus_n_parent_watchdog_kills_ranks_that_never_finish():
+    """A rendezvous or collective that never completes must not hang the caller (the first 8-GPU run is also the first run of RCCL across
+    real ranks): the parent kills the process group it started after JB_BENCH_LAUNCH_TIMEOUT and returns 124 without a result line."""
+    probe = r'''
+import os, subprocess, sys, time
+sys.path.insert(0, %(root)r)
+real = subprocess.Popen
+def sleepy(cmd, **kw):
+    return real([sys.executable, "-c", "import time; print('rank chatter', flush=True); time.sleep(600)"], **kw)
+subprocess.Popen = sleepy
+import bench
+t0 = time.time()
+rc = bench.main(["--gpus", "2", "--steps", "3", "--warmup", "1"])
+sys.stderr.write("PROBE rc=%%d dt=%%.1f\\n" %% (rc, time.time() - t0))
+sys.exit(rc)
+''' % {"root": ROOT}
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["JB_BENCH_LAUNCH_TIMEOUT"] = "3"
+    p = subprocess.run([sys.executable, "-c", probe], capture_output=True, text=True, env=env, timeout=120)
+    assert p.returncode == 124 and p.stdout.strip() == ""
+    assert "PROBE rc=124" in p.stderr and "rank chatter" in p.stderr and "killed" in p.stderr
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_over_rccl_on_one_gpu_succeeds_or_fails_cleanly():
+    """Rehearsal of what the driver's 8-GPU tier does first, as far as a one-GPU box allows: `bench.py --gpus 2` with the DEFAULT backend
+    (nccl = RCCL) and both ranks on device 0.  RCCL may accept that or refuse it ("Duplicate GPU detected"); either way the run must end
+    by itself well inside the watchdog's limit - with one result line (rc 0) or with rc != 0 and no line - and never hang."""
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["JB_BENCH_DEVICE"] = "0"
+    env["JB_BENCH_LAUNCH_TIMEOUT"] = "150"
+    t0 = time.time()
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-steady"],
+                       capture_output=True, text=True, timeout=240, cwd=ROOT, env=env)
+    dt = time.time() - t0
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    print("bench.py --gpus 2 over RCCL on one device: rc %d after %.0f s, %d result line(s); stderr tail: %s" % (p.returncode, dt, len(lines), p.stderr[-400:].replace("\n", " | ")))
+    assert dt < 200 and p.returncode != 124, "the ranks hung until the watchdog"
+    if p.returncode == 0:
+        d = json.loads(lines[0])
+        assert len(lines) == 1 and d["n_gpus"] == 2 and d["finite"] is True
+    else:
+        assert lines == []

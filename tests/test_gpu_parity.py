@@ -193,6 +193,47 @@ def test_lean_kernel_variant_parity():
     a_env.close(); b_env.close()
 
 
+def test_lean_kernel_at_the_size_it_is_selected_for_against_the_oracle():
+    """the LEAN kernel is what variant='auto' (and bench.py) run from 8192 envs per GPU on, but it had only been
+    oracle-checked at 64 envs (one wave per SIMD).  Here: 8192 envs of the nominal model, the product's own variant selection, two resident
+    waves per SIMD, a free-running open-loop rollout of 200 control steps; a 64-env subset spread over the batch is held against the oracle every
+    step from the GPU's own pre-step state (teacher-forced the other way round, like the config-5 shard test)."""
+    from jitterbug_amd.vec_env import JitterbugVecEnv
+    from oracle import oracle as O
+    n, steps, task = 8192, 200, "move_from_origin"
+    env = JitterbugVecEnv(n, task, seed=21, auto_reset=False, variant="auto")
+    assert env.kernel_variant == "lean" and env.envs_per_wave == 4
+    P = model.default_params()
+    idx = np.linspace(0, n - 1, 64).astype(int)
+    o = O.OracleEnv(64, task, P, seed=21)
+    o.reset(); env.reset()
+    rng = np.random.default_rng(5)
+    well_bad = well_tot = ill = 0
+    worst_well = worst_rew = 0.0
+    for t in range(steps):
+        a = rng.uniform(-1, 1, size=n)
+        a[idx[:16]] = 1.0                       # a quarter of the compared robots flat out: some of them tip over (all-geom path)
+        q, v, tg = env.get_state()
+        og, rg, dg, _ = env.step(a)
+        o.set_state(q[idx], v[idx], tg[idx])
+        oo, ro, do = o.step(a[idx], auto_reset=False)
+        well = o.margins() >= MARGIN_TOL
+        err = np.abs(og[idx].astype(np.float64) - oo)
+        w = err <= 1e-4 * np.abs(oo) + 1e-6
+        well_bad += (~w[well]).sum(); well_tot += w[well].size; ill += (~well).sum()
+        if well.any():
+            worst_well = max(worst_well, err[well].max()); worst_rew = max(worst_rew, np.abs(rg[idx] - ro)[well].max())
+    q, v, _ = env.get_state()
+    tipped = float(((1 - 2 * (q[idx, 4] ** 2 + q[idx, 5] ** 2)) < 0.5).mean())
+    print("LEAN at 8192 envs vs the oracle: well-conditioned entries outside the tolerance %d of %d (worst %.1e, worst reward error %.1e), ill-conditioned env-steps %d of %d, tipped %.2f"
+          % (well_bad, well_tot, worst_well, worst_rew, ill, 64 * steps, tipped))
+    assert well_bad <= 2 and worst_well < 2e-5 and worst_rew < 1e-4
+    assert ill < 0.03 * 64 * steps
+    sc, ep, cap = env.counters()
+    assert np.isfinite(q).all() and (sc == steps).all() and cap.sum() < 0.001 * n * steps
+    env.close()
+
+
 def test_lean_variant_at_two_waves_per_simd_is_split_invariant_and_physical():
     """The LEAN variant where it pays (>= 8192 envs on a GPU: 2048+ four-env waves, two resident per SIMD, 20 KB of LDS each): 16 384 envs,
     results bit-identical for any split into LEAN shards (the variant is a per-handle choice - JB_FLAG_LEAN - because its arithmetic is
@@ -663,3 +704,47 @@ def test_wave_composition_invariance_in_the_tipped_regime():
     qt = out[4][:, 3:7]
     up = 1 - 2 * (qt[:, 1] ** 2 + qt[:, 2] ** 2)
     assert (up < 0.5).mean() > 0.05
+
+
+def test_tuned_policies_reach_the_reference_bands():
+    """Behavioural pin (no parity claim), VERDICT r3 item 2 / profiles/r04_policy_search.txt: the reference's own bang-bang policy
+    structure (heuristic_policies.py:28-56) with the parameters a cross-entropy search found SOLVES move_from_origin here (return >= 900,
+    as the reference's DDPG agents do on MuJoCo: fig-rl-perf, median 940-950) and reaches on move_in_direction the top of the band the
+    reference's MuJoCo agents occupy (median 330, p90 550-600: the task is NOT solved there either) - 0.05-0.065 m/s along the target."""
+    from jitterbug_amd.vec_env import JitterbugVecEnv
+    PI = np.pi
+
+    def wrap(a):
+        return (a + PI) % (2 * PI) - PI
+
+    def run(task, amp, kick, off, bias, thr=None, gain=None, n=256):
+        env = JitterbugVecEnv(n, task, seed=0, auto_reset=False)
+        obs = env.reset()
+        ret = np.zeros(n); vel = np.zeros(n)
+        for t in range(999):
+            ma, mv, o = obs[:, 13] * PI, obs[:, 14], off
+            steer = None
+            if task == "move_in_direction":
+                ang = obs[:, 15] * PI
+                sp, sn = (ang > PI / 4) & (ang <= PI), (ang >= -PI) & (ang < -PI / 4)
+                o = off + np.where(sp, PI / 2, 0.0) + np.where(sn, -PI / 2, 0.0)
+                ang2 = np.where(sp, np.abs(np.abs(ang) - PI / 2), np.where(sn, -np.abs(np.abs(ang) - PI / 2), ang))
+                steer = (np.abs(ang2) > thr, 0.9 * gain * np.clip(3 * ang2 / PI, -1, 1))
+            d = wrap(ma - o)
+            s = np.where(d < -kick, 1.0, np.where(d > kick, -1.0, np.where(mv > 0, 1.0, -1.0)))
+            a = np.clip(bias + amp * s, -1, 1)
+            if steer is not None:
+                a = np.where(steer[0], steer[1], a)
+            obs, r, _, _ = env.step(a.astype(np.float32))
+            ret += r
+            if task == "move_in_direction" and t >= 200:
+                vel += obs[:, 16]
+        env.close()
+        return ret, vel / 799.0
+
+    ret, _ = run("move_from_origin", amp=0.579, kick=1.455, off=0.549, bias=-0.162)
+    print("move_from_origin, tuned kick policy: return mean %.0f p10 %.0f, solved %.2f" % (ret.mean(), np.quantile(ret, 0.1), (ret >= 900).mean()))
+    assert ret.mean() > 930 and (ret >= 900).mean() > 0.9
+    ret, speed = run("move_in_direction", amp=0.676, kick=2.033, off=0.156, bias=-0.005, thr=1.458, gain=0.624)
+    print("move_in_direction, tuned kick policy: return mean %.0f (p10 %.0f p90 %.0f), speed along the target %.3f m/s" % (ret.mean(), np.quantile(ret, 0.1), np.quantile(ret, 0.9), speed.mean()))
+    assert 440 < ret.mean() < 680 and 0.035 < speed.mean() < 0.09

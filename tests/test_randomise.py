@@ -191,25 +191,49 @@ def test_config5_shard_8192_device_models_against_the_oracle(variant):
     o.reset()
     env.reset()
     rng = np.random.default_rng(12)
-    well_bad = well_tot = ill = tot_ok = tot = 0
-    worst_well = 0.0
+    # Three classes of robots in the subset, by how deep the mass ever gets into a leg during THIS rollout (the oracle's own narrow phase
+    # on the pre-step states): 0 never touches; 1 touches by less than the leg's radius (a contact MuJoCo's MPR and the geometric
+    # narrow phase agree on); 2 deeper (the leg's axis inside the mass: a robot that could not be built; the fixed-count narrow phase
+    # is only first-order there).  The north-star tolerance is asserted on classes 0 and 1; the loose bound is for class 2 alone.
+    LEG_RADIUS = 0.00061          # reference jitterbug.xml:58-100: every leg cylinder has size 0.00061
+    depth = np.zeros(64)
+    bad = np.zeros((3,), dtype=np.int64); tot_c = np.zeros((3,), dtype=np.int64); ill_c = np.zeros((3,), dtype=np.int64)
+    rew_err = np.zeros(3); worst_c = np.zeros(3)
+    per_step = []
     for t in range(steps):
         a = rng.uniform(-1, 1, size=n)
         q, v, tg = env.get_state()
+        if t % 4 == 0:
+            for j, i in enumerate(idx):
+                for leg in range(4):
+                    okp, dist, _, _ = O.pair_geometric(P[i], q[i], leg)
+                    if okp and dist < 0:
+                        depth[j] = max(depth[j], -dist)
         og, rg, dg, _ = env.step(a)
         o.set_state(q[idx], v[idx], tg[idx])
         oo, ro, do = o.step(a[idx], auto_reset=False)
         well = o.margins() >= 3e-8
         err = np.abs(og[idx].astype(np.float64) - oo)
         w = err <= 1e-4 * np.abs(oo) + 1e-6
-        well_bad += (~w[well]).sum(); well_tot += w[well].size; ill += (~well).sum()
-        tot_ok += w.sum(); tot += w.size
-        if well.any():
-            worst_well = max(worst_well, err[well].max())
-        assert np.abs(rg[idx] - ro).max() < 2e-2
-    print("config-5 shard: well-conditioned entries outside tolerance %d of %d (worst error %.2e), ill-conditioned env-steps %d of %d, all entries within tolerance %.5f"
-          % (well_bad, well_tot, worst_well, ill, 64 * steps, tot_ok / tot))
-    assert well_bad <= 2 and ill < 0.12 * 64 * steps and tot_ok / tot >= 0.999      # (24 of the 64 are robots that touch, some by more than the leg radius: ill-conditioned by definition)
+        per_step.append((well.copy(), (~w).sum(1), err.max(1), np.abs(rg[idx] - ro)))
+    cls = np.where(depth <= 0, 0, np.where(depth < LEG_RADIUS, 1, 2))
+    for well, nbad, emax, rerr in per_step:
+        for c in range(3):
+            m = (cls == c) & well
+            bad[c] += nbad[m].sum(); tot_c[c] += m.sum() * oo.shape[1]; ill_c[c] += ((cls == c) & ~well).sum()
+            if m.any():
+                worst_c[c] = max(worst_c[c], emax[m].max()); rew_err[c] = max(rew_err[c], rerr[m].max())
+    sizes = [int((cls == c).sum()) for c in range(3)]
+    print("config-5 shard [%s]: robots never touching / touching < leg radius (%.2f mm) / deeper: %s; entries of well-conditioned env-steps outside the tolerance %s of %s; "
+          "worst error %s; worst reward error %s; ill-conditioned env-steps %s of %d"
+          % (variant, 1e3 * LEG_RADIUS, sizes, bad.tolist(), tot_c.tolist(), ["%.1e" % x for x in worst_c], ["%.1e" % x for x in rew_err], ill_c.tolist(), 64 * steps))
+    assert sizes[0] >= 30 and sizes[1] + sizes[2] >= 10, sizes
+    # classes 0 and 1: the north-star tolerance on every entry of every well-conditioned env-step, rewards to 2e-4
+    assert bad[0] == 0 and bad[1] == 0, (bad, sizes)
+    assert rew_err[0] < 2e-4 and rew_err[1] < 2e-4, rew_err
+    assert ill_c[0] + ill_c[1] < 0.03 * (sizes[0] + sizes[1]) * steps, ill_c
+    # class 2 (deeper than the leg's radius): bounded, not held to the tolerance
+    assert bad[2] <= 0.002 * max(tot_c[2], 1) + 2 and rew_err[2] < 2e-2, (bad, rew_err)
     q, v, _ = env.get_state()
     sc, ep, cap = env.counters()
     assert np.isfinite(og).all() and np.isfinite(q).all() and np.isfinite(v).all()
