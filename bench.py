@@ -297,7 +297,7 @@ def main(argv=None):
         ws, ds, _, fs = run(args.contacts, 300, 100, gather=(dist is not None))
         ws = rank_max(ws)
         steady = {"value": total_envs * 300 / ws, "unit": "env steps/s", "ms_per_step": ws * 1e3 / 300, "launch_ms": ds / 300, "steps": 300, "warmup": 100,
-                  "window": "steps 100-400 of the episode (some robots have tipped over by then; the window of profiles/r03_*)", "finite": fs}
+                  "window": "steps 100-400 of the episode (some robots have tipped over by then; the window of profiles/r04_*)", "finite": fs}
         if world == 1 and dist is None:
             wf, df, _, ff = run(args.contacts, 1000, 0, gather=False)
             full_episode = {"value": total_envs * 1000 / wf, "unit": "env steps/s", "ms_per_step": wf * 1e3 / 1000, "launch_ms": df / 1000, "steps": 1000, "warmup": 0,
@@ -399,7 +399,7 @@ def main(argv=None):
         lib_sha = hashlib.sha256(open(_lib.LIB_PATH, "rb").read()).hexdigest()
         traffic = None
         compute = None
-        PROFILE = "profiles/r03_pmc_raw.json"
+        PROFILE = "profiles/r04_pmc_raw.json"
         prof_note = "no PMC summary for this build/workload (tools/collect_profiles.sh + tools/summarise_profiles.py write one)"
         try:
             raw = json.load(open(os.path.join(ROOT, PROFILE)))
