@@ -155,6 +155,7 @@ def main(argv=None):
     ap.add_argument("--max-newton", type=int, default=12)
     ap.add_argument("--envs-per-wave", type=int, default=0)
     ap.add_argument("--no-rank-one", action="store_true", help="diagnostic: JB_FLAG_NO_RANK_ONE (every Newton pass is a full pass)")
+    ap.add_argument("--no-reorder", action="store_true", help="diagnostic: JB_FLAG_NO_REORDER (never launch the waves longest-first)")
     ap.add_argument("--no-spread", action="store_true", help="diagnostic: JB_FLAG_NO_SPREAD (contact sweeps never in spread mode)")
     ap.add_argument("--no-pair", action="store_true", help="diagnostic: JB_FLAG_NO_PAIR (floor contacts only, also for per-env models: what rounds 1-2 simulated)")
     ap.add_argument("--lean", action="store_true", help="force the two-waves-per-SIMD kernel variant (JB_FLAG_LEAN); by default the product picks it from the per-GPU batch (jitterbug_amd.variants)")
@@ -213,7 +214,7 @@ def main(argv=None):
         if args.actions == "const1":
             actions.fill_(1.0)
         env_kw = dict(contacts=bool(contacts), max_newton=args.max_newton, envs_per_wave=args.envs_per_wave, variant=variant, per_env_model=args.augmented,
-                      flags=(1 if args.no_rank_one else 0) | (8 if args.no_pair else 0) | (16 if args.no_spread else 0))
+                      flags=(1 if args.no_rank_one else 0) | (8 if args.no_pair else 0) | (16 if args.no_spread else 0) | (32 if args.no_reorder else 0))
         if gather:
             # N > 1: the PRODUCT's sharded env (jitterbug_amd/distributed.py), pipelined: the step kernel writes packed rows
             # [obs | reward | done] itself and rank 0 gathers them every step over RCCL, one step late from a side stream, three row
@@ -317,7 +318,7 @@ def main(argv=None):
                 tape.fill_(1.0)
             env = JitterbugVecEnv(n, task, seed=args.seed, device_id=local_rank, env_offset=rank * n, stream=torch.cuda.current_stream(dev).cuda_stream,
                                   contacts=bool(args.contacts), max_newton=args.max_newton, envs_per_wave=args.envs_per_wave, variant=variant, per_env_model=args.augmented,
-                                  flags=(1 if args.no_rank_one else 0) | (8 if args.no_pair else 0) | (16 if args.no_spread else 0))
+                                  flags=(1 if args.no_rank_one else 0) | (8 if args.no_pair else 0) | (16 if args.no_spread else 0) | (32 if args.no_reorder else 0))
             if args.augmented:
                 env.randomise_models(seed=1000, return_params=False)
             rew = torch.empty((total, n), device=dev, dtype=torch.float32)
@@ -352,6 +353,35 @@ def main(argv=None):
         rollout_fused = {"k1000": fused(1000, "tape"), "k100": fused(100, "tape"), "k1000_policy": fused(1000, "policy"), "k1000_const1": fused(1000, "const1"),
                          "per_step_full_episode": None if full_episode is None else full_episode["value"],
                          "what": "jb_step_many_device: K control steps per launch, bit-identical to K single-step launches (tests/test_gpu_rollout.py); `value` above stays the per-step path"}
+
+    # N > 1: the same fused rollout across the shards (ShardedJitterbugEnv.rollout: K steps in one launch per rank, then ONE gather of the
+    # [K, N_local, D+2] blocks - a hundred times fewer, a hundred times larger collectives than the per-step path).  Next to the headline,
+    # never instead of it; a failure here is recorded, it does not take the line down.
+    if not args.no_steady and dist is not None:
+        try:
+            from jitterbug_amd.distributed import ShardedJitterbugEnv
+            sh = ShardedJitterbugEnv(n * world, task, seed=args.seed, device=dev, pipeline_depth=1, variant=variant, per_env_model=args.augmented,
+                                     contacts=bool(args.contacts), max_newton=args.max_newton, envs_per_wave=args.envs_per_wave)
+            if args.augmented:
+                sh.env.randomise_models(seed=1000, return_params=False)
+            g = torch.Generator(device=dev)
+            g.manual_seed(1234 + rank + 7919 * args.seed)
+            tape = torch.rand((1000, n), generator=g, device=dev, dtype=torch.float32) * 2 - 1
+            sh.env.reset_device()
+            dist.barrier(); torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            last = None
+            for k0 in range(0, 1000, 100):
+                last = sh.rollout(100, local_actions=tape[k0:k0 + 100])
+            dist.barrier(); torch.cuda.synchronize(dev)
+            wf = rank_max(time.perf_counter() - t0)
+            ok = True if rank != 0 else bool(torch.isfinite(last[0]).all().item()) and last[0].shape[1] == n * world
+            rollout_fused = {"k100_sharded": {"value": total_envs * 1000 / wf, "unit": "env steps/s", "ms_per_step": wf * 1e3 / 1000, "launches": 10, "steps_per_launch": 100,
+                                              "gathers": 10, "rows_per_gather": [100, n, D + 2], "finite": ok,
+                                              "what": "ShardedJitterbugEnv.rollout(100): one fused 100-step launch per rank, then one gather of [100, N_local, D+2] rows to rank 0; x 10 = a whole episode"}}
+            sh.env.close()
+        except Exception as e:            # (the first multi-GPU run is also this path's first run over RCCL: never let it take the headline down)
+            rollout_fused = {"k100_sharded": {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}}
 
     def config_label(contacts):
         """which BASELINE.json config this workload is, if any"""

@@ -74,6 +74,9 @@ typedef struct jb_handle jb_handle;
 #define JB_FLAG_NO_SPREAD   16  /* diagnostic: contact sweeps never in spread mode (a robot lying on a leg keeps its 8-9 contacts on that leg's four
                                    lanes, two or three rounds per sweep) */
 
+#define JB_FLAG_NO_REORDER  32  /* diagnostic: never reorder the waves of a launch.  By default a batch with more waves than the device holds at once
+                                   launches them longest-first, by the wave times the previous launch measured (results do not depend on it) */
+
 typedef struct jb_config {
     int32_t  n_envs;        /* N >= 1 */
     int32_t  task_id;       /* JB_TASK_* */

@@ -36,7 +36,7 @@ class RandomiseConfig(C.Structure):
 
 
 VARIANT_NAMES = {0: "ordinary", 1: "pair", 2: "lean", 3: "lean_pair"}      # jb_kernel_variant (JB_VARIANT_*)
-FLAG_NO_RANK_ONE, FLAG_LEAN, FLAG_PAIR, FLAG_NO_PAIR, FLAG_NO_SPREAD = 1, 2, 4, 8, 16
+FLAG_NO_RANK_ONE, FLAG_LEAN, FLAG_PAIR, FLAG_NO_PAIR, FLAG_NO_SPREAD, FLAG_NO_REORDER = 1, 2, 4, 8, 16, 32
 NOFFSET = 31
 RND_LEGS, RND_MASS, RND_CORE1_DENSITY, RND_CORE2_DENSITY, RND_GLOBAL_DENSITY, RND_GEAR = 1, 2, 4, 8, 16, 32
 

@@ -64,6 +64,7 @@ struct StepIO {
     int every_step;                // bit 0 / 1 / 2: obs (rows) / reward / done blocks are written for EVERY step ([K, ...] buffers); clear: only the last step's
     PolicyParams<float> pp;
     unsigned long long* wave_clock;      // nullable [n_waves]: how long each wave lived in this launch (s_memrealtime ticks, 100 MHz): the imbalance a fused rollout removes
+    const int* wave_order;               // nullable [n_waves]: workgroup b steps wave wave_order[b] - the waves of the PREVIOUS launch, longest first (jb_wave_order_kernel)
 };
 
 // Stage the packed constant table(s) of this workgroup (one wave = a.epw envs) into LDS: one LM_TABLE copy for a
@@ -206,7 +207,10 @@ __device__ __forceinline__ void step_body(KArgs a, StepIO io) {
     // so give XCD x one contiguous range of envs; then every 128-byte line of the SoA state arrays is touched by a single
     // XCD's L2 instead of all eight (placement is a speed/traffic matter only, never correctness).
     const int nb = (int)gridDim.x, b = (int)blockIdx.x, xcd = b & 7, per = nb >> 3, rem = nb & 7;
-    const int lblock = xcd * per + (xcd < rem ? xcd : rem) + (b >> 3);
+    // More waves than the device holds at once: the hardware hands out workgroups in index order, so the order decides which waves share
+    // a SIMD's time.  Longest-first by the previous launch's measured wave times (a robot that has tipped over, or whose mass rubs a leg,
+    // stays slow) keeps the slow waves out of the last round; which workgroup steps which envs never shows in the results.
+    const int lblock = io.wave_order ? io.wave_order[b] : xcd * per + (xcd < rem ? xcd : rem) + (b >> 3);
     const int env = lblock * EPW + quad;
     const unsigned long long clock0 = __builtin_amdgcn_s_memrealtime();
     LaneModel<float> m;
@@ -448,6 +452,29 @@ __global__ __launch_bounds__(64) void jb_reward_terms_kernel(KArgs a, float* __r
     terms_out[(size_t)env * 4 + leg] = out[leg];
 }
 
+// ---------------------------------------------------------------------------------------------- launch order of the waves
+// order[0 .. n) = the waves sorted by their last measured lifetime, longest first (a 1024-bin counting sort: exact order inside a bin does
+// not matter).  One workgroup; runs on the handle's stream right after a step launch whenever the batch has more waves than the device
+// holds at once.  All-zero clocks (nothing measured yet) give the identity.
+__global__ __launch_bounds__(1024) void jb_wave_order_kernel(const unsigned long long* __restrict__ clock, int* __restrict__ order, int n) {
+    __shared__ unsigned long long s_max[1024];
+    __shared__ unsigned s_bin[1024], s_pos[1024];
+    const int t = threadIdx.x;
+    unsigned long long mx = 0;
+    for (int i = t; i < n; i += 1024) mx = clock[i] > mx ? clock[i] : mx;
+    s_max[t] = mx; s_bin[t] = 0u;
+    __syncthreads();
+    for (int st = 512; st > 0; st >>= 1) { if (t < st) s_max[t] = s_max[t] > s_max[t + st] ? s_max[t] : s_max[t + st]; __syncthreads(); }
+    mx = s_max[0];
+    if (mx == 0ull) { for (int i = t; i < n; i += 1024) order[i] = i; return; }
+    const double scale = 1023.0 / (double)mx;
+    for (int i = t; i < n; i += 1024) atomicAdd(&s_bin[1023 - (int)((double)clock[i] * scale)], 1u);      // bin 0 = the longest waves
+    __syncthreads();
+    if (t == 0) { unsigned acc = 0; for (int k = 0; k < 1024; k++) { s_pos[k] = acc; acc += s_bin[k]; } }
+    __syncthreads();
+    for (int i = t; i < n; i += 1024) order[atomicAdd(&s_pos[1023 - (int)((double)clock[i] * scale)], 1u)] = i;
+}
+
 // ---------------------------------------------------------------------------------------------- diagnostics
 // Fills LDS with NaN bit patterns (LDS keeps its contents between kernels): a step kernel that reads scratch it has not
 // written in the same launch then produces NaNs deterministically instead of depending on what ran before it.
@@ -604,6 +631,8 @@ struct jb_handle {
     double *d_qpos, *d_qvel, *d_target;
     unsigned long long* d_wave_stats;
     unsigned long long* d_wave_clock;
+    int* d_wave_order;               // launch order of the waves (jb_wave_order_kernel), null while the device holds the whole batch at once
+    int wave_slots;                  // waves the device holds at once with this handle's kernel variant
     size_t model_tables;
     EncArgs enc;          // observation encoder (n_layers = 0: none)
     PolicyParams<float> policy;      // keyword arguments of the reference's heuristic policies
@@ -878,7 +907,7 @@ int jb_destroy(jb_handle* h) {
     guard.enter(h->cfg.device_id);
     if (h->stream || !h->own_stream) hipStreamSynchronize(h->stream);
     if (h->comm && g_rccl.CommDestroy) { g_rccl.CommDestroy(h->comm); h->comm = nullptr; }
-    void* bufs[] = {h->d_wave_clock, h->d_ovc, h->d_terms, h->d_spec, h->d_root, h->d_leg, h->d_model, h->d_step, h->d_episode, h->d_action, h->d_obs, h->d_reward, h->d_done, h->d_mask, h->d_qpos, h->d_qvel, h->d_target, h->d_wave_stats, h->d_enc_params, h->d_code};
+    void* bufs[] = {h->d_wave_order, h->d_wave_clock, h->d_ovc, h->d_terms, h->d_spec, h->d_root, h->d_leg, h->d_model, h->d_step, h->d_episode, h->d_action, h->d_obs, h->d_reward, h->d_done, h->d_mask, h->d_qpos, h->d_qvel, h->d_target, h->d_wave_stats, h->d_enc_params, h->d_code};
     for (void* b : bufs) if (b) hipFree(b);
     if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
     delete h;
@@ -983,6 +1012,23 @@ static int launch_step(jb_handle* h, StepIO io, int packed_rows) {
     }
     io.wave_clock = h->d_wave_clock;
     const int variant = kernel_variant(h);
+    // more waves than the device holds at once -> launch them longest first (the order comes from the previous launch's clocks)
+    bool reorder = false;
+    if (!(h->cfg.flags & JB_FLAG_NO_REORDER)) {
+        if (h->wave_slots == 0) {
+            hipDeviceProp_t prop;
+            JB_HIP(hipGetDeviceProperties(&prop, h->cfg.device_id));
+            h->wave_slots = prop.multiProcessorCount * 4;
+        }
+        const int per_simd_x2 = variant == JB_VARIANT_LEAN ? 4 : variant == JB_VARIANT_LEAN_PAIR ? 3 : 2;      // resident waves per SIMD, times two
+        reorder = (long long)grid.x * 2 > (long long)h->wave_slots * per_simd_x2;
+        if (reorder && !h->d_wave_order) {
+            JB_HIP(hipMalloc(&h->d_wave_order, sizeof(int) * (size_t)h->cfg.n_envs));
+            hipLaunchKernelGGL(jb_wave_order_kernel, dim3(1), dim3(1024), 0, h->stream, h->d_wave_clock, h->d_wave_order, (int)grid.x);      // (clocks all zero: identity)
+            JB_HIP(hipGetLastError());
+        }
+    }
+    io.wave_order = reorder ? h->d_wave_order : nullptr;
     const bool lean_pair = variant == JB_VARIANT_LEAN_PAIR, use_lean = lean_pair || variant == JB_VARIANT_LEAN;
     const size_t lds_bytes = lean_pair ? ((size_t)SC_COUNT_LEAN_PAIR * 4 * h->ka.epw + (size_t)LM_TABLE_SPLIT * h->ka.epw) * sizeof(float)
                                        : ((size_t)(use_lean ? SC_COUNT_LEAN : SC_COUNT) * 4 * h->ka.epw + (size_t)(use_lean ? LM_TABLE_BASE : LM_TABLE) * (h->ka.per_env_model ? h->ka.epw : 1)) * sizeof(float);
@@ -1021,6 +1067,10 @@ static int launch_step(jb_handle* h, StepIO io, int packed_rows) {
 #undef JB_LAUNCH_LEAN
 #undef JB_LAUNCH_PAIR
     JB_HIP(hipGetLastError());
+    if (reorder) {
+        hipLaunchKernelGGL(jb_wave_order_kernel, dim3(1), dim3(1024), 0, h->stream, h->d_wave_clock, h->d_wave_order, (int)grid.x);
+        JB_HIP(hipGetLastError());
+    }
     return JB_OK;
 }
 int jb_kernel_variant(jb_handle* h) { return h ? kernel_variant(h) : JB_E_INVALID; }

@@ -248,6 +248,57 @@ class ShardedJitterbugEnv:
         self._send(prev)                                 # one step late: it overlaps the kernel just launched
         return PendingRows(self, prev)
 
+    def rollout(self, n_steps, actions_global=None, local_actions=None):
+        """n_steps control steps on every shard in ONE kernel launch per rank (jb_step_many_device: every wave keeps its envs for all K
+        steps), then ONE gather of the [K, N_local, D+2] row blocks to rank 0 - K times fewer, K times larger collectives than step()'s.
+        actions: rank 0 passes a tape [K, N_global] (scattered step by step), or every rank its own [K, N_local] float32 device tensor as
+        `local_actions`, or nothing at all: the task's heuristic policy is evaluated inside the kernel (the reference's
+        benchmarks/evaluate_policy.py:29-33 loop, for the whole sharded batch).  Returns (obs [K, N, D], reward [K, N], done [K, N]) on
+        rank 0, None elsewhere.  Results equal n_steps calls of step(): bit for bit on the device path."""
+        import torch
+        import torch.distributed as dist
+        K = int(n_steps)
+        self.flush()
+        D2 = self.env.obs_dim + 2
+        nmax = max(self.sizes)
+        tape = None
+        if local_actions is not None:                                  # (every rank must use the same way of passing actions)
+            tape = local_actions
+        else:
+            ag = None
+            if self.rank == 0 and actions_global is not None:
+                ag = torch.as_tensor(np.asarray(actions_global), dtype=torch.float32).reshape(K, self.n_global)
+            have = torch.tensor([1 if ag is not None else 0], dtype=torch.int32, device=self.device if dist.get_backend(self.group) == "nccl" else "cpu")
+            dist.broadcast(have, src=0, group=self.group)              # does rank 0 bring a tape, or does the in-kernel policy act?
+            if int(have.item()):
+                tape = torch.stack([scatter_actions(None if ag is None else ag[k], self.sizes, self.device, 0, self.group) for k in range(K)], 0)
+        rows = torch.zeros((K, nmax, D2), device=self.device, dtype=torch.float32)
+        if self._device_rows:
+            local = rows if self.n_local == nmax else torch.zeros((K, self.n_local, D2), device=self.device, dtype=torch.float32)
+            cur = torch.cuda.current_stream(self.device)
+            if cur.cuda_stream != self._env_stream.cuda_stream:
+                self._env_stream.wait_stream(cur)                      # the tape / row buffers were produced on the current stream
+            t = None if tape is None else tape.contiguous()
+            self.env.step_many_device(K, None if t is None else t.data_ptr(), rows_ptr=local.data_ptr())
+            if cur.cuda_stream != self._env_stream.cuda_stream:
+                cur.wait_stream(self._env_stream)
+            if local is not rows:
+                rows[:, :self.n_local] = local
+        else:                                                          # host stepper (tests: the oracle stands in for the GPU env)
+            for k in range(K):
+                if tape is None:
+                    raise ValueError("the host stepper has no in-kernel policy: pass a tape")
+                res = self.env.step(tape[k].cpu().numpy())
+                rows[k, :self.n_local] = pack_rows(self._to_tensor(res[0], torch.float32), self._to_tensor(res[1], torch.float32), self._to_tensor(res[2], torch.float32))
+        staged = rows.is_cuda and dist.get_backend(self.group) == "gloo"
+        send = rows.cpu() if staged else rows
+        bufs = [torch.empty_like(send) for _ in range(self.world)] if self.rank == 0 else None
+        dist.gather(send.contiguous(), bufs, dst=0, group=self.group)
+        if self.rank != 0:
+            return None
+        out = torch.cat([b[:, :n] for b, n in zip(bufs, self.sizes)], 1).to(self.device)          # [K, N_global, D+2]
+        return out[..., :-2], out[..., -2], out[..., -1] > 0.5
+
     def flush(self):
         """depth 2: the results of the last step issued (None if there is none pending)"""
         if not getattr(self, "_device_rows", False):

@@ -68,6 +68,32 @@ if rank == 0:
     o2, r2, d2, _ = expected[-1]
     o1, r1, d1 = (x.cpu().numpy() for x in res.get())
     assert np.array_equal(o1, o2) and np.array_equal(r1, r2), "pipelined flush differs"
+# the fused rollout across shards: K steps in one launch per rank, ONE gather of [K, N_local, D+2]; tape from rank 0, per-rank tapes,
+# and the in-kernel heuristic policy - each bit-identical to the same K steps of one unsharded env
+K = 9
+for mode in ("global_tape", "local_tape", "policy"):
+    sh3 = ShardedJitterbugEnv(n, task, seed=4, device="cuda:0", time_limit=0.05)       # 5-step episodes: an auto-reset inside the rollout
+    sh3.reset()
+    rng = np.random.default_rng(3)
+    tape = rng.uniform(-1, 1, size=(K, n)).astype(np.float32)
+    if mode == "global_tape":
+        res = sh3.rollout(K, actions_global=tape if rank == 0 else None)
+    elif mode == "local_tape":
+        res = sh3.rollout(K, local_actions=torch.as_tensor(tape[:, sh3.lo:sh3.hi], device="cuda:0").contiguous())
+    else:
+        res = sh3.rollout(K)
+    if rank == 0:
+        w = JitterbugVecEnv(n, task, seed=4, time_limit=0.05)
+        ob_w = w.reset()
+        o1, r1, d1 = (x.cpu().numpy() for x in res)
+        assert o1.shape == (K, n, w.obs_dim) and d1.sum() == n
+        for k in range(K):
+            a = tape[k] if mode != "policy" else w.policy(ob_w)
+            ob_w, r2, d2, _ = w.step(a)
+            assert np.array_equal(o1[k], ob_w) and np.array_equal(r1[k], r2) and np.array_equal(d1[k], d2.astype(bool)), "rollout (%s) step %d differs" % (mode, k)
+        w.close()
+    else:
+        assert res is None
 dist.barrier()
 if rank == 0:
     print("SHARDED_OK", flush=True)

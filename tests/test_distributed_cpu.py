@@ -149,3 +149,68 @@ def test_every_rank_resolves_the_same_kernel_variant_gloo():
     assert variants.flags_for("lean", 64, flags=8) == 10 and variants.flags_for("ordinary", 10 ** 6, flags=2 | 16) == 16
     with pytest.raises(ValueError):
         variants.resolve("fast", 64)
+
+
+def _rollout_worker(rank, world, port, n_global, K, q):
+    import torch
+    import torch.distributed as dist
+    from jitterbug_amd.distributed import ShardedJitterbugEnv
+    from oracle import oracle as O
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    P = model.default_params()
+
+    class Local:
+        obs_dim = 19
+
+        def __init__(self, n, off):
+            self.e = O.OracleEnv(n, "move_to_pose", P, seed=4, env_offset=off, step_limit=3, nsub=5)
+
+        def reset(self):
+            return self.e.reset()
+
+        def step(self, a):
+            return self.e.step(a)
+
+    env = ShardedJitterbugEnv(n_global, "move_to_pose", seed=4, local_env_factory=lambda n, off: Local(n, off))
+    obs0 = env.reset()
+    rng = np.random.default_rng(0)
+    tape = rng.uniform(-1, 1, size=(K, n_global)).astype(np.float32) if rank == 0 else None
+    out = env.rollout(K, actions_global=tape)
+    if rank == 0:
+        q.put((obs0.numpy(), [t.numpy() for t in out]))
+    else:
+        assert out is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_sharded_rollout_one_gather_of_k_steps_matches_single_process_gloo():
+    """ShardedJitterbugEnv.rollout(K): K steps on every shard, then ONE gather of the [K, N_local, D+2] blocks (ragged shards: 6 + 5) -
+    equal to K steps of one unsharded env, episode ends inside the rollout included."""
+    import torch.multiprocessing as mp
+    from oracle import oracle as O
+    n_global, K, world = 11, 7, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rollout_worker, args=(r, world, port, n_global, K, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    obs0, (ob, rw, dn) = q.get(timeout=240)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert ob.shape == (K, n_global, 19) and rw.shape == (K, n_global) and dn.shape == (K, n_global)
+    ref = O.OracleEnv(n_global, "move_to_pose", model.default_params(), seed=4, step_limit=3, nsub=5)
+    np.testing.assert_allclose(obs0, ref.reset(), rtol=1e-6, atol=1e-7)
+    rng = np.random.default_rng(0)
+    tape = rng.uniform(-1, 1, size=(K, n_global)).astype(np.float32)
+    for k in range(K):
+        ro, rr, rd = ref.step(tape[k])
+        np.testing.assert_allclose(ob[k], ro, rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(rw[k], rr, rtol=1e-5, atol=1e-6)
+        assert np.array_equal(dn[k], rd.astype(bool))
+    assert dn.sum() == 2 * n_global

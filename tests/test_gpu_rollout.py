@@ -187,3 +187,37 @@ def test_step_many_argument_checks_and_variant_refusals():
         env.step(np.zeros(64, np.float32))
     finally:
         env.close()
+
+
+@pytest.mark.parametrize("randomise", [False, True], ids=["nominal", "per-env-models"])
+def test_longest_first_wave_order_does_not_change_a_single_bit(randomise):
+    """A batch with more waves than the device holds at once (8192 envs = 2048 four-env waves on 1024 SIMDs) launches its waves
+    longest-first, by the wave times the previous launch measured (jb_wave_order_kernel); JB_FLAG_NO_REORDER keeps the plain order.
+    Which workgroup steps which envs must never show in the results: single steps and a fused rollout, bit for bit."""
+    from jitterbug_amd import _lib
+    from jitterbug_amd.vec_env import JitterbugVecEnv
+    torch = _torch()
+    dev = torch.device("cuda", 0)
+    n, K = 8192, 24
+    a = JitterbugVecEnv(n, "move_to_pose", seed=13, time_limit=0.2)
+    b = JitterbugVecEnv(n, "move_to_pose", seed=13, time_limit=0.2, flags=_lib.FLAG_NO_REORDER)
+    try:
+        if randomise:
+            a.randomise_models(seed=2, return_params=False); b.randomise_models(seed=2, return_params=False)
+        D = a.obs_dim
+        g = torch.Generator(device=dev); g.manual_seed(8)
+        tape = torch.rand((2 * K, n), generator=g, device=dev, dtype=torch.float32) * 2 - 1
+        tape[:, ::7] = 1.0
+        rows_a = torch.zeros((2 * K, n, D + 2), device=dev); rows_b = torch.zeros((2 * K, n, D + 2), device=dev)
+        a.reset_device(); b.reset_device()
+        for k in range(K):
+            a.step_rows_device(tape[k].data_ptr(), rows_a[k].data_ptr())
+            b.step_rows_device(tape[k].data_ptr(), rows_b[k].data_ptr())
+        a.step_many_device(K, tape[K:].data_ptr(), rows_ptr=rows_a[K:].data_ptr())
+        b.step_many_device(K, tape[K:].data_ptr(), rows_ptr=rows_b[K:].data_ptr())
+        a.synchronize(); b.synchronize()
+        assert np.array_equal(bits(rows_a), bits(rows_b)) and same_state(a, b)
+        wa, wb = a.wave_clocks(), b.wave_clocks()
+        assert wa.shape == wb.shape == (n // 4,) and (wa > 0).all() and (wb > 0).all()
+    finally:
+        a.close(); b.close()

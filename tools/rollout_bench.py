@@ -22,6 +22,7 @@ ap.add_argument("--flags", type=int, default=0)
 ap.add_argument("--task", default="move_from_origin")
 ap.add_argument("--augmented", action="store_true")
 ap.add_argument("--envs-per-wave", type=int, default=0)
+ap.add_argument("--brief", action="store_true", help="only the step-by-step loop and the K = 100 x 10 launches (A/B runs)")
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
 n, K = args.envs, 1000
@@ -73,6 +74,9 @@ ref_rew = rew.clone()
 env.close()
 
 env = fresh()
+if args.brief:
+    env.step_many_device(1, None if policy else tape.data_ptr())          # (nothing to order the first launch by otherwise)
+    env.reset_device()
 t = timed(lambda: env.step_many_device(K, None if policy else tape.data_ptr(), rewards_ptr=rew.data_ptr(), obs_last_ptr=obs.data_ptr(), done_last_ptr=done.data_ptr()))
 wc = env.wave_clocks()
 print("fused K = 1000 (full episode, one launch):    %10.0f env-steps/s   %.4f ms/step   bit-identical rewards: %s" % (n * K / t, 1e3 * t / K, bool(torch.equal(rew, ref_rew))))
@@ -88,6 +92,8 @@ t = timed(lambda: chunks(100))
 print("fused K = 100 x 10 launches (full episode):   %10.0f env-steps/s   %.4f ms/step   bit-identical rewards: %s" % (n * K / t, 1e3 * t / K, bool(torch.equal(rew, ref_rew))))
 env.close()
 
+if args.brief:
+    sys.exit(0)
 env = fresh()
 env.step_many_device(5, None if policy else tape[:5].data_ptr())
 t = timed(lambda: env.step_many_device(20, None if policy else tape[5:25].data_ptr(), rewards_ptr=rew[5:25].data_ptr()))
