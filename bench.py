@@ -69,7 +69,7 @@ def cpu_baseline(n_cores, task, budget_s=12.0):
         e1.step(r1.uniform(-1, 1, size=16), nthreads=1)
         k1 += 1
     one_core = 16 * k1 / (time.perf_counter() - t0)
-    n = 64 * n_cores
+    n = N_ENVS_PER_GPU           # the metric's batch (4096 envs), over as many control steps of the episode as the time budget allows
     env = O.OracleEnv(n, TASK, P, seed=0)
     env.reset()
     rng = np.random.default_rng(0)
@@ -82,7 +82,7 @@ def cpu_baseline(n_cores, task, budget_s=12.0):
         env.step(rng.uniform(-1, 1, size=n), nthreads=n_cores)
     dt = time.perf_counter() - t0
     return {"value": n * steps / dt, "unit": "env steps/s", "cores": n_cores, "kind": "port", "one_core_value": one_core,
-            "sample": "%d envs x %d control steps of %s, fp64 oracle (oracle/jb_oracle.c: Newton contact solve), OpenMP over envs" % (n, steps, TASK)}
+            "sample": "%d envs (the metric's batch) x %d control steps from the reset (of the episode's 1000) of %s, fp64 oracle (oracle/jb_oracle.c: Newton contact solve), OpenMP over envs" % (n, steps, TASK)}
 
 
 def free_port():

@@ -75,25 +75,34 @@ __device__ __forceinline__ void stage_model(const KArgs& a, float* lds, int lblo
     m.c.split = false;
     const int tsz = pair ? LM_TABLE : LM_TABLE_BASE, gsz = LM_TABLE;      // staged prefix / table pitch in global memory
     if (SPLIT) {
-        // split mode (jb_sim.hpp LaneConsts): per env the hot prefix and the pair contact's entries only; the rest stays in global memory
-        const int env0 = lblock * a.epw, hot = LM_INV + 4 * (LM_HOT - LM_INV), ssz = LM_TABLE_SPLIT;
-        for (int i = threadIdx.x; i < ssz * a.epw; i += blockDim.x) {
-            int e = env0 + i / ssz;
+        // split mode (jb_sim.hpp LaneConsts): per env the resident block only - the lane-invariant prefix, the pair's ellipsoid (lane 0's copy)
+        // and the five per-lane entries read after phase A; phase A's per-lane entries are re-staged every substep (restage_overlay)
+        const int env0 = lblock * a.epw, rsz = LM_SPLIT_RES;
+        for (int i = threadIdx.x; i < rsz * a.epw; i += blockDim.x) {
+            int e = env0 + i / rsz;
             if (e >= a.n) e = a.n - 1;
-            const int k = i % ssz;
+            const int k = i % rsz;
             int src = k;
-            if (k >= hot) {
-                const int h2 = (k - hot) >> 2, l = (k - hot) & 3;
-                const int ent = h2 < 11 ? LM_UC_D + h2 : LM_PE_C + (h2 - 11);
-                src = LM_INV + 4 * (ent - LM_INV) + l;
-            }
+            if (k >= LM_INV + 15) { const int r = (k - LM_INV - 15) >> 2, l = (k - LM_INV - 15) & 3; src = LM_INV + 4 * (lm_split_res_entry(r) - LM_INV) + l; }
+            else if (k >= LM_INV) src = LM_INV + 4 * (LM_PE_C + (k - LM_INV) - LM_INV);
             lds[i] = a.lane_model[(size_t)e * gsz + src];
         }
-        __syncthreads();
-        m.c.inv = lds + quad * ssz;
+        m.c.inv = lds + quad * rsz;
+        m.c.tab = m.c.inv + LM_INV + 15 + leg;
         m.c.split = true;
         const int env = lblock * a.epw + quad;
         m.c.cold = a.lane_model + (size_t)(env < a.n ? env : a.n - 1) * gsz + LM_INV + leg;
+        // overlay: scratch entries [SC_SYS, SC_SYS + LM_SPLIT_OVL) of the main lanes (the scratch precedes the resident block in LDS)
+        float* const scratch0 = lds - (size_t)SC_COUNT_LEAN_PAIR * LM_SPLIT_STRIDE;
+        const int l16 = threadIdx.x % LM_SPLIT_STRIDE, j_sub = threadIdx.x / LM_SPLIT_STRIDE;
+        m.c.ovl = scratch0 + SC_SYS * LM_SPLIT_STRIDE + l16;
+        int e_src = lblock * a.epw + (l16 >> 2);
+        if (e_src >= a.n) e_src = a.n - 1;
+        m.c.ovl_src = a.lane_model + (size_t)e_src * gsz + LM_INV + (l16 & 3) + 4 * j_sub;
+        m.c.ovl_dst = scratch0 + SC_SYS * LM_SPLIT_STRIDE + threadIdx.x;
+        __syncthreads();
+        restage_overlay(m.c);             // (preload below reads the per-level weights from it)
+        __syncthreads();
     } else if (a.per_env_model) {
         const int env0 = lblock * a.epw;
         for (int i = threadIdx.x; i < tsz * a.epw; i += blockDim.x) {
@@ -108,7 +117,7 @@ __device__ __forceinline__ void stage_model(const KArgs& a, float* lds, int lblo
         __syncthreads();
         m.c.inv = lds;
     }
-    m.c.tab = m.c.inv + LM_INV + leg;
+    if (!SPLIT) m.c.tab = m.c.inv + LM_INV + leg;
     m.c.preload();
 }
 __device__ __forceinline__ void load_state(const KArgs& a, int env, int lane, LaneState<float>& s) {
@@ -1020,7 +1029,7 @@ static int launch_step(jb_handle* h, StepIO io, int packed_rows) {
             JB_HIP(hipGetDeviceProperties(&prop, h->cfg.device_id));
             h->wave_slots = prop.multiProcessorCount * 4;
         }
-        const int per_simd_x2 = variant == JB_VARIANT_LEAN ? 4 : variant == JB_VARIANT_LEAN_PAIR ? 3 : 2;      // resident waves per SIMD, times two
+        const int per_simd_x2 = (variant == JB_VARIANT_LEAN || variant == JB_VARIANT_LEAN_PAIR) ? 4 : 2;      // resident waves per SIMD, times two
         reorder = (long long)grid.x * 2 > (long long)h->wave_slots * per_simd_x2;
         if (reorder && !h->d_wave_order) {
             JB_HIP(hipMalloc(&h->d_wave_order, sizeof(int) * (size_t)h->cfg.n_envs));
@@ -1030,18 +1039,20 @@ static int launch_step(jb_handle* h, StepIO io, int packed_rows) {
     }
     io.wave_order = reorder ? h->d_wave_order : nullptr;
     const bool lean_pair = variant == JB_VARIANT_LEAN_PAIR, use_lean = lean_pair || variant == JB_VARIANT_LEAN;
-    const size_t lds_bytes = lean_pair ? ((size_t)SC_COUNT_LEAN_PAIR * 4 * h->ka.epw + (size_t)LM_TABLE_SPLIT * h->ka.epw) * sizeof(float)
+    const size_t lds_bytes = lean_pair ? ((size_t)SC_COUNT_LEAN_PAIR * 4 * h->ka.epw + (size_t)LM_SPLIT_RES * h->ka.epw) * sizeof(float)
                                        : ((size_t)(use_lean ? SC_COUNT_LEAN : SC_COUNT) * 4 * h->ka.epw + (size_t)(use_lean ? LM_TABLE_BASE : LM_TABLE) * (h->ka.per_env_model ? h->ka.epw : 1)) * sizeof(float);
+    static const size_t extra_lds = getenv("JB_DEBUG_EXTRA_LDS") ? (size_t)atoi(getenv("JB_DEBUG_EXTRA_LDS")) : 0;      // occupancy experiments only
+    const size_t lds_bytes_x = lds_bytes + extra_lds;
     if (use_lean && !h->d_ovc) {      // the LEAN variant's overflow candidates (beyond the row cache): one block per wave
         const size_t waves = (size_t)grid.x, fl = waves * 4 * (NSLOT - ROW_K) * 4 * h->ka.epw;
         JB_HIP(hipMalloc(&h->d_ovc, fl * sizeof(float)));
         h->ka.ovc_buf = h->d_ovc;
     }
-#define JB_LAUNCH_STEP(E) hipLaunchKernelGGL(jb_step_kernel<E>, grid, dim3(64), lds_bytes, h->stream, h->ka, io)
-#define JB_LAUNCH_LEAN(E) hipLaunchKernelGGL(jb_step_kernel_lean<E>, grid, dim3(64), lds_bytes, h->stream, h->ka, io)
-#define JB_LAUNCH_PAIR(E) hipLaunchKernelGGL(jb_step_kernel_pair<E>, grid, dim3(64), lds_bytes, h->stream, h->ka, io)
+#define JB_LAUNCH_STEP(E) hipLaunchKernelGGL(jb_step_kernel<E>, grid, dim3(64), lds_bytes_x, h->stream, h->ka, io)
+#define JB_LAUNCH_LEAN(E) hipLaunchKernelGGL(jb_step_kernel_lean<E>, grid, dim3(64), lds_bytes_x, h->stream, h->ka, io)
+#define JB_LAUNCH_PAIR(E) hipLaunchKernelGGL(jb_step_kernel_pair<E>, grid, dim3(64), lds_bytes_x, h->stream, h->ka, io)
     if (lean_pair) {
-        hipLaunchKernelGGL(jb_step_kernel_lean_pair<4>, grid, dim3(64), lds_bytes, h->stream, h->ka, io);
+        hipLaunchKernelGGL(jb_step_kernel_lean_pair<4>, grid, dim3(64), lds_bytes_x, h->stream, h->ka, io);
     } else if (variant == JB_VARIANT_PAIR) {
         switch (h->ka.epw) {
         case 1: JB_LAUNCH_PAIR(1); break;

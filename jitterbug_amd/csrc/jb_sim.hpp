@@ -101,8 +101,23 @@ enum LM : int {
     LM_INV = 49,
     LM_TABLE = LM_INV + 4 * (LM_COUNT - LM_INV),
     LM_TABLE_BASE = LM_INV + 4 * (LM_PE_C - LM_INV),      // the table without the pair contact's entries (its tail): what the kernels without that contact stage into LDS
-    LM_TABLE_SPLIT = LM_INV + 4 * (LM_HOT - LM_INV + 29)  // split mode: what is staged per env (the hot prefix + the pair contact's 29 entries)
+    // Split mode (LEAN kernel with one model per env; LaneConsts below): what stays resident in LDS per env - the lane-invariant prefix, the
+    // pair contact's ellipsoid (one geom: the same in the four lanes) and the five per-lane entries that are read after phase A
+    LM_SPLIT_NRES = 5 /* LM_B1, LM_B2, LM_TARGET_Z, LM_ROOT_Z0, LM_IMP_I1MID */,
+    LM_SPLIT_RES = LM_INV + 15 + 4 * LM_SPLIT_NRES,
+    // ... and the overlay: per lane, the entries phase A reads - three runs of the table: all of [LM_INV, LM_HOT), 16 entries from LM_UC_D (the
+    // upper-leg cylinder, the knee tip and one more), 4 entries from LM_PE_IS - 1 (the pair's broad-phase scale) - re-staged from the env's
+    // table in global memory at the start of every substep into scratch that is dead during phase A
+    LM_SPLIT_OVL = (LM_HOT - LM_INV) + 16 + 4
 };
+JB_HD constexpr int lm_split_res_lane(int i) { return i == LM_B1 ? 0 : i == LM_B2 ? 1 : i == LM_TARGET_Z ? 2 : i == LM_ROOT_Z0 ? 3 : i == LM_IMP_I1MID ? 4 : -1; }
+JB_HD constexpr int lm_split_res_entry(int r) { return r == 0 ? LM_B1 : r == 1 ? LM_B2 : r == 2 ? LM_TARGET_Z : r == 3 ? LM_ROOT_Z0 : LM_IMP_I1MID; }
+// overlay slot of a per-lane entry (-1: not in the overlay)
+JB_HD constexpr int lm_split_slot(int i) {
+    return (i >= LM_INV && i < LM_HOT) ? i - LM_INV : (i >= LM_UC_D && i < LM_UC_D + 16) ? (LM_HOT - LM_INV) + i - LM_UC_D
+         : (i >= LM_PE_IS - 1 && i < LM_PE_IS + 3) ? (LM_HOT - LM_INV) + 16 + i - (LM_PE_IS - 1) : -1;
+}
+constexpr int LM_SPLIT_STRIDE = 16;      // the overlay is laid out like the scratch of a four-env wave (the only shape split tables are launched in)
 JB_HD constexpr int lm_offset(int i, int leg) { return i < LM_INV ? i : LM_INV + 4 * (i - LM_INV) + leg; }
 
 // The packed constant table (LM_TABLE floats, see LM_INV) lives in LDS on the device, one copy per workgroup (shared
@@ -129,18 +144,25 @@ template <typename V> struct LaneConsts {
                                     // array so that the pick is a select of values, never an indexed access (which would
                                     // force the whole array into scratch memory)
     JB_HD V tran_of(int level) const { return level == 2 ? tran2 : level == 1 ? tran1 : level == 0 ? tran0 : tranm; }
-    // Split mode (LEAN kernel with one model per env): only the entries read on the common path are staged into LDS - the prefix
-    // [0, LM_HOT) and, behind it, the pair contact's (upper-leg cylinder, mass ellipsoid); the rest (all-geom path, broad-phase boxes) is
-    // read from the env's table in global memory where it is used.
+    // Split mode (LEAN kernel with one model per env: four 3 KB tables do not fit next to the scratch of eight waves per CU).  Resident in LDS
+    // per env (inv, LM_SPLIT_RES floats): the lane-invariant prefix, the pair contact's ellipsoid, and the five per-lane entries that are read
+    // after phase A.  Everything else phase A reads comes from the OVERLAY: scratch entries [SC_SYS, SC_SYS + LM_SPLIT_OVL) of the lane - dead
+    // from the final pass of one substep to the end of phase A of the next - re-staged from the env's table in global memory at the start
+    // of every substep (jb_api.hip restage_overlay).  The rest (all-geom path, broad-phase boxes) is read from global memory where it is used.
     const typename lane_traits<V>::real* cold = nullptr;
+    const typename lane_traits<V>::real* ovl = nullptr;          // the lane's overlay column (stride LM_SPLIT_STRIDE)
+    const typename lane_traits<V>::real* ovl_src = nullptr;      // restage: this lane's source in global memory (the env's table, its leg, its share of the slots)
+    typename lane_traits<V>::real* ovl_dst = nullptr;            // ... and its destination in LDS
     bool split = false;
-    static JB_HD constexpr int hot2_index(int i) { return (i >= LM_UC_D && i < LM_UC_D + 11) ? i - LM_UC_D : (i >= LM_PE_C && i < LM_PE_C + 18) ? 11 + i - LM_PE_C : -1; }
     JB_HD V table(int i) const {
         if (i < LM_INV) return lane_bcast(inv + i, (V*)nullptr);
-        if (!split || i < LM_HOT) return lane_from4(tab + 4 * (i - LM_INV), (V*)nullptr);
-        const int h2 = hot2_index(i);
-        if (h2 >= 0) return lane_from4(tab + 4 * (LM_HOT - LM_INV + h2), (V*)nullptr);
-        return lane_from4(cold + 4 * (i - LM_INV), (V*)nullptr);
+        if (!split) return lane_from4(tab + 4 * (i - LM_INV), (V*)nullptr);
+        const int r = lm_split_res_lane(i);
+        if (r >= 0) return lane_bcast(tab + 4 * r, (V*)nullptr);                                  // (split: tab = the lane's resident entries)
+        if (i >= LM_PE_C && i < LM_PE_C + 15) return lane_bcast(inv + LM_INV + (i - LM_PE_C), (V*)nullptr);
+        const int sl = lm_split_slot(i);
+        if (sl >= 0) return lane_bcast(ovl + sl * LM_SPLIT_STRIDE, (V*)nullptr);
+        return lane_bcast(cold + 4 * (i - LM_INV), (V*)nullptr);
     }
     JB_HD void preload() {
         if (!lean) {
@@ -1432,6 +1454,26 @@ template <typename V> JB_HD void quat_normalise_comp(V (&h)[4], V (&l)[4]) {
     for (int k = 0; k < 4; k++) comp_add(h[k], l[k], -h[k] * half_eps);
 }
 
+#if defined(__HIPCC__)
+// Split tables (LaneConsts): all 64 lanes of the wave copy the overlay's LM_SPLIT_OVL entries x 16 main lanes from the envs' tables in global
+// memory into the scratch.  Load k of a lane fetches slot 4k + (lane / 16) of main lane (lane % 16): a wave-wide load lands in 64
+// consecutive floats of LDS, and every load is an immediate offset from ONE per-lane pointer (ovl_src already points at the lane's first slot).
+static_assert(SC_FAC + 43 - SC_SYS == LM_SPLIT_OVL, "the overlay is exactly the parked system + factorisation");
+static_assert((LM_HOT - LM_INV) % 4 == 0, "the three runs of the overlay start on multiples of four slots");
+__device__ __forceinline__ void restage_overlay(const LaneConsts<float>& c) {
+    constexpr int K0 = (LM_HOT - LM_INV) / 4;
+    float v[K0 + 5];
+#pragma unroll
+    for (int k = 0; k < K0; k++) v[k] = c.ovl_src[16 * k];
+#pragma unroll
+    for (int k = 0; k < 4; k++) v[K0 + k] = c.ovl_src[4 * (LM_UC_D - LM_INV) + 16 * k];
+    v[K0 + 4] = c.ovl_src[4 * (LM_PE_IS - 1 - LM_INV)];
+#pragma unroll
+    for (int k = 0; k < K0 + 5; k++) c.ovl_dst[64 * k] = v[k];
+    wave_sync();
+}
+#endif
+
 // ----------------------------------------------------------------------------- the substep
 template <typename V, bool PAIR = false>
 JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneState<V>& s, const V& ctrl, const SimOpts& o, const bool xtra, const bool xbody, const Mat3<V>& Rw) {
@@ -1985,6 +2027,9 @@ template <typename V, bool PAIR = false>
 JB_HD void substep(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneState<V>& s, const V& ctrl, const SimOpts& o) {
     unsigned xt = 0;          // bit 0: some upper leg may touch the floor, bit 1: some root / motor-body geom may
     Mat3<V> Rw;               // root rotation (main lanes): mj_kinematics normalises the quaternion first
+#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+    if (m.c.split) restage_overlay(m.c);                // split tables: phase A's per-lane constants come back into the (now dead) SC_SYS / SC_FAC scratch
+#endif
     if (o.lean && sc.grp == 0) state_load(sc, s);       // LEAN: the state lives in the scratch between substeps
     const bool rep = sc.grp == 0 || (o.offload && sc.grp == 1);      // main lanes and their replica (SimOpts::offload)
     if (rep) Rw = quat2mat(s.qw, s.qx, s.qy, s.qz);      // the quaternion is kept normalised: normalise_state() once per kernel, phase C after every substep

@@ -4,9 +4,12 @@ all resolve `variant="auto"` here).
 The reference's harness builds a vectorised env with no knobs (benchmarks/benchmark.py:146-171); so does `variant="auto"`:
 
   ordinary   one four-env wave per SIMD (445 registers, 25.6 KB of LDS): the fastest kernel while a GPU holds at most one wave per SIMD
-  lean       two four-env waves per SIMD (<= 256 registers, 20.4 KB of LDS, JB_FLAG_LEAN): pays from 2048 waves per GPU on, i.e. 8192
-             envs with a shared model (measured on MI355X: 8192 envs 1.24 x, 16 384 1.30 x, 65 536 1.44 x) and 16 384 envs with one
-             model per env (8192: 4.45 -> 4.48 M env-steps/s, 16 384: 5.55 -> 6.26 M); DESIGN.md 4
+  lean       two four-env waves per SIMD (<= 256 registers, <= 20.4 KB of LDS: eight waves per CU, JB_FLAG_LEAN): pays from 2048 waves per
+             GPU on, i.e. 8192 envs with a shared model (measured on MI355X, round 4: 8192 envs 7.50 -> 8.75 M env-steps/s per step and
+             8.8 -> 11.8 M as one fused 1000-step launch, 16 384: 8.6 -> 11.5 M, 65 536: 14.1 M).  One model per env (LEAN + PAIR kernel,
+             split tables with a per-substep overlay): from 16 384 envs on (8.2 M per step, 9.2 M in fused 100-step launches); at 8192
+             the one-wave kernel with its waves launched longest-first is ahead per step (5.55 against 5.10 M) although the LEAN kernel
+             wins as ONE fused 1000-step launch (6.76 against 5.56 M) - per step is what "auto" optimises; DESIGN.md 4
 
 The two kernels agree to fp32 rounding, not bit for bit, so every shard of one batch must run the same one: a sharded env resolves
 "auto" from the GLOBAL batch and the world size (the per-GPU count every rank computes identically), never from its own shard length.
