@@ -13,8 +13,11 @@ from jitterbug_amd import _lib
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 mode = sys.argv[3] if len(sys.argv) > 3 else "uniform"
+augmented = len(sys.argv) > 4 and sys.argv[4] == "augmented"
 dev = torch.device("cuda", 0)
-env = JitterbugVecEnv(n, "move_from_origin", seed=0)
+env = JitterbugVecEnv(n, "move_to_pose" if augmented else "move_from_origin", seed=0)
+if augmented:
+    env.randomise_models(seed=1000, return_params=False)
 env.reset_device()
 g = torch.Generator(device=dev); g.manual_seed(1234)
 tape = torch.rand((K, n), generator=g, device=dev, dtype=torch.float32) * 2 - 1
