@@ -141,6 +141,15 @@ def test_integration_md_stub_runs_and_matches_vec_env():
         o1, r1, d1, _ = b.step(act)
         o2, r2, d2, _ = v.step(act)
         assert np.array_equal(o1, o2) and np.array_equal(r1, r2) and np.array_equal(d1, d2.astype(bool))
+    # the second block of the document: the fused rollout stub (jb_step_many_device), as written
+    a2 = src.index("```python", a) + len("```python")
+    exec(src[a2:src.index("```", a2)], ns)
+    import torch
+    K = 12
+    rew = torch.zeros((K, 33), device="cuda:0"); obs = torch.zeros((33, b.D), device="cuda:0"); done = torch.zeros((33,), device="cuda:0", dtype=torch.uint8)
+    ns["rollout"](b, K, None, rew.data_ptr(), obs.data_ptr(), done.data_ptr())          # the heuristic policy acts inside the kernel
+    r2, o2 = v.rollout_policy(K)
+    assert np.array_equal(rew.cpu().numpy(), r2) and np.array_equal(obs.cpu().numpy(), o2)
     v.close()
 
 
