@@ -299,6 +299,7 @@ __device__ __forceinline__ void step_body(KArgs a, StepIO io) {
             if (rep && !ic->use_policy) ctrl = ic->actions[(size_t)k * ka->n + env];
         }
         if (rep) normalise_state(s);          // mj_kinematics normalises the free-joint quaternion; phase C keeps it normalised from here on
+        if (PAIR && rep) scr.st(scr.pd + 11, 0.f);      // the narrow phase starts cold in every control step (its warm start is not simulator state)
         if (LEAN && grp == 0) state_store(scr, s);                   // LEAN: the state lives in the scratch between substeps
 #pragma unroll 1
         for (int i = 0; i < n_substeps; i++) substep<float, PAIR>(m, scr, s, ctrl, o);

@@ -318,8 +318,9 @@ enum SC : int {
     // ---- one wave per SIMD (the ordinary and the PAIR kernels)
     SC_RED = SC_VAR /*56: hand-over of the group reduction's totals to the main lanes*/,
     SC_OVC = SC_RED + 56 /*(NSLOT - ROW_K) x 4: candidates of the live slots beyond the row cache (sc.ovc points here)*/,
-    SC_PD = SC_OVC + 4 * (NSLOT - ROW_K) /*9: contact frame (n, t1, t2) of the pair contact, root coordinates*/,
-    SC_ZERO = SC_PD + 9 /*56 zeros, written once per kernel: what the replica group reads where the main lanes read the reduction's totals (SimOpts::offload)*/,
+    SC_PD = SC_OVC + 4 * (NSLOT - ROW_K) /*9 + 3: contact frame (n, t1, t2) of the pair contact, root coordinates; then the narrow phase's warm start
+                   for the next substep of the same control step: axis parameter, multiplier, valid flag*/,
+    SC_ZERO = SC_PD + 12 /*56 zeros, written once per kernel: what the replica group reads where the main lanes read the reduction's totals (SimOpts::offload)*/,
     SC_COUNT = SC_ZERO + 56,
     // ---- LEAN kernel variant (two waves per SIMD: 20 KB of LDS per wave): long-lived values that the one-wave-per-SIMD kernel keeps in
     // registers are parked here between the phases that use them; no reduction hand-over (the totals are combined in registers), the
@@ -327,7 +328,7 @@ enum SC : int {
     SC_SYS = SC_VAR /*41: joint-space system (the root block without its structural zeros)*/, SC_FAC = SC_SYS + 41 /*43: kept factorisation*/, SC_LSTATE = SC_FAC + 43 /*36: lane state*/,
     SC_COUNT_LEAN = SC_LSTATE + 36,
     // LEAN + PAIR (one model per env on the two-waves-per-SIMD kernel): the cross term's share of the parked factorisation, the pair's frame
-    SC_CX_LEAN = SC_COUNT_LEAN /*2*/, SC_PD_LEAN = SC_CX_LEAN + 2 /*9*/, SC_COUNT_LEAN_PAIR = SC_PD_LEAN + 9
+    SC_CX_LEAN = SC_COUNT_LEAN /*2*/, SC_PD_LEAN = SC_CX_LEAN + 2 /*9 + 3*/, SC_COUNT_LEAN_PAIR = SC_PD_LEAN + 12
 };
 template <typename V> struct LaneScratch {
     V* p;
@@ -1262,7 +1263,7 @@ template <typename V> JB_HD void ell_lambda(const Vec3<V>& s2, const V& lam_min,
 }
 template <typename V>
 JB_HD void pair_narrow(const Vec3<V>& ce, const Mat3<V>& Re, const Vec3<V>& sz, const Vec3<V>& cc, const Vec3<V>& ua, const V& rad, const V& half,
-                       V& dist, Vec3<V>& n, Vec3<V>& pos) {
+                       V& dist, Vec3<V>& n, Vec3<V>& pos, V* t_out = nullptr, V* lam_out = nullptr) {
     const Vec3<V> cl = mulT(Re, cc - ce), ul = mulT(Re, ua);
     const Vec3<V> s2 = v3<V>(sz.x * sz.x, sz.y * sz.y, sz.z * sz.z);
     const V lam_min = V(-0.95) * vmin(s2.x, vmin(s2.y, s2.z)), smax = vmax(sz.x, vmax(sz.y, sz.z));
@@ -1320,7 +1321,68 @@ JB_HD void pair_narrow(const Vec3<V>& ce, const Mat3<V>& Re, const Vec3<V>& sz, 
     const Vec3<V> pl = x - g * (V(0.5) * lam) - nl * (V(0.5) * rad);    // (q + x - r n) / 2 with q = x - lam g
     n = mul(Re, nl);
     pos = ce + mul(Re, pl);
+    if (t_out) { *t_out = tc; *lam_out = lam; }
 }
+// The same contact from the PREVIOUS substep's solution (axis parameter t, multiplier lam): between two substeps the pair moves by a
+// fraction of a millimetre, so Newton on f(t) started there converges quadratically - 3 steps of 3 multiplier iterations instead of the
+// cold scheme's 51.  Returns, per lane, whether it did converge (|f| within 64 ulp of zero, or pinned at an end of the leg with f
+// pointing outwards, and the multiplier's own equation satisfied); a lane that did not takes the cold scheme's result instead - its own
+// data decide, never its wave-mates'.  The first substep of a control step always runs the cold scheme (the warm state is not part of
+// the simulator's state: K single steps and one K-step launch must agree bit for bit).  The oracle keeps the cold scheme: both converge
+// to the same contact to round-off.
+template <typename V>
+JB_HD typename lane_traits<V>::mask pair_narrow_warm(const Vec3<V>& ce, const Mat3<V>& Re, const Vec3<V>& sz, const Vec3<V>& cc, const Vec3<V>& ua, const V& rad, const V& half,
+                                                      V& t, V& lam, V& dist, Vec3<V>& n, Vec3<V>& pos) {
+    using R = typename lane_traits<V>::real;
+    const Vec3<V> cl = mulT(Re, cc - ce), ul = mulT(Re, ua);
+    const Vec3<V> s2 = v3<V>(sz.x * sz.x, sz.y * sz.y, sz.z * sz.z);
+    const V lam_min = V(-0.95) * vmin(s2.x, vmin(s2.y, s2.z)), smax = vmax(sz.x, vmax(sz.y, sz.z));
+    Vec3<V> x, g;
+    auto eval = [&](const V& tt, int iters) -> V {
+        x = cl + ul * tt;
+        ell_lambda<V>(s2, lam_min, x, lam, iters);
+        g = v3<V>(x.x * vrcp(s2.x + lam), x.y * vrcp(s2.y + lam), x.z * vrcp(s2.z + lam));
+        return dot(g, ul) * vrsqrt(dot(g, g));
+    };
+    const V t0 = -dot(cl, ul);
+    const V a0 = vmax(t0 - smax, -half), b0 = vmax(vmin(vmax(t0 + smax, -half), half), a0);
+    lam = vmax(lam, lam_min);
+    V tc = vmin(vmax(t, a0), b0);
+    V fc = eval(tc, 3);
+#pragma unroll 1
+    for (int it = 0; it < 3; it++) {
+        const Vec3<V> A = v3<V>(s2.x * vrcp(s2.x + lam), s2.y * vrcp(s2.y + lam), s2.z * vrcp(s2.z + lam));
+        const Vec3<V> Au = v3<V>(A.x * ul.x, A.y * ul.y, A.z * ul.z), Ag = v3<V>(A.x * g.x, A.y * g.y, A.z * g.z);
+        const V dlam = dot(g, Au) * vrcp(dot(g, Ag));
+        const Vec3<V> dq = Au - Ag * dlam;
+        const Vec3<V> dg = v3<V>(dq.x * vrcp(s2.x), dq.y * vrcp(s2.y), dq.z * vrcp(s2.z));
+        const V gg_ = dot(g, g), ig_ = vrsqrt(gg_);
+        const V ndg = dot(g, dg) * ig_;
+        const V df = (dot(ul, dg) - (dot(g, ul) * ig_) * ndg) * ig_;
+        const auto okd = gt(df, V(1e-12));
+        tc = vmin(vmax(tc - fc * vrcp(sel(okd, df, V(1))) * sel(okd, V(1), V(0)), a0), b0);
+        fc = eval(tc, 3);
+    }
+    // converged?  f at the solution, and the multiplier's equation N(lam) = 1 at that point
+    const V tol = V(R(64) * (sizeof(R) == 4 ? R(1.1920929e-07) : R(2.220446049250313e-16)));
+    const V ix = vrcp(s2.x + lam), iy = vrcp(s2.y + lam), iz = vrcp(s2.z + lam);
+    const V N2 = s2.x * x.x * x.x * ix * ix + s2.y * x.y * x.y * iy * iy + s2.z * x.z * x.z * iz * iz;
+    const auto lam_ok = lt(vabs(N2 - V(1)), V(4) * tol);
+    const auto at_lo = mand(mnot(gt(tc, a0)), mnot(lt(fc, V(0)))), at_hi = mand(mnot(lt(tc, b0)), mnot(gt(fc, V(0))));
+    const auto conv = mand(lam_ok, mor(lt(vabs(fc), tol), mor(at_lo, at_hi)));
+    const V gg = dot(g, g), ig = vrsqrt(gg);
+    const Vec3<V> nl = g * ig;
+    dist = lam * gg * ig - rad;
+    const Vec3<V> pl = x - g * (V(0.5) * lam) - nl * (V(0.5) * rad);
+    n = mul(Re, nl);
+    pos = ce + mul(Re, pl);
+    t = tc;
+    return conv;
+}
+
+#if !defined(__HIPCC__)
+inline long g_pair_narrow_stats[2] = {0, 0};      // host harness only: substeps whose narrow phase was entirely warm-started / needed the cold scheme
+#endif
 
 // ----------------------------------------------------------------------------- options
 struct SimOpts {
@@ -1623,7 +1685,25 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
                 V pdist = V(1);
                 Vec3<V> pn = nb, ppos = uc;
                 if (any_lane(near_pair)) {
-                    pair_narrow<V>(pe, Re, ldc3(m, LM_PE_S), uc, ua, ldc(m, LM_UC_R), uh, pdist, pn, ppos);
+                    // warm start from the previous substep's solution where this lane has one (sc.pd + 9 .. 11), the cold fixed-count scheme
+                    // for the lanes that have none or did not converge from it
+                    V wt = sc.ld(sc.pd + 9), wlam = sc.ld(sc.pd + 10);
+                    MK warm_ok = mand(near_pair, gt(sc.ld(sc.pd + 11), V(0.5)));
+                    if (any_lane(warm_ok)) {
+                        const MK conv = pair_narrow_warm<V>(pe, Re, ldc3(m, LM_PE_S), uc, ua, ldc(m, LM_UC_R), uh, wt, wlam, pdist, pn, ppos);
+                        warm_ok = mand(warm_ok, conv);
+                    }
+#if !defined(__HIPCC__)
+                    if (sc.grp == 0) g_pair_narrow_stats[any_lane(mand(near_pair, mnot(warm_ok))) ? 1 : 0]++;
+#endif
+                    if (any_lane(mand(near_pair, mnot(warm_ok)))) {
+                        V cdist, ct, clam;
+                        Vec3<V> cn, cpos;
+                        pair_narrow<V>(pe, Re, ldc3(m, LM_PE_S), uc, ua, ldc(m, LM_UC_R), uh, cdist, cn, cpos, &ct, &clam);
+                        pdist = sel(warm_ok, pdist, cdist); pn = sel_v3(warm_ok, pn, cn); ppos = sel_v3(warm_ok, ppos, cpos);
+                        wt = sel(warm_ok, wt, ct); wlam = sel(warm_ok, wlam, clam);
+                    }
+                    sc.st(sc.pd + 9, wt); sc.st(sc.pd + 10, wlam);
                     pon = mand(near_pair, lt(pdist, V(0)));
                     if (any_lane(pon)) {
                         // contact frame: MuJoCo's mju_makeFrame on the WORLD normal (y = world y unless the normal is within 60 degrees of
@@ -1636,6 +1716,7 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
                         sc.st3(sc.pd, pn); sc.st3(sc.pd + 3, t1); sc.st3(sc.pd + 6, cross(pn, t1));
                     }
                 }
+                sc.st(sc.pd + 11, sel(near_pair, V(1), V(0)));          // the next substep may start from this one's solution (only while the pair stays near)
                 live_slots |= cand_store(sc, live_slots, SLOT_PAIR, ppos, pdist, pon);
                 any_con = mor(any_con, pon);
             }

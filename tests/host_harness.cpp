@@ -55,10 +55,11 @@ static int run(const double* P, double* qpos, double* qvel, double ctrl, int nsu
         LaneScratch<V> sc; sc.p = scratch; sc.stride = 1; sc.grp = 0; sc.ngrp = 1; sc.gstride = 4; set_ovc(sc);
         for (int k = 0; k < SCMAX; k++) scratch[k] = V(std::numeric_limits<T>::quiet_NaN());
         if (lean) state_store(sc, s);
+        scratch[sc.pd + 11] = V(T(0));         // the narrow phase starts cold in every control step
         for (int i = 0; i < nsub; i++) {
             // poison the scratch: a substep must not read anything it has not written itself (on the device LDS keeps whatever
             // the previous kernel left there); in the LEAN variant the parked state is the one thing that carries over
-            for (int k = 0; k < (lean ? SC_LSTATE : SCMAX); k++) scratch[k] = V(std::numeric_limits<T>::quiet_NaN());
+            for (int k = 0; k < (lean ? SC_LSTATE : SCMAX); k++) if (k < sc.pd + 9 || k > sc.pd + 11) scratch[k] = V(std::numeric_limits<T>::quiet_NaN());      // (the pair's warm start carries over, like on the device)
             for (auto& c : ovcbuf) c = V(std::numeric_limits<T>::quiet_NaN());
             if (pair) substep<V, true>(m, sc, s, V(T(ctrl)), o); else substep<V>(m, sc, s, V(T(ctrl)), o);
         }
@@ -83,7 +84,7 @@ static int run(const double* P, double* qpos, double* qvel, double ctrl, int nsu
             }
             for (int i = 0; i < nsub; i++) {
                 wave.barrier();
-                if (g == 0) { for (int k = 0; k < (lean ? SC_LSTATE : o.offload ? SC_ZERO : SCMAX); k++) scratch[k] = V(std::numeric_limits<T>::quiet_NaN()); for (auto& c : ovcbuf) c = V(std::numeric_limits<T>::quiet_NaN()); }
+                if (g == 0) { for (int k = 0; k < (lean ? SC_LSTATE : o.offload ? SC_ZERO : SCMAX); k++) if (i == 0 || k < sc.pd + 9 || k > sc.pd + 11) scratch[k] = V(std::numeric_limits<T>::quiet_NaN()); if (i == 0) scratch[sc.pd + 11] = V(T(0)); for (auto& c : ovcbuf) c = V(std::numeric_limits<T>::quiet_NaN()); }
                 wave.barrier();
                 if (pair) substep<V, true>(m, sc, st, V(T(ctrl)), o); else substep<V>(m, sc, st, V(T(ctrl)), o);
             }
@@ -251,6 +252,7 @@ extern "C" int jbh_rollout(const double* P, double* qpos, double* qvel, double* 
     return use_float ? rollout<float>(P, qpos, qvel, target, counters, K, actions, task, nsub, step_limit, auto_reset, random_pose, seed, env_global, policy_params, ngroups, rows_out)
                      : rollout<double>(P, qpos, qvel, target, counters, K, actions, task, nsub, step_limit, auto_reset, random_pose, seed, env_global, policy_params, ngroups, rows_out);
 }
+extern "C" void jbh_pair_narrow_stats(long* out, int reset) { out[0] = g_pair_narrow_stats[0]; out[1] = g_pair_narrow_stats[1]; if (reset) g_pair_narrow_stats[0] = g_pair_narrow_stats[1] = 0; }
 extern "C" int jbh_lm_count(void) { return LM_COUNT; }
 // the per-leg constant table (LM_COUNT doubles) for inspection by tests / tools
 extern "C" int jbh_lane_table(const double* P, int leg, double* out) { return build_lane_model<double>(P, leg, out); }

@@ -356,6 +356,24 @@ def test_pair_contact_kernel_source_fp64_equals_oracle():
             q, v = q1, v1
     print("control steps that start with the mass on a leg: %d; fp64 vs oracle %.2e; fp32 median %.1e max %.1e" % (n_pair, worst, np.median(e32), max(e32)))
     assert n_pair >= 20 and worst < 2e-9 and np.median(e32) < 1e-6 and max(e32) < 1e-5
+    # The narrow phase is warm-started from the previous substep's solution (pair_narrow_warm) and falls back, lane by lane, on the cold
+    # fixed-count scheme where that does not converge to 64 ulp; the first substep of a control step is always cold.  The comparison above
+    # already held both builds against the oracle's cold scheme; here: how often each path ran, in fp32 (what the GPU runs) and in fp64.
+    lib.jbh_pair_narrow_stats.argtypes = [C.POINTER(C.c_long), C.c_int]
+    st = (C.c_long * 2)()
+    lib.jbh_pair_narrow_stats(st, 1)
+    P = Ps[bad[0]]
+    shares = {}
+    for f32 in (1, 0):
+        q, v = model.qpos0(P), np.zeros(model.NV)
+        rng = np.random.default_rng(3)
+        for t in range(12):
+            q, v = step(P, q, v, rng.uniform(-1, 1), f32=f32, groups=1)
+        lib.jbh_pair_narrow_stats(st, 1)
+        shares[f32] = (st[0], st[1])
+    print("narrow phase, substeps entirely warm-started / needing the cold scheme: fp32 %s, fp64 %s" % (shares[1], shares[0]))
+    assert shares[1][0] > 3 * shares[1][1] and shares[1][1] >= 1          # fp32: mostly warm; at least the control steps' first substeps cold
+    assert shares[0][0] + shares[0][1] > 0
 
 
 def test_contacts_beyond_the_row_cache_give_the_same_answer(params):
