@@ -310,7 +310,7 @@ def main(argv=None):
     # over the K steps, measured by the kernel itself (jb_wave_clocks: s_memrealtime per wave) and reported against the mean wave.
     rollout_fused = None
     if not args.no_steady and world == 1 and dist is None:
-        def fused(k_launch, source, total=1000):
+        def fused(k_launch, source, total=1000, episodes=1):
             g = torch.Generator(device=dev)
             g.manual_seed(1234 + rank + 7919 * args.seed)
             tape = torch.rand((total, n), generator=g, device=dev, dtype=torch.float32) * 2 - 1
@@ -327,11 +327,15 @@ def main(argv=None):
             env.reset_device(None, obs.data_ptr())
             torch.cuda.synchronize(dev)
             t0 = time.perf_counter()
-            for k0 in range(0, total, k_launch):
-                env.step_many_device(k_launch, None if source == "policy" else tape[k0:k0 + k_launch].data_ptr(), rewards_ptr=rew[k0:k0 + k_launch].data_ptr(),
-                                     obs_last_ptr=obs.data_ptr(), done_last_ptr=done.data_ptr())
-            torch.cuda.synchronize(dev)
-            wall = time.perf_counter() - t0
+            per_episode = []
+            for ep_i in range(episodes):          # consecutive episodes (the tape repeats; resets draw new poses): a fused launch lasts as long as
+                te = time.perf_counter()          # the wave whose robot tips over FIRST, so one episode's figure depends on that robot's luck
+                for k0 in range(0, total, k_launch):
+                    env.step_many_device(k_launch, None if source == "policy" else tape[k0:k0 + k_launch].data_ptr(), rewards_ptr=rew[k0:k0 + k_launch].data_ptr(),
+                                         obs_last_ptr=obs.data_ptr(), done_last_ptr=done.data_ptr())
+                torch.cuda.synchronize(dev)
+                per_episode.append((time.perf_counter() - te) * 1e3 / total)
+            wall = (time.perf_counter() - t0) / episodes
             wc = env.wave_clocks()            # of the last launch
             sc, ep, cap = env.counters()
             ok = bool(torch.isfinite(obs).all().item()) and bool(torch.isfinite(rew).all().item()) and float(cap.max()) < 1000.0 and bool(done.all().item())
@@ -341,7 +345,8 @@ def main(argv=None):
             out = {"value": n * total / wall, "unit": "env steps/s", "ms_per_step": wall * 1e3 / total, "launches": total // k_launch, "steps_per_launch": k_launch,
                    "actions": {"tape": "uniform action tape [K,N] resident in HBM (the headline's actions)", "policy": "heuristic policy evaluated in the kernel (no action buffer)",
                                "const1": "motor flat out (about half the robots tip over)"}[source],
-                   "window": "steps 0-%d: one whole episode from the reset, auto-reset included" % total, "finite": ok, "kernel_variant": kv}
+                   "window": "steps 0-%d: %d whole episode(s) from the reset, auto-reset included" % (total, episodes), "finite": ok, "kernel_variant": kv,
+                   "ms_per_step_by_episode": per_episode}
             if k_launch == total:
                 simds = 1024.0
                 out["wave_clock"] = {"mean_wave_ms_per_step": 1e3 * float(wc.mean()) / total, "slowest_wave_ms_per_step": 1e3 * float(wc.max()) / total,
@@ -350,7 +355,7 @@ def main(argv=None):
                                      "value_over_ceiling": (n * total / wall) / (epw * min(simds, len(wc)) / (float(wc.mean()) / total)),
                                      "what": "per-wave lifetimes of the launch (s_memrealtime): the launch lasts as long as its slowest wave; `ceiling_mean_wave` = envs per wave / mean wave time x waves in flight - what the launch would reach if no wave were slower than the mean.  A robot that has tipped over stays tipped for the rest of its episode (tools/tip_persistence.py), so the slowest wave is the one whose robot tipped first"}
             return out
-        rollout_fused = {"k1000": fused(1000, "tape"), "k100": fused(100, "tape"), "k1000_policy": fused(1000, "policy"), "k1000_const1": fused(1000, "const1"),
+        rollout_fused = {"k1000": fused(1000, "tape", episodes=3), "k100": fused(100, "tape"), "k1000_policy": fused(1000, "policy"), "k1000_const1": fused(1000, "const1"),
                          "per_step_full_episode": None if full_episode is None else full_episode["value"],
                          "what": "jb_step_many_device: K control steps per launch, bit-identical to K single-step launches (tests/test_gpu_rollout.py); `value` above stays the per-step path"}
 
