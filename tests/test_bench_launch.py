@@ -91,7 +91,8 @@ def test_bench_line_names_the_baseline_workload_and_the_loaded_library():
     assert rf["k1000"]["launches"] == 1 and rf["k100"]["launches"] == 10
     wc = rf["k1000"]["wave_clock"]
     assert 0 < wc["mean_over_slowest"] <= 1 and rf["k1000"]["value"] <= wc["ceiling_mean_wave"] * 1.02
-    assert rf["k1000"]["value"] > 1.1 * d["value_full_episode"]          # what the fused launch is for (measured: 6.3 -> 8.3 M env-steps/s)
+    assert rf["k1000"]["value"] > 1.05 * d["value_full_episode"]          # what the fused launch is for (measured: 6.3 -> 7.5-8.3 M env-steps/s: it lasts as long as the wave whose robot tips over first)
+    assert len(rf["k1000"]["ms_per_step_by_episode"]) == 3
 
 
 @pytest.mark.gpu
