@@ -221,3 +221,39 @@ def test_longest_first_wave_order_does_not_change_a_single_bit(randomise):
         assert wa.shape == wb.shape == (n // 4,) and (wa > 0).all() and (wb > 0).all()
     finally:
         a.close(); b.close()
+
+
+@pytest.mark.parametrize("label,n,task,randomise", [("configs3-32768-move_to_pose", 32768, "move_to_pose", False), ("configs4-65536-randomised", 65536, "move_from_origin", True)],
+                         ids=["configs3", "configs4"])
+def test_fused_rollout_at_the_full_baseline_sizes(label, n, task, randomise):
+    """BASELINE configs[3] (32 768 envs, move_to_pose) and configs[4] (65 536 envs, one randomised model each) whole on one GPU, with the
+    product's own variant selection (two waves per SIMD; configs[4]: LEAN + PAIR with the per-substep table overlay), waves launched
+    longest-first: one fused K-step launch = K single steps bit for bit, every env stays physical, an episode ends inside."""
+    from jitterbug_amd.vec_env import JitterbugVecEnv
+    torch = _torch()
+    dev = torch.device("cuda", 0)
+    K = 24
+    kw = dict(seed=5, variant="auto", per_env_model=randomise, time_limit=0.2)
+    a, b = JitterbugVecEnv(n, task, **kw), JitterbugVecEnv(n, task, **kw)
+    try:
+        if randomise:
+            a.randomise_models(seed=9, return_params=False); b.randomise_models(seed=9, return_params=False)
+        assert a.kernel_variant == ("lean_pair" if randomise else "lean")
+        D = a.obs_dim
+        g = torch.Generator(device=dev); g.manual_seed(2)
+        tape = torch.rand((K, n), generator=g, device=dev, dtype=torch.float32) * 2 - 1
+        rows_a = torch.zeros((K, n, D + 2), device=dev); rows_b = torch.zeros((K, n, D + 2), device=dev)
+        a.reset_device(); b.reset_device()
+        for k in range(K):
+            a.step_rows_device(tape[k].data_ptr(), rows_a[k].data_ptr())
+        b.step_many_device(K, tape.data_ptr(), rows_ptr=rows_b.data_ptr())
+        a.synchronize(); b.synchronize()
+        assert np.array_equal(bits(rows_a), bits(rows_b)) and same_state(a, b)
+        r = rows_b.cpu().numpy()
+        assert np.isfinite(r).all() and r[19, :, D + 1].all() and r[:, :, D + 1].sum() == n
+        z = (r[-1, :, 2] + 1) / 20
+        assert z.min() > 0.005 and z.max() < 0.08 and np.abs(np.linalg.norm(r[-1, :, 3:7], axis=1) - 1).max() < 1e-5
+        sc, ep, cap = b.counters()
+        assert cap.sum() < 0.001 * n * K
+    finally:
+        a.close(); b.close()
