@@ -186,6 +186,8 @@ int jb_rollout_policy(jb_handle* h, int32_t n_steps, float* rewards_out, float* 
  * jb_step_device / jb_step_rows_device ARE this kernel with K = 1: K single-step calls and one K-step call give bit-identical
  * states, rows and rewards (tests/test_gpu_rollout.py), in-kernel auto-reset included. */
 int jb_step_many_device(jb_handle* h, int32_t n_steps, const float* d_actions, float* d_rows_out, float* d_rewards, float* d_obs_last, uint8_t* d_done_last);
+/* host-buffer form (synchronous): actions [K, N] or NULL = in-kernel policy, rows_out [K, N, D+2] nullable */
+int jb_step_many(jb_handle* h, int32_t n_steps, const float* actions, float* rows_out);
 /* seconds each wave of the LAST step launch was alive (one wave = jb_envs_per_wave envs), out[0 .. min(n_waves, max_waves)); returns the
  * number of waves.  Mean against maximum is the load imbalance of the launch (roofline). */
 int jb_wave_clocks(jb_handle* h, double* out, int32_t max_waves);

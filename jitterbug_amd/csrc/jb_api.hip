@@ -190,7 +190,9 @@ __device__ __forceinline__ void store_target(const KArgs& a, int env, const EnvC
 // (so the loads cannot be hoisted above the substep loop): a handful of s_load per control step.
 typedef const __attribute__((address_space(4))) KArgs* KArgsC;
 typedef const __attribute__((address_space(4))) StepIO* StepIOC;
+// (AMDGPU kernarg ABI: the explicit arguments lie in declaration order, each at its natural alignment - KArgs at 0, StepIO behind it)
 constexpr unsigned STEPIO_KERNARG_OFFSET = (unsigned)((sizeof(KArgs) + alignof(StepIO) - 1) / alignof(StepIO) * alignof(StepIO));
+static_assert(alignof(KArgs) == 8 && alignof(StepIO) == 8 && std::is_trivially_copyable<KArgs>::value && std::is_trivially_copyable<StepIO>::value, "kernel arguments are plain data with pointer alignment");
 __device__ __forceinline__ const __attribute__((address_space(4))) char* kernarg_base() {
     const __attribute__((address_space(4))) char* p = (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(p));
@@ -1117,6 +1119,29 @@ int jb_step_many_device(jb_handle* h, int32_t n_steps, const float* d_actions, f
     io.obs_out = d_obs_last; io.reward_out = d_rewards; io.done_out = d_done_last;
     io.every_step = 2;
     return launch_step(h, io, 0);
+}
+// host-buffer form of jb_step_many_device: actions [K, N] (NULL: the in-kernel heuristic policy), rows_out [K, N, D+2] (nullable);
+// device staging is allocated for the call, the results are valid on return
+int jb_step_many(jb_handle* h, int32_t n_steps, const float* actions, float* rows_out) {
+    if (!h) return fail(JB_E_INVALID, "handle is NULL");
+    if (n_steps < 0) return fail(JB_E_INVALID, "n_steps < 0");
+    if (n_steps == 0) return JB_OK;
+    JB_ENTER(h);
+    const size_t N = (size_t)h->cfg.n_envs, K = (size_t)n_steps, W = (size_t)h->D + 2;
+    float *d_act = nullptr, *d_rows = nullptr;
+    int rc = JB_OK;
+    auto cleanup = [&]() { if (d_act) hipFree(d_act); if (d_rows) hipFree(d_rows); };
+    if (actions) {
+        if (hipMalloc(&d_act, sizeof(float) * K * N) != hipSuccess) { cleanup(); return fail(JB_E_HIP, "jb_step_many: out of device memory for the action tape"); }
+        if (hipMemcpyAsync(d_act, actions, sizeof(float) * K * N, hipMemcpyHostToDevice, h->stream) != hipSuccess) { cleanup(); return fail(JB_E_HIP, "jb_step_many: copy of the action tape failed"); }
+    }
+    if (rows_out && hipMalloc(&d_rows, sizeof(float) * K * N * W) != hipSuccess) { cleanup(); return fail(JB_E_HIP, "jb_step_many: out of device memory for the rows"); }
+    rc = jb_step_many_device(h, n_steps, d_act, d_rows, nullptr, nullptr, nullptr);
+    if (!rc && rows_out && hipMemcpyAsync(rows_out, d_rows, sizeof(float) * K * N * W, hipMemcpyDeviceToHost, h->stream) != hipSuccess) rc = fail(JB_E_HIP, "jb_step_many: copy of the rows failed");
+    const hipError_t e = hipStreamSynchronize(h->stream);
+    cleanup();
+    if (!rc && e != hipSuccess) rc = fail(JB_E_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(e));
+    return rc;
 }
 // how long each wave of the last step launch lived, in seconds (s_memrealtime, 100 MHz): out[0 .. n_waves); returns the number of waves
 int jb_wave_clocks(jb_handle* h, double* out, int32_t max_waves) {

@@ -334,6 +334,20 @@ class JitterbugVecEnv:
         _lib.check(self._L.jb_step_many_device(self._h, int(n_steps), actions_ptr, rows_ptr, rewards_ptr, obs_last_ptr, done_last_ptr))
         self.state_version += 1
 
+    def rollout(self, n_steps, actions=None):
+        """n_steps control steps in ONE kernel launch, host arrays in and out (jb_step_many): `actions` [n_steps, N] float32, or None =
+        the task's heuristic policy evaluated in the kernel (set_policy_params).  Returns (obs [K, N, D], reward [K, N], done [K, N]) -
+        what n_steps calls of step() would have returned, bit for bit (auto-reset included: the row of a finished episode's last step
+        holds the new episode's first observation)."""
+        K = int(n_steps)
+        a = None
+        if actions is not None:
+            a = np.ascontiguousarray(np.asarray(actions, dtype=np.float32).reshape(K, self.num_envs))
+        rows = np.empty((K, self.num_envs, self.obs_dim + 2), dtype=np.float32)
+        _lib.check(self._L.jb_step_many(self._h, K, _lib.ptr(a), _lib.ptr(rows)))
+        self.state_version += 1
+        return rows[..., :-2].copy(), rows[..., -2].copy(), rows[..., -1] > 0.5
+
     def wave_clocks(self):
         """Seconds each wave of the last step launch was alive (its load imbalance: mean against max)."""
         out = np.zeros(self.num_envs, dtype=np.float64)

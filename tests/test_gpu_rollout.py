@@ -257,3 +257,28 @@ def test_fused_rollout_at_the_full_baseline_sizes(label, n, task, randomise):
         assert cap.sum() < 0.001 * n * K
     finally:
         a.close(); b.close()
+
+
+def test_host_buffer_rollout_equals_step_by_step():
+    """JitterbugVecEnv.rollout (jb_step_many: numpy in, numpy out - no torch needed) = the same steps through step(), bit for bit, for an
+    action tape and for the in-kernel policy; the reference's evaluate_policy loop (benchmarks/evaluate_policy.py:29-33) in one call."""
+    from jitterbug_amd.vec_env import JitterbugVecEnv
+    n, K = 300, 40
+    a, b = JitterbugVecEnv(n, "move_to_position", seed=2, time_limit=0.25), JitterbugVecEnv(n, "move_to_position", seed=2, time_limit=0.25)
+    try:
+        rng = np.random.default_rng(0)
+        tape = rng.uniform(-1, 1, size=(K, n)).astype(np.float32)
+        a.reset(); b.reset()
+        ob, rw, dn = b.rollout(K, tape)
+        for k in range(K):
+            o1, r1, d1, _ = a.step(tape[k])
+            assert np.array_equal(o1, ob[k]) and np.array_equal(r1, rw[k]) and np.array_equal(d1, dn[k]), k
+        assert dn.sum() == n and same_state(a, b)
+        oa = a.observe()[0]
+        ob2, rw2, dn2 = b.rollout(K)                     # the heuristic policy acts inside the kernel
+        for k in range(K):
+            oa, r1, d1, _ = a.step(a.policy(oa))
+            assert np.array_equal(oa, ob2[k]) and np.array_equal(r1, rw2[k]) and np.array_equal(d1, dn2[k]), k
+        assert same_state(a, b)
+    finally:
+        a.close(); b.close()
