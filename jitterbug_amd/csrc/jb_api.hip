@@ -399,6 +399,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     step_body<EPW, true, true>(a, io);
 }
 
+// Self-check of the kernarg-segment reads above, run once per process before the first handle is handed out: a kernel with the step kernels'
+// argument list compares what it reads through kernarg_base() with the arguments it received by value.
+__global__ void jb_kernarg_probe_kernel(KArgs a, StepIO io, int* ok) {
+    const auto kb = kernarg_base();
+    const KArgsC ka = (KArgsC)kb;
+    const StepIOC ic = (StepIOC)(kb + STEPIO_KERNARG_OFFSET);
+    *ok = (ka->n == a.n && ka->seed == a.seed && ka->root == a.root && ka->step_limit == a.step_limit && ic->n_steps == io.n_steps && ic->obs_out == io.obs_out &&
+           ic->every_step == io.every_step && ic->wave_clock == io.wave_clock && ic->pp.angle_threshold == io.pp.angle_threshold) ? 1 : 0;
+}
+
 // ---------------------------------------------------------------------------------------------- reset / observe
 __global__ __launch_bounds__(64) void jb_reset_kernel(KArgs a, const unsigned char* __restrict__ mask, float* __restrict__ obs_out) {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -876,6 +886,23 @@ static int create_impl(jb_handle* h) {      // every failure returns through jb_
         k.epw = epw;
     }
     k.root = h->d_root; k.leg = h->d_leg; k.step_count = h->d_step; k.episode = h->d_episode; k.wave_stats = h->d_wave_stats;
+    {   // the step kernels read part of their arguments through the kernarg segment: make sure that layout is what they assume (once per process)
+        static int probed = 0;
+        if (!probed) {
+            int* d_ok = nullptr;
+            JB_HIP(hipMalloc(&d_ok, sizeof(int)));
+            KArgs pa = KArgs(); StepIO pio = StepIO();
+            pa.n = 0x1234567; pa.seed = 0x0123456789ABCDEFull; pa.root = (float*)0x10002000; pa.step_limit = 777;
+            pio.n_steps = 4242; pio.obs_out = (float*)0x30004000; pio.every_step = 5; pio.wave_clock = (unsigned long long*)0x50006000; pio.pp.angle_threshold = 0.625f;
+            hipLaunchKernelGGL(jb_kernarg_probe_kernel, dim3(1), dim3(1), 0, h->stream, pa, pio, d_ok);
+            int ok = 0;
+            const hipError_t e1 = hipGetLastError(), e2 = hipMemcpyAsync(&ok, d_ok, sizeof(int), hipMemcpyDeviceToHost, h->stream), e3 = hipStreamSynchronize(h->stream);
+            hipFree(d_ok);
+            if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) return fail(JB_E_HIP, "kernarg probe failed to run");
+            if (!ok) return fail(JB_E_HIP, "the step kernels' view of the kernarg segment does not match their arguments (compiler ABI change?): rebuild is needed with the layout fixed");
+            probed = 1;
+        }
+    }
     int rc = upload_model(h, JB_DEFAULT_PARAMS, 1);
     if (rc) return rc;
     rc = jb_reset_device(h, nullptr, nullptr);     // every env starts in a valid episode-0 state
