@@ -152,7 +152,7 @@ def main(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true")
     ap.add_argument("--no-host-rate", action="store_true", help="skip the host-buffer (jb_step) rate measured next to the headline")
-    ap.add_argument("--max-newton", type=int, default=12)
+    ap.add_argument("--max-newton", type=int, default=20)
     ap.add_argument("--envs-per-wave", type=int, default=0)
     ap.add_argument("--no-rank-one", action="store_true", help="diagnostic: JB_FLAG_NO_RANK_ONE (every Newton pass is a full pass)")
     ap.add_argument("--no-reorder", action="store_true", help="diagnostic: JB_FLAG_NO_REORDER (never launch the waves longest-first)")

@@ -87,7 +87,7 @@ typedef struct jb_config {
     int32_t  step_limit;    /* control steps per episode (reference: 10/(0.0002*50) = 1000) */
     int32_t  auto_reset;    /* 1: VecEnv semantics - an env that reports done is reset inside the
                                   same call and its returned observation is the new episode's first */
-    int32_t  max_newton;    /* cap on contact-solver iterations per substep (0 -> default 12) */
+    int32_t  max_newton;    /* cap on contact-solver iterations per substep (0 -> default 20; from the sixth on every second one is a half step, jb_sim.hpp "cycle breaker") */
     int32_t  use_caller_stream; /* 1: launch on `stream` below even when it is NULL (the legacy default stream) */
     int32_t  envs_per_wave; /* environments per 64-lane wavefront (4 lanes each): 1, 2, 4 or 8 (larger requests run as 8), 0 = choose so that the batch
                                spreads over all SIMDs of the device (small batches use partially filled waves) */

@@ -833,7 +833,7 @@ int jb_default_config(jb_config* cfg, int32_t n_envs, int32_t task_id) {
     if (!cfg) return fail(JB_E_INVALID, "cfg is NULL");
     std::memset(cfg, 0, sizeof *cfg);
     cfg->n_envs = n_envs; cfg->task_id = task_id; cfg->device_id = 0; cfg->random_pose = 1; cfg->contacts = 1;
-    cfg->substeps = 50; cfg->step_limit = 1000; cfg->auto_reset = 1; cfg->max_newton = 12; cfg->seed = 0; cfg->env_offset = 0; cfg->stream = nullptr;
+    cfg->substeps = 50; cfg->step_limit = 1000; cfg->auto_reset = 1; cfg->max_newton = 20; cfg->seed = 0; cfg->env_offset = 0; cfg->stream = nullptr;
     return JB_OK;
 }
 
@@ -926,7 +926,7 @@ int jb_create(const jb_config* cfg, jb_handle** out) {
     if (!h) return fail(JB_E_INVALID, "out of host memory");
     std::memset(h, 0, sizeof *h);
     h->cfg = *cfg;
-    if (h->cfg.max_newton <= 0) h->cfg.max_newton = 12;
+    if (h->cfg.max_newton <= 0) h->cfg.max_newton = 20;
     h->D = obs_dim(cfg->task_id);
     h->policy = default_policy_params<float>();
     const int rc = create_impl(h);

@@ -1384,6 +1384,11 @@ JB_HD typename lane_traits<V>::mask pair_narrow_warm(const Vec3<V>& ce, const Ma
 inline long g_pair_narrow_stats[2] = {0, 0};      // host harness only: substeps whose narrow phase was entirely warm-started / needed the cold scheme
 #endif
 
+#ifndef JB_DAMP_AFTER
+#define JB_DAMP_AFTER 6
+#endif
+constexpr int NEWTON_DAMP_AFTER = JB_DAMP_AFTER;      // checks of a substep after which every second Newton update is a half step (substep_impl, "cycle breaker")
+
 // ----------------------------------------------------------------------------- options
 struct SimOpts {
     int contacts;        // 0: contacts disabled (MuJoCo disableflags=contact)
@@ -1842,6 +1847,7 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
         bool final_pass = !any_contact;
         MK unconverged = lt(V(0), V(1));
         MK fac_valid = lt(V(1), V(0)), fast_env = lt(V(1), V(0));
+        MK damped_last = lt(V(1), V(0));
         U prev_bw0 = zero_u<V>(), prev_bw1 = zero_u<V>(), prev_xh = zero_u<V>();
         if (any_contact) {
 #pragma unroll
@@ -1906,6 +1912,20 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
                     if (is_main) {
                         // envs whose active set already repeated keep their (exact) solution, rank-one envs theirs
                         const MK take = mand(unconverged, mnot(fast_env));
+                        // Cycle breaker.  The undamped active-set iteration can cycle between two sets (robots lying on their side, a dozen contacts on the
+                        // body geoms: ~1e-6 of the substeps with the motor flat out) and then runs into the cap with an iterate that minimises
+                        // nothing - every such env-step is off by a contact impulse (tools/parity_outliers.py).  From the sixth check on, every
+                        // second update goes only HALF way to the new set's minimiser: the point in between picks another set, and the following
+                        // full step is judged as usual.  A damped iterate is never accepted as converged (`damped_last`).  The decision is the
+                        // env's own (an env that is still unconverged at check k has been so since the substep began), and substeps that
+                        // converge in fewer than six checks - all but a few in a million - keep their bits.
+                        damped_last = lt(V(1), V(0));
+                        if (it >= NEWTON_DAMP_AFTER && ((it - NEWTON_DAMP_AFTER) & 1) == 0) {      // (wave-uniform: `it` counts the checks of this substep)
+#pragma unroll
+                            for (int i = 0; i < 6; i++) nyr[i] = yr[i] + V(0.5) * (nyr[i] - yr[i]);
+                            nyl[0] = yl[0] + V(0.5) * (nyl[0] - yl[0]); nyl[1] = yl[1] + V(0.5) * (nyl[1] - yl[1]); nym = ym + V(0.5) * (nym - ym);
+                            damped_last = take;
+                        }
 #pragma unroll
                         for (int i = 0; i < 6; i++) yr[i] = sel(take, nyr[i], yr[i]);
                         yl[0] = sel(take, nyl[0], yl[0]); yl[1] = sel(take, nyl[1], yl[1]); ym = sel(take, nym, ym);
@@ -1934,6 +1954,7 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
                     if (is_main) {
                         MK changed = mor(mor(neq_u(acc.bw0, prev_bw0), neq_u(acc.bw1, prev_bw1)), neq_u(acc.xh, prev_xh));
                         unconverged = neq_u(quad_sum_u(mbit(changed)), zero_u<V>());
+                        unconverged = mor(unconverged, damped_last);      // a damped iterate is not the minimiser of any set: it only picks the next set
 #if defined(JB_WAVE_STATS) && defined(__HIPCC__)
                                             if (o.hist && !xtra) {      // how many active-set bits flipped per unconverged env (ordinary substeps: exact records)
                                                 const unsigned fl = quad_sum_u((unsigned)__builtin_popcount(acc.bw0 ^ prev_bw0));
@@ -1972,7 +1993,7 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
                             const MK undecodable = mand(neq_u(or_u(dfl, dfl1), zero_u<V>()), mnot(mand(f_is, lt_u(f_entry, (unsigned)ROW_K))));
                             const MK rows_ok = eq_u(quad_sum_u(mbit(undecodable)), zero_u<V>());
                             fast_env = mand(mand(unconverged, fac_valid), mand(mand(one_flip, xh_same), rows_ok));
-                            if (!o.rank_one) fast_env = lt(V(1), V(0));
+                            if (!o.rank_one || it >= NEWTON_DAMP_AFTER) fast_env = lt(V(1), V(0));      // (the cycle breaker works on full passes)
                             full = any_lane(mand(unconverged, mnot(fast_env))) ? 1u : 0u;
                             if (any_lane(fast_env)) {
                                 V fyr[6], fyl[2], fym;

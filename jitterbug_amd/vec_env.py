@@ -56,7 +56,7 @@ class JitterbugVecEnv:
 
     def __init__(self, n_envs, task="move_from_origin", seed=0, device_id=0, random_pose=True, contacts=True,
                  time_limit=DEFAULT_TIME_LIMIT, control_timestep=DEFAULT_CONTROL_TIMESTEP, auto_reset=True,
-                 env_offset=0, max_newton=12, stream=None, params=None, envs_per_wave=0, flags=0, variant=None, per_env_model=False,
+                 env_offset=0, max_newton=20, stream=None, params=None, envs_per_wave=0, flags=0, variant=None, per_env_model=False,
                  envs_per_gpu=None):
         """variant: 'auto' | 'ordinary' | 'lean' (jitterbug_amd.variants: 'auto' picks the two-waves-per-SIMD kernel from 8192 envs per
         GPU on, 16 384 with one model per env); None keeps `flags` as given (JB_FLAG_LEAN = 2 by hand).  per_env_model: the batch will get
