@@ -45,6 +45,15 @@ D = fresh().obs_dim
 obs = torch.zeros((n, D), device=dev); rew = torch.zeros((K, n), device=dev); done = torch.zeros((n,), device=dev, dtype=torch.uint8); act = torch.zeros((n,), device=dev)
 
 
+def prime(env):
+    """--brief: one step and a reset before the measured episode, on EVERY env of this run alike (the first launch of a handle has no
+    wave clocks to order its waves by; the reset after a step starts the NEXT episode, so all the runs must do it to compare bits)"""
+    if args.brief:
+        env.step_many_device(1, None if policy else tape.data_ptr())
+        env.reset_device()
+    return env
+
+
 def timed(fn):
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
@@ -53,7 +62,7 @@ def timed(fn):
     return time.perf_counter() - t0
 
 
-env = fresh()
+env = prime(fresh())
 print("kernel variant %s, %d envs per wave, actions %s" % (env.kernel_variant, env.envs_per_wave, args.actions))
 
 
@@ -73,10 +82,7 @@ print("step by step, 1000 launches (full episode):   %10.0f env-steps/s   %.4f m
 ref_rew = rew.clone()
 env.close()
 
-env = fresh()
-if args.brief:
-    env.step_many_device(1, None if policy else tape.data_ptr())          # (nothing to order the first launch by otherwise)
-    env.reset_device()
+env = prime(fresh())
 t = timed(lambda: env.step_many_device(K, None if policy else tape.data_ptr(), rewards_ptr=rew.data_ptr(), obs_last_ptr=obs.data_ptr(), done_last_ptr=done.data_ptr()))
 wc = env.wave_clocks()
 print("fused K = 1000 (full episode, one launch):    %10.0f env-steps/s   %.4f ms/step   bit-identical rewards: %s" % (n * K / t, 1e3 * t / K, bool(torch.equal(rew, ref_rew))))
@@ -84,7 +90,7 @@ print("    per-wave clocks of that launch: mean %.1f ms, median %.1f, p99 %.1f, 
     1e3 * wc.mean(), 1e3 * np.median(wc), 1e3 * np.percentile(wc, 99), 1e3 * wc.max(), wc.mean() / wc.max(), n * K / wc.mean()))
 env.close()
 
-env = fresh()
+env = prime(fresh())
 def chunks(c):
     for k0 in range(0, K, c):
         env.step_many_device(c, None if policy else tape[k0:k0 + c].data_ptr(), rewards_ptr=rew[k0:k0 + c].data_ptr(), obs_last_ptr=obs.data_ptr(), done_last_ptr=done.data_ptr())
@@ -94,7 +100,7 @@ env.close()
 
 if args.brief:
     sys.exit(0)
-env = fresh()
+env = prime(fresh())
 env.step_many_device(5, None if policy else tape[:5].data_ptr())
 t = timed(lambda: env.step_many_device(20, None if policy else tape[5:25].data_ptr(), rewards_ptr=rew[5:25].data_ptr()))
 print("fused K = 20 (steps 5-25, the driver's window): %8.0f env-steps/s   %.4f ms/step" % (n * 20 / t, 1e3 * t / 20))
