@@ -195,19 +195,89 @@ def main(argv=None):
     # JB_BENCH_FORCE_DIST=1 (under torch.distributed.run with one rank): take the N>1 code path - process group, per-step
     # gather, barrier, max-reduction - with a world of one, to exercise the real RCCL calls on a one-GPU box
     force_dist = world == 1 and os.environ.get("JB_BENCH_FORCE_DIST") == "1"
+    ctl = None                 # control group (gloo, CPU tensors): barriers, error agreement and the max over ranks never depend on RCCL being healthy
+    dist_notes = []
     if world > 1 or force_dist:
         import torch.distributed as dist
         if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)          # RCCL over xGMI
+            try:
+                dist.init_process_group("nccl", device_id=dev)          # RCCL over xGMI (device_id: the communicator is built here, errors surface here)
+                ctl = dist.new_group(backend="gloo")
+            except Exception as e:
+                # The first multi-GPU run is also RCCL's first run across real ranks here.  Without it the shards are still independent
+                # (no data-path collective is needed to advance them): time them without the row gather, over gloo, and say so.
+                dist_notes.append("RCCL process group failed (%s: %s): ranks timed WITHOUT the per-step row gather, control over gloo" % (type(e).__name__, str(e)[:200]))
+                try:
+                    dist.destroy_process_group()
+                except Exception:
+                    pass
+                dist.init_process_group("gloo")
+                args.dist_backend = "gloo-control-only"
         else:
             dist.init_process_group(args.dist_backend)
     local_rank = dev_index
+    use_gather = dist is not None and args.dist_backend != "gloo-control-only"
+
+    class RanksDisagree(RuntimeError):
+        pass
+
+    def rank_max(x):
+        t = torch.tensor([x], dtype=torch.float64)
+        if dist is not None:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=ctl)
+        return float(t.item())
+
+    def sync_point(failure=None):
+        """barrier + agreement: every rank waits here (device idle first); raises on EVERY rank if any rank brought a failure"""
+        try:
+            torch.cuda.synchronize(dev)
+        except Exception as e:
+            failure = failure or e
+        if dist is None:
+            if failure is not None:
+                raise failure
+            return
+        bad = rank_max(0.0 if failure is None else 1.0)
+        if bad:
+            raise RanksDisagree("a rank failed: %s" % (("%s: %s" % (type(failure).__name__, str(failure)[:300])) if failure is not None else "another rank"))
 
     n = args.envs_per_gpu
     D = model.OBS_DIM[task]
     K, W = args.steps, args.warmup
 
     def run(contacts, steps, warmup, gather):
+        """One timed run.  Every rank passes the same three sync points whatever happens to it, so ranks whose gather path raises (its
+        first run over real links, say) leave this run together - RanksDisagree - and nobody is left in a barrier.  (A rank that fails
+        alone INSIDE a collective still leaves the others waiting in it: that ends at the process group's timeout / the launcher's
+        watchdog, without a line.)"""
+        failure = None
+        try:
+            setup = run_setup(contacts, steps, warmup, gather)
+        except Exception as e:
+            failure, setup = e, None
+        sync_point(failure)
+        env, sh, one, drain, obs, last = setup
+        t0 = time.perf_counter()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        try:
+            ev0.record()
+            for i in range(warmup, warmup + steps):
+                one(i)
+            ev1.record()
+            drain()
+            torch.cuda.synchronize(dev)
+        except Exception as e:
+            failure = e
+        wall = time.perf_counter() - t0
+        sync_point(failure)
+        try:
+            out = run_finish(env, sh, obs, last, wall, ev0.elapsed_time(ev1))
+        except Exception as e:
+            failure, out = e, None
+        sync_point(failure)
+        return out
+
+    def run_setup(contacts, steps, warmup, gather):
         g = torch.Generator(device=dev)
         g.manual_seed(1234 + rank + 7919 * args.seed)
         actions = torch.rand((steps + warmup, n), generator=g, device=dev, dtype=torch.float32) * 2 - 1
@@ -215,6 +285,8 @@ def main(argv=None):
             actions.fill_(1.0)
         env_kw = dict(contacts=bool(contacts), max_newton=args.max_newton, envs_per_wave=args.envs_per_wave, variant=variant, per_env_model=args.augmented,
                       flags=(1 if args.no_rank_one else 0) | (8 if args.no_pair else 0) | (16 if args.no_spread else 0) | (32 if args.no_reorder else 0))
+        if gather and os.environ.get("JB_BENCH_TEST_FAIL_GATHER") == "1":          # (every rank: an error a collective reports on all of them)
+            raise RuntimeError("injected failure of the gather path on rank %d (tests/test_bench_launch.py)" % rank)
         if gather:
             # N > 1: the PRODUCT's sharded env (jitterbug_amd/distributed.py), pipelined: the step kernel writes packed rows
             # [obs | reward | done] itself and rank 0 gathers them every step over RCCL, one step late from a side stream, three row
@@ -252,25 +324,15 @@ def main(argv=None):
         for i in range(warmup):
             one(i)
         drain()
-        finite_warm = bool(torch.isfinite(sh.last_local_rows() if (sh is not None and warmup) else obs).all().item()) if warmup else True
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        t0 = time.perf_counter()
-        ev0.record()
-        for i in range(warmup, warmup + steps):
-            one(i)
-        ev1.record()
-        drain()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-        wall = time.perf_counter() - t0
-        dev_ms = ev0.elapsed_time(ev1)
+        finite_warm[0] = bool(torch.isfinite(sh.last_local_rows() if (sh is not None and warmup) else obs).all().item()) if warmup else True
+        return env, sh, one, drain, obs, last
+
+    finite_warm = [True]
+
+    def run_finish(env, sh, obs, last, wall, dev_ms):
         sc, ep, cap = env.counters()
         lastrows = sh.last_local_rows()[:, :D] if sh is not None else obs
-        finite = finite_warm and bool(torch.isfinite(lastrows).all().item())      # checked after the warm-up and after the timed steps
+        finite = finite_warm[0] and bool(torch.isfinite(lastrows).all().item())      # checked after the warm-up and after the timed steps
         finite = finite and float(cap.max()) < 1000.0                             # ... and no env ever ended a step non-finite (kernel-side flag)
         if sh is not None and rank == 0:                # the gathered block of the last step really holds every rank's rows
             ob_all, rw_all, dn_all = last[0].get()
@@ -278,13 +340,15 @@ def main(argv=None):
         env.close()
         return wall, dev_ms, float(cap.sum()), finite
 
-    def rank_max(x):
-        t = torch.tensor([x], device=dev if args.dist_backend == "nccl" else "cpu", dtype=torch.float64)
-        if dist is not None:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item())
-
-    wall, dev_ms, cap_hits, finite = run(args.contacts, K, W, gather=(dist is not None))
+    try:
+        wall, dev_ms, cap_hits, finite = run(args.contacts, K, W, gather=use_gather)
+    except RanksDisagree as e:
+        if not use_gather:
+            raise
+        # the gather path failed somewhere: the shards do not need it to advance - time them without it, and say so in the line
+        dist_notes.append("per-step row gather failed (%s): ranks timed WITHOUT it" % str(e)[:300])
+        use_gather = False
+        wall, dev_ms, cap_hits, finite = run(args.contacts, K, W, gather=False)
     wall_max = rank_max(wall)
     total_envs = n * world
     value = total_envs * K / wall_max
@@ -295,7 +359,7 @@ def main(argv=None):
     #   full_episode  0 + 1000 steps from the reset, including the in-kernel auto-reset of the last step
     steady = full_episode = None
     if not args.no_steady:
-        ws, ds, _, fs = run(args.contacts, 300, 100, gather=(dist is not None))
+        ws, ds, _, fs = run(args.contacts, 300, 100, gather=use_gather)
         ws = rank_max(ws)
         steady = {"value": total_envs * 300 / ws, "unit": "env steps/s", "ms_per_step": ws * 1e3 / 300, "launch_ms": ds / 300, "steps": 300, "warmup": 100,
                   "window": "steps 100-400 of the episode (some robots have tipped over by then; the window of profiles/r04_*)", "finite": fs}
@@ -362,7 +426,7 @@ def main(argv=None):
     # N > 1: the same fused rollout across the shards (ShardedJitterbugEnv.rollout: K steps in one launch per rank, then ONE gather of the
     # [K, N_local, D+2] blocks - a hundred times fewer, a hundred times larger collectives than the per-step path).  Next to the headline,
     # never instead of it; a failure here is recorded, it does not take the line down.
-    if not args.no_steady and dist is not None:
+    if not args.no_steady and dist is not None and use_gather:
         try:
             from jitterbug_amd.distributed import ShardedJitterbugEnv
             sh = ShardedJitterbugEnv(n * world, task, seed=args.seed, device=dev, pipeline_depth=1, variant=variant, per_env_model=args.augmented,
@@ -373,12 +437,12 @@ def main(argv=None):
             g.manual_seed(1234 + rank + 7919 * args.seed)
             tape = torch.rand((1000, n), generator=g, device=dev, dtype=torch.float32) * 2 - 1
             sh.env.reset_device()
-            dist.barrier(); torch.cuda.synchronize(dev)
+            sync_point()
             t0 = time.perf_counter()
             last = None
             for k0 in range(0, 1000, 100):
                 last = sh.rollout(100, local_actions=tape[k0:k0 + 100])
-            dist.barrier(); torch.cuda.synchronize(dev)
+            sync_point()
             wf = rank_max(time.perf_counter() - t0)
             ok = True if rank != 0 else bool(torch.isfinite(last[0]).all().item()) and last[0].shape[1] == n * world
             rollout_fused = {"k100_sharded": {"value": total_envs * 1000 / wf, "unit": "env steps/s", "ms_per_step": wf * 1e3 / 1000, "launches": 10, "steps_per_launch": 100,
@@ -481,7 +545,9 @@ def main(argv=None):
         algo_bytes = ALGO_BYTES_PER_ENV_STEP + 4 * (D - 15) + (12 if task != TASK else 0) + (202 * 4 * 4 if args.augmented else 0)
         achieved = algo_bytes * n / launch_s / 1e9
         gather_txt = ""
-        if world > 1 or dist is not None:
+        if dist is not None and not use_gather:
+            gather_txt = ", NO data-path collective in this run (the shards are independent; see dist_notes)"
+        elif world > 1 or dist is not None:
             gather_txt = ", %s gather of [N,D+2] rows to rank 0 every step, issued one step late from a side stream, three row buffers (jitterbug_amd.distributed.ShardedJitterbugEnv, pipeline_depth=2)" % ("RCCL" if args.dist_backend == "nccl" else args.dist_backend + " (rehearsal, staged through the host)")
         res = {
             "metric": "env steps/s at N_envs=%d, %s" % (n, task),
@@ -497,11 +563,11 @@ def main(argv=None):
                          "window": "the headline's: steps %d-%d of an episode from the reset (achieved / frac / launch_ms); `steady` below repeats them for steps 100-400, the window of `traffic` and `compute`" % (W, W + K),
                          "steady": None if steady is None else {"launch_ms": steady["launch_ms"], "achieved": algo_bytes * n / (steady["launch_ms"] * 1e-3) / 1e9,
                                                                   "frac": algo_bytes * n / (steady["launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "window": "steps 100-400"},
-                         "launch_ms_is": "average jb_step_kernel launch" if dist is None else "average step INCLUDING the stream waits on the row gather (N > 1 path), not the bare kernel",
+                         "launch_ms_is": "average jb_step_kernel launch" if (dist is None or not use_gather) else "average step INCLUDING the stream waits on the row gather (N > 1 path), not the bare kernel",
                          "algorithmic_bytes_per_launch": algo_bytes * n,
                          "note": "path is fp32-VALU/latency bound, not HBM bound (SURVEY.md §8d): 317 B per env step vs ~1e5-1e6 dependent flops",
                          "compute": compute, "profile": prof_note},
-            "solver_cap_hits": cap_hits, "finite": finite, "lib_sha256": lib_sha, "src_sha256": _lib.load().jb_source_sha256().decode(), "kernel_variant": used_variant[0],
+            "solver_cap_hits": cap_hits, "finite": finite, "lib_sha256": lib_sha, "src_sha256": _lib.load().jb_source_sha256().decode(), "kernel_variant": used_variant[0], "dist_notes": dist_notes,
         }
         res["window"] = "steps %d-%d of an episode from the reset" % (W, W + K)
         if steady:

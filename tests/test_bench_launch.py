@@ -129,6 +129,24 @@ def test_bench_gpus_2_starts_itself_on_one_gpu_over_gloo():
     assert d["n_gpus"] == 2 and d["config"]["global_envs"] == 8192 and d["finite"] is True and d["scaling"] == "weak"
 
 
+@pytest.mark.gpu
+def test_bench_gpus_2_a_failing_gather_falls_back_to_independent_shards():
+    """The first 8-GPU run is also the first run of the row gather across real ranks.  If the gather path raises, every rank must leave that
+    run together (no rank left behind in a barrier) and the shards are timed without the data-path collective - which they never needed
+    to advance - with the reason in the line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["JB_BENCH_DEVICE"] = "0"
+    env["JB_BENCH_TEST_FAIL_GATHER"] = "1"
+    env["JB_BENCH_LAUNCH_TIMEOUT"] = "150"
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dist-backend", "gloo", "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-steady"],
+                       capture_output=True, text=True, timeout=240, cwd=ROOT, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    d = json.loads(lines[0])
+    assert len(lines) == 1 and d["n_gpus"] == 2 and d["finite"] is True and d["value"] > 0
+    assert len(d["dist_notes"]) == 1 and "injected failure" in d["dist_notes"][0] and "NO data-path collective" in d["config"]["parallelism"]
+
+
 def test_gpus_n_parent_watchdog_kills_ranks_that_never_finish():
     """A rendezvous or collective that never completes must not hang the caller (the first 8-GPU run is also the first run of RCCL across
     real ranks): the parent kills the process group it started after JB_BENCH_LAUNCH_TIMEOUT and returns 124 without a result line."""
