@@ -350,6 +350,10 @@ __device__ __forceinline__ void step_body(KArgs a, StepIO io) {
     if (threadIdx.x == 0 && a.wave_stats) {
         unsigned long long* ws = a.wave_stats + (size_t)lblock * 16;
         ws[10] = __builtin_amdgcn_s_memrealtime() - rt_start;
+        {   // where the wave ran: [63] = workgroup index << 40 | XCC_ID << 32 | HW_ID (se, sh, cu, simd, wave slot) - tools/debug/placement.py
+            const unsigned hw = __builtin_amdgcn_s_getreg(63492), xcc = __builtin_amdgcn_s_getreg(63508);
+            a.wave_stats[(size_t)16 * a.n + (size_t)64 * lblock + 63] = ((unsigned long long)blockIdx.x << 40) | ((unsigned long long)(xcc & 0xfu) << 32) | hw;
+        }
         ws[0] = __builtin_amdgcn_s_memtime() - t_start;
         for (int i = 0; i < 5; i++) ws[4 + i] = prof_local[i]; ws[1] = (unsigned long long)s.st_xtra; ws[2] = (unsigned long long)s.st_sweeps; ws[3] = (unsigned long long)s.st_contact; ws[11] = (unsigned long long)s.st_slots; ws[15] = (unsigned long long)s.st_fast; ws[9] = (unsigned long long)s.st_checks; ws[12] = prof_local[5]; ws[13] = prof_local[6]; ws[14] = prof_local[7];
     }
@@ -478,7 +482,11 @@ __global__ __launch_bounds__(64) void jb_reward_terms_kernel(KArgs a, float* __r
 // order[0 .. n) = the waves sorted by their last measured lifetime, longest first (a 1024-bin counting sort: exact order inside a bin does
 // not matter).  One workgroup; runs on the handle's stream right after a step launch whenever the batch has more waves than the device
 // holds at once.  All-zero clocks (nothing measured yet) give the identity.
-__global__ __launch_bounds__(1024) void jb_wave_order_kernel(const unsigned long long* __restrict__ clock, int* __restrict__ order, int n) {
+// fold_from > 0 (two-waves-per-SIMD kernels whose batch fits the device at once, but only with both wave slots of some SIMDs in use): the
+// hardware gives workgroups b and b + fold_from the same SIMD (measured, tools/debug/placement.py: all 1024 SIMDs, index distance 1024),
+// so the sorted list is FOLDED: with n <= 2 fold_from waves the 2 fold_from - n longest get a SIMD to themselves, and of the others the
+// longest shares its SIMD with the shortest, the second longest with the second shortest.
+__global__ __launch_bounds__(1024) void jb_wave_order_kernel(const unsigned long long* __restrict__ clock, int* __restrict__ order, int n, int fold_from) {
     __shared__ unsigned long long s_max[1024];
     __shared__ unsigned s_bin[1024], s_pos[1024];
     const int t = threadIdx.x;
@@ -494,7 +502,14 @@ __global__ __launch_bounds__(1024) void jb_wave_order_kernel(const unsigned long
     __syncthreads();
     if (t == 0) { unsigned acc = 0; for (int k = 0; k < 1024; k++) { s_pos[k] = acc; acc += s_bin[k]; } }
     __syncthreads();
-    for (int i = t; i < n; i += 1024) order[atomicAdd(&s_pos[1023 - (int)((double)clock[i] * scale)], 1u)] = i;
+    for (int i = t; i < n; i += 1024) {
+        int p = (int)atomicAdd(&s_pos[1023 - (int)((double)clock[i] * scale)], 1u);
+        if (fold_from > 0) {      // S = fold_from SIMDs, n <= 2 S waves: the 2 S - n longest run alone, the rest pair longest with shortest
+            const int S = fold_from, alone = 2 * S - n;
+            p = p < alone ? (n - S) + p : p < S ? p - alone : S + (n - 1 - p);
+        }
+        order[p] = i;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- diagnostics
@@ -1053,6 +1068,7 @@ static int launch_step(jb_handle* h, StepIO io, int packed_rows) {
     const int variant = kernel_variant(h);
     // more waves than the device holds at once -> launch them longest first (the order comes from the previous launch's clocks)
     bool reorder = false;
+    int fold_from = 0;
     if (!(h->cfg.flags & JB_FLAG_NO_REORDER)) {
         if (h->wave_slots == 0) {
             hipDeviceProp_t prop;
@@ -1061,9 +1077,11 @@ static int launch_step(jb_handle* h, StepIO io, int packed_rows) {
         }
         const int per_simd_x2 = (variant == JB_VARIANT_LEAN || variant == JB_VARIANT_LEAN_PAIR) ? 4 : 2;      // resident waves per SIMD, times two
         reorder = (long long)grid.x * 2 > (long long)h->wave_slots * per_simd_x2;
+        // two waves per SIMD and the whole batch resident: no launch ORDER to choose, but who shares a SIMD with whom (jb_wave_order_kernel)
+        if (per_simd_x2 == 4 && (int)grid.x > h->wave_slots && !reorder) { reorder = true; fold_from = h->wave_slots; }
         if (reorder && !h->d_wave_order) {
             JB_HIP(hipMalloc(&h->d_wave_order, sizeof(int) * (size_t)h->cfg.n_envs));
-            hipLaunchKernelGGL(jb_wave_order_kernel, dim3(1), dim3(1024), 0, h->stream, h->d_wave_clock, h->d_wave_order, (int)grid.x);      // (clocks all zero: identity)
+            hipLaunchKernelGGL(jb_wave_order_kernel, dim3(1), dim3(1024), 0, h->stream, h->d_wave_clock, h->d_wave_order, (int)grid.x, fold_from);      // (clocks all zero: identity)
             JB_HIP(hipGetLastError());
         }
     }
@@ -1109,7 +1127,7 @@ static int launch_step(jb_handle* h, StepIO io, int packed_rows) {
 #undef JB_LAUNCH_PAIR
     JB_HIP(hipGetLastError());
     if (reorder) {
-        hipLaunchKernelGGL(jb_wave_order_kernel, dim3(1), dim3(1024), 0, h->stream, h->d_wave_clock, h->d_wave_order, (int)grid.x);
+        hipLaunchKernelGGL(jb_wave_order_kernel, dim3(1), dim3(1024), 0, h->stream, h->d_wave_clock, h->d_wave_order, (int)grid.x, fold_from);
         JB_HIP(hipGetLastError());
     }
     return JB_OK;

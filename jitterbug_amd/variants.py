@@ -4,18 +4,20 @@ all resolve `variant="auto"` here).
 The reference's harness builds a vectorised env with no knobs (benchmarks/benchmark.py:146-171); so does `variant="auto"`:
 
   ordinary   one four-env wave per SIMD (445 registers, 25.6 KB of LDS): the fastest kernel while a GPU holds at most one wave per SIMD
-  lean       two four-env waves per SIMD (<= 256 registers, <= 20.4 KB of LDS: eight waves per CU, JB_FLAG_LEAN): pays from 2048 waves per
-             GPU on, i.e. 8192 envs with a shared model (measured on MI355X, round 4: 8192 envs 7.50 -> 8.75 M env-steps/s per step and
-             8.8 -> 11.8 M as one fused 1000-step launch, 16 384: 8.6 -> 11.5 M, 65 536: 14.1 M).  One model per env (LEAN + PAIR kernel,
-             split tables with a per-substep overlay): from 16 384 envs on (8.2 M per step, 9.2 M in fused 100-step launches); at 8192
-             the one-wave kernel with its waves launched longest-first is ahead per step (5.55 against 5.10 M) although the LEAN kernel
-             wins as ONE fused 1000-step launch (6.76 against 5.56 M) - per step is what "auto" optimises; DESIGN.md 4
+  lean       two four-env waves per SIMD (<= 256 registers, <= 20.4 KB of LDS: eight waves per CU, JB_FLAG_LEAN): pays as soon as a GPU has
+             more waves than SIMDs, i.e. from 4097 envs with a shared model - the one-wave kernel would need a second round for the
+             rest.  While the batch still fits the device at once (up to two waves per SIMD) the library chooses WHO shares a SIMD with
+             whom: the hardware puts workgroups b and b + 1024 on one SIMD, and the launch order is folded so that the longest wave of
+             the previous launch runs alone or with the shortest (jb_wave_order_kernel).  Measured on MI355X, round 4, per step:
+             4608 envs 5.38 -> 6.47 M env-steps/s, 6144: 6.88 -> 7.73 M, 8192: 7.82 -> 9.68 M, 65 536: 14.1 M.  One model per env (LEAN +
+             PAIR kernel, split tables with a per-substep overlay): from 8192 envs on (8192: 5.95 -> 6.28 M per step with the folded
+             pairing, 12 288: 6.74 -> 7.86 M; at 6144 the one-wave kernel is still ahead, 5.36 against 4.85 M); DESIGN.md 4
 
 The two kernels agree to fp32 rounding, not bit for bit, so every shard of one batch must run the same one: a sharded env resolves
 "auto" from the GLOBAL batch and the world size (the per-GPU count every rank computes identically), never from its own shard length.
 """
-LEAN_MIN_ENVS_PER_GPU = 8192                  # shared model
-LEAN_MIN_ENVS_PER_GPU_PER_ENV_MODEL = 16384   # one model per env (LEAN + PAIR kernel, split constant tables)
+LEAN_MIN_ENVS_PER_GPU = 4097                  # shared model: more envs than one four-env wave per SIMD holds (1024 SIMDs)
+LEAN_MIN_ENVS_PER_GPU_PER_ENV_MODEL = 8192    # one model per env (LEAN + PAIR kernel, split constant tables)
 FLAG_LEAN = 2                                 # include/jitterbug_hip.h JB_FLAG_LEAN
 VARIANTS = ("auto", "ordinary", "lean")
 

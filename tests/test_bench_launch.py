@@ -97,8 +97,8 @@ def test_bench_line_names_the_baseline_workload_and_the_loaded_library():
 
 @pytest.mark.gpu
 def test_bench_resolves_the_kernel_variant_in_the_product_and_reports_the_one_launched():
-    """No threshold lives in bench.py: `variant="auto"` is resolved by jitterbug_amd.variants (8192 envs per GPU -> the two-waves-per-SIMD
-    kernel), and the line reports jb_kernel_variant of the handle that was timed."""
+    """No threshold lives in bench.py: `variant="auto"` is resolved by jitterbug_amd.variants (more than 4096 envs per GPU -> the two-waves-per-SIMD
+    kernel; one model per env: from 8192), and the line reports jb_kernel_variant of the handle that was timed."""
     src = open(BENCH).read()
     assert "8192" not in src.split("def main")[1].split("import numpy")[0] and "16384" not in src.split("def main")[1].split("import numpy")[0]
     p = subprocess.run([sys.executable, BENCH, "--envs-per-gpu", "8192", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-also", "--no-host-rate", "--no-steady"],
@@ -107,6 +107,11 @@ def test_bench_resolves_the_kernel_variant_in_the_product_and_reports_the_one_la
     d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
     assert d["kernel_variant"] == "lean" and "LEAN kernel variant" in d["config"]["workload"] and d["finite"] is True
     p = subprocess.run([sys.executable, BENCH, "--envs-per-gpu", "8192", "--augmented", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-also", "--no-host-rate", "--no-steady"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    assert d["kernel_variant"] == "lean_pair" and "LEAN + PAIR kernel variant" in d["config"]["workload"] and d["finite"] is True
+    p = subprocess.run([sys.executable, BENCH, "--envs-per-gpu", "2048", "--augmented", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-also", "--no-host-rate", "--no-steady"],
                        capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-2000:]
     d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])

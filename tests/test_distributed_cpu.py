@@ -114,7 +114,7 @@ def _variant_worker(rank, world, port, q):
             self.n, self.off = n, off
 
     out = []
-    for n_global, kw in ((16383, {}), (16383, dict(per_env_model=True)), (16380, {}), (32768, dict(per_env_model=True)), (16383, dict(variant="ordinary"))):
+    for n_global, kw in ((8193, {}), (16383, dict(per_env_model=True)), (8192, {}), (16382, dict(per_env_model=True)), (8193, dict(variant="ordinary"))):
         env = ShardedJitterbugEnv(n_global, "move_from_origin", local_env_factory=lambda n, off: Stub(n, off), **kw)
         out.append((n_global, tuple(sorted(kw.items())), env.n_local, env.variant))
     q.put((rank, out))
@@ -124,8 +124,8 @@ def _variant_worker(rank, world, port, q):
 
 @pytest.mark.timeout(300)
 def test_every_rank_resolves_the_same_kernel_variant_gloo():
-    """variant='auto' is resolved from the GLOBAL batch and the world size, never from a rank's own shard length: with 16 383 envs on two
-    ranks (8192 + 8191) a per-shard rule would run the LEAN kernel on rank 0 and the ordinary one on rank 1 - two roundings in one
+    """variant='auto' is resolved from the GLOBAL batch and the world size, never from a rank's own shard length: with 8193 envs on two
+    ranks (4097 + 4096) a per-shard rule would run the LEAN kernel on rank 0 and the ordinary one on rank 1 - two roundings in one
     batch.  (The reference's harness builds its vec env with no knobs: benchmarks/benchmark.py:146-171.)"""
     import torch.multiprocessing as mp
     from jitterbug_amd import variants
@@ -141,11 +141,11 @@ def test_every_rank_resolves_the_same_kernel_variant_gloo():
         p.join(60)
         assert p.exitcode == 0
     r0, r1 = got[0], got[1]
-    assert [x[3] for x in r0] == [x[3] for x in r1] == ["lean", "ordinary", "ordinary", "lean", "ordinary"]
-    assert r0[0][2] == 8192 and r1[0][2] == 8191          # ... although the shards straddle the threshold
+    assert [x[3] for x in r0] == [x[3] for x in r1] == ["lean", "lean", "ordinary", "ordinary", "ordinary"]
+    assert r0[0][2] == 4097 and r1[0][2] == 4096 and r0[1][2] == 8192 and r1[1][2] == 8191          # ... although the shards straddle the thresholds
     # the thresholds themselves, in the one place they live
-    assert variants.resolve("auto", 8191) == "ordinary" and variants.resolve("auto", 8192) == "lean"
-    assert variants.resolve("auto", 16383, per_env_model=True) == "ordinary" and variants.resolve("auto", 16384, per_env_model=True) == "lean"
+    assert variants.resolve("auto", 4096) == "ordinary" and variants.resolve("auto", 4097) == "lean"
+    assert variants.resolve("auto", 8191, per_env_model=True) == "ordinary" and variants.resolve("auto", 8192, per_env_model=True) == "lean"
     assert variants.flags_for("lean", 64, flags=8) == 10 and variants.flags_for("ordinary", 10 ** 6, flags=2 | 16) == 16
     with pytest.raises(ValueError):
         variants.resolve("fast", 64)

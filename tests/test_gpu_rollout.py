@@ -189,18 +189,22 @@ def test_step_many_argument_checks_and_variant_refusals():
         env.close()
 
 
+@pytest.mark.parametrize("layout,n,lean", [("one-wave-two-rounds", 8192, False), ("two-waves-folded", 8192, True), ("two-waves-folded-ragged", 6004, True)],
+                         ids=["one-wave-two-rounds", "two-waves-folded", "two-waves-folded-ragged"])
 @pytest.mark.parametrize("randomise", [False, True], ids=["nominal", "per-env-models"])
-def test_longest_first_wave_order_does_not_change_a_single_bit(randomise):
+def test_longest_first_wave_order_does_not_change_a_single_bit(randomise, layout, n, lean):
     """A batch with more waves than the device holds at once (8192 envs = 2048 four-env waves on 1024 SIMDs) launches its waves
-    longest-first, by the wave times the previous launch measured (jb_wave_order_kernel); JB_FLAG_NO_REORDER keeps the plain order.
+    longest-first, by the wave times the previous launch measured (jb_wave_order_kernel); the two-waves-per-SIMD kernels, while the batch
+    still fits the device at once, FOLD that order so that the longest wave shares its SIMD with the shortest (workgroups b and b + 1024
+    land on one SIMD), 6004 envs: 477 waves keep a SIMD to themselves; JB_FLAG_NO_REORDER keeps the plain order.
     Which workgroup steps which envs must never show in the results: single steps and a fused rollout, bit for bit."""
     from jitterbug_amd import _lib
     from jitterbug_amd.vec_env import JitterbugVecEnv
     torch = _torch()
     dev = torch.device("cuda", 0)
-    n, K = 8192, 24
-    a = JitterbugVecEnv(n, "move_to_pose", seed=13, time_limit=0.2)
-    b = JitterbugVecEnv(n, "move_to_pose", seed=13, time_limit=0.2, flags=_lib.FLAG_NO_REORDER)
+    K = 24
+    a = JitterbugVecEnv(n, "move_to_pose", seed=13, time_limit=0.2, flags=_lib.FLAG_LEAN if lean else 0)
+    b = JitterbugVecEnv(n, "move_to_pose", seed=13, time_limit=0.2, flags=_lib.FLAG_NO_REORDER | (_lib.FLAG_LEAN if lean else 0))
     try:
         if randomise:
             a.randomise_models(seed=2, return_params=False); b.randomise_models(seed=2, return_params=False)
@@ -219,6 +223,7 @@ def test_longest_first_wave_order_does_not_change_a_single_bit(randomise):
         assert np.array_equal(bits(rows_a), bits(rows_b)) and same_state(a, b)
         wa, wb = a.wave_clocks(), b.wave_clocks()
         assert wa.shape == wb.shape == (n // 4,) and (wa > 0).all() and (wb > 0).all()
+        assert a.kernel_variant == b.kernel_variant == (("lean_pair" if randomise else "lean") if lean else ("pair" if randomise else "ordinary"))
     finally:
         a.close(); b.close()
 
