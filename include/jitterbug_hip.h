@@ -62,7 +62,7 @@ typedef struct jb_handle jb_handle;
 #define JB_FLAG_LEAN        2   /* the two-waves-per-SIMD kernel variant (<= 256 registers and 20 KB of LDS per four-env wave; state / system /
                                   factorisation parked in LDS).  It agrees with the ordinary kernel to fp32 rounding, NOT bit for bit (the
                                   compiler fuses multiply-adds differently in the two instantiations): give every shard of one batch the
-                                  same flag.  Pays when a GPU holds >= 2048 four-env waves (8192 envs; one model per env: 16 384), see
+                                  same flag.  Pays when a GPU holds more four-env waves than SIMDs (> 4096 envs; one model per env: from 8192), see
                                   jitterbug_amd.variants / DESIGN.md 4.  A combination it cannot run (a model that needs the pair contact
                                   unless that is one model per env at 4 envs per wave) is refused with JB_E_INVALID, never run silently as
                                   the ordinary kernel; jb_kernel_variant() reports what a handle launches */

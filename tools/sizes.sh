@@ -1,6 +1,6 @@
 #!/bin/bash
 # Throughput of the current build at the other BASELINE sizes / modes (run on the GPU box): tools/sizes.sh > gpurun_out/r03_sizes.txt
-# (the product picks the LEAN kernel variant from 8192 envs per GPU on - jitterbug_amd.variants; --no-lean is the ordinary kernel on the same batch)
+# (the product picks the LEAN kernel variant above 4096 envs per GPU, with one model per env from 8192 - jitterbug_amd.variants; --no-lean is the one-wave kernel on the same batch)
 # Second part: the same sizes as fused rollouts (tools/rollout_bench.py --brief: step by step / one 1000-step launch / ten 100-step launches).
 run() { python bench.py --steps 300 --warmup 50 --no-cpu-baseline --no-also --no-host-rate --no-steady "$@" 2>/dev/null | python -c "
 import sys, json
@@ -8,6 +8,8 @@ d = json.loads(sys.stdin.read().strip().split('\n')[-1]); print('%-70s %10.0f en
 run
 run --contacts 0
 run --task move_to_pose
+run --envs-per-gpu 6144 --no-lean
+run --envs-per-gpu 6144
 run --envs-per-gpu 8192 --no-lean
 run --envs-per-gpu 8192
 run --envs-per-gpu 16384 --no-lean
@@ -17,6 +19,7 @@ run --envs-per-gpu 65536
 run --task move_to_pose --envs-per-gpu 32768 --no-lean
 run --task move_to_pose --envs-per-gpu 32768
 run --augmented --envs-per-gpu 8192 --task move_to_pose
+run --augmented --envs-per-gpu 8192 --task move_to_pose --no-lean
 run --augmented --envs-per-gpu 8192 --task move_to_pose --no-pair
 run --augmented --envs-per-gpu 4096
 run --actions const1
