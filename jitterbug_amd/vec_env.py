@@ -58,8 +58,8 @@ class JitterbugVecEnv:
                  time_limit=DEFAULT_TIME_LIMIT, control_timestep=DEFAULT_CONTROL_TIMESTEP, auto_reset=True,
                  env_offset=0, max_newton=20, stream=None, params=None, envs_per_wave=0, flags=0, variant=None, per_env_model=False,
                  envs_per_gpu=None):
-        """variant: 'auto' | 'ordinary' | 'lean' (jitterbug_amd.variants: 'auto' picks the two-waves-per-SIMD kernel from 8192 envs per
-        GPU on, 16 384 with one model per env); None keeps `flags` as given (JB_FLAG_LEAN = 2 by hand).  per_env_model: the batch will get
+        """variant: 'auto' | 'ordinary' | 'lean' (jitterbug_amd.variants: 'auto' picks the two-waves-per-SIMD kernel above 4096 envs per
+        GPU, from 8192 with one model per env); None keeps `flags` as given (JB_FLAG_LEAN = 2 by hand).  per_env_model: the batch will get
         one model per env (randomise_models / set_model_params with N tables) - 'auto' needs to know at creation.  envs_per_gpu: what
         'auto' is resolved from when this env is one shard of a larger batch (every shard must make the same choice); default n_envs."""
         if task not in TASKS:
