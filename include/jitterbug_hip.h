@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define JB_ABI_VERSION 3
+#define JB_ABI_VERSION 4
 
 #define JB_OK            0
 #define JB_E_INVALID    -1   /* bad argument */
@@ -87,7 +87,7 @@ typedef struct jb_config {
     int32_t  step_limit;    /* control steps per episode (reference: 10/(0.0002*50) = 1000) */
     int32_t  auto_reset;    /* 1: VecEnv semantics - an env that reports done is reset inside the
                                   same call and its returned observation is the new episode's first */
-    int32_t  max_newton;    /* cap on contact-solver iterations per substep (0 -> default 20; from the sixth on every second one is a half step, jb_sim.hpp "cycle breaker") */
+    int32_t  max_newton;    /* checks of the active set per substep after which the contact problem goes to the line-searched Newton solve (0 -> default 12; jb_sim.hpp newton_phase) */
     int32_t  use_caller_stream; /* 1: launch on `stream` below even when it is NULL (the legacy default stream) */
     int32_t  envs_per_wave; /* environments per 64-lane wavefront (4 lanes each): 1, 2, 4 or 8 (larger requests run as 8), 0 = choose so that the batch
                                spreads over all SIMDs of the device (small batches use partially filled waves) */
@@ -109,9 +109,14 @@ int jb_step(jb_handle* h, const float* action /*[N]*/, float* obs_out /*[N,D]*/,
 int jb_observe(jb_handle* h, float* obs_out /*[N,D]*/, float* reward_out /*[N] nullable*/);
 int jb_get_state(jb_handle* h, double* qpos /*[N,16]*/, double* qvel /*[N,15]*/, double* target /*[N,3]*/);
 int jb_set_state(jb_handle* h, const double* qpos, const double* qvel, const double* target);   /* any may be NULL = keep */
-/* solver_cap_hits: +1 for every substep whose Newton iteration hit max_newton, +1000 for every control step that ended in a
- * non-finite state (never expected; the env stays non-finite until its next reset) - cumulative over the handle's life */
+/* solver_cap_hits: +1 for every substep whose contact solve did NOT converge - neither the active-set iteration within max_newton checks
+ * nor the line-searched Newton solve that takes over then (never expected: MuJoCo's own solver, reference jitterbug.xml:18 defaults) -,
+ * +1000 for every control step that ended in a non-finite state (never expected; the env stays non-finite until its next reset) -
+ * cumulative over the handle's life */
 int jb_get_counters(jb_handle* h, int32_t* step_count /*[N]*/, uint32_t* episode /*[N]*/, float* solver_cap_hits /*[N]*/);
+/* how often the plain active-set iteration did not settle within max_newton checks and the substep's contact problem was solved again with
+ * the exact line search: wave-substeps (a wave = jb_envs_per_wave envs) since jb_create - a few in ten million */
+int jb_solver_stats(jb_handle* h, uint64_t* resolved_wave_substeps);
 /* n_tables is 1 (shared) or N (one table per env); each table is JB_NPARAM doubles (jitterbug_model.h) */
 int jb_set_model_params(jb_handle* h, const double* params, int32_t n_tables);
 

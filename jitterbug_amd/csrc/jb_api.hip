@@ -30,6 +30,10 @@
 
 using namespace jb;
 
+#ifndef JB_DEFAULT_MAX_NEWTON
+#define JB_DEFAULT_MAX_NEWTON 12      // checks of the active set after which a substep's contact problem goes to the line-searched solve (jb_sim.hpp newton_phase)
+#endif
+
 namespace {
 
 enum RootF : int { RF_P = 0, RF_Q = 3, RF_V = 7, RF_W = 10, RF_PHI = 13, RF_PHID = 14, RF_TURNS = 15, RF_WA = 16, RF_WL = 19, RF_WM = 22, RF_FAIL = 23, RF_TGT = 24, RF_LO = 27 /*5: low-order words of z and the quaternion*/, ROOT_F = 32 };
@@ -48,6 +52,8 @@ struct KArgs {
     int* step_count; unsigned* episode;
     float* ovc_buf;    // LEAN variant: per wave, the candidates of the live slots beyond the row cache (global memory: the variant's 20 KB of LDS have no room)
     unsigned long long* wave_stats;   // diagnostic builds (-DJB_WAVE_STATS): [n_waves][4] = cycles, rare-path substeps, Newton sweeps, contact substeps
+    float* capture; unsigned* capture_count;      // diagnostic builds (-DJB_CAPTURE): SimOpts::capture
+    unsigned long long* resolve_count;   // [1]: wave-substeps whose contact solve ran a second time with the exact line search (jb_sim.hpp newton_phase), since jb_create
 };
 
 // What one launch of a step kernel reads and writes besides the state: K control steps in ONE launch (jb_step_many_device; K = 1 is the
@@ -257,6 +263,9 @@ __device__ __forceinline__ void step_body(KArgs a, StepIO io) {
     s.st_xtra = 0.f; s.st_sweeps = 0.f; s.st_contact = 0.f; s.st_slots = 0.f; s.st_fast = 0.f; s.st_checks = 0.f;
 #endif
     SimOpts o; o.contacts = a.contacts; o.max_newton = a.max_newton; o.implicit_damp = 1; o.rank_one = a.rank_one; o.lean = LEAN ? 1 : 0; o.offload = OFFLOAD ? 1 : 0; o.spread = a.spread; o.prof = nullptr; o.hist = nullptr;
+#ifdef JB_CAPTURE
+    o.capture = a.capture; o.capture_count = a.capture_count;
+#endif
 #ifdef JB_WAVE_STATS
     const unsigned long long rt_start = __builtin_amdgcn_s_memrealtime();
     unsigned long long prof_local[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // accumulated in registers, written once at the end
@@ -304,7 +313,11 @@ __device__ __forceinline__ void step_body(KArgs a, StepIO io) {
         if (PAIR && rep) scr.st(scr.pd + 11, 0.f);      // the narrow phase starts cold in every control step (its warm start is not simulator state)
         if (LEAN && grp == 0) state_store(scr, s);                   // LEAN: the state lives in the scratch between substeps
 #pragma unroll 1
-        for (int i = 0; i < n_substeps; i++) substep<float, PAIR>(m, scr, s, ctrl, o);
+        for (int i = 0; i < n_substeps; i++) {
+            if (__builtin_expect(substep<float, PAIR>(m, scr, s, ctrl, o), false)) {      // rare (a few substeps in ten million): counted for jb_solver_stats
+                if (threadIdx.x == 0) atomicAdd(((KArgsC)kernarg_base())->resolve_count, 1ull);
+            }
+        }
         const auto kb = kernarg_base();
         const KArgsC ka = (KArgsC)kb;
         const StepIOC ic = (StepIOC)(kb + STEPIO_KERNARG_OFFSET);
@@ -668,6 +681,8 @@ struct jb_handle {
     double *d_qpos, *d_qvel, *d_target;
     unsigned long long* d_wave_stats;
     unsigned long long* d_wave_clock;
+    unsigned long long* d_resolve;    // [1]: KArgs::resolve_count
+    float* d_capture; unsigned* d_capture_count;      // diagnostic builds (-DJB_CAPTURE)
     int* d_wave_order;               // launch order of the waves (jb_wave_order_kernel), null while the device holds the whole batch at once
     int wave_slots;                  // waves the device holds at once with this handle's kernel variant
     size_t model_tables;
@@ -848,7 +863,7 @@ int jb_default_config(jb_config* cfg, int32_t n_envs, int32_t task_id) {
     if (!cfg) return fail(JB_E_INVALID, "cfg is NULL");
     std::memset(cfg, 0, sizeof *cfg);
     cfg->n_envs = n_envs; cfg->task_id = task_id; cfg->device_id = 0; cfg->random_pose = 1; cfg->contacts = 1;
-    cfg->substeps = 50; cfg->step_limit = 1000; cfg->auto_reset = 1; cfg->max_newton = 20; cfg->seed = 0; cfg->env_offset = 0; cfg->stream = nullptr;
+    cfg->substeps = 50; cfg->step_limit = 1000; cfg->auto_reset = 1; cfg->max_newton = JB_DEFAULT_MAX_NEWTON; cfg->seed = 0; cfg->env_offset = 0; cfg->stream = nullptr;
     return JB_OK;
 }
 
@@ -870,6 +885,13 @@ static int create_impl(jb_handle* h) {      // every failure returns through jb_
     JB_HIP(hipMalloc(&h->d_qvel, sizeof(double) * 15 * N));
     JB_HIP(hipMalloc(&h->d_target, sizeof(double) * 3 * N));
     JB_HIP(hipMalloc(&h->d_terms, sizeof(float) * 4 * N));
+    JB_HIP(hipMalloc(&h->d_resolve, sizeof(unsigned long long)));
+#ifdef JB_CAPTURE
+    JB_HIP(hipMalloc(&h->d_capture, sizeof(float) * 64 * JB_CAPTURE_SLOTS));
+    JB_HIP(hipMalloc(&h->d_capture_count, sizeof(unsigned)));
+    JB_HIP(hipMemsetAsync(h->d_capture_count, 0, sizeof(unsigned), h->stream));
+#endif
+    JB_HIP(hipMemsetAsync(h->d_resolve, 0, sizeof(unsigned long long), h->stream));
 #ifdef JB_WAVE_STATS
     JB_HIP(hipMalloc(&h->d_wave_stats, sizeof(unsigned long long) * (size_t)(16 + 64) * N));
     JB_HIP(hipMemset(h->d_wave_stats, 0, sizeof(unsigned long long) * (size_t)(16 + 64) * N));
@@ -900,7 +922,7 @@ static int create_impl(jb_handle* h) {      // every failure returns through jb_
         if (k.lean) { if (cfg->envs_per_wave <= 0) epw = 4; if (epw > 4) epw = 4; }     // LEAN: 4 envs per wave, 20 KB of LDS each: 8 waves per CU, two per SIMD
         k.epw = epw;
     }
-    k.root = h->d_root; k.leg = h->d_leg; k.step_count = h->d_step; k.episode = h->d_episode; k.wave_stats = h->d_wave_stats;
+    k.root = h->d_root; k.leg = h->d_leg; k.step_count = h->d_step; k.episode = h->d_episode; k.wave_stats = h->d_wave_stats; k.resolve_count = h->d_resolve; k.capture = h->d_capture; k.capture_count = h->d_capture_count;
     {   // the step kernels read part of their arguments through the kernarg segment: make sure that layout is what they assume (once per process)
         static int probed = 0;
         if (!probed) {
@@ -941,7 +963,7 @@ int jb_create(const jb_config* cfg, jb_handle** out) {
     if (!h) return fail(JB_E_INVALID, "out of host memory");
     std::memset(h, 0, sizeof *h);
     h->cfg = *cfg;
-    if (h->cfg.max_newton <= 0) h->cfg.max_newton = 20;
+    if (h->cfg.max_newton <= 0) h->cfg.max_newton = JB_DEFAULT_MAX_NEWTON;
     h->D = obs_dim(cfg->task_id);
     h->policy = default_policy_params<float>();
     const int rc = create_impl(h);
@@ -961,7 +983,7 @@ int jb_destroy(jb_handle* h) {
     guard.enter(h->cfg.device_id);
     if (h->stream || !h->own_stream) hipStreamSynchronize(h->stream);
     if (h->comm && g_rccl.CommDestroy) { g_rccl.CommDestroy(h->comm); h->comm = nullptr; }
-    void* bufs[] = {h->d_wave_order, h->d_wave_clock, h->d_ovc, h->d_terms, h->d_spec, h->d_root, h->d_leg, h->d_model, h->d_step, h->d_episode, h->d_action, h->d_obs, h->d_reward, h->d_done, h->d_mask, h->d_qpos, h->d_qvel, h->d_target, h->d_wave_stats, h->d_enc_params, h->d_code};
+    void* bufs[] = {h->d_capture, h->d_capture_count, h->d_resolve, h->d_wave_order, h->d_wave_clock, h->d_ovc, h->d_terms, h->d_spec, h->d_root, h->d_leg, h->d_model, h->d_step, h->d_episode, h->d_action, h->d_obs, h->d_reward, h->d_done, h->d_mask, h->d_qpos, h->d_qvel, h->d_target, h->d_wave_stats, h->d_enc_params, h->d_code};
     for (void* b : bufs) if (b) hipFree(b);
     if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
     delete h;
@@ -1344,6 +1366,28 @@ int jb_get_counters(jb_handle* h, int32_t* step_count, uint32_t* episode, float*
     if (solver_cap_hits) JB_HIP(hipMemcpy(solver_cap_hits, h->d_root + RF_FAIL * N, sizeof(float) * N, hipMemcpyDeviceToHost));
     return JB_OK;
 }
+// how often the contact solve needed its second, line-searched pass: wave-substeps since jb_create (jb_sim.hpp newton_phase<LS = true>)
+int jb_solver_stats(jb_handle* h, uint64_t* resolved_wave_substeps) {
+    if (!h || !resolved_wave_substeps) return fail(JB_E_INVALID, "handle/out is NULL");
+    JB_ENTER(h);
+    JB_HIP(hipStreamSynchronize(h->stream));
+    unsigned long long v = 0;
+    JB_HIP(hipMemcpy(&v, h->d_resolve, sizeof v, hipMemcpyDeviceToHost));
+    *resolved_wave_substeps = (uint64_t)v;
+    return JB_OK;
+}
+#ifdef JB_CAPTURE
+// diagnostic builds only: the captured records (SimOpts::capture), out[max_records][64]; returns how many substeps stayed unconverged
+int jb_debug_captured(jb_handle* h, float* out, int32_t max_records) {
+    if (!h || !out) return fail(JB_E_INVALID, "NULL");
+    JB_HIP(hipStreamSynchronize(h->stream));
+    unsigned n = 0;
+    JB_HIP(hipMemcpy(&n, h->d_capture_count, sizeof n, hipMemcpyDeviceToHost));
+    const int m = (int)n < max_records ? (int)n : max_records;
+    JB_HIP(hipMemcpy(out, h->d_capture, sizeof(float) * 64 * (size_t)(m < JB_CAPTURE_SLOTS ? m : JB_CAPTURE_SLOTS), hipMemcpyDeviceToHost));
+    return (int)n;
+}
+#endif
 #ifdef JB_WAVE_STATS
 // diagnostic builds only: per-wave [cycles, rare-path substeps, Newton sweeps, contact substeps] of the last step launch
 int jb_debug_wave_stats(jb_handle* h, unsigned long long* out, int32_t n_waves) {

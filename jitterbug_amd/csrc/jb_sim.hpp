@@ -31,6 +31,9 @@
 // motor accel (1, replicated)].
 #pragma once
 #include <type_traits>
+#if !defined(__HIPCC__)
+#include <cstdio>      // (host harness: trace of the line-searched solve)
+#endif
 
 #include "jb_lane.hpp"
 
@@ -359,6 +362,10 @@ template <typename V> JB_HD typename lane_traits<V>::uint group_sum_u(const Lane
     else if (sc.ngrp == 2) x = xor_sum_u(x, sc.gstride, false);
     return x;
 }
+// Line search (newton_phase<LS = true>): where the main lanes leave the direction (9 floats) and the trial step for the sweeps of every lane
+// group - the reduction hand-over, or in the LEAN layout the head of the kept factorisation (dead there: the line-searched iteration makes
+// no rank-one passes).
+template <typename V> JB_HD int ls_mailbox(const LaneScratch<V>& sc) { return sc.red_lds ? (int)SC_RED : (int)SC_FAC; }
 JB_HD constexpr int tri(int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
 
 // Accumulator of the contact terms of the Newton system for the lane (everything here is ADDED to M / tau,
@@ -372,7 +379,11 @@ template <typename V> struct NewtonAcc {
     V rr[6], rl[2], rm;      // additive rhs parts
     typename lane_traits<V>::uint bw0, bw1;   // active-set records of the leg slots: 5 bits (4 pyramid edges + valid) each, exact; bw0: slots 0-4, bw1: slots 5-9
     typename lane_traits<V>::uint xh;      // polynomial hash of the records of the rarely-evaluated slots (lane-private, never summed across lanes)
+    V ls_g, ls_h, ls_a;      // line search (sweeps of mode 3): sums over this lane's contacts and pyramid edges of D min(0, r + alpha s) s, of D s^2 over the
+                             // edges active at alpha, and of |D r s| over the edges active at alpha (the size of the terms phi' is a difference of)
 };
+// direction and step of the line search, handed to the sweeps of mode 3
+template <typename V> struct LineDir { V dr[6], dl[2], dm, alpha; };
 template <typename V> JB_HD void acc_clear(NewtonAcc<V>& acc) {
 #pragma unroll
     for (int i = 0; i < 21; i++) acc.A[i] = V(0);
@@ -641,11 +652,28 @@ template <typename V> JB_HD void row_load(const LaneScratch<V>& sc, int entry, R
     for (int k = 0; k < 3; k++) { r.jsh[k] = sc.ld(e0 + 4 + k); r.j7[k] = sc.ld(e0 + 7 + k); r.ah[k] = sc.ld(e0 + 10 + k); }
 }
 
+// the share of one contact (residuals rho at y, slopes sg along the direction; weight D) in phi'(alpha), phi''(alpha) of the line search
+template <typename V>
+JB_HD void line_terms(const V& D, const V& mu, const V (&rho)[3], const V (&sg)[3], const V& alpha, NewtonAcc<V>& acc) {
+    const V mr1 = mu * rho[1], mr2 = mu * rho[2], ms1 = mu * sg[1], ms2 = mu * sg[2];
+    const V r[4] = {rho[0] + mr1, rho[0] - mr1, rho[0] + mr2, rho[0] - mr2}, sv[4] = {sg[0] + ms1, sg[0] - ms1, sg[0] + ms2, sg[0] - ms2};
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        const V ra = r[e] + alpha * sv[e];
+        const auto on = lt(ra, V(0));
+        const V t = D * ra * sv[e];
+        acc.ls_g = acc.ls_g + sel(on, t, V(0));
+        acc.ls_h = acc.ls_h + sel(on, D * sv[e] * sv[e], V(0));
+        acc.ls_a = acc.ls_a + sel(on, vabs(t), V(0));
+    }
+}
+
 // One cached contact against the iterate y.  mode 0: accumulate the Newton matrix / rhs terms for the active set at y;
-// mode 2: only record the active set (the cheap convergence check).
-template <typename V, bool PAIR = false>
+// mode 2: only record the active set (the cheap convergence check); mode 3 (LS instantiations only): the contact's share of the
+// line search's phi' and phi'' at y + ld->alpha * (ld's direction).
+template <typename V, bool PAIR = false, bool LS = false>
 JB_HD void contact_apply(const RowVals<V>& rv, const Vec3<V> (&dk)[3], const V& mu, int slot, bool lane_on, int mode,
-                         const V (&yr)[6], const V (&yl)[2], const V& ym, NewtonAcc<V>& acc) {
+                         const V (&yr)[6], const V (&yl)[2], const V& ym, NewtonAcc<V>& acc, const LineDir<V>* ld = nullptr) {
     using U = typename lane_traits<V>::uint;
     const int level = slot_level(slot);
     const bool is_pair = PAIR && level == 4;
@@ -673,6 +701,19 @@ JB_HD void contact_apply(const RowVals<V>& rv, const Vec3<V> (&dk)[3], const V& 
         rho[k] = t + Bj[k][7] * y7;
     }
     const auto valid = gt(D, V(0));
+    if (LS && mode == 3) {
+        const V d7 = has_kn ? ld->dl[1] : ld->dm;
+        V sg[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            V t = Bj[k][0] * ld->dr[0];
+            t = t + Bj[k][1] * ld->dr[1]; t = t + Bj[k][2] * ld->dr[2]; t = t + Bj[k][3] * ld->dr[3]; t = t + Bj[k][4] * ld->dr[4]; t = t + Bj[k][5] * ld->dr[5];
+            t = t + Bj[k][6] * ld->dl[0];
+            sg[k] = t + Bj[k][7] * d7;
+        }
+        line_terms<V>(D, mu, rho, sg, ld->alpha, acc);
+        return;
+    }
     // pyramid edges  r = rho_n +- mu rho_t
     V mr1 = mu * rho[1], mr2 = mu * rho[2];
     auto a1 = lt(rho[0] + mr1, V(0)), a2 = lt(rho[0] - mr1, V(0)), a3 = lt(rho[0] + mr2, V(0)), a4 = lt(rho[0] - mr2, V(0));
@@ -799,9 +840,9 @@ template <typename V> JB_HD typename lane_traits<V>::uint quad_seg_sum_u(const t
 // One cached contact of a LEG slot (0-9) of leg `it.src` of this lane's env against the iterate (spread sweeps).  The arithmetic of
 // contact_apply for a lower-leg slot: an upper-leg slot's cached knee column is zero, so its extra terms add zeros.  yl: the joint part
 // of the iterate of leg it.src.
-template <typename V>
+template <typename V, bool LS = false>
 JB_HD void contact_apply_leg(const RowVals<V>& rv, const Vec3<V> (&dk)[3], const V& mu, const SpreadItem<V>& it, int mode,
-                             const V (&yr)[6], const V (&yl)[2], NewtonAcc<V>& acc) {
+                             const V (&yr)[6], const V (&yl)[2], NewtonAcc<V>& acc, const LineDir<V>* ld = nullptr, const V* dls = nullptr) {
     using U = typename lane_traits<V>::uint;
     using MK = typename lane_traits<V>::mask;
     V Bj[3][8], rho[3], ahat[3];
@@ -823,6 +864,18 @@ JB_HD void contact_apply_leg(const RowVals<V>& rv, const Vec3<V> (&dk)[3], const
         rho[k] = t + Bj[k][7] * yl[1];
     }
     const MK valid = gt(D, V(0));
+    if (LS && mode == 3) {      // line search (see contact_apply); dls: the joint part of the direction for leg it.src
+        V sg[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            V t = Bj[k][0] * ld->dr[0];
+            t = t + Bj[k][1] * ld->dr[1]; t = t + Bj[k][2] * ld->dr[2]; t = t + Bj[k][3] * ld->dr[3]; t = t + Bj[k][4] * ld->dr[4]; t = t + Bj[k][5] * ld->dr[5];
+            t = t + Bj[k][6] * dls[0];
+            sg[k] = t + Bj[k][7] * dls[1];
+        }
+        line_terms<V>(D, mu, rho, sg, ld->alpha, acc);
+        return;
+    }
     V mr1 = mu * rho[1], mr2 = mu * rho[2];
     auto a1 = lt(rho[0] + mr1, V(0)), a2 = lt(rho[0] - mr1, V(0)), a3 = lt(rho[0] + mr2, V(0)), a4 = lt(rho[0] - mr2, V(0));
     // whose leg is it?  tags of the quad's four lanes against this lane's position
@@ -1068,7 +1121,7 @@ JB_HD void contact_rows_build_all(const LaneModel<V>& m, const LaneScratch<V>& s
 // every live candidate slot against the iterate y kept in the scratch (SC_Y); with helper groups the partial sums of the
 // groups are combined by cross-lane exchanges so that every group ends with the complete accumulator
 // (returns the number of spread rounds it made: diagnostics only)
-template <typename V, bool PAIR = false>
+template <typename V, bool PAIR = false, bool LS = false>
 JB_HD int contact_sweep(const LaneModel<V>& m, const LaneScratch<V>& sc, bool xtra, const SlotPlan& plan, const SpreadPlan<V>& sp, int mode, const Vec3<V> (&dk)[3], NewtonAcc<V>& acc, const bool zero_g1 = false) {
     // zero_g1 (SimOpts::offload): group 1 must leave with an all-zero accumulator - it factorises M + h diag(b)
     // with the instruction stream that factorises the main lanes' Newton system (substep_impl)
@@ -1076,7 +1129,15 @@ JB_HD int contact_sweep(const LaneModel<V>& m, const LaneScratch<V>& sc, bool xt
     int spread_rounds = 0;
     if (!plan.grouped && sc.grp != 0 && !g1z) return 0;
     if (mode == 2) { acc.bw0 = zero_u<V>(); acc.bw1 = zero_u<V>(); acc.xh = zero_u<V>(); }      // the check only records the active set
+    else if (LS && mode == 3) { acc.ls_g = V(0); acc.ls_h = V(0); acc.ls_a = V(0); }                  // the line search only sums its scalars
     else acc_clear(acc);
+    LineDir<V> ldir;
+    const int box = ls_mailbox(sc);
+    if (LS && mode == 3) {      // direction and trial step: left in the mailbox by the main lanes (newton_phase)
+#pragma unroll
+        for (int i = 0; i < 6; i++) ldir.dr[i] = sc.ld(box + i);
+        ldir.dl[0] = sc.ld(box + 6); ldir.dl[1] = sc.ld(box + 7); ldir.dm = sc.ld(box + 8); ldir.alpha = sc.ld(box + 9);
+    }
     const V mu = m.c[LM_MU];
     V yr[6], yl[2], ym;
 #pragma unroll
@@ -1104,7 +1165,11 @@ JB_HD int contact_sweep(const LaneModel<V>& m, const LaneScratch<V>& sc, bool xt
             }
             V yls[2];
             yls[0] = ld_leg(sc.p, sc.stride, zero_u<V>() + (unsigned)(SC_Y + 6), it.src, me); yls[1] = ld_leg(sc.p, sc.stride, zero_u<V>() + (unsigned)(SC_Y + 7), it.src, me);
-            contact_apply_leg<V>(rv, dk, mu, it, mode, yr, yls, acc);
+            if (LS && mode == 3) {
+                V dls[2];
+                dls[0] = ld_leg(sc.p, sc.stride, zero_u<V>() + (unsigned)(box + 6), it.src, me); dls[1] = ld_leg(sc.p, sc.stride, zero_u<V>() + (unsigned)(box + 7), it.src, me);
+                contact_apply_leg<V, LS>(rv, dk, mu, it, 3, yr, yls, acc, &ldir, dls);
+            } else contact_apply_leg<V, LS>(rv, dk, mu, it, mode, yr, yls, acc);
             spread_rounds = r + 1;
             if (!any_lane(it.more)) break;
         }
@@ -1122,7 +1187,12 @@ JB_HD int contact_sweep(const LaneModel<V>& m, const LaneScratch<V>& sc, bool xt
             const int c0 = 4 * (rank - ROW_K) * sc.ovc_stride;
             row_values<V, PAIR>(m, sc, xtra, slot, v3<V>(sc.ovc[c0], sc.ovc[c0 + sc.ovc_stride], sc.ovc[c0 + 2 * sc.ovc_stride]), sc.ovc[c0 + 3 * sc.ovc_stride], rv);
         }
-        contact_apply<V, PAIR>(rv, dk, mu, slot, lane_on, mode, yr, yl, ym, acc);
+        contact_apply<V, PAIR, LS>(rv, dk, mu, slot, lane_on, mode, yr, yl, ym, acc, (LS && mode == 3) ? &ldir : nullptr);
+    }
+    if (LS && mode == 3) {      // the env's totals on every lane: over the legs, then over the lane groups
+        acc.ls_g = quad_sum(acc.ls_g); acc.ls_h = quad_sum(acc.ls_h); acc.ls_a = quad_sum(acc.ls_a);
+        if (plan.grouped) { acc.ls_g = group_sum(sc, acc.ls_g); acc.ls_h = group_sum(sc, acc.ls_h); acc.ls_a = group_sum(sc, acc.ls_a); }
+        return spread_rounds + 8 * rest_rounds;
     }
     if (plan.grouped) {
         acc.bw0 = group_sum_u<V>(sc, acc.bw0); acc.bw1 = group_sum_u<V>(sc, acc.bw1); acc.xh = group_sum_u<V>(sc, acc.xh);
@@ -1131,7 +1201,7 @@ JB_HD int contact_sweep(const LaneModel<V>& m, const LaneScratch<V>& sc, bool xt
             // of value 4k+g, hand the totals over through the scratch (the overflow row entries are dead here) and let the
             // main lanes read all of them.  Same association as group_sum, a quarter of its instructions.
             constexpr int NQ4 = PAIR ? 14 : 13;       // quadruples of values (PAIR: X rides as value 52, padded with zeros)
-            V v[4 * NQ4];
+            V v[56];
             acc_pack(acc, v);
             if (PAIR) { v[52] = acc.X; v[53] = V(0); v[54] = V(0); v[55] = V(0); }
             static_assert(4 * NQ4 <= 56, "reduction buffer");
@@ -1384,11 +1454,6 @@ JB_HD typename lane_traits<V>::mask pair_narrow_warm(const Vec3<V>& ce, const Ma
 inline long g_pair_narrow_stats[2] = {0, 0};      // host harness only: substeps whose narrow phase was entirely warm-started / needed the cold scheme
 #endif
 
-#ifndef JB_DAMP_AFTER
-#define JB_DAMP_AFTER 6
-#endif
-constexpr int NEWTON_DAMP_AFTER = JB_DAMP_AFTER;      // checks of a substep after which every second Newton update is a half step (substep_impl, "cycle breaker")
-
 // ----------------------------------------------------------------------------- options
 struct SimOpts {
     int contacts;        // 0: contacts disabled (MuJoCo disableflags=contact)
@@ -1404,6 +1469,8 @@ struct SimOpts {
                          //    and a 9-value hand-over instead of a second factorisation on the critical path.  Bit-identical results.
     int spread = 1;      // 1: a plan with more than one round sweeps the leg slots in spread mode (lanes of idle legs adopt contacts of a leg that has
                          //    several: "spread sweeps" below); 0: diagnostic, the ordinary sweep only
+    float* capture = nullptr;           // diagnostic builds (-DJB_CAPTURE): ring of JB_CAPTURE_SLOTS records x 64 floats - the entry state of substeps whose contact solve stayed
+    unsigned* capture_count = nullptr;  //   unconverged after the line-searched pass (substep_impl), and how many there were
     unsigned long long* prof;   // diagnostic builds: per-wave cycle accumulators [phaseA, check sweeps, full sweeps, solves, integrate]
     unsigned long long* hist;   // diagnostic builds: per-wave [0..27] live-slot counts over all-geom substeps, [28..35] rounds histogram, [36..43] same for ordinary substeps
 };
@@ -1541,9 +1608,388 @@ __device__ __forceinline__ void restage_overlay(const LaneConsts<float>& c) {
 }
 #endif
 
+// ----------------------------------------------------------------------------- phase B of a substep: the contact solve
+// Primal Newton on the active set, then MuJoCo's Euler step with implicit joint damping, ONE loop:
+//   while the active set changes:  H(active set at y) y' = tau + contact rhs          (M without damping)
+//   then:  (M + h diag(b)) qacc = tau + qfrc_constraint(y)
+// Main lanes own the iterate and the solves; every decision that steers the loop is broadcast so that the helper groups follow the same
+// control flow.  Reads phase A's products (the system `sys`, the slot plans, the built rows in the scratch, the warm start in `s`) and
+// leaves them as they were: it may be called twice for one substep.
+//
+// LS = false - the hot instantiation: full Newton steps, rank-one passes while they suffice; stops when every env's set repeats (exact
+//   minimisers) or at o.max_newton checks.  Returns whether some env of the wave was still moving at the cap (`capped`: which, on the
+//   main lanes); such a wave calls the other instantiation for the same substep (substep_impl).
+// LS = true - MuJoCo's Newton solver (reference jitterbug.xml:18 leaves <option> at its defaults: Newton, exact line search): every
+//   update goes to the minimum of the cost along the Newton direction.  The cost along  y + alpha d,  d = (this pass's solution) - y,  is
+//   convex and piecewise quadratic:
+//       phi'(alpha) = d.(M (y + alpha d) - tau) + sum over contacts and pyramid edges of D min(0, r + alpha s) s,
+//   r, s = the edge's residual at y and its slope along d.  Safeguarded Newton on phi' in [0, 1] with a fixed count; every lane group
+//   sweeps its share of the contacts (contact_sweep mode 3), the main lanes hold M and steer.  alpha = 1 - the full Newton step - whenever
+//   that is still downhill.  No rank-one passes.  Cold code: it runs for a few substeps in ten million.
+#if !defined(__HIPCC__)
+inline int g_ls_trace = 0;                    // host harness only: print the line-searched iteration
+inline long g_ls_stats[4] = {0, 0, 0, 0};      // host harness only: substeps solved a second time / outer passes of those solves / line searches that shortened a step / solves that hit NEWTON_LS_CAP
+#endif
+#ifndef JB_CAPTURE_SLOTS
+#define JB_CAPTURE_SLOTS 256
+#endif
+#ifndef JB_LS_CAP
+#define JB_LS_CAP 60
+#endif
+#ifndef JB_LS_EVALS
+#define JB_LS_EVALS 8
+#endif
+#ifndef JB_TINY_STEP
+#define JB_TINY_STEP 1e-12f
+#endif
+constexpr int NEWTON_LS_CAP = JB_LS_CAP;          // outer passes of the line-searched solve
+constexpr int NEWTON_LS_EVALS = JB_LS_EVALS;      // evaluations of phi' per line search
+constexpr float NEWTON_TINY_STEP = JB_TINY_STEP;  // |d|^2 / |y|^2 below which a step is rounding noise and the iterate is accepted
+#if !defined(__HIPCC__)
+template <typename V, typename MK> inline void ls_trace_pass(int, const V&, const MK&, const MK&, const V (&)[6], const V (&)[6], const V (&)[2], const V (&)[2], const V&, const V&) {}
+template <typename T> inline void ls_trace_pass(int it, const Quad<T>& al, const Mask4& take, const Mask4& tiny, const Quad<T> (&yr)[6], const Quad<T> (&nyr)[6], const Quad<T> (&yl)[2], const Quad<T> (&nyl)[2], const Quad<T>& ym, const Quad<T>& nym) {
+    double dn = 0, yn = 0;
+    for (int i = 0; i < 6; i++) { dn += (double)(nyr[i].v[0] - yr[i].v[0]) * (nyr[i].v[0] - yr[i].v[0]); yn += (double)nyr[i].v[0] * nyr[i].v[0]; }
+    for (int l = 0; l < 4; l++) for (int j = 0; j < 2; j++) { dn += (double)(nyl[j].v[l] - yl[j].v[l]) * (nyl[j].v[l] - yl[j].v[l]); yn += (double)nyl[j].v[l] * nyl[j].v[l]; }
+    dn += (double)(nym.v[0] - ym.v[0]) * (nym.v[0] - ym.v[0]); yn += (double)nym.v[0] * nym.v[0];
+    std::printf("  pass it=%2d alpha %.6f take %d tiny %d  |step|/|y| %.3e  y0 %.8g yl0 %.8g ym %.8g\n", it, (double)al.v[0], (int)take.v[0], (int)tiny.v[0], std::sqrt(dn / (yn + 1e-300)), (double)nyr[0].v[0], (double)nyl[0].v[0], (double)nym.v[0]);
+}
+template <typename MK, typename U> inline void ls_trace_check(int, const MK&, const U&, const U&, const U&, const U&, const U&, const U&) {}
+inline void ls_trace_check(int it, const Mask4& unc, const UQuad& b0, const UQuad& p0, const UQuad& b1, const UQuad& p1, const UQuad& xh, const UQuad& pxh) {
+    std::printf("  check it=%2d changed %d | bw0 %08x %08x %08x %08x (flips %08x %08x %08x %08x) bw1 flips %08x %08x %08x %08x xh-changed %d%d%d%d\n", it, (int)unc.v[0], b0.v[0], b0.v[1], b0.v[2], b0.v[3],
+                b0.v[0] ^ p0.v[0], b0.v[1] ^ p0.v[1], b0.v[2] ^ p0.v[2], b0.v[3] ^ p0.v[3], b1.v[0] ^ p1.v[0], b1.v[1] ^ p1.v[1], b1.v[2] ^ p1.v[2], b1.v[3] ^ p1.v[3],
+                (int)(xh.v[0] != pxh.v[0]), (int)(xh.v[1] != pxh.v[1]), (int)(xh.v[2] != pxh.v[2]), (int)(xh.v[3] != pxh.v[3]));
+}
+#endif
+template <typename V, bool PAIR, bool LS>
+JB_HD bool newton_phase(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneState<V>& s, const SimOpts& o, const bool xtra, const SlotPlan& plan, const SpreadPlan<V>& spl,
+                        const Mat3<V>& Rw, StarSys<V>& sys, const Vec3<V> (&dk)[3], const bool any_contact, const typename lane_traits<V>::mask& env_con,
+                        V (&yr)[6], V (&yl)[2], V& ym, typename lane_traits<V>::mask& capped) {
+    using MK = typename lane_traits<V>::mask;
+    using U = typename lane_traits<V>::uint;
+    const V h = m.c[LM_H];
+    const bool is_main = (sc.grp == 0);
+    const bool g1 = o.offload && sc.grp == 1;       // the replica group (its LDS stores repeat the main lanes': same address, same value)
+    const bool rep = is_main || g1;
+    const int cap = LS ? NEWTON_LS_CAP : o.max_newton;
+    bool wave_capped = false;
+    JB_PROF_T0();
+    {
+        NewtonAcc<V> acc;
+        StarFactor<V> fac;      // factorisation of the last Newton system (main lanes)
+        bool final_pass = !any_contact;
+        MK unconverged = lt(V(0), V(1));
+        MK fac_valid = lt(V(1), V(0)), fast_env = lt(V(1), V(0));
+        // LS only (a lane word, not three masks: the scalar registers are the scarce ones in this loop).
+        //   bit 0  the last update was a shortened step: its iterate minimises no set and is never accepted as converged
+        //   bit 1  the last step was below the iterate's rounding: whatever the sets say, this is the solution
+        //   bit 2  the last shortened step stayed on its pass's set - that set's minimiser is the WHOLE step: take it next time
+        U ls_flags = zero_u<V>();
+        U prev_bw0 = zero_u<V>(), prev_bw1 = zero_u<V>(), prev_xh = zero_u<V>();
+        if (any_contact) {
+            if (is_main) {      // warm start (world linear part rotated into the root frame)
+                Vec3<V> lw = mulT(Rw, v3<V>(s.wl[0], s.wl[1], s.wl[2]));
+                yr[0] = s.wa[0]; yr[1] = s.wa[1]; yr[2] = s.wa[2]; yr[3] = lw.x; yr[4] = lw.y; yr[5] = lw.z;
+                yl[0] = s.wj[0]; yl[1] = s.wj[1]; ym = s.wm;
+#pragma unroll
+                for (int i = 0; i < 6; i++) sc.st(SC_Y + i, yr[i]);
+                sc.st(SC_Y + 6, yl[0]); sc.st(SC_Y + 7, yl[1]); sc.st(SC_Y + 8, ym);
+            }
+            wave_sync();          // the helper groups read the iterate from the scratch
+        } else {
+            acc_clear(acc);
+        }
+        const V hb1 = o.implicit_damp ? h * m.c[LM_B1] : V(0), hb2 = o.implicit_damp ? h * m.c[LM_B2] : V(0);
+        // offload: the replica leaves every full pass with the factorisation of M + h diag(b).  A wave without any contact makes one turn of the
+        // outer loop too (no sweep, zero accumulator), so that this factorisation always comes from the SAME instructions: an env's bits must
+        // not depend on whether a wave-mate has a contact (two inlined copies of one expression may fuse their multiply-adds differently).
+        const bool have_dfac = o.offload != 0;
+#ifdef JB_WAVE_STATS
+        if (!LS && is_main && any_contact) { s.st_contact = s.st_contact + V(1); s.st_slots = s.st_slots + V((float)__builtin_popcount(plan.live)); }
+        if (!LS) stats_hist(o, sc, plan, xtra, any_contact);
+#endif
+        // Two nested loops.  OUTER: one FULL pass per turn - a sweep over every live slot and a new factorisation, always at the top, so that
+        // the factorisation object has a single definition per turn (a conditional redefinition inside one loop costs a register copy per
+        // value and iteration once the object is live after the loop, as the replica's is).  INNER: checks of the active set at the new
+        // iterate, with rank-one passes while every env that still moves differs from its factorisation by a single pyramid edge.
+        int it = 0;
+        if (any_contact || have_dfac) {
+#pragma unroll 1
+            for (;;) {
+                // ---- full pass (reads the iterate of the last check from the scratch: rank-one results are stored only after this pass)
+                if (any_contact) {
+                    const int sweep_rounds = contact_sweep<V, PAIR, LS>(m, sc, xtra, plan, spl, 0, dk, acc, have_dfac);
+                    (void)sweep_rounds;
+                    prev_bw0 = acc.bw0; prev_bw1 = acc.bw1; prev_xh = acc.xh;
+                    JB_PROF_ADD(o, 2);
+#ifdef JB_WAVE_STATS
+                    if (is_main) s.st_sweeps = s.st_sweeps + V(1);
+#if defined(__HIPCC__)
+                    if (o.hist && (threadIdx.x & 63) == 0) {      // full sweeps by the rounds they took: [53 + spread rounds (0-3)], [57 + rest rounds (0-3)]
+                        o.hist[53 + ((sweep_rounds & 7) < 3 ? (sweep_rounds & 7) : 3)] += 1ull;
+                        o.hist[57 + ((sweep_rounds >> 3) < 3 ? (sweep_rounds >> 3) : 3)] += 1ull;
+                    }
+#endif
+#endif
+                }
+                // (LS: every lane group comes along - the line search below has hand-over points that all groups must pass; the helper groups'
+                // solve works on whatever their registers hold and nobody reads it)
+                if (o.offload || is_main || LS) {
+                    V nyr[6], nyl[2], nym;
+                    if (o.lean) sys_load(sc, sys);
+                    // offload: EVERY lane runs this - the replica on M + h diag(b) (zero accumulator from the sweep, hb on its diagonal), in
+                    // every full pass; the other helper groups on whatever their registers hold (nobody reads their result).  No lane
+                    // predicate on register-only work.
+                    const V hx1 = g1 ? hb1 : V(0), hx2 = g1 ? hb2 : V(0);
+                    star_solve<V, PAIR>(sys, acc, hx1, hx2, fac, nyr, nyl, nym);
+                    if (o.lean && is_main) { fac_store(sc, fac); if (PAIR) fac_store_cx(sc, fac); }
+                    JB_PROF_ADD(o, 6);
+                    V ls_alpha = V(1);
+                    MK ls_tiny = lt(V(1), V(0));
+                    if (LS && any_contact) {
+                        const int box = ls_mailbox(sc);
+                        V dr[6], dl[2], dm;
+#pragma unroll
+                        for (int i = 0; i < 6; i++) dr[i] = nyr[i] - yr[i];
+                        dl[0] = nyl[0] - yl[0]; dl[1] = nyl[1] - yl[1]; dm = nym - ym;
+                        auto matvec = [&](const V (&vr)[6], const V (&vl)[2], const V& vm, V (&wr)[6], V (&wl)[2], V& wm) {
+                            wl[0] = sys.C[0] * vl[0] + sys.C[1] * vl[1]; wl[1] = sys.C[1] * vl[0] + sys.C[2] * vl[1]; wm = sys.Cm * vm;
+#pragma unroll
+                            for (int i = 0; i < 6; i++) {
+                                V t = quad_sum(sys.B[i][0] * vl[0] + sys.B[i][1] * vl[1]) + sys.Bm[i] * vm;
+#pragma unroll
+                                for (int j = 0; j < 6; j++) t = t + sys.A[tri(i, j)] * vr[j];
+                                wr[i] = t;
+                                wl[0] = wl[0] + sys.B[i][0] * vr[i]; wl[1] = wl[1] + sys.B[i][1] * vr[i]; wm = wm + sys.Bm[i] * vr[i];
+                            }
+                        };
+                        V myr[6], myl[2], mym, mdr[6], mdl[2], mdm;
+                        matvec(yr, yl, ym, myr, myl, mym);
+                        matvec(dr, dl, dm, mdr, mdl, mdm);
+                        V g0 = quad_sum(dl[0] * (myl[0] - sys.tl[0]) + dl[1] * (myl[1] - sys.tl[1])) + dm * (mym - sys.tm);
+                        V g1_ = quad_sum(dl[0] * mdl[0] + dl[1] * mdl[1]) + dm * mdm;
+#pragma unroll
+                        for (int i = 0; i < 6; i++) { g0 = g0 + dr[i] * (myr[i] - sys.tr[i]); g1_ = g1_ + dr[i] * mdr[i]; }
+                        if (is_main) {
+#pragma unroll
+                            for (int i = 0; i < 6; i++) sc.st(box + i, dr[i]);
+                            sc.st(box + 6, dl[0]); sc.st(box + 7, dl[1]); sc.st(box + 8, dm); sc.st(box + 9, V(1));
+                        }
+                        V lo = V(0), hi = V(1), al = V(1);
+#pragma unroll 1
+                        for (int li = 0; li < NEWTON_LS_EVALS; li++) {
+                            wave_sync();
+                            contact_sweep<V, PAIR, LS>(m, sc, xtra, plan, spl, 3, dk, acc);
+                            const V f1 = g0 + al * g1_ + acc.ls_g, f2 = g1_ + acc.ls_h;
+                            const auto below = lt(f1, V(0));
+                            lo = sel(below, al, lo); hi = sel(below, hi, al);
+                            V an = al - f1 * vrcp(vmax(f2, V(1e-30)));
+                            an = sel(mand(gt(an, lo), lt(an, hi)), an, V(0.5) * (lo + hi));
+                            al = an;
+                            wave_sync();
+                            if (is_main) sc.st(box + 9, al);
+                        }
+                        {   // A step below the iterate's own rounding: nothing left to gain.  An edge whose residual is zero to within the rounding of the
+                            // solve flips for ever - the minimisers of the two sets lie a few 1e-6 |y| apart (fp32 through a Schur solve) and each sends
+                            // the iteration to the other.  A line-searched Newton iteration on this convex cost is past its large steps within a few
+                            // passes, so what counts as rounding GROWS with the pass count: |d|^2 < 1e-12 * 2^it * |y|^2 - 1e-6 |y| at once,
+                            // 3e-5 |y| after ten passes, and every iteration ends (the error it leaves is bounded by the step it declined to take).
+                            V dn = quad_sum(dl[0] * dl[0] + dl[1] * dl[1]) + dm * dm, yn = quad_sum(yl[0] * yl[0] + yl[1] * yl[1]) + ym * ym;
+#pragma unroll
+                            for (int i = 0; i < 6; i++) { dn = dn + dr[i] * dr[i]; yn = yn + yr[i] * yr[i]; }
+                            ls_tiny = lt(dn, V(NEWTON_TINY_STEP * (float)(1u << (it < 30 ? it : 30))) * yn);
+                        }
+                        // A minimum short of the full step sits on a kink of the cost - an edge's residual crossing zero - and the next pass must be
+                        // built on the set BEYOND it, or it would propose the same step again: go a thousandth further, so that the check
+                        // classifies that edge on the far side.  Such an iterate is never accepted as converged (`ls_flags` bit 0).
+                        const auto whole = gt(al, V(0.999));
+                        ls_alpha = sel(whole, V(1), al * V(1.001) + V(1e-6));
+                        wave_sync();      // (the mailbox is the reduction hand-over of the next full sweep)
+                    }
+                    if (is_main) {
+                        // envs whose active set already repeated keep their (exact) solution, rank-one envs theirs
+                        const MK take = mand(unconverged, mnot(fast_env));
+                        if (LS) {      // the step to the minimum of the cost along the Newton direction
+                            // Close to the solution d is tiny, phi' is a difference of large terms and alpha is rounding noise: a shortened step that
+                            // stayed on the set the pass was built on (the cost is ONE quadratic from y to there) is followed by the whole step.
+                            ls_alpha = sel(mor(neq_u(and_u(ls_flags, zero_u<V>() + 4u), zero_u<V>()), ls_tiny), V(1), ls_alpha);
+                            const MK part = lt(ls_alpha, V(1));      // (a whole step keeps the pass's own bits)
+#pragma unroll
+                            for (int i = 0; i < 6; i++) nyr[i] = sel(part, yr[i] + ls_alpha * (nyr[i] - yr[i]), nyr[i]);
+                            nyl[0] = sel(part, yl[0] + ls_alpha * (nyl[0] - yl[0]), nyl[0]); nyl[1] = sel(part, yl[1] + ls_alpha * (nyl[1] - yl[1]), nyl[1]);
+                            nym = sel(part, ym + ls_alpha * (nym - ym), nym);
+                            ls_flags = mbit(mand(take, part)) + mbit(mand(take, ls_tiny)) * 2u;
+#if !defined(__HIPCC__)
+                            if (g_ls_trace) ls_trace_pass(it, ls_alpha, take, ls_tiny, yr, nyr, yl, nyl, ym, nym);
+                            g_ls_stats[1]++;
+                            if (any_lane(mand(take, part))) g_ls_stats[2]++;
+#endif
+                        }
+#pragma unroll
+                        for (int i = 0; i < 6; i++) yr[i] = sel(take, nyr[i], yr[i]);
+                        yl[0] = sel(take, nyl[0], yl[0]); yl[1] = sel(take, nyl[1], yl[1]); ym = sel(take, nym, ym);
+                        fac_valid = mnot(fast_env);         // a rank-one env's factorisation is one edge behind its set
+#pragma unroll
+                        for (int i = 0; i < 6; i++) sc.st(SC_Y + i, yr[i]);
+                        sc.st(SC_Y + 6, yl[0]); sc.st(SC_Y + 7, yl[1]); sc.st(SC_Y + 8, ym);
+                    }
+                }
+                JB_PROF_ADD(o, 3);
+                wave_sync();          // new iterate stored by the main lanes -> read by every group's next sweep
+                if (!any_contact) break;      // (nothing to iterate on: the turn was for the replica's factorisation)
+                // ---- checks (and rank-one passes) until the sets repeat or some env needs a full pass
+                bool full_pass = false;
+#pragma unroll 1
+                for (;;) {
+                    it++;
+                    // cheap pass: only the active set at the new iterate.  The ENV's set changed if any lane of the quad
+                    // saw a different record; when nobody's changed, every y is the exact minimiser
+                    contact_sweep<V, PAIR, LS>(m, sc, xtra, plan, spl, 2, dk, acc);
+                    JB_PROF_ADD(o, 1);
+#ifdef JB_WAVE_STATS
+                    if (is_main) s.st_checks = s.st_checks + V(1);
+#endif
+                    unsigned fin = 0u, full = 1u;
+                    if (is_main) {
+                        MK changed = mor(mor(neq_u(acc.bw0, prev_bw0), neq_u(acc.bw1, prev_bw1)), neq_u(acc.xh, prev_xh));
+                        unconverged = neq_u(quad_sum_u(mbit(changed)), zero_u<V>());
+#if !defined(__HIPCC__)
+                        if (LS && g_ls_trace) ls_trace_check(it, unconverged, acc.bw0, prev_bw0, acc.bw1, prev_bw1, acc.xh, prev_xh);
+#endif
+                        if (LS) {      // the last update came from the line search
+                            const MK shortened = neq_u(and_u(ls_flags, zero_u<V>() + 1u), zero_u<V>()), settled = neq_u(and_u(ls_flags, zero_u<V>() + 2u), zero_u<V>());
+                            ls_flags = mbit(mand(shortened, mnot(unconverged))) * 4u;
+                            unconverged = mand(mor(unconverged, shortened), mnot(settled));
+                        }
+#if defined(JB_WAVE_STATS) && defined(__HIPCC__)
+                                            if (!LS && o.hist && !xtra) {      // how many active-set bits flipped per unconverged env (ordinary substeps: exact records)
+                                                const unsigned fl = quad_sum_u((unsigned)__builtin_popcount(acc.bw0 ^ prev_bw0));
+                                                const bool unc = unconverged;
+                                                const unsigned long long m_unc = __builtin_amdgcn_ballot_w64(unc), m_multi = __builtin_amdgcn_ballot_w64(unc && fl > 1u);
+                                                const unsigned long long m1 = __builtin_amdgcn_ballot_w64(unc && fl == 1u), m2 = __builtin_amdgcn_ballot_w64(unc && fl == 2u), m3 = __builtin_amdgcn_ballot_w64(unc && fl == 3u), m4 = __builtin_amdgcn_ballot_w64(unc && fl >= 4u);
+                                                if ((threadIdx.x & 63) == 0 && m_unc) {
+                                                    o.hist[44] += 1ull; if (!m_multi) o.hist[45] += 1ull;
+                                                    o.hist[46] += __builtin_popcountll(m1) / 4; o.hist[47] += __builtin_popcountll(m2) / 4; o.hist[48] += __builtin_popcountll(m3) / 4; o.hist[49] += __builtin_popcountll(m4) / 4;
+                                                }
+                                                // of the multi-flip envs: those whose flips sit in different lanes (at most one per leg) - what a per-lane rank-k pass could take
+                                                const unsigned lane_fl = (unsigned)__builtin_popcount(acc.bw0 ^ prev_bw0) + (unsigned)__builtin_popcount(acc.bw1 ^ prev_bw1);
+                                                const bool spread = quad_sum_u(lane_fl > 1u ? 1u : 0u) == 0u;
+                                                const unsigned long long m_sp = __builtin_amdgcn_ballot_w64(unc && fl > 1u && spread), m_sp2 = __builtin_amdgcn_ballot_w64(unc && fl == 2u && spread);
+                                                const unsigned long long m_bad = __builtin_amdgcn_ballot_w64(unc && !spread);
+                                                if ((threadIdx.x & 63) == 0 && m_unc) {
+                                                    o.hist[50] += __builtin_popcountll(m_sp) / 4; o.hist[51] += __builtin_popcountll(m_sp2) / 4;
+                                                    if (m_multi && !m_bad) o.hist[52] += 1ull;          // a changed-set check that needs a full pass today and would not with per-lane rank-k
+                                                }
+                                            }
+#endif
+                        if (!any_lane(unconverged) || it >= cap) {
+                            capped = unconverged;                      // (all false unless the cap ended the iteration)
+                            fin = any_lane(unconverged) ? 2u : 1u;
+                        } else {
+                            // An env whose set differs from the factored one by a single pyramid edge of a leg slot (exact
+                            // records) takes a rank-one pass; the decision is the ENV's own (its records, its factorisation),
+                            // so its arithmetic never depends on its wave-mates.  A full pass runs only if some env needs one.
+                            const U dfl = xor_u(acc.bw0, prev_bw0), dfl1 = xor_u(acc.bw1, prev_bw1);
+                            const MK one_flip = eq_u(quad_sum_u(popc_u(dfl) + popc_u(dfl1)), zero_u<V>() + 1u);
+                            const MK xh_same = eq_u(quad_sum_u(mbit(neq_u(acc.xh, prev_xh))), zero_u<V>());
+                            U f_entry;
+                            MK f_is, f_plus, f_tan2, f_on;
+                            flip_decode(dfl, dfl1, acc.bw0, acc.bw1, plan.live, f_entry, f_is, f_plus, f_tan2, f_on);
+                            // the flipped contact's row must be in the row cache (beyond ROW_K live slots rows are rebuilt per pass)
+                            const MK undecodable = mand(neq_u(or_u(dfl, dfl1), zero_u<V>()), mnot(mand(f_is, lt_u(f_entry, (unsigned)ROW_K))));
+                            const MK rows_ok = eq_u(quad_sum_u(mbit(undecodable)), zero_u<V>());
+                            fast_env = mand(mand(unconverged, fac_valid), mand(mand(one_flip, xh_same), rows_ok));
+                            if (LS || !o.rank_one) fast_env = lt(V(1), V(0));      // (the line-searched iteration works on full passes)
+                            full = any_lane(mand(unconverged, mnot(fast_env))) ? 1u : 0u;
+                            if (!LS && any_lane(fast_env)) {
+                                V fyr[6], fyl[2], fym;
+                                if (o.lean) { fac_load(sc, fac); if (PAIR) fac_load_cx(sc, fac); }
+                                rank_one_pass<V, PAIR>(sc, fac, dk, m.c[LM_MU], f_entry, f_is, f_plus, f_tan2, f_on, yr, yl, ym, fyr, fyl, fym);
+#pragma unroll
+                                for (int i = 0; i < 6; i++) yr[i] = sel(fast_env, fyr[i], yr[i]);
+                                yl[0] = sel(fast_env, fyl[0], yl[0]); yl[1] = sel(fast_env, fyl[1], yl[1]); ym = sel(fast_env, fym, ym);
+#ifdef JB_WAVE_STATS
+                                s.st_fast = s.st_fast + V(1);
+#endif
+                            }
+                            prev_bw0 = acc.bw0; prev_bw1 = acc.bw1; prev_xh = acc.xh;      // the sets the new iterates are solved for
+                        }
+                    }
+                    {
+                        const unsigned f = wave_bcast_u(fin);
+                        final_pass = f != 0u;
+                        wave_capped = f == 2u;
+                    }
+                    full_pass = wave_bcast_u(full) != 0u;
+                    JB_PROF_ADD(o, 7);
+                    if (final_pass || full_pass) break;
+                    if (is_main) {      // rank-one passes only: their iterates go to the scratch for the next check
+                        fac_valid = mand(fac_valid, mnot(fast_env));
+#pragma unroll
+                        for (int i = 0; i < 6; i++) sc.st(SC_Y + i, yr[i]);
+                        sc.st(SC_Y + 6, yl[0]); sc.st(SC_Y + 7, yl[1]); sc.st(SC_Y + 8, ym);
+                    }
+                    JB_PROF_ADD(o, 3);
+                    wave_sync();
+                }
+                if (final_pass) break;
+            }
+        }
+#if !defined(__HIPCC__)
+        if (LS && is_main && wave_capped) g_ls_stats[3]++;
+#endif
+        // ---- the final pass: MuJoCo's Euler step with implicit joint damping.
+        // At the minimiser  H y = tau + sum B^T W ahat,  so the constraint force is  qfrc = M y - tau  and the step solves
+        //     (M + h diag(b)) qacc = tau + qfrc = M y,  i.e.  qacc = y - d,   (M + h diag(b)) d = h diag(b) y        (nonzero only in the leg rows).
+        // star_subst adds tau itself, so the contact envs cancel it (replicated parts enter the quad sums as 1/4).
+        // An env without contacts has qfrc = 0 exactly, whatever the rest of its wave is doing: plain solve.
+        if (have_dfac || rep) {
+            V nyr[6], nyl[2], nym;
+            if (o.lean) sys_load(sc, sys);
+            if (have_dfac) {
+                // Every lane takes the iterate from the scratch (what the main lanes hold in registers) and runs the substitution on whatever
+                // factorisation it holds: the REPLICA's is the one of M + h diag(b), and only its result is handed on.
+#pragma unroll
+                for (int i = 0; i < 6; i++) yr[i] = sc.ld(SC_Y + i);
+                yl[0] = sc.ld(SC_Y + 6); yl[1] = sc.ld(SC_Y + 7); ym = sc.ld(SC_Y + 8);
+            }
+            if (any_contact) {
+#pragma unroll
+                for (int i = 0; i < 6; i++) acc.rr[i] = sel(env_con, V(-0.25) * sys.tr[i], V(0));
+                acc.rl[0] = sel(env_con, hb1 * yl[0] - sys.tl[0], V(0));
+                acc.rl[1] = sel(env_con, hb2 * yl[1] - sys.tl[1], V(0));
+                acc.rm = sel(env_con, V(-0.25) * sys.tm, V(0));
+            }
+            if (!have_dfac) {      // (no replica - the LEAN variant, a single lane group: the main lanes factorise on the spot)
+                StarFactor<V> fd;
+                star_factor<V, false>(sys, acc, hb1, hb2, fd);           // acc holds only right-hand sides here
+                star_subst<V>(fd, acc.rr, sys.tr, sys.tl[0] + acc.rl[0], sys.tl[1] + acc.rl[1], sys.tm + quad_sum(acc.rm), nyr, nyl, nym);
+            } else {
+                star_subst<V>(fac, acc.rr, sys.tr, sys.tl[0] + acc.rl[0], sys.tl[1] + acc.rl[1], sys.tm + quad_sum(acc.rm), nyr, nyl, nym);
+            }
+            JB_PROF_ADD(o, 6);
+            if (have_dfac) {
+                if (g1) {
+#pragma unroll
+                    for (int i = 0; i < 6; i++) sc.st(SC_RED + i, nyr[i]);
+                    sc.st(SC_RED + 6, nyl[0]); sc.st(SC_RED + 7, nyl[1]); sc.st(SC_RED + 8, nym);
+                }
+                wave_sync();
+#pragma unroll
+                for (int i = 0; i < 6; i++) nyr[i] = sc.ld(SC_RED + i);
+                nyl[0] = sc.ld(SC_RED + 6); nyl[1] = sc.ld(SC_RED + 7); nym = sc.ld(SC_RED + 8);
+            }
+#pragma unroll
+            for (int i = 0; i < 6; i++) yr[i] = sel(env_con, yr[i] - nyr[i], nyr[i]);
+            yl[0] = sel(env_con, yl[0] - nyl[0], nyl[0]); yl[1] = sel(env_con, yl[1] - nyl[1], nyl[1]); ym = sel(env_con, ym - nym, nym);
+        }
+    }
+    return wave_capped;
+}
+
 // ----------------------------------------------------------------------------- the substep
 template <typename V, bool PAIR = false>
-JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneState<V>& s, const V& ctrl, const SimOpts& o, const bool xtra, const bool xbody, const Mat3<V>& Rw) {
+JB_HD bool substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneState<V>& s, const V& ctrl, const SimOpts& o, const bool xtra, const bool xbody, const Mat3<V>& Rw) {
     using MK = typename lane_traits<V>::mask;
     using U = typename lane_traits<V>::uint;
     const V h = m.c[LM_H];
@@ -1833,251 +2279,70 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
     const SlotPlan plan = make_slot_plan(sc, live_slots);
     const SpreadPlan<V> spl = make_spread_plan<V>(sc, plan, o.spread != 0 && any_contact);
 
-    // ================= phase B: contact solve (primal Newton on the active set) and final acceleration, ONE loop:
-    //   while the active set changes:  H(active set at y) y' = tau + contact rhs          (M without damping)
-    //   then:  (M + h diag(b)) qacc = tau + qfrc_constraint(y)                            (MuJoCo Euler, implicit joint damping)
-    // Main lanes own the iterate and the solves; every decision that steers the loop is broadcast so that the helper groups
-    // follow the same control flow.
+    // ================= phase B: contact solve (primal Newton on the active set) and final acceleration: newton_phase above.
+    // The y-independent rows of the live contacts are built ONCE per substep; the solve may run twice.
+    Vec3<V> dk[3];
+    if (any_contact) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) dk[k] = sc.ld3(SC_DD + 3 * k);      // contact-frame directions: once per substep, every lane
+        contact_rows_build_all<V, PAIR>(m, sc, xtra, plan, spl);
+        JB_PROF_ADD(o, 5);
+    }
     V yr[6], yl[2], ym;
-    V fail_inc = V(0);          // LEAN: Newton cap hits of this substep (the state is parked during the solve; added in phase C)
-    {
-        NewtonAcc<V> acc;
-        StarFactor<V> fac;      // factorisation of the last Newton system (main lanes)
-        Vec3<V> dk[3];
-        bool final_pass = !any_contact;
-        MK unconverged = lt(V(0), V(1));
-        MK fac_valid = lt(V(1), V(0)), fast_env = lt(V(1), V(0));
-        MK damped_last = lt(V(1), V(0));
-        U prev_bw0 = zero_u<V>(), prev_bw1 = zero_u<V>(), prev_xh = zero_u<V>();
-        if (any_contact) {
+    MK capped = lt(V(1), V(0));        // main lanes: this env's iteration ran into the cap
+    bool redone = newton_phase<V, PAIR, false>(m, sc, s, o, xtra, plan, spl, Rw, sys, dk, any_contact, env_con, yr, yl, ym, capped);
+#ifdef JB_NO_RESOLVE      // A/B measurements only: the hot instantiation alone (a capped substep keeps its last iterate and is not counted)
+    redone = false;
+#endif
+    // The plain active-set iteration takes full Newton steps and can cycle between sets (robots lying on their side, a dozen contacts on
+    // the body geoms: a few substeps in ten million).  A wave in which some env hit the cap solves THIS substep's contact problem again the
+    // way MuJoCo's Newton solver does - every step to the exact minimum of the cost along the Newton direction (newton_phase<LS = true>) - from
+    // the same warm start; the substep's entry state is untouched until phase C, and phase A's system, plan and rows are still there.
+    // Only the envs that hit the cap take the second solve's accelerations: their decision and their arithmetic are their own, their
+    // wave-mates keep the bits of the first solve.  The code sits in a cold block outside the Newton loop: the other substeps - all but a
+    // few in ten million - pay one scalar branch.
+    if (__builtin_expect(redone, false)) {
+        const U cf = group_sum_u<V>(sc, mbit(capped));      // every lane group learns which envs it concerns (helper lanes contribute zeros)
+        V zr[6], zl[2], zm;
+        MK capped2 = lt(V(1), V(0));
+        (void)newton_phase<V, PAIR, true>(m, sc, s, o, xtra, plan, spl, Rw, sys, dk, any_contact, env_con, zr, zl, zm, capped2);
+        const U cf2 = group_sum_u<V>(sc, mbit(capped2));
+        const MK re = neq_u(cf, zero_u<V>());
 #pragma unroll
-            for (int k = 0; k < 3; k++) dk[k] = sc.ld3(SC_DD + 3 * k);      // contact-frame directions: once per substep, every lane
-            contact_rows_build_all<V, PAIR>(m, sc, xtra, plan, spl);
-            JB_PROF_ADD(o, 5);
-            if (is_main) {      // warm start (world linear part rotated into the root frame)
-                Vec3<V> lw = mulT(Rw, v3<V>(s.wl[0], s.wl[1], s.wl[2]));
-                yr[0] = s.wa[0]; yr[1] = s.wa[1]; yr[2] = s.wa[2]; yr[3] = lw.x; yr[4] = lw.y; yr[5] = lw.z;
-                yl[0] = s.wj[0]; yl[1] = s.wj[1]; ym = s.wm;
-#pragma unroll
-                for (int i = 0; i < 6; i++) sc.st(SC_Y + i, yr[i]);
-                sc.st(SC_Y + 6, yl[0]); sc.st(SC_Y + 7, yl[1]); sc.st(SC_Y + 8, ym);
-            }
-            wave_sync();          // the helper groups read the iterate from the scratch
-        } else {
-            acc_clear(acc);
-        }
-        const V hb1 = o.implicit_damp ? h * m.c[LM_B1] : V(0), hb2 = o.implicit_damp ? h * m.c[LM_B2] : V(0);
-        // offload: the replica leaves every full pass with the factorisation of M + h diag(b).  A wave without any contact makes one turn of the
-        // outer loop too (no sweep, zero accumulator), so that this factorisation always comes from the SAME instructions: an env's bits must
-        // not depend on whether a wave-mate has a contact (two inlined copies of one expression may fuse their multiply-adds differently).
-        const bool have_dfac = o.offload != 0;
-#ifdef JB_WAVE_STATS
-        if (is_main && any_contact) { s.st_contact = s.st_contact + V(1); s.st_slots = s.st_slots + V((float)__builtin_popcount(plan.live)); }
-        stats_hist(o, sc, plan, xtra, any_contact);
+        for (int i = 0; i < 6; i++) yr[i] = sel(re, zr[i], yr[i]);
+        yl[0] = sel(re, zl[0], yl[0]); yl[1] = sel(re, zl[1], yl[1]); ym = sel(re, zm, ym);
+        // the failure counter records what even the line-searched solve did not settle (LEAN: the state is parked in the scratch)
+        const V inc = sel(mand(re, neq_u(cf2, zero_u<V>())), V(1), V(0));
+        if (o.lean) { if (is_main) sc.st(SC_LSTATE + 34, sc.ld(SC_LSTATE + 34) + inc); }
+        else s.fail = s.fail + inc;
+#if !defined(__HIPCC__)
+        if (is_main) g_ls_stats[0]++;
 #endif
-        // Two nested loops.  OUTER: one FULL pass per turn - a sweep over every live slot and a new factorisation, always at the top, so that
-        // the factorisation object has a single definition per turn (a conditional redefinition inside one loop costs a register copy per
-        // value and iteration once the object is live after the loop, as the replica's is).  INNER: checks of the active set at the new
-        // iterate, with rank-one passes while every env that still moves differs from its factorisation by a single pyramid edge.
-        int it = 0;
-        if (any_contact || have_dfac) {
-#pragma unroll 1
-            for (;;) {
-                // ---- full pass (reads the iterate of the last check from the scratch: rank-one results are stored only after this pass)
-                if (any_contact) {
-                    const int sweep_rounds = contact_sweep<V, PAIR>(m, sc, xtra, plan, spl, 0, dk, acc, have_dfac);
-                    (void)sweep_rounds;
-                    prev_bw0 = acc.bw0; prev_bw1 = acc.bw1; prev_xh = acc.xh;
-                    JB_PROF_ADD(o, 2);
-#ifdef JB_WAVE_STATS
-                    if (is_main) s.st_sweeps = s.st_sweeps + V(1);
-#if defined(__HIPCC__)
-                    if (o.hist && (threadIdx.x & 63) == 0) {      // full sweeps by the rounds they took: [53 + spread rounds (0-3)], [57 + rest rounds (0-3)]
-                        o.hist[53 + ((sweep_rounds & 7) < 3 ? (sweep_rounds & 7) : 3)] += 1ull;
-                        o.hist[57 + ((sweep_rounds >> 3) < 3 ? (sweep_rounds >> 3) : 3)] += 1ull;
-                    }
-#endif
-#endif
+#if defined(JB_CAPTURE) && defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+        if (o.capture && is_main) {      // the substep's entry state of an env that stayed unconverged (LEAN: not supported by this diagnostic)
+            const bool bad = mand(re, neq_u(cf2, zero_u<V>()));
+            unsigned slot = 0u;
+            if (bad && (threadIdx.x & 3) == 0) slot = atomicAdd(o.capture_count, 1u);
+            slot = quad_bcast_u<0>(slot);
+            if (bad && slot < (unsigned)JB_CAPTURE_SLOTS) {
+                float* r = o.capture + (size_t)slot * 64;
+                const int leg = threadIdx.x & 3;
+                if (leg == 0) {
+                    const float root[28] = {ctrl, s.px, s.py, s.pz, s.qw, s.qx, s.qy, s.qz, s.pz_lo, s.qw_lo, s.qx_lo, s.qy_lo, s.qz_lo, s.vx, s.vy, s.vz, s.wx, s.wy, s.wz, s.phi, s.phid, s.turns,
+                                            s.wa[0], s.wa[1], s.wa[2], s.wl[0], s.wl[1], s.wl[2]};
+                    for (int i = 0; i < 28; i++) r[i] = root[i];
+                    r[28] = s.wm; r[29] = (float)xtra; r[30] = (float)__builtin_popcount(plan.live); r[31] = (float)plan.live;
                 }
-                if (o.offload || is_main) {
-                    V nyr[6], nyl[2], nym;
-                    if (o.lean) sys_load(sc, sys);
-                    // offload: EVERY lane runs this - the replica on M + h diag(b) (zero accumulator from the sweep, hb on its diagonal), in
-                    // every full pass; the other helper groups on whatever their registers hold (nobody reads their result).  No lane
-                    // predicate on register-only work.
-                    const V hx1 = g1 ? hb1 : V(0), hx2 = g1 ? hb2 : V(0);
-                    star_solve<V, PAIR>(sys, acc, hx1, hx2, fac, nyr, nyl, nym);
-                    if (o.lean) { fac_store(sc, fac); if (PAIR) fac_store_cx(sc, fac); }
-                    JB_PROF_ADD(o, 6);
-                    if (is_main) {
-                        // envs whose active set already repeated keep their (exact) solution, rank-one envs theirs
-                        const MK take = mand(unconverged, mnot(fast_env));
-                        // Cycle breaker.  The undamped active-set iteration can cycle between two sets (robots lying on their side, a dozen contacts on the
-                        // body geoms: ~1e-6 of the substeps with the motor flat out) and then runs into the cap with an iterate that minimises
-                        // nothing - every such env-step is off by a contact impulse (tools/parity_outliers.py).  From the sixth check on, every
-                        // second update goes only PART of the way (a half, then a quarter) to the new set's minimiser: the point in between picks another set, and the following
-                        // full step is judged as usual.  A damped iterate is never accepted as converged (`damped_last`).  The decision is the
-                        // env's own (an env that is still unconverged at check k has been so since the substep began), and substeps that
-                        // converge in fewer than six checks - all but a few in a million - keep their bits.
-                        damped_last = lt(V(1), V(0));
-                        const int dk_ = it - NEWTON_DAMP_AFTER;
-                        if (dk_ >= 0 && (dk_ & 1) == 0) {      // (wave-uniform: `it` counts the checks of this substep)
-                            const V al = V(((dk_ >> 1) & 1) ? 0.25f : 0.5f);      // half way, then a quarter of the way, alternating (measured best of four schedules)
-#pragma unroll
-                            for (int i = 0; i < 6; i++) nyr[i] = yr[i] + al * (nyr[i] - yr[i]);
-                            nyl[0] = yl[0] + al * (nyl[0] - yl[0]); nyl[1] = yl[1] + al * (nyl[1] - yl[1]); nym = ym + al * (nym - ym);
-                            damped_last = take;
-                        }
-#pragma unroll
-                        for (int i = 0; i < 6; i++) yr[i] = sel(take, nyr[i], yr[i]);
-                        yl[0] = sel(take, nyl[0], yl[0]); yl[1] = sel(take, nyl[1], yl[1]); ym = sel(take, nym, ym);
-                        fac_valid = mnot(fast_env);         // a rank-one env's factorisation is one edge behind its set
-#pragma unroll
-                        for (int i = 0; i < 6; i++) sc.st(SC_Y + i, yr[i]);
-                        sc.st(SC_Y + 6, yl[0]); sc.st(SC_Y + 7, yl[1]); sc.st(SC_Y + 8, ym);
-                    }
-                }
-                JB_PROF_ADD(o, 3);
-                wave_sync();          // new iterate stored by the main lanes -> read by every group's next sweep
-                if (!any_contact) break;      // (nothing to iterate on: the turn was for the replica's factorisation)
-                // ---- checks (and rank-one passes) until the sets repeat or some env needs a full pass
-                bool full_pass = false;
-#pragma unroll 1
-                for (;;) {
-                    it++;
-                    // cheap pass: only the active set at the new iterate.  The ENV's set changed if any lane of the quad
-                    // saw a different record; when nobody's changed, every y is the exact minimiser
-                    contact_sweep<V, PAIR>(m, sc, xtra, plan, spl, 2, dk, acc);
-                    JB_PROF_ADD(o, 1);
-#ifdef JB_WAVE_STATS
-                    if (is_main) s.st_checks = s.st_checks + V(1);
-#endif
-                    unsigned fin = 0u, full = 1u;
-                    if (is_main) {
-                        MK changed = mor(mor(neq_u(acc.bw0, prev_bw0), neq_u(acc.bw1, prev_bw1)), neq_u(acc.xh, prev_xh));
-                        unconverged = neq_u(quad_sum_u(mbit(changed)), zero_u<V>());
-                        unconverged = mor(unconverged, damped_last);      // a damped iterate is not the minimiser of any set: it only picks the next set
-#if defined(JB_WAVE_STATS) && defined(__HIPCC__)
-                                            if (o.hist && !xtra) {      // how many active-set bits flipped per unconverged env (ordinary substeps: exact records)
-                                                const unsigned fl = quad_sum_u((unsigned)__builtin_popcount(acc.bw0 ^ prev_bw0));
-                                                const bool unc = unconverged;
-                                                const unsigned long long m_unc = __builtin_amdgcn_ballot_w64(unc), m_multi = __builtin_amdgcn_ballot_w64(unc && fl > 1u);
-                                                const unsigned long long m1 = __builtin_amdgcn_ballot_w64(unc && fl == 1u), m2 = __builtin_amdgcn_ballot_w64(unc && fl == 2u), m3 = __builtin_amdgcn_ballot_w64(unc && fl == 3u), m4 = __builtin_amdgcn_ballot_w64(unc && fl >= 4u);
-                                                if ((threadIdx.x & 63) == 0 && m_unc) {
-                                                    o.hist[44] += 1ull; if (!m_multi) o.hist[45] += 1ull;
-                                                    o.hist[46] += __builtin_popcountll(m1) / 4; o.hist[47] += __builtin_popcountll(m2) / 4; o.hist[48] += __builtin_popcountll(m3) / 4; o.hist[49] += __builtin_popcountll(m4) / 4;
-                                                }
-                                                // of the multi-flip envs: those whose flips sit in different lanes (at most one per leg) - what a per-lane rank-k pass could take
-                                                const unsigned lane_fl = (unsigned)__builtin_popcount(acc.bw0 ^ prev_bw0) + (unsigned)__builtin_popcount(acc.bw1 ^ prev_bw1);
-                                                const bool spread = quad_sum_u(lane_fl > 1u ? 1u : 0u) == 0u;
-                                                const unsigned long long m_sp = __builtin_amdgcn_ballot_w64(unc && fl > 1u && spread), m_sp2 = __builtin_amdgcn_ballot_w64(unc && fl == 2u && spread);
-                                                const unsigned long long m_bad = __builtin_amdgcn_ballot_w64(unc && !spread);
-                                                if ((threadIdx.x & 63) == 0 && m_unc) {
-                                                    o.hist[50] += __builtin_popcountll(m_sp) / 4; o.hist[51] += __builtin_popcountll(m_sp2) / 4;
-                                                    if (m_multi && !m_bad) o.hist[52] += 1ull;          // a changed-set check that needs a full pass today and would not with per-lane rank-k
-                                                }
-                                            }
-#endif
-                        if (!any_lane(unconverged) || it >= o.max_newton) {
-                            if (o.lean) fail_inc = fail_inc + sel(unconverged, V(1), V(0)); else s.fail = s.fail + sel(unconverged, V(1), V(0));
-                            fin = 1u;
-                        } else {
-                            // An env whose set differs from the factored one by a single pyramid edge of a leg slot (exact
-                            // records) takes a rank-one pass; the decision is the ENV's own (its records, its factorisation),
-                            // so its arithmetic never depends on its wave-mates.  A full pass runs only if some env needs one.
-                            const U dfl = xor_u(acc.bw0, prev_bw0), dfl1 = xor_u(acc.bw1, prev_bw1);
-                            const MK one_flip = eq_u(quad_sum_u(popc_u(dfl) + popc_u(dfl1)), zero_u<V>() + 1u);
-                            const MK xh_same = eq_u(quad_sum_u(mbit(neq_u(acc.xh, prev_xh))), zero_u<V>());
-                            U f_entry;
-                            MK f_is, f_plus, f_tan2, f_on;
-                            flip_decode(dfl, dfl1, acc.bw0, acc.bw1, plan.live, f_entry, f_is, f_plus, f_tan2, f_on);
-                            // the flipped contact's row must be in the row cache (beyond ROW_K live slots rows are rebuilt per pass)
-                            const MK undecodable = mand(neq_u(or_u(dfl, dfl1), zero_u<V>()), mnot(mand(f_is, lt_u(f_entry, (unsigned)ROW_K))));
-                            const MK rows_ok = eq_u(quad_sum_u(mbit(undecodable)), zero_u<V>());
-                            fast_env = mand(mand(unconverged, fac_valid), mand(mand(one_flip, xh_same), rows_ok));
-                            if (!o.rank_one || it >= NEWTON_DAMP_AFTER) fast_env = lt(V(1), V(0));      // (the cycle breaker works on full passes)
-                            full = any_lane(mand(unconverged, mnot(fast_env))) ? 1u : 0u;
-                            if (any_lane(fast_env)) {
-                                V fyr[6], fyl[2], fym;
-                                if (o.lean) { fac_load(sc, fac); if (PAIR) fac_load_cx(sc, fac); }
-                                rank_one_pass<V, PAIR>(sc, fac, dk, m.c[LM_MU], f_entry, f_is, f_plus, f_tan2, f_on, yr, yl, ym, fyr, fyl, fym);
-#pragma unroll
-                                for (int i = 0; i < 6; i++) yr[i] = sel(fast_env, fyr[i], yr[i]);
-                                yl[0] = sel(fast_env, fyl[0], yl[0]); yl[1] = sel(fast_env, fyl[1], yl[1]); ym = sel(fast_env, fym, ym);
-#ifdef JB_WAVE_STATS
-                                s.st_fast = s.st_fast + V(1);
-#endif
-                            }
-                            prev_bw0 = acc.bw0; prev_bw1 = acc.bw1; prev_xh = acc.xh;      // the sets the new iterates are solved for
-                        }
-                    }
-                    final_pass = wave_bcast_u(fin) != 0u;
-                    full_pass = wave_bcast_u(full) != 0u;
-                    JB_PROF_ADD(o, 7);
-                    if (final_pass || full_pass) break;
-                    if (is_main) {      // rank-one passes only: their iterates go to the scratch for the next check
-                        fac_valid = mand(fac_valid, mnot(fast_env));
-#pragma unroll
-                        for (int i = 0; i < 6; i++) sc.st(SC_Y + i, yr[i]);
-                        sc.st(SC_Y + 6, yl[0]); sc.st(SC_Y + 7, yl[1]); sc.st(SC_Y + 8, ym);
-                    }
-                    JB_PROF_ADD(o, 3);
-                    wave_sync();
-                }
-                if (final_pass) break;
+                r[32 + 6 * leg + 0] = s.th1; r[32 + 6 * leg + 1] = s.th2; r[32 + 6 * leg + 2] = s.thd1; r[32 + 6 * leg + 3] = s.thd2; r[32 + 6 * leg + 4] = s.wj[0]; r[32 + 6 * leg + 5] = s.wj[1];
             }
         }
-        // ---- the final pass: MuJoCo's Euler step with implicit joint damping.
-        // At the minimiser  H y = tau + sum B^T W ahat,  so the constraint force is  qfrc = M y - tau  and the step solves
-        //     (M + h diag(b)) qacc = tau + qfrc = M y,  i.e.  qacc = y - d,   (M + h diag(b)) d = h diag(b) y        (nonzero only in the leg rows).
-        // star_subst adds tau itself, so the contact envs cancel it (replicated parts enter the quad sums as 1/4).
-        // An env without contacts has qfrc = 0 exactly, whatever the rest of its wave is doing: plain solve.
-        if (have_dfac || rep) {
-            V nyr[6], nyl[2], nym;
-            if (o.lean) sys_load(sc, sys);
-            if (have_dfac) {
-                // Every lane takes the iterate from the scratch (what the main lanes hold in registers) and runs the substitution on whatever
-                // factorisation it holds: the REPLICA's is the one of M + h diag(b), and only its result is handed on.
-#pragma unroll
-                for (int i = 0; i < 6; i++) yr[i] = sc.ld(SC_Y + i);
-                yl[0] = sc.ld(SC_Y + 6); yl[1] = sc.ld(SC_Y + 7); ym = sc.ld(SC_Y + 8);
-            }
-            if (any_contact) {
-#pragma unroll
-                for (int i = 0; i < 6; i++) acc.rr[i] = sel(env_con, V(-0.25) * sys.tr[i], V(0));
-                acc.rl[0] = sel(env_con, hb1 * yl[0] - sys.tl[0], V(0));
-                acc.rl[1] = sel(env_con, hb2 * yl[1] - sys.tl[1], V(0));
-                acc.rm = sel(env_con, V(-0.25) * sys.tm, V(0));
-            }
-            if (!have_dfac) {      // (no replica - the LEAN variant, a single lane group: the main lanes factorise on the spot)
-                StarFactor<V> fd;
-                star_factor<V, false>(sys, acc, hb1, hb2, fd);           // acc holds only right-hand sides here
-                star_subst<V>(fd, acc.rr, sys.tr, sys.tl[0] + acc.rl[0], sys.tl[1] + acc.rl[1], sys.tm + quad_sum(acc.rm), nyr, nyl, nym);
-            } else {
-                star_subst<V>(fac, acc.rr, sys.tr, sys.tl[0] + acc.rl[0], sys.tl[1] + acc.rl[1], sys.tm + quad_sum(acc.rm), nyr, nyl, nym);
-            }
-            JB_PROF_ADD(o, 6);
-            if (have_dfac) {
-                if (g1) {
-#pragma unroll
-                    for (int i = 0; i < 6; i++) sc.st(SC_RED + i, nyr[i]);
-                    sc.st(SC_RED + 6, nyl[0]); sc.st(SC_RED + 7, nyl[1]); sc.st(SC_RED + 8, nym);
-                }
-                wave_sync();
-#pragma unroll
-                for (int i = 0; i < 6; i++) nyr[i] = sc.ld(SC_RED + i);
-                nyl[0] = sc.ld(SC_RED + 6); nyl[1] = sc.ld(SC_RED + 7); nym = sc.ld(SC_RED + 8);
-            }
-#pragma unroll
-            for (int i = 0; i < 6; i++) yr[i] = sel(env_con, yr[i] - nyr[i], nyr[i]);
-            yl[0] = sel(env_con, yl[0] - nyl[0], nyl[0]); yl[1] = sel(env_con, yl[1] - nyl[1], nyl[1]); ym = sel(env_con, ym - nym, nym);
-        }
+#endif
     }
     JB_SCHED_FENCE();
-    if (!rep) return;
+    if (!rep) return redone;
 
     // ================= phase C: integrate (the replica too: it starts the next substep from the same state)
-    if (o.lean) { state_load(sc, s); s.fail = s.fail + fail_inc; }
+    if (o.lean) state_load(sc, s);
     Vec3<V> lin = mul(Rw, v3<V>(yr[3], yr[4], yr[5]));
     s.wa[0] = yr[0]; s.wa[1] = yr[1]; s.wa[2] = yr[2]; s.wl[0] = lin.x; s.wl[1] = lin.y; s.wl[2] = lin.z; s.wj[0] = yl[0]; s.wj[1] = yl[1]; s.wm = ym;
     // mj_advance: velocities, then positions with the new velocities
@@ -2114,6 +2379,7 @@ JB_HD void substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
     }
     if (o.lean) state_store(sc, s);
     JB_PROF_ADD(o, 4);
+    return redone;      // (wave-uniform: the caller may count the substeps that were solved twice)
 }
 
 // mj_kinematics normalises the free-joint quaternion; here once when a state enters the simulator (kernel start, host harness)
@@ -2126,9 +2392,10 @@ template <typename V> JB_HD void normalise_state(LaneState<V>& s) {
 }
 
 // One physics substep.  A wave-uniform broadphase decides whether only the foot sphere + lower-leg cylinder can
-// touch the floor (common) or every geom of the model has to be tested (rare).
+// touch the floor (common) or every geom of the model has to be tested (rare).  Returns (wave-uniform) whether the contact solve ran a
+// second time with the exact line search (newton_phase).
 template <typename V, bool PAIR = false>
-JB_HD void substep(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneState<V>& s, const V& ctrl, const SimOpts& o) {
+JB_HD bool substep(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneState<V>& s, const V& ctrl, const SimOpts& o) {
     unsigned xt = 0;          // bit 0: some upper leg may touch the floor, bit 1: some root / motor-body geom may
     Mat3<V> Rw;               // root rotation (main lanes): mj_kinematics normalises the quaternion first
 #if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
@@ -2165,7 +2432,7 @@ JB_HD void substep(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneState<V>
 #ifdef JB_WAVE_STATS
     if (xtra && sc.grp == 0) s.st_xtra = s.st_xtra + V(1);
 #endif
-    substep_impl<V, PAIR>(m, sc, s, ctrl, o, xtra, xbody, Rw);
+    return substep_impl<V, PAIR>(m, sc, s, ctrl, o, xtra, xbody, Rw);
 }
 
 }  // namespace jb

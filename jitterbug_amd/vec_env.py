@@ -56,7 +56,7 @@ class JitterbugVecEnv:
 
     def __init__(self, n_envs, task="move_from_origin", seed=0, device_id=0, random_pose=True, contacts=True,
                  time_limit=DEFAULT_TIME_LIMIT, control_timestep=DEFAULT_CONTROL_TIMESTEP, auto_reset=True,
-                 env_offset=0, max_newton=20, stream=None, params=None, envs_per_wave=0, flags=0, variant=None, per_env_model=False,
+                 env_offset=0, max_newton=0, stream=None, params=None, envs_per_wave=0, flags=0, variant=None, per_env_model=False,
                  envs_per_gpu=None):
         """variant: 'auto' | 'ordinary' | 'lean' (jitterbug_amd.variants: 'auto' picks the two-waves-per-SIMD kernel above 4096 envs per
         GPU, from 8192 with one model per env); None keeps `flags` as given (JB_FLAG_LEAN = 2 by hand).  per_env_model: the batch will get
@@ -171,6 +171,14 @@ class JitterbugVecEnv:
         cap = np.zeros(self.num_envs, dtype=np.float32)
         _lib.check(self._L.jb_get_counters(self._h, _lib.ptr(sc), _lib.ptr(ep), _lib.ptr(cap)))
         return sc, ep, cap
+
+    def solver_stats(self):
+        """Wave-substeps (since the env was created) whose contact problem went to the line-searched Newton solve because the plain
+        active-set iteration had not settled within `max_newton` checks (jb_solver_stats)."""
+        import ctypes
+        v = ctypes.c_uint64(0)
+        _lib.check(self._L.jb_solver_stats(self._h, ctypes.byref(v)))
+        return int(v.value)
 
     def set_model_params(self, params):
         p = np.ascontiguousarray(params, dtype=np.float64)

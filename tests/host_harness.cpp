@@ -252,6 +252,68 @@ extern "C" int jbh_rollout(const double* P, double* qpos, double* qvel, double* 
     return use_float ? rollout<float>(P, qpos, qvel, target, counters, K, actions, task, nsub, step_limit, auto_reset, random_pose, seed, env_global, policy_params, ngroups, rows_out)
                      : rollout<double>(P, qpos, qvel, target, counters, K, actions, task, nsub, step_limit, auto_reset, random_pose, seed, env_global, policy_params, ngroups, rows_out);
 }
+// ONE substep from a captured fp32 record (jb_sim.hpp SimOpts::capture: the substep's entry state with its warm start, 64 floats), main lanes +
+// three helper groups; returns the failure counter's increment.  trace = 1 prints the line-searched iteration.
+extern "C" int jbh_substep_record(const double* P, const float* rec, int max_newton, int ngroups, int trace, double* fail_out) {
+    using T = float;
+    using V = Quad<T>;
+    LaneModel<V> m;
+    T tab[LM_TABLE];
+    { int rc = build_packed_model<T>(P, tab); if (rc) return rc; }
+    m.c.inv = tab; m.c.tab = tab + LM_INV; m.c.lean = false; m.c.preload();
+    LaneState<V> s0;
+    const T ctrl = rec[0];
+    s0.px = V(rec[1]); s0.py = V(rec[2]); s0.pz = V(rec[3]); s0.qw = V(rec[4]); s0.qx = V(rec[5]); s0.qy = V(rec[6]); s0.qz = V(rec[7]);
+    s0.pz_lo = V(rec[8]); s0.qw_lo = V(rec[9]); s0.qx_lo = V(rec[10]); s0.qy_lo = V(rec[11]); s0.qz_lo = V(rec[12]);
+    s0.vx = V(rec[13]); s0.vy = V(rec[14]); s0.vz = V(rec[15]); s0.wx = V(rec[16]); s0.wy = V(rec[17]); s0.wz = V(rec[18]);
+    s0.phi = V(rec[19]); s0.phid = V(rec[20]); s0.turns = V(rec[21]);
+    for (int i = 0; i < 3; i++) { s0.wa[i] = V(rec[22 + i]); s0.wl[i] = V(rec[25 + i]); }
+    s0.wm = V(rec[28]);
+    const float* l = rec + 32;
+    s0.th1 = V(l[0], l[6], l[12], l[18]); s0.th2 = V(l[1], l[7], l[13], l[19]); s0.thd1 = V(l[2], l[8], l[14], l[20]); s0.thd2 = V(l[3], l[9], l[15], l[21]);
+    s0.wj[0] = V(l[4], l[10], l[16], l[22]); s0.wj[1] = V(l[5], l[11], l[17], l[23]);
+    s0.fail = V(T(0));
+    SimOpts o; o.contacts = 1; o.max_newton = max_newton; o.implicit_damp = 1; o.rank_one = 1; o.lean = 0; o.offload = (g_offload && ngroups >= 2) ? 1 : 0; o.prof = nullptr; o.hist = nullptr;
+    o.spread = g_spread;
+    V scratch[SC_COUNT];
+    HostWave wave;
+    wave.ngrp = ngroups; wave.gstride = 16;
+    LaneState<V> s_final;
+    g_ls_trace = trace;
+    auto body = [&](int g) {
+        if (ngroups > 1) { g_host_wave = &wave; g_host_grp = g; }
+        LaneScratch<V> sc; sc.p = scratch; sc.stride = 1; sc.grp = g; sc.ngrp = ngroups; sc.gstride = ngroups > 1 ? 16 : 4;
+        sc.ovc = scratch + SC_OVC; sc.ovc_stride = 1; sc.red_lds = true; sc.pd = SC_PD;
+        const bool rep = g == 0 || (o.offload && g == 1);
+        LaneState<V> s = s0;
+        if (!rep) {
+            s.px = s.py = s.pz = V(T(0)); s.qw = V(T(1)); s.qx = s.qy = s.qz = V(T(0)); s.vx = s.vy = s.vz = s.wx = s.wy = s.wz = V(T(0));
+            s.pz_lo = s.qw_lo = s.qx_lo = s.qy_lo = s.qz_lo = V(T(0));
+            s.phi = s.phid = s.turns = V(T(0)); s.th1 = s.th2 = s.thd1 = s.thd2 = V(T(0));
+        }
+        if (g == 0) {
+            for (int k = 0; k < SC_COUNT; k++) scratch[k] = V(std::numeric_limits<T>::quiet_NaN());
+            if (o.offload) for (int k = 0; k < 56; k++) scratch[SC_ZERO + k] = V(T(0));
+        }
+        if (ngroups > 1) wave.barrier();
+        substep<V>(m, sc, s, V(ctrl), o);
+        if (g == 0) s_final = s;
+        g_host_wave = nullptr;
+    };
+    if (ngroups <= 1) body(0);
+    else {
+        std::vector<std::thread> th;
+        for (int g = 1; g < ngroups; g++) th.emplace_back(body, g);
+        body(0);
+        for (auto& t : th) t.join();
+    }
+    g_ls_trace = 0;
+    if (fail_out) *fail_out = s_final.fail.v[0];
+    return 0;
+}
+// the line-searched second solve (jb_sim.hpp newton_phase<LS = true>): [substeps solved a second time, outer passes of those solves, passes whose
+// line search shortened the step, second solves that ended at NEWTON_LS_CAP]
+extern "C" void jbh_ls_stats(long* out, int reset) { for (int i = 0; i < 4; i++) { out[i] = g_ls_stats[i]; if (reset) g_ls_stats[i] = 0; } }
 extern "C" void jbh_pair_narrow_stats(long* out, int reset) { out[0] = g_pair_narrow_stats[0]; out[1] = g_pair_narrow_stats[1]; if (reset) g_pair_narrow_stats[0] = g_pair_narrow_stats[1] = 0; }
 extern "C" int jbh_lm_count(void) { return LM_COUNT; }
 // the per-leg constant table (LM_COUNT doubles) for inspection by tests / tools

@@ -507,3 +507,62 @@ def test_rollout_loop_in_loop_policy_fp64_equals_oracle_with_the_python_policy(h
         rows, *_ = hrollout(q[0], v[0], t[0], [sc[0], ep[0]], K, None, task, limit, seed, env_global, policy_params=[kw["kick_angle"], kw["speed"], kw["angle_threshold"]])
         assert len(set(np.sign(acts))) == 2 and ref[:, D + 1].sum() == 1          # the policy really switches, and an episode ends inside
         np.testing.assert_allclose(rows, ref, rtol=0, atol=2e-8)
+
+
+# ---- the line-searched second solve (jb_sim.hpp newton_phase<LS = true>: MuJoCo's Newton solver, reference jitterbug.xml:18 defaults)
+def _ls_stats(reset=True):
+    import tests.build_harness as bh
+    lib = C.CDLL(bh.build())
+    lib.jbh_ls_stats.argtypes = [C.POINTER(C.c_long), C.c_int]
+    a = (C.c_long * 4)()
+    lib.jbh_ls_stats(a, 1 if reset else 0)
+    return list(a)
+
+
+@pytest.mark.parametrize("groups", [1, 4])
+def test_line_searched_solve_fp64_equals_oracle(gstep, params, groups):
+    """max_newton = 1: the plain iteration gets ONE check, so every substep whose active set does not repeat at once goes to the line-searched
+    solve - which must reach the minimiser the oracle's Newton (exact line search, fp64) reaches: walking and lying robots, main lanes alone and
+    with helper groups (the line search's sweeps are shared out like every other sweep)."""
+    worst = 0.0
+    resolved = 0
+    for tipped in (False, True):
+        env = _contact_states(params, 10, tipped)
+        rng = np.random.default_rng(11)
+        _ls_stats()
+        for t in range(5):
+            a = np.ones(10) if tipped else rng.uniform(-1, 1, size=10)
+            q0, v0, _ = env.get_state()
+            env.step(a, auto_reset=False)
+            q1, v1, _ = env.get_state()
+            for i in range(10):
+                qg, vg, cap = gstep(q0[i], v0[i], a[i], groups=groups, maxn=1)
+                assert cap == 0
+                worst = max(worst, np.abs(qg - q1[i]).max(), (np.abs(vg - v1[i]) / (1 + np.abs(v1[i]))).max())
+        st = _ls_stats()
+        assert st[0] > 200 and st[1] >= st[0] and st[2] > 0 and st[3] == 0, st      # many substeps were solved twice, some line searches shortened a step, none ended at the cap
+        resolved += st[0]
+    print("line-searched solve vs oracle (%d groups): %.2e over %d re-solved substeps" % (groups, worst, resolved))
+    assert worst < 1e-10, worst
+
+
+def test_line_searched_solve_settles_rounding_level_cycles_fp32(params):
+    """Entry states of substeps (captured on MI355X, fp32 words) in which the plain iteration ran into its cap: most are an edge whose residual is
+    zero to within the rounding of the solve, so that the two sets' minimisers - a few 1e-6 |y| apart - send the iteration to each other for
+    ever; the first two records do that on the host too, line search or not.  The second solve's growing rounding tolerance ends them."""
+    import os
+    import tests.build_harness as bh
+    lib = C.CDLL(bh.build())
+    dp, fp = C.POINTER(C.c_double), C.POINTER(C.c_float)
+    lib.jbh_substep_record.argtypes = [dp, fp, C.c_int, C.c_int, C.c_int, dp]
+    recs = np.load(os.path.join(os.path.dirname(__file__), "golden", "ls_records.npy"))
+    P = np.ascontiguousarray(params, dtype=np.float64)
+    _ls_stats()
+    for groups in (1, 4):
+        for r in recs:
+            r = np.ascontiguousarray(r, dtype=np.float32)
+            fail = np.zeros(1)
+            assert lib.jbh_substep_record(P.ctypes.data_as(dp), r.ctypes.data_as(fp), 12, groups, 0, fail.ctypes.data_as(dp)) == 0
+            assert fail[0] == 0
+    st = _ls_stats()
+    assert st[0] >= 4 and st[3] == 0, st          # the cycling records did go through the second solve, and it settled every one

@@ -25,8 +25,12 @@ for label, n, kw, rnd, const in (("configs[2] uniform", 4096, {}, False, False),
         assert bool(torch.isfinite(rew).all()) and bool(torch.isfinite(obs).all()), (label, e)
     sc, ep, cap = env.counters()
     q, v, _ = env.get_state()
-    print("%-28s %d episodes x %d envs: %.2f M env-steps/s (per episode ms/step min %.3f max %.3f), episodes %d, solver cap hits %.0f (%.2e of the substeps), non-finite steps %d, |quat| error %.1e, z in [%.4f, %.4f]"
-          % (label, E, n, n * 1000 * E / (time.time() - t0) / 1e6, min(ms), max(ms), int(ep[0]), float(cap[cap < 1000].sum()), float(cap[cap < 1000].sum()) / (n * 1000.0 * E * 50), int((cap >= 1000).sum()),
+    try:
+        resolved = env.solver_stats()
+    except AttributeError:          # (an A/B library of an older ABI)
+        resolved = -1
+    print("%-28s %d episodes x %d envs: %.2f M env-steps/s (per episode ms/step min %.3f max %.3f), episodes %d, unconverged substeps %.0f (%.2e of the substeps), wave-substeps solved a second time with the line search %d (%.2e of the wave-substeps), non-finite steps %d, |quat| error %.1e, z in [%.4f, %.4f]"
+          % (label, E, n, n * 1000 * E / (time.time() - t0) / 1e6, min(ms), max(ms), int(ep[0]), float(cap[cap < 1000].sum()), float(cap[cap < 1000].sum()) / (n * 1000.0 * E * 50), resolved, resolved / (n / 4 * 1000.0 * E * 50), int((cap >= 1000).sum()),
              float(np.abs(np.linalg.norm(q[:, 3:7], axis=1) - 1).max()), q[:, 2].min(), q[:, 2].max()))
     assert (cap < 1000).all()
     env.close()
