@@ -136,6 +136,10 @@ def self_launch(n_gpus, argv):
     if rc == 0 and line is None:
         sys.stderr.write("bench.py: the ranks exited cleanly but printed no result line\n")
         rc = 1
+    if line is not None and '"degraded": true' in line:
+        # a DEGRADED line (no data-path collective ran: `value` is null; the ranks exit 3, which torch.distributed.run reports as 1): relayed, rc 3
+        print(line, flush=True)
+        return 3
     if rc == 0:
         print(line, flush=True)
     return rc
@@ -152,7 +156,7 @@ def main(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true")
     ap.add_argument("--no-host-rate", action="store_true", help="skip the host-buffer (jb_step) rate measured next to the headline")
-    ap.add_argument("--max-newton", type=int, default=20)
+    ap.add_argument("--max-newton", type=int, default=0, help="checks of the active set before a substep goes to the line-searched solve (0: the library's default, 12)")
     ap.add_argument("--envs-per-wave", type=int, default=0)
     ap.add_argument("--no-rank-one", action="store_true", help="diagnostic: JB_FLAG_NO_RANK_ONE (every Newton pass is a full pass)")
     ap.add_argument("--no-reorder", action="store_true", help="diagnostic: JB_FLAG_NO_REORDER (never launch the waves longest-first)")
@@ -162,7 +166,10 @@ def main(argv=None):
     ap.add_argument("--no-lean", action="store_true", help="never the LEAN variant")
     ap.add_argument("--actions", default="uniform", help="uniform (default, the metric's workload) | const1 (motor flat out: about half the robots tip over - diagnostic)")
     ap.add_argument("--seed", type=int, default=0, help="reset / action stream seed (the committed numbers use 0)")
-    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the measured path); gloo is a CPU-staged rehearsal of the N>1 control flow")
+    ap.add_argument("--dist-backend", default="nccl", help="--collective torch only: nccl (= RCCL through PyTorch); gloo is a CPU-staged rehearsal of the N>1 control flow")
+    ap.add_argument("--collective", default="cabi", choices=["cabi", "torch"],
+                    help="N > 1: who moves the rows.  cabi (default): the library's own RCCL binding (jb_comm_init / jb_gather_rows_device; torch.distributed carries only control traffic over gloo); "
+                         "torch: torch.distributed's gather.  If the chosen path fails the other is tried, then the shards are timed without any collective and the line says degraded")
     ap.add_argument("--task", default=TASK, help="default move_from_origin (the BASELINE metric); move_to_pose is BASELINE configs[3]'s task")
     ap.add_argument("--augmented", action="store_true", help="one randomised model per env (BASELINE configs[4], augment_Jitterbug semantics)")
     ap.add_argument("--no-steady", action="store_true", help="skip the steady-state (steps 100-400) and full-episode blocks measured next to the headline")
@@ -197,26 +204,36 @@ def main(argv=None):
     force_dist = world == 1 and os.environ.get("JB_BENCH_FORCE_DIST") == "1"
     ctl = None                 # control group (gloo, CPU tensors): barriers, error agreement and the max over ranks never depend on RCCL being healthy
     dist_notes = []
+    nccl_group = [None]        # --collective torch when the default group is gloo: an RCCL subgroup, built on first use
     if world > 1 or force_dist:
         import torch.distributed as dist
-        if args.dist_backend == "nccl":
+        if args.collective == "cabi" or args.dist_backend != "nccl":
+            # control traffic (barriers, the max over ranks, failure agreement, the 128-byte communicator id) over gloo; the rows travel through
+            # the library's own RCCL communicator (cabi) or, --dist-backend gloo, staged through the host (rehearsal)
+            dist.init_process_group("gloo")
+        else:
             try:
                 dist.init_process_group("nccl", device_id=dev)          # RCCL over xGMI (device_id: the communicator is built here, errors surface here)
                 ctl = dist.new_group(backend="gloo")
             except Exception as e:
-                # The first multi-GPU run is also RCCL's first run across real ranks here.  Without it the shards are still independent
-                # (no data-path collective is needed to advance them): time them without the row gather, over gloo, and say so.
-                dist_notes.append("RCCL process group failed (%s: %s): ranks timed WITHOUT the per-step row gather, control over gloo" % (type(e).__name__, str(e)[:200]))
+                dist_notes.append("RCCL process group through PyTorch failed (%s: %s)" % (type(e).__name__, str(e)[:200]))
                 try:
                     dist.destroy_process_group()
                 except Exception:
                     pass
                 dist.init_process_group("gloo")
                 args.dist_backend = "gloo-control-only"
-        else:
-            dist.init_process_group(args.dist_backend)
     local_rank = dev_index
-    use_gather = dist is not None and args.dist_backend != "gloo-control-only"
+    # the data paths to try, in order: what was asked for, then the other RCCL path; after that the shards are timed alone and the line is DEGRADED
+    gather_modes = []
+    if dist is not None:
+        if args.dist_backend == "gloo":
+            gather_modes = ["torch"]                     # rehearsal: torch.distributed over gloo
+        elif args.dist_backend == "gloo-control-only":
+            gather_modes = ["cabi"]                      # PyTorch's RCCL did not come up: the library's own may
+        else:
+            gather_modes = ["cabi", "torch"] if args.collective == "cabi" else ["torch", "cabi"]
+    use_gather = gather_modes[0] if gather_modes else None
 
     class RanksDisagree(RuntimeError):
         pass
@@ -292,7 +309,7 @@ def main(argv=None):
             # [obs | reward | done] itself and rank 0 gathers them every step over RCCL, one step late from a side stream, three row
             # buffers rotating (see ShardedJitterbugEnv).  Actions are resident on every rank (local_actions).
             from jitterbug_amd.distributed import ShardedJitterbugEnv
-            sh = ShardedJitterbugEnv(n * world, task, seed=args.seed, device=dev, pipeline_depth=2, **env_kw)
+            sh = ShardedJitterbugEnv(n * world, task, seed=args.seed, device=dev, pipeline_depth=2, collective=gather, group=torch_group(gather), **env_kw)
             env = sh.env
         else:
             # the handle launches on torch's current stream so torch.cuda.Event brackets exactly these kernels
@@ -329,6 +346,15 @@ def main(argv=None):
 
     finite_warm = [True]
 
+    def torch_group(mode):
+        """the process group the sharded env's torch.distributed calls use: the default one, or - rows through PyTorch's RCCL while the default
+        group is gloo - an nccl subgroup built on first use (collective: every rank comes here together)"""
+        if mode != "torch" or dist.get_backend() != "gloo" or args.dist_backend == "gloo":
+            return None
+        if nccl_group[0] is None:
+            nccl_group[0] = dist.new_group(backend="nccl")
+        return nccl_group[0]
+
     def run_finish(env, sh, obs, last, wall, dev_ms):
         sc, ep, cap = env.counters()
         lastrows = sh.last_local_rows()[:, :D] if sh is not None else obs
@@ -340,15 +366,25 @@ def main(argv=None):
         env.close()
         return wall, dev_ms, float(cap.sum()), finite
 
-    try:
-        wall, dev_ms, cap_hits, finite = run(args.contacts, K, W, gather=use_gather)
-    except RanksDisagree as e:
-        if not use_gather:
-            raise
-        # the gather path failed somewhere: the shards do not need it to advance - time them without it, and say so in the line
-        dist_notes.append("per-step row gather failed (%s): ranks timed WITHOUT it" % str(e)[:300])
-        use_gather = False
-        wall, dev_ms, cap_hits, finite = run(args.contacts, K, W, gather=False)
+    measured = None
+    while True:
+        try:
+            measured = run(args.contacts, K, W, gather=use_gather)
+            break
+        except RanksDisagree as e:
+            if use_gather is None:
+                raise
+            # the data path failed somewhere: try the next one; the shards do not need any to advance - in the end they are timed alone, and
+            # the line says so in a field a driver can read (`degraded`)
+            dist_notes.append("row gather through %s failed (%s)" % ({"cabi": "the library's RCCL binding (jb_gather_rows_device)", "torch": "torch.distributed"}[use_gather], str(e)[:300]))
+            gather_modes = gather_modes[1:]
+            use_gather = gather_modes[0] if gather_modes else None
+    wall, dev_ms, cap_hits, finite = measured
+    degraded = dist is not None and use_gather is None
+    if dist is not None:
+        dist_notes.append("NO data-path collective: the ranks were timed as independent shards" if degraded else
+                          "rows gathered through %s" % {"cabi": "the library's own RCCL communicator (jb_comm_init / jb_gather_rows_device), torch.distributed carries control traffic only (gloo)",
+                                                         "torch": "torch.distributed (%s)" % ("RCCL" if args.dist_backend != "gloo" else "gloo, staged through the host: a rehearsal")}[use_gather])
     wall_max = rank_max(wall)
     total_envs = n * world
     value = total_envs * K / wall_max
@@ -362,7 +398,7 @@ def main(argv=None):
         ws, ds, _, fs = run(args.contacts, 300, 100, gather=use_gather)
         ws = rank_max(ws)
         steady = {"value": total_envs * 300 / ws, "unit": "env steps/s", "ms_per_step": ws * 1e3 / 300, "launch_ms": ds / 300, "steps": 300, "warmup": 100,
-                  "window": "steps 100-400 of the episode (some robots have tipped over by then; the window of profiles/r04_*)", "finite": fs}
+                  "window": "steps 100-400 of the episode (some robots have tipped over by then; the window of profiles/r05_*)", "finite": fs}
         if world == 1 and dist is None:
             wf, df, _, ff = run(args.contacts, 1000, 0, gather=False)
             full_episode = {"value": total_envs * 1000 / wf, "unit": "env steps/s", "ms_per_step": wf * 1e3 / 1000, "launch_ms": df / 1000, "steps": 1000, "warmup": 0,
@@ -427,9 +463,12 @@ def main(argv=None):
     # [K, N_local, D+2] blocks - a hundred times fewer, a hundred times larger collectives than the per-step path).  Next to the headline,
     # never instead of it; a failure here is recorded, it does not take the line down.
     if not args.no_steady and dist is not None and use_gather:
+        # every rank passes the same sync points whatever happens to it (like run()): a rank that fails alone brings its failure to the next
+        # sync point instead of leaving the others in it
+        failure, sh, tape = None, None, None
         try:
             from jitterbug_amd.distributed import ShardedJitterbugEnv
-            sh = ShardedJitterbugEnv(n * world, task, seed=args.seed, device=dev, pipeline_depth=1, variant=variant, per_env_model=args.augmented,
+            sh = ShardedJitterbugEnv(n * world, task, seed=args.seed, device=dev, pipeline_depth=1, variant=variant, per_env_model=args.augmented, collective=use_gather, group=torch_group(use_gather),
                                      contacts=bool(args.contacts), max_newton=args.max_newton, envs_per_wave=args.envs_per_wave)
             if args.augmented:
                 sh.env.randomise_models(seed=1000, return_params=False)
@@ -437,19 +476,25 @@ def main(argv=None):
             g.manual_seed(1234 + rank + 7919 * args.seed)
             tape = torch.rand((1000, n), generator=g, device=dev, dtype=torch.float32) * 2 - 1
             sh.env.reset_device()
-            sync_point()
+        except Exception as e:
+            failure = e
+        try:
+            sync_point(failure)
             t0 = time.perf_counter()
             last = None
-            for k0 in range(0, 1000, 100):
-                last = sh.rollout(100, local_actions=tape[k0:k0 + 100])
-            sync_point()
+            try:
+                for k0 in range(0, 1000, 100):
+                    last = sh.rollout(100, local_actions=tape[k0:k0 + 100])
+            except Exception as e:
+                failure = e
+            sync_point(failure)
             wf = rank_max(time.perf_counter() - t0)
             ok = True if rank != 0 else bool(torch.isfinite(last[0]).all().item()) and last[0].shape[1] == n * world
             rollout_fused = {"k100_sharded": {"value": total_envs * 1000 / wf, "unit": "env steps/s", "ms_per_step": wf * 1e3 / 1000, "launches": 10, "steps_per_launch": 100,
-                                              "gathers": 10, "rows_per_gather": [100, n, D + 2], "finite": ok,
+                                              "gathers": 10, "rows_per_gather": [100, n, D + 2], "finite": ok, "collective": use_gather,
                                               "what": "ShardedJitterbugEnv.rollout(100): one fused 100-step launch per rank, then one gather of [100, N_local, D+2] rows to rank 0; x 10 = a whole episode"}}
             sh.env.close()
-        except Exception as e:            # (the first multi-GPU run is also this path's first run over RCCL: never let it take the headline down)
+        except Exception as e:            # (RanksDisagree on every rank, or a local error after the last sync point: recorded, the headline stands)
             rollout_fused = {"k100_sharded": {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}}
 
     def config_label(contacts):
@@ -498,7 +543,7 @@ def main(argv=None):
         lib_sha = hashlib.sha256(open(_lib.LIB_PATH, "rb").read()).hexdigest()
         traffic = None
         compute = None
-        PROFILE = "profiles/r04_pmc_raw.json"
+        PROFILE = "profiles/r05_pmc_raw.json"
         prof_note = "no PMC summary for this build/workload (tools/collect_profiles.sh + tools/summarise_profiles.py write one)"
         try:
             raw = json.load(open(os.path.join(ROOT, PROFILE)))
@@ -545,13 +590,14 @@ def main(argv=None):
         algo_bytes = ALGO_BYTES_PER_ENV_STEP + 4 * (D - 15) + (12 if task != TASK else 0) + (202 * 4 * 4 if args.augmented else 0)
         achieved = algo_bytes * n / launch_s / 1e9
         gather_txt = ""
-        if dist is not None and not use_gather:
+        if degraded:
             gather_txt = ", NO data-path collective in this run (the shards are independent; see dist_notes)"
         elif world > 1 or dist is not None:
-            gather_txt = ", %s gather of [N,D+2] rows to rank 0 every step, issued one step late from a side stream, three row buffers (jitterbug_amd.distributed.ShardedJitterbugEnv, pipeline_depth=2)" % ("RCCL" if args.dist_backend == "nccl" else args.dist_backend + " (rehearsal, staged through the host)")
+            how = {"cabi": "the library's own RCCL communicator (jb_gather_rows_device: grouped ncclSend / ncclRecv)", "torch": "torch.distributed (%s)" % ("RCCL" if args.dist_backend != "gloo" else "gloo rehearsal, staged through the host")}[use_gather]
+            gather_txt = ", gather of [N,D+2] rows to rank 0 every step through %s, issued one step late from a side stream, three row buffers (jitterbug_amd.distributed.ShardedJitterbugEnv, pipeline_depth=2)" % how
         res = {
             "metric": "env steps/s at N_envs=%d, %s" % (n, task),
-            "value": value, "unit": "env steps/s", "n_gpus": world, "steps": K, "warmup": W,
+            "value": None if degraded else value, "unit": "env steps/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": wall_max * 1e3 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s, N_envs=%d per GPU, %s, 50 substeps/step, in-kernel auto-reset (%s)"
@@ -568,7 +614,11 @@ def main(argv=None):
                          "note": "path is fp32-VALU/latency bound, not HBM bound (SURVEY.md §8d): 317 B per env step vs ~1e5-1e6 dependent flops",
                          "compute": compute, "profile": prof_note},
             "solver_cap_hits": cap_hits, "finite": finite, "lib_sha256": lib_sha, "src_sha256": _lib.load().jb_source_sha256().decode(), "kernel_variant": used_variant[0], "dist_notes": dist_notes,
+            "data_path_collective": (None if dist is None else (use_gather or False)), "degraded": degraded,
         }
+        if degraded:          # a multi-GPU line without the gather is NOT the multi-GPU result: no headline value, the shards' rate on the side, rc 3
+            res["value_independent_shards"] = value
+            res["degraded_why"] = "every data path for the per-step row gather failed (dist_notes); `value_independent_shards` is communication-free and must not be read as scaling"
         res["window"] = "steps %d-%d of an episode from the reset" % (W, W + K)
         if steady:
             res["steady"] = steady
@@ -587,6 +637,7 @@ def main(argv=None):
         print(json.dumps(res))
     if dist is not None:
         dist.destroy_process_group()
+    return 3 if (dist is not None and use_gather is None) else 0
 
 
 if __name__ == "__main__":

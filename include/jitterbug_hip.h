@@ -191,7 +191,8 @@ int jb_rollout_policy(jb_handle* h, int32_t n_steps, float* rewards_out, float* 
  * jb_step_device / jb_step_rows_device ARE this kernel with K = 1: K single-step calls and one K-step call give bit-identical
  * states, rows and rewards (tests/test_gpu_rollout.py), in-kernel auto-reset included. */
 int jb_step_many_device(jb_handle* h, int32_t n_steps, const float* d_actions, float* d_rows_out, float* d_rewards, float* d_obs_last, uint8_t* d_done_last);
-/* host-buffer form (synchronous): actions [K, N] or NULL = in-kernel policy, rows_out [K, N, D+2] nullable */
+/* host-buffer form (synchronous): actions [K, N] or NULL = in-kernel policy, rows_out [K, N, D+2] nullable; the device staging belongs to the
+ * handle and only grows (no allocation from the second call of a size on) */
 int jb_step_many(jb_handle* h, int32_t n_steps, const float* actions, float* rows_out);
 /* seconds each wave of the LAST step launch was alive (one wave = jb_envs_per_wave envs), out[0 .. min(n_waves, max_waves)); returns the
  * number of waves.  Mean against maximum is the load imbalance of the launch (roofline). */
@@ -208,6 +209,8 @@ int jb_comm_unique_id(void* id_out /*[JB_COMM_ID_BYTES]*/);
 int jb_comm_init(jb_handle* h, int32_t n_ranks, int32_t rank, const void* id);
 int jb_comm_destroy(jb_handle* h);
 int jb_gather_rows_device(jb_handle* h, const float* d_rows, float* d_all /*rank 0: [n_ranks, N_local, D+2]; others: NULL*/, void* stream, int32_t use_stream);
+/* the same exchange for `count` floats per rank (equal on every rank): the [K, N_local, D+2] block a fused K-step rollout returns (jb_step_many_device) */
+int jb_gather_block_device(jb_handle* h, const float* d_src, float* d_all /*rank 0: [n_ranks, count]; others: NULL*/, int64_t count, void* stream, int32_t use_stream);
 
 /* Observation-encoder hook (reference jitterbug.py:760-761 -> encode_obs :927-993): a tiny dense network applied to every
  * observation row on the GPU.  n_layers <= JB_ENC_MAX_LAYERS dense layers; dims[0] must be the task's observation width and

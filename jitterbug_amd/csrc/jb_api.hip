@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -683,6 +684,8 @@ struct jb_handle {
     unsigned long long* d_wave_clock;
     unsigned long long* d_resolve;    // [1]: KArgs::resolve_count
     float* d_capture; unsigned* d_capture_count;      // diagnostic builds (-DJB_CAPTURE)
+    float *d_tape, *d_rows_stage, *d_rew_stage;       // staging of the host-buffer rollouts (jb_step_many, jb_rollout_policy): grow-only, freed in jb_destroy
+    size_t tape_cap, rows_cap, rew_cap;               //   their capacities in floats
     int* d_wave_order;               // launch order of the waves (jb_wave_order_kernel), null while the device holds the whole batch at once
     int wave_slots;                  // waves the device holds at once with this handle's kernel variant
     size_t model_tables;
@@ -923,8 +926,11 @@ static int create_impl(jb_handle* h) {      // every failure returns through jb_
         k.epw = epw;
     }
     k.root = h->d_root; k.leg = h->d_leg; k.step_count = h->d_step; k.episode = h->d_episode; k.wave_stats = h->d_wave_stats; k.resolve_count = h->d_resolve; k.capture = h->d_capture; k.capture_count = h->d_capture_count;
-    {   // the step kernels read part of their arguments through the kernarg segment: make sure that layout is what they assume (once per process)
-        static int probed = 0;
+    {   // the step kernels read part of their arguments through the kernarg segment: make sure that layout is what they assume (once per
+        // process; handles created from several threads at once are serialised here)
+        static std::mutex probe_mutex;
+        static bool probed = false;
+        std::lock_guard<std::mutex> lock(probe_mutex);
         if (!probed) {
             int* d_ok = nullptr;
             JB_HIP(hipMalloc(&d_ok, sizeof(int)));
@@ -934,10 +940,10 @@ static int create_impl(jb_handle* h) {      // every failure returns through jb_
             hipLaunchKernelGGL(jb_kernarg_probe_kernel, dim3(1), dim3(1), 0, h->stream, pa, pio, d_ok);
             int ok = 0;
             const hipError_t e1 = hipGetLastError(), e2 = hipMemcpyAsync(&ok, d_ok, sizeof(int), hipMemcpyDeviceToHost, h->stream), e3 = hipStreamSynchronize(h->stream);
-            hipFree(d_ok);
+            hipFree(d_ok);          // (on every path: nothing below returns before this)
             if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) return fail(JB_E_HIP, "kernarg probe failed to run");
             if (!ok) return fail(JB_E_HIP, "the step kernels' view of the kernarg segment does not match their arguments (compiler ABI change?): rebuild is needed with the layout fixed");
-            probed = 1;
+            probed = true;
         }
     }
     int rc = upload_model(h, JB_DEFAULT_PARAMS, 1);
@@ -983,7 +989,7 @@ int jb_destroy(jb_handle* h) {
     guard.enter(h->cfg.device_id);
     if (h->stream || !h->own_stream) hipStreamSynchronize(h->stream);
     if (h->comm && g_rccl.CommDestroy) { g_rccl.CommDestroy(h->comm); h->comm = nullptr; }
-    void* bufs[] = {h->d_capture, h->d_capture_count, h->d_resolve, h->d_wave_order, h->d_wave_clock, h->d_ovc, h->d_terms, h->d_spec, h->d_root, h->d_leg, h->d_model, h->d_step, h->d_episode, h->d_action, h->d_obs, h->d_reward, h->d_done, h->d_mask, h->d_qpos, h->d_qvel, h->d_target, h->d_wave_stats, h->d_enc_params, h->d_code};
+    void* bufs[] = {h->d_tape, h->d_rows_stage, h->d_rew_stage, h->d_capture, h->d_capture_count, h->d_resolve, h->d_wave_order, h->d_wave_clock, h->d_ovc, h->d_terms, h->d_spec, h->d_root, h->d_leg, h->d_model, h->d_step, h->d_episode, h->d_action, h->d_obs, h->d_reward, h->d_done, h->d_mask, h->d_qpos, h->d_qvel, h->d_target, h->d_wave_stats, h->d_enc_params, h->d_code};
     for (void* b : bufs) if (b) hipFree(b);
     if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
     delete h;
@@ -1111,8 +1117,12 @@ static int launch_step(jb_handle* h, StepIO io, int packed_rows) {
     const bool lean_pair = variant == JB_VARIANT_LEAN_PAIR, use_lean = lean_pair || variant == JB_VARIANT_LEAN;
     const size_t lds_bytes = lean_pair ? ((size_t)SC_COUNT_LEAN_PAIR * 4 * h->ka.epw + (size_t)LM_SPLIT_RES * h->ka.epw) * sizeof(float)
                                        : ((size_t)(use_lean ? SC_COUNT_LEAN : SC_COUNT) * 4 * h->ka.epw + (size_t)(use_lean ? LM_TABLE_BASE : LM_TABLE) * (h->ka.per_env_model ? h->ka.epw : 1)) * sizeof(float);
-    static const size_t extra_lds = getenv("JB_DEBUG_EXTRA_LDS") ? (size_t)atoi(getenv("JB_DEBUG_EXTRA_LDS")) : 0;      // occupancy experiments only
+#ifdef JB_DEBUG
+    static const size_t extra_lds = getenv("JB_DEBUG_EXTRA_LDS") ? (size_t)atoi(getenv("JB_DEBUG_EXTRA_LDS")) : 0;      // occupancy experiments (-DJB_DEBUG builds only)
     const size_t lds_bytes_x = lds_bytes + extra_lds;
+#else
+    const size_t lds_bytes_x = lds_bytes;
+#endif
     if (use_lean && !h->d_ovc) {      // the LEAN variant's overflow candidates (beyond the row cache): one block per wave
         const size_t waves = (size_t)grid.x, fl = waves * 4 * (NSLOT - ROW_K) * 4 * h->ka.epw;
         JB_HIP(hipMalloc(&h->d_ovc, fl * sizeof(float)));
@@ -1187,26 +1197,32 @@ int jb_step_many_device(jb_handle* h, int32_t n_steps, const float* d_actions, f
     io.every_step = 2;
     return launch_step(h, io, 0);
 }
+// grow-only device staging owned by the handle: (re)allocated only when a call needs more than any call before it
+static int ensure_stage(jb_handle* h, float** buf, size_t* cap, size_t floats, const char* what) {
+    if (floats <= *cap) return JB_OK;
+    if (*buf) { JB_HIP(hipStreamSynchronize(h->stream)); JB_HIP(hipFree(*buf)); *buf = nullptr; *cap = 0; }
+    if (hipMalloc(buf, sizeof(float) * floats) != hipSuccess) { *buf = nullptr; return fail(JB_E_HIP, std::string("out of device memory for ") + what); }
+    *cap = floats;
+    return JB_OK;
+}
 // host-buffer form of jb_step_many_device: actions [K, N] (NULL: the in-kernel heuristic policy), rows_out [K, N, D+2] (nullable);
-// device staging is allocated for the call, the results are valid on return
+// the device staging belongs to the handle and only ever grows (no allocation after the first call of a given size); the results are valid on return
 int jb_step_many(jb_handle* h, int32_t n_steps, const float* actions, float* rows_out) {
     if (!h) return fail(JB_E_INVALID, "handle is NULL");
     if (n_steps < 0) return fail(JB_E_INVALID, "n_steps < 0");
     if (n_steps == 0) return JB_OK;
     JB_ENTER(h);
     const size_t N = (size_t)h->cfg.n_envs, K = (size_t)n_steps, W = (size_t)h->D + 2;
-    float *d_act = nullptr, *d_rows = nullptr;
     int rc = JB_OK;
-    auto cleanup = [&]() { if (d_act) hipFree(d_act); if (d_rows) hipFree(d_rows); };
     if (actions) {
-        if (hipMalloc(&d_act, sizeof(float) * K * N) != hipSuccess) { cleanup(); return fail(JB_E_HIP, "jb_step_many: out of device memory for the action tape"); }
-        if (hipMemcpyAsync(d_act, actions, sizeof(float) * K * N, hipMemcpyHostToDevice, h->stream) != hipSuccess) { cleanup(); return fail(JB_E_HIP, "jb_step_many: copy of the action tape failed"); }
+        rc = ensure_stage(h, &h->d_tape, &h->tape_cap, K * N, "the action tape");
+        if (rc) return rc;
+        JB_HIP(hipMemcpyAsync(h->d_tape, actions, sizeof(float) * K * N, hipMemcpyHostToDevice, h->stream));
     }
-    if (rows_out && hipMalloc(&d_rows, sizeof(float) * K * N * W) != hipSuccess) { cleanup(); return fail(JB_E_HIP, "jb_step_many: out of device memory for the rows"); }
-    rc = jb_step_many_device(h, n_steps, d_act, d_rows, nullptr, nullptr, nullptr);
-    if (!rc && rows_out && hipMemcpyAsync(rows_out, d_rows, sizeof(float) * K * N * W, hipMemcpyDeviceToHost, h->stream) != hipSuccess) rc = fail(JB_E_HIP, "jb_step_many: copy of the rows failed");
+    if (rows_out) { rc = ensure_stage(h, &h->d_rows_stage, &h->rows_cap, K * N * W, "the rows"); if (rc) return rc; }
+    rc = jb_step_many_device(h, n_steps, actions ? h->d_tape : nullptr, rows_out ? h->d_rows_stage : nullptr, nullptr, nullptr, nullptr);
+    if (!rc && rows_out && hipMemcpyAsync(rows_out, h->d_rows_stage, sizeof(float) * K * N * W, hipMemcpyDeviceToHost, h->stream) != hipSuccess) rc = fail(JB_E_HIP, "jb_step_many: copy of the rows failed");
     const hipError_t e = hipStreamSynchronize(h->stream);
-    cleanup();
     if (!rc && e != hipSuccess) rc = fail(JB_E_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(e));
     return rc;
 }
@@ -1290,14 +1306,13 @@ int jb_rollout_policy(jb_handle* h, int32_t n_steps, float* rewards_out /*[K,N] 
     if (!h || n_steps < 0) return fail(JB_E_INVALID, "handle is NULL or n_steps < 0");
     JB_ENTER(h);
     const size_t N = (size_t)h->cfg.n_envs;
-    float* d_rew = nullptr;
-    if (rewards_out && n_steps > 0) JB_HIP(hipMalloc(&d_rew, sizeof(float) * N * (size_t)n_steps));
+    const bool want_rew = rewards_out && n_steps > 0;
+    if (want_rew) { int rc0 = ensure_stage(h, &h->d_rew_stage, &h->rew_cap, N * (size_t)n_steps, "the rewards"); if (rc0) return rc0; }
     int rc = jb_observe_device(h, h->d_obs, nullptr);
-    if (!rc) rc = jb_rollout_policy_device(h, n_steps, h->d_obs, d_rew, nullptr);
-    if (!rc && d_rew && hipMemcpyAsync(rewards_out, d_rew, sizeof(float) * N * (size_t)n_steps, hipMemcpyDeviceToHost, h->stream) != hipSuccess) rc = fail(JB_E_HIP, "copy of rewards failed");
+    if (!rc) rc = jb_rollout_policy_device(h, n_steps, h->d_obs, want_rew ? h->d_rew_stage : nullptr, nullptr);
+    if (!rc && want_rew && hipMemcpyAsync(rewards_out, h->d_rew_stage, sizeof(float) * N * (size_t)n_steps, hipMemcpyDeviceToHost, h->stream) != hipSuccess) rc = fail(JB_E_HIP, "copy of rewards failed");
     if (!rc && obs_out && hipMemcpyAsync(obs_out, h->d_obs, sizeof(float) * N * h->D, hipMemcpyDeviceToHost, h->stream) != hipSuccess) rc = fail(JB_E_HIP, "copy of observations failed");
     hipError_t e = hipStreamSynchronize(h->stream);
-    if (d_rew) hipFree(d_rew);
     if (!rc && e != hipSuccess) rc = fail(JB_E_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(e));
     return rc;
 }
@@ -1327,6 +1342,7 @@ int jb_reward_terms_device(jb_handle* h, float* d_terms_out) {
 }
 int jb_reward_terms(jb_handle* h, float* terms_out) {
     if (!h || !terms_out) return fail(JB_E_INVALID, "handle/terms is NULL");
+    JB_ENTER(h);
     int rc = jb_reward_terms_device(h, h->d_terms);
     if (rc) return rc;
     JB_HIP(hipMemcpyAsync(terms_out, h->d_terms, sizeof(float) * 4 * (size_t)h->cfg.n_envs, hipMemcpyDeviceToHost, h->stream));
@@ -1525,6 +1541,23 @@ int jb_comm_init(jb_handle* h, int32_t n_ranks, int32_t rank, const void* id) {
 int jb_comm_destroy(jb_handle* h) {
     if (!h) return fail(JB_E_INVALID, "handle is NULL");
     if (h->comm) { JB_ENTER(h); hipStreamSynchronize(h->stream); JB_NCCL(g_rccl.CommDestroy(h->comm)); h->comm = nullptr; }
+    return JB_OK;
+}
+// the same exchange for a block of `count` floats per rank (equal on every rank): what a fused K-step rollout returns, [K, N_local, D+2]
+int jb_gather_block_device(jb_handle* h, const float* d_src, float* d_all, int64_t count, void* stream, int32_t use_stream) {
+    if (!h || !d_src || count < 1) return fail(JB_E_INVALID, "handle/src is NULL or count < 1");
+    if (!h->comm) return fail(JB_E_INVALID, "no communicator (jb_comm_init)");
+    if (h->comm_rank == 0 && !d_all) return fail(JB_E_INVALID, "rank 0 needs the receive buffer [n_ranks, count]");
+    JB_ENTER(h);
+    RoctxRange range("jb_gather_block");
+    hipStream_t st = use_stream ? (hipStream_t)stream : h->stream;
+    JB_NCCL(g_rccl.GroupStart());
+    int err = 0;              // a failed Send/Recv must not leave the RCCL group open: close it, then report the first error
+    if (h->comm_rank == 0)
+        for (int r = 0; r < h->comm_ranks && !err; r++) err = g_rccl.Recv(d_all + (size_t)r * (size_t)count, (size_t)count, 7 /*ncclFloat*/, r, h->comm, st);
+    if (!err) err = g_rccl.Send(d_src, (size_t)count, 7 /*ncclFloat*/, 0, h->comm, st);
+    const int end = g_rccl.GroupEnd();
+    if (err || end) return fail(JB_E_HIP, std::string("RCCL block gather: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(err ? err : end) : "RCCL error"));
     return JB_OK;
 }
 int jb_gather_rows_device(jb_handle* h, const float* d_rows, float* d_all, void* stream, int32_t use_stream) {

@@ -5,7 +5,14 @@ term; the reference's own parallelism is process-level env replication, benchmar
 the contiguous global env range [r*N/R, (r+1)*N/R); RNG streams are keyed by the GLOBAL env index (jb_config.env_offset)
 so results do not depend on R.  The only exchange per control step is the return of results to the host-facing rank:
 a gather of packed rows [N_local, D+2] = obs | reward | done (fp32), and the scatter of actions the other way.
-There is no all-reduce anywhere.  On 8 MI355X the gather is 7 concurrent single-hop xGMI sends into rank 0."""
+There is no all-reduce anywhere.  On 8 MI355X the gather is 7 concurrent single-hop xGMI sends into rank 0.
+
+Two data paths for the rows (ShardedJitterbugEnv(collective=...)):
+  "torch"  torch.distributed's gather (RCCL through PyTorch; gloo for CPU rehearsals)
+  "cabi"   the library's own RCCL binding (jb_comm_init / jb_gather_rows_device / jb_gather_block_device: grouped ncclSend / ncclRecv to
+           rank 0 on a stream of the caller's choosing) - the north-star's "thin C-ABI ... RCCL-over-xGMI gather", with no torch.distributed
+           call on the data path: the process group only carries the 128-byte communicator id once (any group will do; bench.py uses gloo)
+           and actions that rank 0 chooses to scatter."""
 import numpy as np
 
 
@@ -89,6 +96,42 @@ class PendingRows:
         return self._value
 
 
+class _EventPending:
+    """the `work` handle of a gather issued through the C ABI: wait() makes the CURRENT stream wait for the event recorded behind it"""
+
+    def __init__(self, ops, event):
+        self._ops, self._event = ops, event
+
+    def wait(self):
+        self._ops.wait_event(self._ops.current_stream(), self._event)
+
+
+class _CudaStreamOps:
+    """the stream / event vocabulary the C-ABI data path needs, on torch.cuda (torch is plumbing here: streams, events, buffers)"""
+
+    def __init__(self, device):
+        import torch
+        self.torch, self.device = torch, device
+
+    def side_stream(self):
+        return self.torch.cuda.Stream(device=self.device)
+
+    def event(self):
+        return self.torch.cuda.Event()
+
+    def record(self, event, stream):
+        event.record(stream)
+
+    def wait_event(self, stream, event):
+        stream.wait_event(event)
+
+    def current_stream(self):
+        return self.torch.cuda.current_stream(self.device)
+
+    def raw(self, stream):
+        return stream.cuda_stream
+
+
 class ShardedJitterbugEnv:
     """One shard of a global batch per rank.  `local_env_factory(n_local, env_offset)` builds the local stepper
     (default: JitterbugVecEnv on this rank's GPU); it must offer reset()/step(actions) over numpy arrays or the
@@ -102,13 +145,24 @@ class ShardedJitterbugEnv:
     the path `bench.py --gpus N` times (the reference's own vectorisation, stable-baselines SubprocVecEnv, has the same
     step_async / step_wait split: benchmarks/benchmark.py:146-171)."""
 
-    def __init__(self, n_global, task="move_from_origin", seed=0, device=None, local_env_factory=None, group=None, pipeline_depth=1, variant="auto", **env_kwargs):
+    def __init__(self, n_global, task="move_from_origin", seed=0, device=None, local_env_factory=None, group=None, pipeline_depth=1, variant="auto", collective="torch",
+                 stream_ops=None, **env_kwargs):
+        """variant: "auto" (default) resolves the step kernel from the GLOBAL batch and the world size (jitterbug_amd.variants) and takes
+        precedence over a JB_FLAG_LEAN bit in `flags`: below the threshold "auto" CLEARS that bit.  A caller who wants to force a kernel by
+        flags passes variant=None (and then owns the duty of giving every shard the same one); passing both "auto" and JB_FLAG_LEAN is refused.
+        collective: "torch" | "cabi" (module docstring).  stream_ops: the stream / event vocabulary of the "cabi" path (tests pass a stub)."""
         import torch
         import torch.distributed as dist
         from . import variants
         self.group = group
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
         self.n_global = int(n_global)
+        if collective not in ("torch", "cabi"):
+            raise ValueError("collective must be 'torch' or 'cabi'")
+        self.collective = collective
+        if variant == "auto" and (int(env_kwargs.get("flags", 0)) & 2):
+            raise ValueError("variant='auto' chooses the kernel from the global batch and would clear JB_FLAG_LEAN from `flags` below its threshold: "
+                             "pass variant='lean' (every shard), or variant=None to keep the flags as they are")
         # the kernel variant is resolved from the GLOBAL batch and the world size - numbers every rank holds - so that all shards of the batch
         # run the same kernel (the variants agree to rounding only); a caller that passes flags by hand (variant=None) owns that duty
         self.variant = None if variant is None else variants.resolve(variant, variants.envs_per_gpu(n_global, self.world), bool(env_kwargs.get("per_env_model", False)))
@@ -132,8 +186,20 @@ class ShardedJitterbugEnv:
         if pipeline_depth not in (1, 2):
             raise ValueError("pipeline_depth must be 1 or 2")
         self.depth = int(pipeline_depth)
-        self._device_rows = self.on_gpu and hasattr(self.env, "step_rows_device")
-        self._nccl = self._device_rows and dist.get_backend(group) == "nccl"
+        self._cabi = collective == "cabi"
+        self._device_rows = (self.on_gpu or (self._cabi and stream_ops is not None)) and hasattr(self.env, "step_rows_device")
+        if self._cabi:
+            if not self._device_rows:
+                raise ValueError("collective='cabi' needs the device path (a GPU env with step_rows_device)")
+            if min(self.sizes) != max(self.sizes):
+                raise ValueError("collective='cabi': jb_gather_rows_device moves equal blocks - n_global must divide by the world size (got shards %s)" % self.sizes)
+            # the communicator id: made by rank 0, handed round once over the process group (control traffic; 128 bytes)
+            box = [self.env.comm_unique_id() if self.rank == 0 else None]
+            dist.broadcast_object_list(box, src=0, group=group)
+            self.env.comm_init(self.world, self.rank, box[0])
+            self._ops = stream_ops if stream_ops is not None else _CudaStreamOps(self.device)
+        # (in the row-buffer logic below "nccl" means: rows stay on the device and the gather is ordered by streams - true of both RCCL paths)
+        self._nccl = self._device_rows and (self._cabi or dist.get_backend(group) == "nccl")
         self._i = 0                      # steps issued
         self._prev = None                # depth 2 on the blocking paths: the result held back one step
         if self._device_rows:
@@ -149,17 +215,23 @@ class ShardedJitterbugEnv:
             self._gathered = [[blk[r] for r in range(self.world)] for blk in self._blocks] if self.rank == 0 else [None] * self._NB
             self._stage = None if self._nccl else [torch.empty((nmax, D2), dtype=torch.float32).pin_memory() for _ in range(self._NB)]
             self._pending = [None] * self._NB
-            self._side = torch.cuda.Stream(device=self.device) if (self._nccl and self.depth == 2) else None
-            # The step kernel runs on the ENV's stream (the one captured when it was built, or its own): events are recorded on, and
-            # the gathers ordered against, that stream - not whatever torch stream happens to be current when step() is called.
-            sp = self.env.stream
-            self._env_stream = torch.cuda.ExternalStream(int(sp), device=self.device) if sp else torch.cuda.default_stream(self.device)
-            try:
-                torch.cuda.nvtx.range_push("jb_sharded_env"); torch.cuda.nvtx.range_pop()
-                self._nvtx = True
-            except Exception:
+            if self._cabi:
+                self._side = self._ops.side_stream() if self.depth == 2 else None
+                self._env_stream = self._ops.env_stream(self.env) if hasattr(self._ops, "env_stream") else (torch.cuda.ExternalStream(int(self.env.stream), device=self.device) if self.env.stream else torch.cuda.default_stream(self.device))
                 self._nvtx = False
-            self._step_done = [torch.cuda.Event() for _ in range(self._NB)] if self._side is not None else None
+                self._step_done = [self._ops.event() for _ in range(self._NB)] if self._side is not None else None
+            else:
+                self._side = torch.cuda.Stream(device=self.device) if (self._nccl and self.depth == 2) else None
+                # The step kernel runs on the ENV's stream (the one captured when it was built, or its own): events are recorded on, and
+                # the gathers ordered against, that stream - not whatever torch stream happens to be current when step() is called.
+                sp = self.env.stream
+                self._env_stream = torch.cuda.ExternalStream(int(sp), device=self.device) if sp else torch.cuda.default_stream(self.device)
+                try:
+                    torch.cuda.nvtx.range_push("jb_sharded_env"); torch.cuda.nvtx.range_pop()
+                    self._nvtx = True
+                except Exception:
+                    self._nvtx = False
+                self._step_done = [torch.cuda.Event() for _ in range(self._NB)] if self._side is not None else None
             self._late = None            # index of the step whose rows still have to be sent (depth 2)
 
     def last_local_rows(self):
@@ -195,6 +267,18 @@ class ShardedJitterbugEnv:
     def _send_impl(self, j, b):
         import torch
         import torch.distributed as dist
+        if self._cabi:
+            # the library's own collective (jb_gather_rows_device: grouped ncclSend / ncclRecv to rank 0) on the side stream (depth 2: it waits
+            # only for the event of the step that wrote the rows) or on the env's stream (depth 1); an event behind it is what consumers wait for
+            ops = self._ops
+            st = self._side if self._side is not None else self._env_stream
+            if self._side is not None:
+                ops.wait_event(self._side, self._step_done[b])
+            self.env.gather_rows_device(self._rows[b].data_ptr(), self._blocks[b].data_ptr() if self.rank == 0 else None, ops.raw(st))
+            ev = ops.event()
+            ops.record(ev, st)
+            self._pending[b] = _EventPending(ops, ev)
+            return
         if self._side is not None:
             with torch.cuda.stream(self._side):
                 self._side.wait_event(self._step_done[b])
@@ -213,8 +297,8 @@ class ShardedJitterbugEnv:
         import torch
         b = j % self._NB
         if self._pending[b] is not None:
-            self._pending[b].wait()                      # the current stream waits for the gather (stream order, no host sync)
-            self._pending[b] = None
+            self._pending[b].wait()                      # the current stream waits for the gather (stream order, no host sync); the handle stays:
+                                                         # the ENV's stream waits for it too before the buffer is rewritten (_step_device)
         if self.rank != 0:
             return None
         if min(self.sizes) == max(self.sizes):
@@ -228,19 +312,26 @@ class ShardedJitterbugEnv:
         i = self._i
         b = i % self._NB
         if self._pending[b] is not None:                 # the buffer is rewritten only after the gather that read it:
-            with torch.cuda.stream(self._env_stream):    # the ENV's stream (where the kernel that rewrites it runs) waits for that gather
-                self._pending[b].wait()
+            if self._cabi:                               # the ENV's stream (where the kernel that rewrites it runs) waits for that gather
+                self._ops.wait_event(self._env_stream, self._pending[b]._event)
+            else:
+                with torch.cuda.stream(self._env_stream):
+                    self._pending[b].wait()
             self._pending[b] = None
-        cur = torch.cuda.current_stream(self.device)
-        if cur.cuda_stream != self._env_stream.cuda_stream:      # actions produced on another stream: the kernel waits for them.  (RAW handles:
-            self._env_stream.wait_stream(cur)                    # a pool Stream and an ExternalStream never compare equal even when both wrap one hipStream)
+        if self.on_gpu:
+            cur = torch.cuda.current_stream(self.device)
+            if cur.cuda_stream != self._env_stream.cuda_stream:      # actions produced on another stream: the kernel waits for them.  (RAW handles:
+                self._env_stream.wait_stream(cur)                    # a pool Stream and an ExternalStream never compare equal even when both wrap one hipStream)
         self.env.step_rows_device(a.data_ptr(), self._rows[b].data_ptr())
         self._i += 1
         if self.depth == 1:
             self._send(i)
             return self._result(i)
         if self._side is not None:
-            self._step_done[b].record(self._env_stream)
+            if self._cabi:
+                self._ops.record(self._step_done[b], self._env_stream)
+            else:
+                self._step_done[b].record(self._env_stream)
         prev = self._late
         self._late = i
         if prev is None:
@@ -275,12 +366,12 @@ class ShardedJitterbugEnv:
         rows = torch.zeros((K, nmax, D2), device=self.device, dtype=torch.float32)
         if self._device_rows:
             local = rows if self.n_local == nmax else torch.zeros((K, self.n_local, D2), device=self.device, dtype=torch.float32)
-            cur = torch.cuda.current_stream(self.device)
-            if cur.cuda_stream != self._env_stream.cuda_stream:
+            cur = torch.cuda.current_stream(self.device) if self.on_gpu else None
+            if cur is not None and cur.cuda_stream != self._env_stream.cuda_stream:
                 self._env_stream.wait_stream(cur)                      # the tape / row buffers were produced on the current stream
             t = None if tape is None else tape.contiguous()
             self.env.step_many_device(K, None if t is None else t.data_ptr(), rows_ptr=local.data_ptr())
-            if cur.cuda_stream != self._env_stream.cuda_stream:
+            if cur is not None and cur.cuda_stream != self._env_stream.cuda_stream:
                 cur.wait_stream(self._env_stream)
             if local is not rows:
                 rows[:, :self.n_local] = local
@@ -290,6 +381,16 @@ class ShardedJitterbugEnv:
                     raise ValueError("the host stepper has no in-kernel policy: pass a tape")
                 res = self.env.step(tape[k].cpu().numpy())
                 rows[k, :self.n_local] = pack_rows(self._to_tensor(res[0], torch.float32), self._to_tensor(res[1], torch.float32), self._to_tensor(res[2], torch.float32))
+        if self._cabi:          # ONE block gather through the library's own communicator, on the env's stream behind the launch
+            blk = torch.empty((self.world, K, nmax, D2), device=rows.device, dtype=torch.float32) if self.rank == 0 else None
+            self.env.gather_block_device(rows.data_ptr(), None if blk is None else blk.data_ptr(), K * nmax * D2, self._ops.raw(self._env_stream))
+            ev = self._ops.event()
+            self._ops.record(ev, self._env_stream)
+            self._ops.wait_event(self._ops.current_stream(), ev)
+            if self.rank != 0:
+                return None
+            out = torch.cat([blk[r][:, :n] for r, n in enumerate(self.sizes)], 1)          # [K, N_global, D+2]
+            return out[..., :-2], out[..., -2], out[..., -1] > 0.5
         staged = rows.is_cuda and dist.get_backend(self.group) == "gloo"
         send = rows.cpu() if staged else rows
         bufs = [torch.empty_like(send) for _ in range(self.world)] if self.rank == 0 else None

@@ -5,8 +5,9 @@
 ``evaluate_heuristic_batch`` is the MI355X way to get the same statistic: one repeat per env of a batch, the reference's
 heuristic policy evaluated on the device, and all ``_step_limit - 1`` steps chained on the GPU without host round trips.
 
-Note for callers that also use torch in the same process: import torch (and touch the GPU) BEFORE creating a handle, as
-bench.py does; two HIP runtimes initialised in the other order fail to see the device."""
+Callers that also use torch in the same process may create handles and torch tensors in either order: jitterbug_amd._lib binds to the
+HIP runtime PyTorch-ROCm ships before it loads the library, so the process holds one runtime whatever the import order
+(tests/test_gpu_surface.py::test_handles_and_torch_tensors_in_either_order)."""
 import numpy as np
 
 

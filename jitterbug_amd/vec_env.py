@@ -356,6 +356,33 @@ class JitterbugVecEnv:
         self.state_version += 1
         return rows[..., :-2].copy(), rows[..., -2].copy(), rows[..., -1] > 0.5
 
+    # ---- rows between GPUs through the library's own RCCL binding (jb_comm_*: no torch.distributed on the data path)
+    @staticmethod
+    def comm_unique_id():
+        """128 bytes that rank 0 makes and hands to every rank by its own means (jb_comm_unique_id)."""
+        import ctypes
+        uid = (ctypes.c_char * 128)()
+        _lib.check(_lib.load().jb_comm_unique_id(uid))
+        return bytes(uid)
+
+    def comm_init(self, n_ranks, rank, uid):
+        """Collective over the ranks: one RCCL communicator for this handle (jb_comm_init)."""
+        import ctypes
+        buf = (ctypes.c_char * 128).from_buffer_copy(bytes(uid))
+        _lib.check(self._L.jb_comm_init(self._h, int(n_ranks), int(rank), buf))
+
+    def comm_destroy(self):
+        _lib.check(self._L.jb_comm_destroy(self._h))
+
+    def gather_rows_device(self, rows_ptr, all_ptr=None, stream=None):
+        """This rank's packed rows [N, D+2] to rank 0's [n_ranks, N, D+2] (grouped ncclSend / ncclRecv); asynchronous on `stream` (a raw
+        hipStream_t) or, when None, on the handle's stream."""
+        _lib.check(self._L.jb_gather_rows_device(self._h, rows_ptr, all_ptr, stream, 0 if stream is None else 1))
+
+    def gather_block_device(self, src_ptr, all_ptr, count, stream=None):
+        """`count` floats of every rank to rank 0's [n_ranks, count] (a fused rollout's [K, N, D+2] block)."""
+        _lib.check(self._L.jb_gather_block_device(self._h, src_ptr, all_ptr, int(count), stream, 0 if stream is None else 1))
+
     def wave_clocks(self):
         """Seconds each wave of the last step launch was alive (its load imbalance: mean against max)."""
         out = np.zeros(self.num_envs, dtype=np.float64)

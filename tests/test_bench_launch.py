@@ -135,21 +135,23 @@ def test_bench_gpus_2_starts_itself_on_one_gpu_over_gloo():
 
 
 @pytest.mark.gpu
-def test_bench_gpus_2_a_failing_gather_falls_back_to_independent_shards():
-    """The first 8-GPU run is also the first run of the row gather across real ranks.  If the gather path raises, every rank must leave that
-    run together (no rank left behind in a barrier) and the shards are timed without the data-path collective - which they never needed
-    to advance - with the reason in the line."""
+def test_bench_gpus_2_a_failing_gather_gives_a_degraded_line_not_a_result():
+    """The first 8-GPU run is also the first run of the row gather across real ranks.  If every gather path raises, every rank must leave
+    together (no rank left behind in a barrier); the shards are then timed without the data-path collective - which they never needed to
+    advance - but that is NOT the multi-GPU result: the line says `degraded`, carries no headline `value` (the shards' rate sits in
+    `value_independent_shards`) and the run exits 3, so that a driver reading `value` / `n_gpus` cannot book it as scaling."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     env["JB_BENCH_DEVICE"] = "0"
     env["JB_BENCH_TEST_FAIL_GATHER"] = "1"
     env["JB_BENCH_LAUNCH_TIMEOUT"] = "150"
     p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dist-backend", "gloo", "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-steady"],
                        capture_output=True, text=True, timeout=240, cwd=ROOT, env=env)
-    assert p.returncode == 0, p.stderr[-2000:]
+    assert p.returncode == 3, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     d = json.loads(lines[0])
-    assert len(lines) == 1 and d["n_gpus"] == 2 and d["finite"] is True and d["value"] > 0
-    assert len(d["dist_notes"]) == 1 and "injected failure" in d["dist_notes"][0] and "NO data-path collective" in d["config"]["parallelism"]
+    assert len(lines) == 1 and d["n_gpus"] == 2 and d["finite"] is True
+    assert d["degraded"] is True and d["data_path_collective"] is False and d["value"] is None and d["value_independent_shards"] > 0
+    assert any("injected failure" in x for x in d["dist_notes"]) and "NO data-path collective" in d["dist_notes"][-1] and "NO data-path collective" in d["config"]["parallelism"]
 
 
 def test_gpus_n_parent_watchdog_kills_ranks_that_never_finish():
@@ -177,10 +179,11 @@ sys.exit(rc)
 
 @pytest.mark.gpu
 def test_bench_gpus_2_over_rccl_on_one_gpu_succeeds_or_fails_cleanly():
-    """Rehearsal of what the driver's 8-GPU tier does first, as far as a one-GPU box allows: `bench.py --gpus 2` with the DEFAULT backend
-    (nccl = RCCL) and both ranks on device 0.  RCCL may accept that or refuse it (ncclInvalidUsage / "Duplicate GPU detected" - what this
-    pool's does: the ranks then fall back to independent shards together); either way the run must end by itself well inside the
-    watchdog's limit - with one result line (rc 0) or with rc != 0 and no line - and never hang."""
+    """Rehearsal of what the driver's 8-GPU tier does first, as far as a one-GPU box allows: `bench.py --gpus 2` with the DEFAULT data path
+    (--collective cabi: the library's own RCCL communicator; control over gloo) and both ranks on device 0.  RCCL may accept two ranks on one
+    device or refuse them (ncclInvalidUsage / "Duplicate GPU detected" - what this pool's does: cabi fails, torch's RCCL is tried and fails
+    the same way, the ranks then time their shards alone and say `degraded`).  Either way the run must end by itself well inside the
+    watchdog's limit - with one result line (rc 0: gathered; rc 3: degraded) or with another rc and no line - and never hang."""
     import time
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     env["JB_BENCH_DEVICE"] = "0"
@@ -194,8 +197,26 @@ def test_bench_gpus_2_over_rccl_on_one_gpu_succeeds_or_fails_cleanly():
     assert dt < 200 and p.returncode != 124, "the ranks hung until the watchdog"
     if p.returncode == 0:
         d = json.loads(lines[0])
-        assert len(lines) == 1 and d["n_gpus"] == 2 and d["finite"] is True
-        # RCCL took two ranks on one device (then the rows were gathered), or refused and every rank fell back together - and the line says which
-        assert (d["dist_notes"] == [] and "RCCL gather" in d["config"]["parallelism"]) or ("RCCL process group failed" in d["dist_notes"][0] and "NO data-path collective" in d["config"]["parallelism"])
+        assert len(lines) == 1 and d["n_gpus"] == 2 and d["finite"] is True and d["degraded"] is False and d["value"] > 0
+        assert d["data_path_collective"] in ("cabi", "torch") and "rows gathered through" in d["dist_notes"][-1]
+    elif p.returncode == 3:
+        d = json.loads(lines[0])
+        assert len(lines) == 1 and d["n_gpus"] == 2 and d["degraded"] is True and d["value"] is None and d["value_independent_shards"] > 0
+        assert "NO data-path collective" in d["dist_notes"][-1] and len(d["dist_notes"]) >= 3          # both RCCL paths were tried, and the line says why each failed
     else:
         assert lines == []
+
+
+@pytest.mark.gpu
+def test_bench_one_rank_through_the_librarys_own_collective():
+    """JB_BENCH_FORCE_DIST=1: the N > 1 code path with a world of one - process group (gloo, control only), ShardedJitterbugEnv(collective=
+    'cabi'): jb_comm_init with one rank, the pipelined jb_gather_rows_device on the side stream every step, the fused rollout's
+    jb_gather_block_device - through real RCCL calls on a one-GPU box, and the line names the collective that ran."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update({"JB_BENCH_FORCE_DIST": "1", "WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29631"})
+    p = subprocess.run([sys.executable, BENCH, "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-also", "--no-host-rate"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    assert d["data_path_collective"] == "cabi" and d["degraded"] is False and d["finite"] is True and d["value"] > 0
+    assert "the library's own RCCL communicator" in d["dist_notes"][-1] and "jb_gather_rows_device" in d["config"]["parallelism"]
+    assert d["rollout_fused"]["k100_sharded"]["finite"] is True and d["rollout_fused"]["k100_sharded"]["collective"] == "cabi"

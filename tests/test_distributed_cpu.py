@@ -214,3 +214,177 @@ def test_sharded_rollout_one_gather_of_k_steps_matches_single_process_gloo():
         np.testing.assert_allclose(rw[k], rr, rtol=1e-5, atol=1e-6)
         assert np.array_equal(dn[k], rd.astype(bool))
     assert dn.sum() == 2 * n_global
+
+
+# ---- collective="cabi": the control flow of the library's own row gather with a STUB library (no GPU here)
+def _cabi_worker(rank, world, port, n_global, steps, q, depth):
+    """The stub stands in for libjitterbug_hip.so's C ABI: step_rows_device / step_many_device write packed rows through raw pointers (the
+    CPU oracle computes them), comm_unique_id / comm_init record the exchange, gather_rows_device / gather_block_device move `count` floats
+    to rank 0 (over gloo, where the library uses grouped ncclSend / ncclRecv).  Streams and events are recorded, not executed: the test
+    checks the ORDER of what ShardedJitterbugEnv issues (rotating buffers, the one-step-late gather, who waits for what)."""
+    import ctypes as C
+    import torch
+    import torch.distributed as dist
+    from jitterbug_amd.distributed import ShardedJitterbugEnv
+    from oracle import oracle as O
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    P = model.default_params()
+    log = []
+
+    def view(ptr, n):
+        return np.ctypeslib.as_array((C.c_float * n).from_address(ptr))
+
+    class StubLib:
+        obs_dim = model.OBS_DIM["move_to_pose"]
+        stream = 0
+
+        def __init__(self, n, off):
+            self.n, self.e = n, O.OracleEnv(n, "move_to_pose", P, seed=4, env_offset=off, step_limit=3, nsub=5)
+            self.comm = None
+
+        def reset(self):
+            return self.e.reset()
+
+        @staticmethod
+        def comm_unique_id():
+            return bytes(range(128))
+
+        def comm_init(self, n_ranks, r, uid):
+            assert uid == bytes(range(128)) and self.comm is None
+            self.comm = (n_ranks, r)
+            log.append(("comm_init", n_ranks, r))
+
+        def _rows(self, a):
+            o, r, d = self.e.step(a)
+            return np.concatenate([o, r[:, None], d[:, None].astype(np.float64)], 1).astype(np.float32)
+
+        def step_rows_device(self, a_ptr, rows_ptr):
+            view(rows_ptr, self.n * (self.obs_dim + 2))[:] = self._rows(view(a_ptr, self.n).copy()).ravel()
+            log.append(("step", rows_ptr))
+
+        def step_many_device(self, K, a_ptr, rows_ptr=None):
+            W = self.obs_dim + 2
+            tape = view(a_ptr, K * self.n).reshape(K, self.n).copy()
+            out = view(rows_ptr, K * self.n * W).reshape(K, self.n, W)
+            for k in range(K):
+                out[k] = self._rows(tape[k])
+            log.append(("step_many", K))
+
+        def _gather(self, src_ptr, all_ptr, count, stream):
+            assert self.comm == (world, rank)
+            src = torch.from_numpy(view(src_ptr, count).copy())
+            bufs = [torch.empty_like(src) for _ in range(world)] if rank == 0 else None
+            dist.gather(src, bufs, dst=0)
+            if rank == 0:
+                view(all_ptr, world * count)[:] = torch.cat(bufs).numpy()
+
+        def gather_rows_device(self, rows_ptr, all_ptr=None, stream=None):
+            log.append(("gather", rows_ptr, stream))
+            self._gather(rows_ptr, all_ptr, self.n * (self.obs_dim + 2), stream)
+
+        def gather_block_device(self, src_ptr, all_ptr, count, stream=None):
+            log.append(("gather_block", count, stream))
+            self._gather(src_ptr, all_ptr, count, stream)
+
+    class StubOps:                      # streams / events as labels: every call is logged
+        def __init__(self):
+            self.n_ev = 0
+
+        def side_stream(self):
+            return "side"
+
+        def env_stream(self, env):
+            return "env"
+
+        def event(self):
+            self.n_ev += 1
+            return "ev%d" % self.n_ev
+
+        def record(self, ev, stream):
+            log.append(("record", ev, stream))
+
+        def wait_event(self, stream, ev):
+            log.append(("wait", stream, ev))
+
+        def current_stream(self):
+            return "cur"
+
+        def raw(self, stream):
+            return stream
+
+    env = ShardedJitterbugEnv(n_global, "move_to_pose", seed=4, local_env_factory=lambda n, off: StubLib(n, off), pipeline_depth=depth, collective="cabi", stream_ops=StubOps())
+    assert log[0] == ("comm_init", world, rank)
+    env.env.reset()
+    rng = np.random.default_rng(0)
+    outs = []
+    for t in range(steps):
+        acts = torch.from_numpy(rng.uniform(-1, 1, size=n_global).astype(np.float32))[env.lo:env.hi].contiguous()
+        r = env.step(local_actions=acts)
+        keep = lambda x: None if x is None else tuple(v.clone() for v in x)      # (results are views of the rotating receive buffers: valid until they come round again)
+        if depth == 1:
+            outs.append(keep(r))
+        elif t > 0:
+            outs.append(keep(r.get()))
+    if depth == 2:
+        outs.append(keep(env.flush().get()))
+    tape = torch.from_numpy(rng.uniform(-1, 1, size=(4, n_global)).astype(np.float32))[:, env.lo:env.hi].contiguous()
+    ro = env.rollout(4, local_actions=tape)
+    if rank == 0:
+        q.put(([(o.numpy(), r.numpy(), d.numpy()) for o, r, d in outs], (ro[0].numpy(), ro[1].numpy(), ro[2].numpy()), log))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("depth", [1, 2])
+def test_sharded_env_cabi_collective_control_flow_with_a_stub_library(depth):
+    """ShardedJitterbugEnv(collective='cabi'): id exchange, jb_comm_init, one jb_gather_rows_device per step (depth 2: one step late, on the
+    side stream, behind the event of the step that wrote the rows; three rotating buffers, a buffer rewritten only after its gather's
+    event), one jb_gather_block_device per rollout - and the results equal one unsharded env."""
+    import torch.multiprocessing as mp
+    from oracle import oracle as O
+    n_global, steps, world = 12, 5, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_cabi_worker, args=(r, world, port, n_global, steps, q, depth)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs, ro, log = q.get(timeout=240)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    ref = O.OracleEnv(n_global, "move_to_pose", model.default_params(), seed=4, step_limit=3, nsub=5)
+    ref.reset()
+    rng = np.random.default_rng(0)
+    assert len(outs) == steps
+    for (o, r, d) in outs:
+        a = rng.uniform(-1, 1, size=n_global).astype(np.float32)
+        eo, er, ed = ref.step(a)
+        np.testing.assert_allclose(o, eo, rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(r, er, rtol=1e-5, atol=1e-6)
+        assert np.array_equal(d, ed.astype(bool))
+    tape = rng.uniform(-1, 1, size=(4, n_global)).astype(np.float32)
+    for k in range(4):
+        eo, er, ed = ref.step(tape[k])
+        np.testing.assert_allclose(ro[0][k], eo, rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(ro[1][k], er, rtol=1e-5, atol=1e-6)
+    # the order of what was issued (rank 0's log)
+    i_steps = [i for i, e in enumerate(log) if e[0] == "step"]
+    i_gathers = [i for i, e in enumerate(log) if e[0] == "gather"]
+    assert len(i_steps) == steps and len(i_gathers) == steps and sum(e[0] == "gather_block" for e in log) == 1
+    if depth == 2:
+        bufs = [log[i][1] for i in i_steps]
+        assert len(set(bufs[:3])) == 3 and bufs[3] == bufs[0] and bufs[4] == bufs[1]                 # three row buffers, rotating
+        for k, i_g in enumerate(i_gathers):
+            assert log[i_g][2] == "side" and log[i_g][1] == bufs[k]                                  # every gather on the side stream, of step k's buffer,
+            if k + 1 < steps:
+                assert i_g > i_steps[k + 1]                                                          # issued after step k + 1's kernel (one step late),
+            assert log[i_g - 1][0] == "wait" and log[i_g - 1][1] == "side"                           # behind the event of the step that wrote the rows
+            assert log[i_g + 1][0] == "record" and log[i_g + 1][2] == "side"                         # and an event behind it for its consumers
+        assert log[i_steps[3] - 1][0] == "wait" and log[i_steps[3] - 1][1] == "env"                  # buffer 0 is rewritten only after gather 0's event
+        assert log[i_steps[3] - 1][2] == log[i_gathers[0] + 1][1]
+    else:
+        assert all(log[i][2] == "env" for i in i_gathers)

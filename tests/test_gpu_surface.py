@@ -119,6 +119,46 @@ def test_sharded_env_two_ranks_one_gpu():
     assert r.returncode == 0 and "SHARDED_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
 
 
+@pytest.mark.parametrize("torch_first", [True, False])
+def test_handles_and_torch_tensors_in_either_order(torch_first):
+    """INTEGRATION.md 3 / evaluate_policy.py: a process holds ONE HIP runtime whatever the order in which torch touches the GPU and a handle
+    is created (jitterbug_amd._lib preloads the copy PyTorch-ROCm ships).  Each order in a fresh process: a step through device pointers of
+    torch tensors, and a torch kernel on the result."""
+    import os, subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import sys
+        sys.path.insert(0, %r)
+        torch_first = %r
+        if torch_first:
+            import torch
+            x = torch.ones(8, device="cuda:0") * 2
+            assert float(x.sum()) == 16.0
+        from jitterbug_amd.vec_env import JitterbugVecEnv
+        env = JitterbugVecEnv(64, "move_from_origin", seed=2)
+        env.reset()
+        import torch
+        dev = torch.device("cuda", 0)
+        a = torch.zeros(64, device=dev); obs = torch.zeros((64, env.obs_dim), device=dev); rew = torch.zeros(64, device=dev); done = torch.zeros(64, device=dev, dtype=torch.uint8)
+        torch.cuda.synchronize()
+        env.step_device(a.data_ptr(), obs.data_ptr(), rew.data_ptr(), done.data_ptr()); env.synchronize()
+        assert bool(torch.isfinite(obs).all()) and float(obs.abs().sum()) > 0
+        env.close()
+        print("ORDER_OK")
+    """) % (root, torch_first)
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ORDER_OK" in r.stdout, (r.stdout[-1000:], r.stderr[-2000:])
+
+
+def test_sharded_env_over_the_librarys_own_collective_one_rank():
+    """ShardedJitterbugEnv(collective='cabi') - the product class on the C ABI's own RCCL gather - with a world of one on the
+    one-GPU box: both pipeline depths and the fused rollout, bit-identical to one plain env (tests/_sharded_cabi_worker.py)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "_sharded_cabi_worker.py")], cwd=root, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "CABI_SHARDED_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
 def test_integration_md_stub_runs_and_matches_vec_env():
     """The ctypes stub printed in INTEGRATION.md is executed as written (only the library path is substituted)."""
     import os
