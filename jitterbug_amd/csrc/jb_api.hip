@@ -76,8 +76,9 @@ struct StepIO {
 
 // Stage the packed constant table(s) of this workgroup (one wave = a.epw envs) into LDS: one LM_TABLE copy for a
 // shared model, epw copies for per-env models.  Called by all 64 threads before the idle quads retire.
+// aux_grp: -1 = no aux bodies in this kernel; otherwise the caller's lane group (groups 2 and 3 are the aux lanes: SimOpts::aux)
 template <bool SPLIT = false>
-__device__ __forceinline__ void stage_model(const KArgs& a, float* lds, int lblock, int quad, int leg, LaneModel<float>& m, bool lean = false, bool pair = true) {
+__device__ __forceinline__ void stage_model(const KArgs& a, float* lds, int lblock, int quad, int leg, LaneModel<float>& m, bool lean = false, bool pair = true, int aux_grp = -1) {
     m.c.lean = lean;
     m.c.split = false;
     const int tsz = pair ? LM_TABLE : LM_TABLE_BASE, gsz = LM_TABLE;      // staged prefix / table pitch in global memory
@@ -117,14 +118,25 @@ __device__ __forceinline__ void stage_model(const KArgs& a, float* lds, int lblo
             if (e >= a.n) e = a.n - 1;
             lds[i] = a.lane_model[(size_t)e * gsz + (i % tsz)];
         }
+        if (aux_grp >= 0)          // one aux block per env behind the tables (jb_sim.hpp build_aux_block)
+            for (int k = threadIdx.x; k < LM_AUX * a.epw; k += blockDim.x) {
+                int e = env0 + k / LM_AUX;
+                if (e >= a.n) e = a.n - 1;
+                const int kk = k % LM_AUX;
+                lds[tsz * a.epw + k] = aux_entry<float>(a.lane_model + (size_t)e * gsz, LM_INV + (kk >> 2), kk & 3);
+            }
         __syncthreads();
         m.c.inv = lds + quad * tsz;
+        if (aux_grp >= 2) { m.c.tab_rare = m.c.inv + LM_INV + leg; m.c.tab = lds + tsz * a.epw + quad * LM_AUX + leg; }
     } else {
         for (int i = threadIdx.x; i < tsz; i += blockDim.x) lds[i] = a.lane_model[i];
+        if (aux_grp >= 0)          // the aux block behind the table (jb_sim.hpp build_aux_block): the motor body and the root body as two "legs"
+            for (int k = threadIdx.x; k < LM_AUX; k += blockDim.x) lds[tsz + k] = aux_entry<float>(a.lane_model, LM_INV + (k >> 2), k & 3);
         __syncthreads();
         m.c.inv = lds;
     }
-    if (!SPLIT) m.c.tab = m.c.inv + LM_INV + leg;
+    if (!SPLIT && !(a.per_env_model && aux_grp >= 2)) m.c.tab = m.c.inv + LM_INV + leg;
+    if (!SPLIT && !a.per_env_model && aux_grp >= 2) { m.c.tab_rare = m.c.tab; m.c.tab = lds + tsz + leg; }      // an aux lane: hot per-lane entries from the aux block, the rest from the leg it mirrors
     m.c.preload();
 }
 __device__ __forceinline__ void load_state(const KArgs& a, int env, int lane, LaneState<float>& s) {
@@ -233,7 +245,11 @@ __device__ __forceinline__ void step_body(KArgs a, StepIO io) {
     const unsigned long long clock0 = __builtin_amdgcn_s_memrealtime();
     LaneModel<float> m;
     constexpr int SCN = LEAN ? (PAIR ? SC_COUNT_LEAN_PAIR : SC_COUNT_LEAN) : SC_COUNT;      // floats of per-lane scratch
-    stage_model<LEAN && PAIR>(a, lds + SCN * 4 * EPW, lblock, quad, leg, m, LEAN, PAIR || !LEAN);      // (LEAN + PAIR is only launched with one model per env: split tables)
+    // AUX bodies (jb_sim.hpp SimOpts::aux): the ordinary kernel with four lane groups and a shared model - groups 2 and 3 run phase A on the
+    // motor body and the root body's own mass instead of idling while every leg lane repeats that work
+    constexpr bool AUX = !LEAN && !PAIR && NGRP == 4;
+    constexpr bool aux_on = AUX;
+    stage_model<LEAN && PAIR>(a, lds + SCN * 4 * EPW, lblock, quad, leg, m, LEAN, PAIR || !LEAN, aux_on ? grp : -1);      // (LEAN + PAIR is only launched with one model per env: split tables)
     if (grp >= NGRP || env >= a.n) return;       // whole quads (and their mirrors in every group) retire together
     const int lane = env * 4 + leg;
     LaneScratch<float> scr;
@@ -244,14 +260,15 @@ __device__ __forceinline__ void step_body(KArgs a, StepIO io) {
     else { scr.ovc = lds + SC_OVC * MAIN + lane_in_grp; scr.red_lds = true; }
     scr.ovc_stride = MAIN;
     scr.pd = LEAN ? SC_PD_LEAN : SC_PD;
+    scr.aux_lane = aux_on && grp >= 2;
 #ifdef JB_WAVE_STATS
     const unsigned long long t_start = __builtin_amdgcn_s_memtime();
 #endif
     LaneState<float> s;
     constexpr bool OFFLOAD = !LEAN;              // lane group 1 replicates the main lanes (jb_sim.hpp SimOpts::offload)
-    // the lanes that hold an env's state: the main lanes and their replica.  Both run everything below that changes the state
+    // the lanes that hold an env's state: the main lanes, their replica and the aux lanes.  All run everything below that changes the state
     // (substeps, failure flag, episode reset) with the very same instructions; only the main lanes write to memory.
-    const bool rep = grp == 0 || (OFFLOAD && grp == 1);
+    const bool rep = grp == 0 || (OFFLOAD && grp == 1) || scr.aux_lane;
     if (rep) load_state(a, env, lane, s);
     else {
         s.px = s.py = s.pz = 0.f; s.qw = 1.f; s.qx = s.qy = s.qz = 0.f; s.vx = s.vy = s.vz = s.wx = s.wy = s.wz = 0.f;
@@ -264,6 +281,7 @@ __device__ __forceinline__ void step_body(KArgs a, StepIO io) {
     s.st_xtra = 0.f; s.st_sweeps = 0.f; s.st_contact = 0.f; s.st_slots = 0.f; s.st_fast = 0.f; s.st_checks = 0.f;
 #endif
     SimOpts o; o.contacts = a.contacts; o.max_newton = a.max_newton; o.implicit_damp = 1; o.rank_one = a.rank_one; o.lean = LEAN ? 1 : 0; o.offload = OFFLOAD ? 1 : 0; o.spread = a.spread; o.prof = nullptr; o.hist = nullptr;
+    o.aux = aux_on ? 1 : 0;
 #ifdef JB_CAPTURE
     o.capture = a.capture; o.capture_count = a.capture_count;
 #endif
@@ -1115,8 +1133,9 @@ static int launch_step(jb_handle* h, StepIO io, int packed_rows) {
     }
     io.wave_order = reorder ? h->d_wave_order : nullptr;
     const bool lean_pair = variant == JB_VARIANT_LEAN_PAIR, use_lean = lean_pair || variant == JB_VARIANT_LEAN;
+    const bool aux_bodies = variant == JB_VARIANT_ORDINARY && h->ka.epw <= 4;      // (step_body: AUX - an aux block behind every staged table)
     const size_t lds_bytes = lean_pair ? ((size_t)SC_COUNT_LEAN_PAIR * 4 * h->ka.epw + (size_t)LM_SPLIT_RES * h->ka.epw) * sizeof(float)
-                                       : ((size_t)(use_lean ? SC_COUNT_LEAN : SC_COUNT) * 4 * h->ka.epw + (size_t)(use_lean ? LM_TABLE_BASE : LM_TABLE) * (h->ka.per_env_model ? h->ka.epw : 1)) * sizeof(float);
+                                       : ((size_t)(use_lean ? SC_COUNT_LEAN : SC_COUNT) * 4 * h->ka.epw + ((size_t)(use_lean ? LM_TABLE_BASE : LM_TABLE) + (aux_bodies ? LM_AUX : 0)) * (h->ka.per_env_model ? h->ka.epw : 1)) * sizeof(float);
 #ifdef JB_DEBUG
     static const size_t extra_lds = getenv("JB_DEBUG_EXTRA_LDS") ? (size_t)atoi(getenv("JB_DEBUG_EXTRA_LDS")) : 0;      // occupancy experiments (-DJB_DEBUG builds only)
     const size_t lds_bytes_x = lds_bytes + extra_lds;

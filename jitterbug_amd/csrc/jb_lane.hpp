@@ -75,6 +75,23 @@ JB_D float row_transpose_sum(float v0, float v1, float v2, float v3) {
     auto r = __builtin_amdgcn_permlane16_swap(b(s02), b(s13), false, false);
     return f(r[0]) + f(r[1]);
 }
+// The value lane L ^ off holds (off = 32, 16 or 8: the distance to the lane group two groups on).  Exact for the lanes of the LOWER
+// group of each pair (what jb_sim.hpp's aux bodies need: groups 0 / 1 read groups 2 / 3); the upper group's result is unspecified.
+JB_D unsigned xor_get_bits(unsigned u, int off) {
+    if (off == 32) { auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false); return r[1]; }      // (vsrc's lower half receives vdst's upper half)
+    if (off == 16) { auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false); return r[1]; }      // (vsrc's even rows receive vdst's odd rows)
+    if (off == 8) return (unsigned)__builtin_amdgcn_update_dpp(0, (int)u, 0x128, 0xF, 0xF, false);      // row_ror:8
+    return (unsigned)__shfl_xor((int)u, off, 64);
+}
+// ... exact for every lane (two more integer operations)
+JB_D unsigned xor_get_any_u(unsigned u, int off) {
+    if (off == 32) { auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false); return r[0] ^ r[1] ^ u; }
+    if (off == 16) { auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false); return r[0] ^ r[1] ^ u; }
+    return xor_get_bits(u, off);
+}
+JB_D float xor_get(float x, int off) { return __builtin_bit_cast(float, xor_get_bits(__builtin_bit_cast(unsigned, x), off)); }
+JB_D unsigned xor_get_u(unsigned x, int off) { return xor_get_bits(x, off); }
+template <int J> JB_D float quad_bcast(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), J * 0x55, 0xF, 0xF, false)); }
 JB_D float xor_sum(float x, int off, bool sym2) { return __builtin_bit_cast(float, xor_sum_bits(__builtin_bit_cast(unsigned, x), off, sym2, true)); }
 JB_D unsigned xor_sum_u(unsigned x, int off, bool sym2) { return xor_sum_bits(x, off, sym2, false); }
 JB_D unsigned wave_bcast_u(unsigned x) { return (unsigned)__builtin_amdgcn_readfirstlane((int)x); }   // value of the first active lane
@@ -291,6 +308,23 @@ inline UQuad xor_sum_u(const UQuad& x, int off, bool) {
     w->barrier();
     return r;
 }
+template <typename T> inline Quad<T> xor_get(const Quad<T>& x, int off) {
+    if (!g_host_wave) return x;
+    return host_exchange(x, g_host_grp ^ (off / g_host_wave->gstride));
+}
+inline UQuad xor_get_u(const UQuad& x, int off) {
+    HostWave* w = g_host_wave;
+    if (!w) return x;
+    for (int i = 0; i < 4; i++) w->umbox[g_host_grp][i] = x.v[i];
+    w->barrier();
+    UQuad r;
+    const int partner = g_host_grp ^ (off / w->gstride);
+    for (int i = 0; i < 4; i++) r.v[i] = w->umbox[partner][i];
+    w->barrier();
+    return r;
+}
+inline UQuad xor_get_any_u(const UQuad& x, int off) { return xor_get_u(x, off); }
+template <int J, typename T> inline Quad<T> quad_bcast(const Quad<T>& x) { return Quad<T>(x.v[J]); }
 inline unsigned wave_bcast_u(unsigned x) {           // the first lane of the wave is a lane of group 0
     HostWave* w = g_host_wave;
     if (!w) return x;

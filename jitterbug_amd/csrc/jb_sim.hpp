@@ -138,6 +138,8 @@ template <typename T> inline Quad<T> lane_bcast(const T* p, Quad<T>*) { return Q
 template <typename V> struct LaneConsts {
     const typename lane_traits<V>::real* inv;
     const typename lane_traits<V>::real* tab;
+    const typename lane_traits<V>::real* tab_rare = nullptr;     // per-lane entries >= LM_HOT, addressed like `tab`: the same block for ordinary lanes; the AUX lanes (SimOpts::aux)
+                                                                 // take their hot entries from an aux block and everything else from the leg they mirror
     // The entries used every substep are read from the table ONCE per kernel (preload()) and then live in registers: with
     // one wave per SIMD the kernel owns all 512 registers of its lanes, and the allocator parks these long-lived values in
     // the accumulation half, one v_accvgpr_read away - no LDS round trip, no s_waitcnt in the middle of the dynamics.
@@ -159,7 +161,7 @@ template <typename V> struct LaneConsts {
     bool split = false;
     JB_HD V table(int i) const {
         if (i < LM_INV) return lane_bcast(inv + i, (V*)nullptr);
-        if (!split) return lane_from4(tab + 4 * (i - LM_INV), (V*)nullptr);
+        if (!split) return lane_from4((i < LM_HOT || !tab_rare ? tab : tab_rare) + 4 * (i - LM_INV), (V*)nullptr);
         const int r = lm_split_res_lane(i);
         if (r >= 0) return lane_bcast(tab + 4 * r, (V*)nullptr);                                  // (split: tab = the lane's resident entries)
         if (i >= LM_PE_C && i < LM_PE_C + 15) return lane_bcast(inv + LM_INV + (i - LM_PE_C), (V*)nullptr);
@@ -176,6 +178,30 @@ template <typename V> struct LaneConsts {
     }
     JB_HD V operator[](int i) const { return (i < LM_HOT && !lean) ? hot[i] : table(i); }
 };
+// The AUX block (SimOpts::aux): the hot per-lane entries [LM_INV, LM_HOT) of the four lanes of a helper quad that runs phase A for the two bodies
+// every leg lane would otherwise repeat - lane 0: the MOTOR body as "an upper leg whose lower leg has no mass" (hinge em at am, COM offset dcm,
+// inertia Im, mass mm; its angle is the motor's), lane 1: the ROOT body's own mass likewise (no hinge: axis 0, COM c0, inertia I0, mass m0),
+// lanes 2, 3: nothing.  Everything outside the body entries [LM_A1, LM_B2] is the mirrored leg's own value (the contact-row weights TRAN1 /
+// TRAN2 that the lanes use as helper lanes in phase B, the task constants the control-step tail reads).  tab: a packed table (LM_TABLE layout).
+template <typename R> JB_HD R aux_entry(const R* tab, int i, int lane) {
+    if (i < LM_A1 || i > LM_B2) return tab[LM_INV + 4 * (i - LM_INV) + lane];
+    if (lane == 0) {
+        if (i >= LM_A1 && i < LM_A1 + 3) return tab[LM_AM + (i - LM_A1)];
+        if (i >= LM_E1 && i < LM_E1 + 3) return tab[LM_EM + (i - LM_E1)];
+        if (i >= LM_DC1 && i < LM_DC1 + 3) return tab[LM_DCM + (i - LM_DC1)];
+        if (i >= LM_I1 && i < LM_I1 + 6) return tab[LM_IM + (i - LM_I1)];
+        if (i == LM_M1) return tab[LM_MM];
+    } else if (lane == 1) {
+        if (i >= LM_DC1 && i < LM_DC1 + 3) return tab[LM_C0 + (i - LM_DC1)];
+        if (i >= LM_I1 && i < LM_I1 + 6) return tab[LM_I0 + (i - LM_I1)];
+        if (i == LM_M1) return tab[LM_M0];
+    }
+    return R(0);
+}
+constexpr int LM_AUX = 4 * (LM_HOT - LM_INV);        // floats of an aux block, laid out like the per-lane part of a table: [LM_HOT - LM_INV][4]
+template <typename R> JB_HD void build_aux_block(const R* tab, R* aux) {
+    for (int k = 0; k < LM_AUX; k++) aux[k] = aux_entry<R>(tab, LM_INV + (k >> 2), k & 3);
+}
 template <typename V> struct LaneModel { LaneConsts<V> c; };
 template <typename V> JB_HD V ldc(const LaneModel<V>& m, int i) { return m.c[i]; }
 
@@ -342,6 +368,7 @@ template <typename V> struct LaneScratch {
     V* ovc;                   // candidates of the live slots beyond the row cache: [i * ovc_stride], LDS (SC_OVC) or, in the LEAN variant, global memory
     int ovc_stride;
     int pd;                   // where the pair contact's frame lives (SC_PD, or SC_PD_LEAN in the LEAN layout)
+    bool aux_lane = false;    // this lane is an AUX lane (SimOpts::aux): it runs phase A on a body of its own and must not write the scratch of the leg it mirrors
     bool red_lds;             // the group reduction hands its totals over through SC_RED (false: combined in registers, the LEAN variant has no room for the buffer)
     JB_HD V ld(int i) const { return p[i * stride]; }
     JB_HD void st(int i, const V& v) const { p[i * stride] = v; }
@@ -1290,6 +1317,7 @@ JB_HD unsigned cand_store(const LaneScratch<V>& sc, unsigned live_before, int sl
     if (own) *own = *own + selu(on, zero_u<V>() + (1u << slot), zero_u<V>());      // leg slots: which of them are contacts of THIS lane's leg
     const int rank = __builtin_popcount(live_before & ((1u << slot) - 1u));
     const V d = sel(on, dist, V(1));
+    if (sc.aux_lane) return 1u << slot;          // (an aux lane's masks are never set; it mirrors a leg lane's addresses and must not write there)
     if (rank < ROW_K) {
         const int e0 = SC_ROWS + ROW_F * rank;
         sc.st3(e0, x); sc.st(e0 + 3, d);
@@ -1467,6 +1495,11 @@ struct SimOpts {
                          //    While the main lanes factorise the first Newton system of a substep, the replica factorises M + h diag(b) with the
                          //    very same instructions (zero accumulator, hb on its diagonal); the final pass is then a substitution in the replica
                          //    and a 9-value hand-over instead of a second factorisation on the critical path.  Bit-identical results.
+    int aux = 0;         // 1 (offload kernels with four lane groups, shared model): lane groups 2 and 3 - idle in phase A otherwise - hold the env's root state too and run
+                         //    phase A / C WITH the main lanes and their replica, instruction for instruction, on two "legs" of their own: the motor body
+                         //    (lane 0 of their quad) and the root body's own mass (lane 1); build_aux_block.  What the four leg lanes (and the replica) used to
+                         //    repeat - motor kinematics, composite inertia and bias, root bias: ~9 % of a substep's instructions - is then computed ONCE, by the
+                         //    very instructions that compute the legs, and handed over with 23 cross-lane swaps (group 0 <- 2, group 1 <- 3).
     int spread = 1;      // 1: a plan with more than one round sweeps the leg slots in spread mode (lanes of idle legs adopt contacts of a leg that has
                          //    several: "spread sweeps" below); 0: diagnostic, the ordinary sweep only
     float* capture = nullptr;           // diagnostic builds (-DJB_CAPTURE): ring of JB_CAPTURE_SLOTS records x 64 floats - the entry state of substeps whose contact solve stayed
@@ -2002,9 +2035,19 @@ JB_HD bool substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
     const bool is_main = (sc.grp == 0);
     const bool g1 = o.offload && sc.grp == 1;       // the replica group (its LDS stores repeat the main lanes': same address, same value)
     const bool rep = is_main || g1;
+    // AUX lanes (SimOpts::aux: lane groups 2 and 3): the same phase A / C on the motor body (lane 0 of the quad) and the root body's own mass
+    // (lane 1) as "legs"; what they find goes to the main lanes (group 0 <- 2) and the replica (1 <- 3) by cross-lane swaps below.
+    const bool axl = o.aux != 0 && sc.grp >= 2;
+    const int axoff = 2 * sc.gstride;               // lane distance to the partner group
+    const MK ax_mask = axl ? lt(V(0), V(1)) : lt(V(1), V(0));
+    const MK ax_motor = mand(ax_mask, eq_u(quad_lane_id((const V*)nullptr), 0u));
+    const MK lane_ok = mnot(ax_mask);               // this lane stands for a real leg: it may have contacts
+    if (axl) {      // the aux lanes' "leg" state: the motor's angle and rate in the shoulder slot of lane 0, nothing else
+        s.th1 = sel(ax_motor, s.phi, V(0)); s.thd1 = sel(ax_motor, s.phid, V(0)); s.th2 = V(0); s.thd2 = V(0);
+    }
     StarSys<V> sys;     // written and read by the main lanes (and their replica) only
-    if (rep) {   // ================= phase A: kinematics, composite inertia, bias forces, contact candidates -> scratch
-        sc.st3(SC_ST, w); sc.st(SC_ST + 3, s.thd1); sc.st(SC_ST + 4, s.thd2); sc.st(SC_ST + 5, s.phid);      // for the helper groups
+    if (rep || axl) {   // ================= phase A: kinematics, composite inertia, bias forces, contact candidates -> scratch
+        if (!axl) { sc.st3(SC_ST, w); sc.st(SC_ST + 3, s.thd1); sc.st(SC_ST + 4, s.thd2); sc.st(SC_ST + 5, s.phid); }      // for the helper groups
         const Mat3<V>& R = Rw;                                       // root rotation of the normalised quaternion (substep())
         Vec3<V> nb = v3<V>(R.m[6], R.m[7], R.m[8]);                 // R^T ez
         Vec3<V> u = mulT(R, v3<V>(s.vx, s.vy, s.vz));
@@ -2015,7 +2058,13 @@ JB_HD bool substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
         V s1, c1, s2, c2;
         sincos_small(s.th1, s1, c1);
         sincos_small(s.th2, s2, c2);
-        if (any_lane(mor(gt(vabs(s.th1), V(0.9)), gt(vabs(s.th2), V(0.9))))) { s1 = vsin(s.th1); c1 = vcos(s.th1); s2 = vsin(s.th2); c2 = vcos(s.th2); }
+        if (any_lane(mand(lane_ok, mor(gt(vabs(s.th1), V(0.9)), gt(vabs(s.th2), V(0.9)))))) { s1 = vsin(s.th1); c1 = vcos(s.th1); s2 = vsin(s.th2); c2 = vcos(s.th2); }
+        V sp, cp;
+        vsincos_pi(s.phi, sp, cp);
+#ifdef JB_EXP_NO_MOTOR      // (measurement only, wrong physics: what the replicated motor-body work costs a substep)
+        sp = V(0); cp = V(1);
+#endif
+        if (o.aux) { s1 = sel(ax_motor, sp, s1); c1 = sel(ax_motor, cp, c1); }      // the motor's angle is wrapped to [-pi, pi): its own sine / cosine routine
         Mat3<V> R1 = rodrigues(e1, s1, c1);
         Mat3<V> R12 = mul(R1, rodrigues(ldv3(m, LM_E2), s2, c2));
         Vec3<V> a2 = a1 + mul(R1, ldv3(m, LM_DA2));
@@ -2026,13 +2075,16 @@ JB_HD bool substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
         Sym3<V> I2 = rotate(R12, ldsym(m, LM_I2));
         const V m1 = m.c[LM_M1], m2 = m.c[LM_M2];
 
-        // ---- motor body kinematics (replicated)
+        // ---- motor body kinematics (replicated in every lane - unless the aux lanes have the motor body: SimOpts::aux)
         Vec3<V> am = ldv3(m, LM_AM), em = ldv3(m, LM_EM);
-        V sp, cp;
-        vsincos_pi(s.phi, sp, cp);
-        Mat3<V> Rm = rodrigues(em, sp, cp);
-        Vec3<V> cm = am + mul(Rm, ldv3(m, LM_DCM));
-        Sym3<V> Im = rotate(Rm, ldsym(m, LM_IM));
+        Mat3<V> Rm;
+        Vec3<V> cm;
+        Sym3<V> Im;
+        if (!o.aux) {
+            Rm = rodrigues(em, sp, cp);
+            cm = am + mul(Rm, ldv3(m, LM_DCM));
+            Im = rotate(Rm, ldsym(m, LM_IM));
+        }
         const V mm = m.c[LM_MM], m0 = m.c[LM_M0];
         Vec3<V> c0 = ldv3(m, LM_C0);
         Sym3<V> I0 = ldsym(m, LM_I0);
@@ -2043,10 +2095,10 @@ JB_HD bool substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
             U own = zero_u<V>();            // the leg slots in which this lane's leg has a contact
             Vec3<V> foot = a2 + mul(R12, ldv3(m, LM_DFOOT));
             V fdist = (s.pz + dot(foot, nb) - m.c[LM_FOOT_R]) + s.pz_lo;
-            MK fon = lt(fdist, V(0));
+            MK fon = mand(lane_ok, lt(fdist, V(0)));
             live_slots |= cand_store(sc, live_slots, 0, foot - nb * (m.c[LM_FOOT_R] + fdist * V(0.5)), fdist, fon, &own);
             CylContacts<V> lc;
-            MK all_on = lt(V(0), V(1));
+            MK all_on = lane_ok;
             cylinder_floor(a2 + mul(R12, ldv3(m, LM_LC_D)), mul(R12, ldv3(m, LM_LC_AX)), mul(R12, ldv3(m, LM_LC_XA)), m.c[LM_LC_R], m.c[LM_LC_H], nb, s.pz, s.pz_lo, all_on, lc);
             live_slots |= cand_store_cyl(sc, live_slots, 1, lc, all_on, &own);
             MK any_con = mor(fon, lc.on[0]);
@@ -2058,14 +2110,15 @@ JB_HD bool substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
                 any_con = mor(any_con, cy.on[0]);
                 Vec3<V> tip = a1 + mul(R1, ldc3(m, LM_DTIP));
                 V tipd = (s.pz + dot(tip, nb) - ldc(m, LM_TIP_R)) + s.pz_lo;
-                live_slots |= cand_store(sc, live_slots, 9, tip - nb * (ldc(m, LM_TIP_R) + tipd * V(0.5)), tipd, lt(tipd, V(0)), &own);
-                any_con = mor(any_con, lt(tipd, V(0)));
+                live_slots |= cand_store(sc, live_slots, 9, tip - nb * (ldc(m, LM_TIP_R) + tipd * V(0.5)), tipd, mand(lane_ok, lt(tipd, V(0))), &own);
+                any_con = mor(any_con, mand(lane_ok, lt(tipd, V(0))));
               if (xbody) {
+                if (o.aux) Rm = rodrigues(em, sp, cp);          // (the motor body's rotation for its geoms: rare path, computed where it is needed)
                 // lane cylinder (root body: lane 2 screw1; motor body: lane 3 threadMass)
                 MK x_onm = gt(ldc(m, LM_X_ONM), V(0.5));
                 Vec3<V> xc_c = ldc3(m, LM_XC_C), xc_ax = ldc3(m, LM_XC_AX), xc_xa = ldc3(m, LM_XC_XA);
                 cylinder_floor(sel_v3(x_onm, am + mul(Rm, xc_c - am), xc_c), sel_v3(x_onm, mul(Rm, xc_ax), xc_ax), sel_v3(x_onm, mul(Rm, xc_xa), xc_xa),
-                               ldc(m, LM_XC_R), ldc(m, LM_XC_H), nb, s.pz, s.pz_lo, gt(ldc(m, LM_XC_EN), V(0.5)), cy);
+                               ldc(m, LM_XC_R), ldc(m, LM_XC_H), nb, s.pz, s.pz_lo, mand(lane_ok, gt(ldc(m, LM_XC_EN), V(0.5))), cy);
                 live_slots |= cand_store_cyl(sc, live_slots, 10, cy, mnot(x_onm));      // (slots in increasing order: 10-13, 14, 15-22, then the motor body's 23-27)
                 any_con = mor(any_con, cy.on[0]);
                 Vec3<V> ellx_m;
@@ -2085,7 +2138,7 @@ JB_HD bool substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
                     V iden = vrsqrt(sz.x * sz.x * dl.x * dl.x + sz.y * sz.y * dl.y * dl.y + sz.z * sz.z * dl.z * dl.z);
                     Vec3<V> sup = ec + mul(Re, v3<V>(sz.x * sz.x * dl.x * iden, sz.y * sz.y * dl.y * iden, sz.z * sz.z * dl.z * iden));
                     V elld = (s.pz + dot(sup, nb)) + s.pz_lo;
-                    MK ellon = mand(gt(ldc(m, LM_XE_EN), V(0.5)), lt(elld, V(0)));
+                    MK ellon = mand(mand(lane_ok, gt(ldc(m, LM_XE_EN), V(0.5))), lt(elld, V(0)));
                     Vec3<V> ellx = sup - nb * (elld * V(0.5));
                     live_slots |= cand_store(sc, live_slots, 14, ellx, elld, mand(ellon, mnot(x_onm)));
                     ellx_m = ellx; elld_m = elld; ellon_m = mand(ellon, x_onm);
@@ -2096,7 +2149,7 @@ JB_HD bool substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
 #pragma unroll
                     for (int i = 0; i < 9; i++) Rb.m[i] = ldc(m, LM_XB_R + i);
                     Vec3<V> bc = ldc3(m, LM_XB_C), bs = ldc3(m, LM_XB_S);
-                    MK ben = gt(ldc(m, LM_XB_EN), V(0.5));
+                    MK ben = mand(lane_ok, gt(ldc(m, LM_XB_EN), V(0.5)));
                     V cnt = V(0);
 #pragma unroll
                     for (int vtx = 0; vtx < 8; vtx++) {
@@ -2173,8 +2226,12 @@ JB_HD bool substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
             }
             any_contact = any_lane(any_con);
             env_con = neq_u(quad_sum_u(mbit(any_con)), zero_u<V>());
-            if (any_contact) sc.st(SC_OWN, utov(own, (const V*)nullptr));
-            if (any_contact) {
+            if (o.aux) {      // the aux lanes integrate the env's root state too (phase C): they need to know whether THEIR env has a contact
+                const U ec = xor_get_any_u(mbit(env_con), axoff);
+                if (axl) env_con = neq_u(ec, zero_u<V>());
+            }
+            if (any_contact && !axl) sc.st(SC_OWN, utov(own, (const V*)nullptr));
+            if (any_contact && !axl) {
                 // direction data for the contact frame (n, t1, t2) = R^T (ez, ey, -ex)
 #pragma unroll
                 for (int k = 0; k < 3; k++) {
@@ -2193,7 +2250,7 @@ JB_HD bool substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
         Sym3<V> J12 = about_origin(I1, m1, cc1) + J2;
         Vec3<V> h12 = h1 + h2;
         V m12 = m1 + m2;
-        Vec3<V> sK = cross(a2, e2), sS = cross(a1, e1), sM = cross(am, em);          // linear part of the joint motion vectors
+        Vec3<V> sK = cross(a2, e2), sS = cross(a1, e1);          // linear part of the joint motion vectors
         Vec3<V> fK = sK * m2 + cross(e2, h2), nK = mul(J2, e2) + cross(h2, sK);
         Vec3<V> fS = sS * m12 + cross(e1, h12), nS = mul(J12, e1) + cross(h12, sS);
         sys.B[0][0] = nS.x; sys.B[1][0] = nS.y; sys.B[2][0] = nS.z; sys.B[3][0] = fS.x; sys.B[4][0] = fS.y; sys.B[5][0] = fS.z;
@@ -2201,14 +2258,32 @@ JB_HD bool substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
         sys.C[0] = dot(e1, nS) + dot(sS, fS);
         sys.C[1] = dot(e1, nK) + dot(sS, fK);
         sys.C[2] = dot(e2, nK) + dot(sK, fK);
-        Vec3<V> hm = cm * mm;
-        Sym3<V> Jm = about_origin(Im, mm, cm);
-        Vec3<V> fM = sM * mm + cross(em, hm), nM = mul(Jm, em) + cross(hm, sM);
-        sys.Bm[0] = nM.x; sys.Bm[1] = nM.y; sys.Bm[2] = nM.z; sys.Bm[3] = fM.x; sys.Bm[4] = fM.y; sys.Bm[5] = fM.z;
-        sys.Cm = dot(em, nM) + dot(sM, fM);
+        // the legs' sums over the quad; in the aux quads the same instructions sum the motor body and the root body's own mass
+        const Vec3<V> h12q = qsum(h12);
+        const Sym3<V> J12q = qsum(J12);
+        Vec3<V> ht;
+        Sym3<V> Jt;
+        if (o.aux) {
+            // hand-over 1 of 2 (group 0 <- 2, group 1 <- 3): the aux quad's sums, and its lane 0's shoulder column = the motor's column
+            ht = v3<V>(xor_get(h12q.x, axoff), xor_get(h12q.y, axoff), xor_get(h12q.z, axoff)) + h12q;
+            Sym3<V> Jx;
+            Jx.xx = xor_get(J12q.xx, axoff); Jx.yy = xor_get(J12q.yy, axoff); Jx.zz = xor_get(J12q.zz, axoff);
+            Jx.xy = xor_get(J12q.xy, axoff); Jx.xz = xor_get(J12q.xz, axoff); Jx.yz = xor_get(J12q.yz, axoff);
+            Jt = Jx + J12q;
+#pragma unroll
+            for (int i = 0; i < 6; i++) sys.Bm[i] = xor_get(quad_bcast<0>(sys.B[i][0]), axoff);
+            sys.Cm = xor_get(quad_bcast<0>(sys.C[0]), axoff);
+        } else {
+            Vec3<V> sM = cross(am, em);
+            Vec3<V> hm = cm * mm;
+            Sym3<V> Jm = about_origin(Im, mm, cm);
+            Vec3<V> fM = sM * mm + cross(em, hm), nM = mul(Jm, em) + cross(hm, sM);
+            sys.Bm[0] = nM.x; sys.Bm[1] = nM.y; sys.Bm[2] = nM.z; sys.Bm[3] = fM.x; sys.Bm[4] = fM.y; sys.Bm[5] = fM.z;
+            sys.Cm = dot(em, nM) + dot(sM, fM);
+            ht = c0 * m0 + hm + h12q;
+            Jt = about_origin(I0, m0, c0) + Jm + J12q;
+        }
         {
-            Vec3<V> ht = c0 * m0 + hm + qsum(h12);
-            Sym3<V> Jt = about_origin(I0, m0, c0) + Jm + qsum(J12);
             V mt = m.c[LM_MTOT];
             V Z = V(0);
             // [[J, [h]x], [[h]x^T, m 1]] with [h]x = [[0,-hz,hy],[hz,0,-hx],[-hy,hx,0]]
@@ -2228,8 +2303,6 @@ JB_HD bool substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
             auto wxwx = [](const Vec3<V>& ww, const V& ww2, const Vec3<V>& r) { V d = dot(ww, r); return v3<V>(ww.x * d - r.x * ww2, ww.y * d - r.y * ww2, ww.z * d - r.z * ww2); };
             const V w_2 = dot(w, w);
             auto accel_at = [&](const Vec3<V>& x) { return AO + wxwx(w, w_2, x); };
-            Vec3<V> F0 = accel_at(c0) * m0;
-            Vec3<V> N0 = cross(w, mul(I0, w));
             // own leg
             Vec3<V> Aa1 = accel_at(a1);
             Vec3<V> w1 = w + e1 * s.thd1;
@@ -2249,15 +2322,27 @@ JB_HD bool substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
             V cS = dot(e1, N1 + cross(r1, F1) + N2 + cross(cc2 - a1, F2));
             Vec3<V> legF = F1 + F2;
             Vec3<V> legN = N1 + cross(cc1, F1) + N2 + cross(cc2, F2);
-            // motor body
-            Vec3<V> wm = w + em * s.phid;
-            Vec3<V> alm = cross(w, em) * s.phid;
-            Vec3<V> rm = cm - am;
-            Vec3<V> Fm = (accel_at(am) + cross(alm, rm) + wxwx(wm, dot(wm, wm), rm)) * mm;
-            Vec3<V> Nm = mul(Im, alm) + cross(wm, mul(Im, wm));
-            V cM = dot(em, Nm + cross(rm, Fm));
-            Vec3<V> bl = F0 + Fm + qsum(legF);
-            Vec3<V> ba = N0 + cross(c0, F0) + Nm + cross(cm, Fm) + qsum(legN);
+            const Vec3<V> legFq = qsum(legF), legNq = qsum(legN);
+            Vec3<V> bl, ba;
+            V cM;
+            if (o.aux) {
+                // hand-over 2 of 2: the aux quad's force / moment sums (motor body + root body) and its lane 0's shoulder bias = the motor's
+                bl = v3<V>(xor_get(legFq.x, axoff), xor_get(legFq.y, axoff), xor_get(legFq.z, axoff)) + legFq;
+                ba = v3<V>(xor_get(legNq.x, axoff), xor_get(legNq.y, axoff), xor_get(legNq.z, axoff)) + legNq;
+                cM = xor_get(quad_bcast<0>(cS), axoff);
+            } else {
+                Vec3<V> F0 = accel_at(c0) * m0;
+                Vec3<V> N0 = cross(w, mul(I0, w));
+                // motor body
+                Vec3<V> wm = w + em * s.phid;
+                Vec3<V> alm = cross(w, em) * s.phid;
+                Vec3<V> rm = cm - am;
+                Vec3<V> Fm = (accel_at(am) + cross(alm, rm) + wxwx(wm, dot(wm, wm), rm)) * mm;
+                Vec3<V> Nm = mul(Im, alm) + cross(wm, mul(Im, wm));
+                cM = dot(em, Nm + cross(rm, Fm));
+                bl = F0 + Fm + legFq;
+                ba = N0 + cross(c0, F0) + Nm + cross(cm, Fm) + legNq;
+            }
             sys.tr[0] = -ba.x; sys.tr[1] = -ba.y; sys.tr[2] = -ba.z; sys.tr[3] = -bl.x; sys.tr[4] = -bl.y; sys.tr[5] = -bl.z;
             sys.tl[0] = -cS - m.c[LM_K1] * s.th1 - m.c[LM_B1] * s.thd1;
             sys.tl[1] = -cK - m.c[LM_K2] * s.th2 - m.c[LM_B2] * s.thd2;
@@ -2339,7 +2424,7 @@ JB_HD bool substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
 #endif
     }
     JB_SCHED_FENCE();
-    if (!rep) return redone;
+    if (!rep && !axl) return redone;
 
     // ================= phase C: integrate (the replica too: it starts the next substep from the same state)
     if (o.lean) state_load(sc, s);
@@ -2403,7 +2488,7 @@ JB_HD bool substep(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneState<V>
 #endif
     if (o.lean && sc.grp == 0) state_load(sc, s);       // LEAN: the state lives in the scratch between substeps
     const bool rep = sc.grp == 0 || (o.offload && sc.grp == 1);      // main lanes and their replica (SimOpts::offload)
-    if (rep) Rw = quat2mat(s.qw, s.qx, s.qy, s.qz);      // the quaternion is kept normalised: normalise_state() once per kernel, phase C after every substep
+    if (rep || (o.aux && sc.grp >= 2)) Rw = quat2mat(s.qw, s.qx, s.qy, s.qz);      // (every lane that holds the root state) the quaternion is kept normalised: normalise_state() once per kernel, phase C after every substep
     if (o.contacts && rep) {
         const Vec3<V> nb = v3<V>(Rw.m[6], Rw.m[7], Rw.m[8]);         // floor normal in root coordinates
         // upper leg: sphere around the upper cylinder (+ slack for the shoulder angle)

@@ -394,6 +394,8 @@ class JitterbugVecEnv:
     @property
     def kernel_variant(self):
         """'ordinary' | 'pair' | 'lean' | 'lean_pair': the step kernel this handle launches (jb_kernel_variant)."""
+        if not hasattr(self._L, "jb_kernel_variant"):          # (an A/B library of an older ABI)
+            return "ordinary"
         return _lib.VARIANT_NAMES[int(self._L.jb_kernel_variant(self._h))]
 
     @property

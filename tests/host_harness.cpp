@@ -17,6 +17,8 @@ using namespace jb;
 // the rank-one pass on rows other groups built, the broadcast loop decisions): the same code paths the device takes with helper lanes.
 static int g_offload = 1;      // lane group 1 as the main lanes' replica (SimOpts::offload), as the one-wave-per-SIMD kernels run it
 extern "C" void jbh_set_offload(int on) { g_offload = on; }
+static int g_aux = 1;          // aux bodies on lane groups 2 / 3 (SimOpts::aux)
+extern "C" void jbh_set_aux(int on) { g_aux = on; }
 static int g_spread = 1;       // spread contact sweeps (SimOpts::spread)
 extern "C" void jbh_set_spread(int on) { g_spread = on; }
 template <typename T>
@@ -44,6 +46,11 @@ static int run(const double* P, double* qpos, double* qvel, double ctrl, int nsu
     s.wj[0] = s.wj[1] = V(T(0)); s.wm = V(T(0)); s.fail = V(T(0));
     SimOpts o; o.contacts = contacts; o.max_newton = max_newton; o.implicit_damp = implicit_damp; o.rank_one = rank_one; o.lean = lean; o.offload = (g_offload && !lean && ngroups >= 2) ? 1 : 0; o.prof = nullptr; o.hist = nullptr;
     o.spread = g_spread;
+    o.aux = (g_aux && o.offload && ngroups == 4 && !pair) ? 1 : 0;          // groups 2 and 3 run phase A on the motor body and the root body (SimOpts::aux), like the ordinary device kernel
+    T auxtab[LM_AUX];
+    build_aux_block<T>(tab, auxtab);
+    LaneModel<V> m_aux = m;
+    m_aux.c.tab = auxtab; m_aux.c.tab_rare = tab + LM_INV; m_aux.c.preload();
     constexpr int SCMAX = SC_COUNT > SC_COUNT_LEAN_PAIR ? SC_COUNT : SC_COUNT_LEAN_PAIR;
     V scratch[SCMAX];                  // (the LEAN variant parks state / system / factorisation where the ordinary one has its reduction buffer and overflow candidates)
     V ovcbuf[4 * (NSLOT - ROW_K)];     // LEAN: the candidates beyond the row cache live outside the scratch (global memory on the device)
@@ -70,9 +77,11 @@ static int run(const double* P, double* qpos, double* qvel, double ctrl, int nsu
         auto body = [&](int g) {
             g_host_wave = &wave; g_host_grp = g;
             LaneScratch<V> sc; sc.p = scratch; sc.stride = 1; sc.grp = g; sc.ngrp = ngroups; sc.gstride = ngroups == 2 ? 32 : 16; set_ovc(sc);
-            LaneState<V> hs = s;                            // helper lanes start from a harmless state, like the kernel's
+            sc.aux_lane = o.aux && g >= 2;
+            const LaneModel<V>& mg = sc.aux_lane ? m_aux : m;
+            LaneState<V> hs = s;                            // helper lanes start from a harmless state, like the kernel's (replica and aux lanes: from the env's state)
             LaneState<V>& st = (g == 0) ? s : hs;
-            if (g != 0 && !(o.offload && g == 1)) {
+            if (g != 0 && !(o.offload && g == 1) && !sc.aux_lane) {
                 hs.px = hs.py = hs.pz = V(T(0)); hs.qw = V(T(1)); hs.qx = hs.qy = hs.qz = V(T(0)); hs.vx = hs.vy = hs.vz = hs.wx = hs.wy = hs.wz = V(T(0));
                 hs.pz_lo = hs.qw_lo = hs.qx_lo = hs.qy_lo = hs.qz_lo = V(T(0));
                 hs.phi = hs.phid = hs.turns = V(T(0)); hs.th1 = hs.th2 = hs.thd1 = hs.thd2 = V(T(0));
@@ -86,7 +95,7 @@ static int run(const double* P, double* qpos, double* qvel, double ctrl, int nsu
                 wave.barrier();
                 if (g == 0) { for (int k = 0; k < (lean ? SC_LSTATE : o.offload ? SC_ZERO : SCMAX); k++) if (i == 0 || k < sc.pd + 9 || k > sc.pd + 11) scratch[k] = V(std::numeric_limits<T>::quiet_NaN()); if (i == 0) scratch[sc.pd + 11] = V(T(0)); for (auto& c : ovcbuf) c = V(std::numeric_limits<T>::quiet_NaN()); }
                 wave.barrier();
-                if (pair) substep<V, true>(m, sc, st, V(T(ctrl)), o); else substep<V>(m, sc, st, V(T(ctrl)), o);
+                if (pair) substep<V, true>(mg, sc, st, V(T(ctrl)), o); else substep<V>(mg, sc, st, V(T(ctrl)), o);
             }
             if (g == 0 && lean) state_load(sc, st);
             g_host_wave = nullptr;
@@ -168,6 +177,11 @@ static int rollout(const double* P, double* qpos, double* qvel, double* target, 
     s0.wj[0] = s0.wj[1] = V(T(0)); s0.wm = V(T(0)); s0.fail = V(T(0));
     SimOpts o; o.contacts = 1; o.max_newton = 12; o.implicit_damp = 1; o.rank_one = 1; o.lean = 0; o.offload = (g_offload && ngroups >= 2) ? 1 : 0; o.prof = nullptr; o.hist = nullptr;
     o.spread = g_spread;
+    o.aux = (g_aux && o.offload && ngroups == 4) ? 1 : 0;
+    T auxtab[LM_AUX];
+    build_aux_block<T>(tab, auxtab);
+    LaneModel<V> m_aux = m;
+    m_aux.c.tab = auxtab; m_aux.c.tab_rare = tab + LM_INV; m_aux.c.preload();
     V scratch[SC_COUNT];
     const int D = obs_dim(task);
     TaskOpts topt; topt.task = task; topt.step_limit = step_limit; topt.auto_reset = auto_reset; topt.random_pose = random_pose; topt.seed = seed; topt.env_global = env_global;
@@ -181,7 +195,9 @@ static int rollout(const double* P, double* qpos, double* qvel, double* target, 
         if (ngroups > 1) { g_host_wave = &wave; g_host_grp = g; }
         LaneScratch<V> sc; sc.p = scratch; sc.stride = 1; sc.grp = g; sc.ngrp = ngroups; sc.gstride = ngroups > 1 ? 16 : 4;
         sc.ovc = scratch + SC_OVC; sc.ovc_stride = 1; sc.red_lds = true; sc.pd = SC_PD;
-        const bool rep = g == 0 || (o.offload && g == 1);
+        sc.aux_lane = o.aux && g >= 2;
+        const LaneModel<V>& mg = sc.aux_lane ? m_aux : m;
+        const bool rep = g == 0 || (o.offload && g == 1) || sc.aux_lane;          // the lanes that hold the env's state (main, replica, aux)
         LaneState<V> s = s0;
         if (!rep) {
             s.px = s.py = s.pz = V(T(0)); s.qw = V(T(1)); s.qx = s.qy = s.qz = V(T(0)); s.vx = s.vy = s.vz = s.wx = s.wy = s.wz = V(T(0));
@@ -199,8 +215,8 @@ static int rollout(const double* P, double* qpos, double* qvel, double* target, 
         if (!actions && rep) {
             T obs0[19];
             EnvCore<T> e0;
-            core_from_lane_state<V>(m, s, er.tgt, e0);
-            observe<T>(task, e0, lane0(m.c[LM_TARGET_Z]), obs0, 1);
+            core_from_lane_state<V>(mg, s, er.tgt, e0);
+            observe<T>(task, e0, lane0(mg.c[LM_TARGET_Z]), obs0, 1);
             ctrl_next = heuristic_policy<T>(task, obs0, 1, pp);
         }
         for (int k = 0; k < K; k++) {
@@ -211,12 +227,12 @@ static int rollout(const double* P, double* qpos, double* qvel, double* target, 
                 if (ngroups > 1) wave.barrier();
                 if (g == 0) for (int q = 0; q < (o.offload ? SC_ZERO : SC_COUNT); q++) scratch[q] = V(std::numeric_limits<T>::quiet_NaN());
                 if (ngroups > 1) wave.barrier();
-                substep<V>(m, sc, s, V(ctrl), o);
+                substep<V>(mg, sc, s, V(ctrl), o);
             }
             if (!rep) continue;
             T obs[19], rew;
             bool done;
-            control_step_tail<V>(topt, m, s, er, obs, rew, done);
+            control_step_tail<V>(topt, mg, s, er, obs, rew, done);
             if (!actions) ctrl_next = heuristic_policy<T>(task, obs, 1, pp);
             if (g == 0) {
                 double* row = rows_out + (size_t)k * (D + 2);
@@ -275,6 +291,11 @@ extern "C" int jbh_substep_record(const double* P, const float* rec, int max_new
     s0.fail = V(T(0));
     SimOpts o; o.contacts = 1; o.max_newton = max_newton; o.implicit_damp = 1; o.rank_one = 1; o.lean = 0; o.offload = (g_offload && ngroups >= 2) ? 1 : 0; o.prof = nullptr; o.hist = nullptr;
     o.spread = g_spread;
+    o.aux = (g_aux && o.offload && ngroups == 4) ? 1 : 0;
+    T auxtab[LM_AUX];
+    build_aux_block<T>(tab, auxtab);
+    LaneModel<V> m_aux = m;
+    m_aux.c.tab = auxtab; m_aux.c.tab_rare = tab + LM_INV; m_aux.c.preload();
     V scratch[SC_COUNT];
     HostWave wave;
     wave.ngrp = ngroups; wave.gstride = 16;
@@ -284,7 +305,8 @@ extern "C" int jbh_substep_record(const double* P, const float* rec, int max_new
         if (ngroups > 1) { g_host_wave = &wave; g_host_grp = g; }
         LaneScratch<V> sc; sc.p = scratch; sc.stride = 1; sc.grp = g; sc.ngrp = ngroups; sc.gstride = ngroups > 1 ? 16 : 4;
         sc.ovc = scratch + SC_OVC; sc.ovc_stride = 1; sc.red_lds = true; sc.pd = SC_PD;
-        const bool rep = g == 0 || (o.offload && g == 1);
+        sc.aux_lane = o.aux && g >= 2;
+        const bool rep = g == 0 || (o.offload && g == 1) || sc.aux_lane;
         LaneState<V> s = s0;
         if (!rep) {
             s.px = s.py = s.pz = V(T(0)); s.qw = V(T(1)); s.qx = s.qy = s.qz = V(T(0)); s.vx = s.vy = s.vz = s.wx = s.wy = s.wz = V(T(0));
@@ -296,7 +318,7 @@ extern "C" int jbh_substep_record(const double* P, const float* rec, int max_new
             if (o.offload) for (int k = 0; k < 56; k++) scratch[SC_ZERO + k] = V(T(0));
         }
         if (ngroups > 1) wave.barrier();
-        substep<V>(m, sc, s, V(ctrl), o);
+        substep<V>(sc.aux_lane ? m_aux : m, sc, s, V(ctrl), o);
         if (g == 0) s_final = s;
         g_host_wave = nullptr;
     };

@@ -215,14 +215,52 @@ def test_lean_variant_is_bit_identical_on_the_host(params):
         assert fn(P.ctypes.data_as(dp), q.ctypes.data_as(dp), v.ctypes.data_as(dp), 0.3, 50, 1, 20, f32, groups, 1, fail.ctypes.data_as(dp)) == 0
         return q, v
 
+    lib.jbh_set_aux(0)          # (the aux bodies of the ordinary kernel sum the motor / root terms in another order: compared separately below)
+    try:
+        for tipped in (False, True):
+            env = _contact_states(params, 6, tipped)
+            q0, v0, _ = env.get_state()
+            for i in range(6):
+                for groups in (1, 4):
+                    for f32 in (0, 1):
+                        a, b = run(lib.jbh_step_groups, q0[i], v0[i], groups, f32), run(lib.jbh_step_lean, q0[i], v0[i], groups, f32)
+                        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), (tipped, i, groups, f32)
+    finally:
+        lib.jbh_set_aux(1)
+
+
+def test_aux_bodies_on_the_helper_groups_equal_the_replicated_path(params):
+    """SimOpts::aux (the ordinary device kernel with four lane groups): lane groups 2 / 3 run phase A on the motor body and the root body's own
+    mass as two more "legs" - the same instruction stream as the legs - and hand the sums over with cross-lane swaps, instead of every leg
+    lane repeating that work.  Same physics, another order of summation: fp64 agrees with the replicated path to round-off (and with the
+    oracle: test_helper_groups_fp64_equal_single_group_and_oracle runs with it on), fp32 to its own rounding; walking and tipped over."""
+    import tests.build_harness as bh
+    lib = C.CDLL(bh.build())
+    dp = C.POINTER(C.c_double)
+    lib.jbh_step_groups.argtypes = [dp, dp, dp, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, dp]
+    P = np.ascontiguousarray(params)
+
+    def run(q, v, f32, aux):
+        lib.jbh_set_aux(aux)
+        q, v, fail = q.copy(), v.copy(), np.zeros(1)
+        try:
+            assert lib.jbh_step_groups(P.ctypes.data_as(dp), q.ctypes.data_as(dp), v.ctypes.data_as(dp), 0.6, 50, 1, 20, f32, 4, 1, fail.ctypes.data_as(dp)) == 0
+        finally:
+            lib.jbh_set_aux(1)
+        assert fail[0] == 0
+        return q, v
+
+    w64, w32 = 0.0, []
     for tipped in (False, True):
-        env = _contact_states(params, 6, tipped)
+        env = _contact_states(params, 8, tipped)
         q0, v0, _ = env.get_state()
-        for i in range(6):
-            for groups in (1, 4):
-                for f32 in (0, 1):
-                    a, b = run(lib.jbh_step_groups, q0[i], v0[i], groups, f32), run(lib.jbh_step_lean, q0[i], v0[i], groups, f32)
-                    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), (tipped, i, groups, f32)
+        for i in range(8):
+            a, b = run(q0[i], v0[i], 0, 1), run(q0[i], v0[i], 0, 0)
+            w64 = max(w64, np.abs(a[0] - b[0]).max(), (np.abs(a[1] - b[1]) / (1 + np.abs(b[1]))).max())
+            a, b = run(q0[i], v0[i], 1, 1), run(q0[i], v0[i], 1, 0)
+            w32.append(max(np.abs(a[0][:7] - b[0][:7]).max(), np.abs(a[1][:6] - b[1][:6]).max() / 35))
+    print("aux bodies vs replicated path: fp64 %.2e, fp32 median %.2e" % (w64, np.median(w32)))
+    assert w64 < 1e-11 and np.median(w32) < 2e-6
 
 
 def test_replica_group_offload_is_bit_identical_on_the_host(params):
@@ -238,11 +276,13 @@ def test_replica_group_offload_is_bit_identical_on_the_host(params):
 
     def run(fn, q, v, f32, offload, u):
         lib.jbh_set_offload(offload)
+        lib.jbh_set_aux(0)          # (the aux bodies ride on the offload layout and reorder the motor / root sums: they have their own test)
         q, v, fail = q.copy(), v.copy(), np.zeros(1)
         try:
             assert fn(P.ctypes.data_as(dp), q.ctypes.data_as(dp), v.ctypes.data_as(dp), u, 50, 1, 20, f32, 4, 1, fail.ctypes.data_as(dp)) == 0
         finally:
             lib.jbh_set_offload(1)
+            lib.jbh_set_aux(1)
         return q, v
 
     for tipped in (False, True):
