@@ -132,6 +132,59 @@ template <typename T> JB_HD int build_lane_model(const double* P, int leg, T* ou
         put3(LM_PE_S, ge + JB_G_SIZE);
         for (int i = 0; i < 3; i++) out[LM_PE_IS + i] = T((int)ge[JB_G_TYPE] == JB_GEOM_ELLIPSOID ? 1.0 / (ge[JB_G_SIZE + i] + gu[JB_G_SIZE] + 2e-4) : -1.0);
     }
+    {   // the motor-axis thread for every lane (PAIR kernels: its contact with the lane's own upper-leg cylinder), and the flag that says whether
+        // this lane's leg can come near it at all: the smallest distance of the two AXES over the shoulder angles |th1| <= 0.4 rad (rollouts
+        // stay below 0.15) and a full turn of the motor, against r_thread + r_leg + 1 mm.  The flag is the SIGN of LM_PE_IS + 1.
+        const double* gth = geom(20);
+        put3(LM_PT_C, gth + JB_G_CENTER);
+        const double tax[3] = {gth[JB_G_ROT + 2], gth[JB_G_ROT + 5], gth[JB_G_ROT + 8]};
+        for (int i = 0; i < 3; i++) out[LM_PT_AX + i] = T(tax[i]);
+        out[LM_PT_R] = T(gth[JB_G_SIZE]); out[LM_PT_H] = T(gth[JB_G_SIZE + 1]);
+        bool near = false;
+        if ((int)gth[JB_G_TYPE] == JB_GEOM_CYLINDER && (int)gu[JB_G_TYPE] == JB_GEOM_CYLINDER) {
+            const double* h1 = hinge(2 * leg);
+            const double* hm = hinge(8);
+            const double* a1 = h1 + JB_H_ANCHOR;
+            const double* e1 = h1 + JB_H_AXIS;
+            const double* am_ = hm + JB_H_ANCHOR;
+            const double* em = hm + JB_H_AXIS;
+            const double uax[3] = {gu[JB_G_ROT + 2], gu[JB_G_ROT + 5], gu[JB_G_ROT + 8]};
+            auto rot = [](const double* e, double ang, const double* v, double* o) {      // Rodrigues
+                const double c = cos(ang), s = sin(ang), d = e[0] * v[0] + e[1] * v[1] + e[2] * v[2];
+                const double cr[3] = {e[1] * v[2] - e[2] * v[1], e[2] * v[0] - e[0] * v[2], e[0] * v[1] - e[1] * v[0]};
+                for (int i = 0; i < 3; i++) o[i] = v[i] * c + cr[i] * s + e[i] * d * (1 - c);
+            };
+            const double lim = gth[JB_G_SIZE] + gu[JB_G_SIZE] + 1e-3;
+            for (int ia = 0; ia <= 8 && !near; ia++) {
+                const double th = -0.4 + 0.1 * ia;
+                double rel[3], uc[3], ua[3];
+                for (int i = 0; i < 3; i++) rel[i] = gu[JB_G_CENTER + i] - a1[i];
+                rot(e1, th, rel, uc);
+                for (int i = 0; i < 3; i++) uc[i] += a1[i];
+                rot(e1, th, uax, ua);
+                for (int ip = 0; ip < 16 && !near; ip++) {
+                    const double ph = 0.39269908169872414 * ip;
+                    double relt[3], tc[3], ta[3];
+                    for (int i = 0; i < 3; i++) relt[i] = gth[JB_G_CENTER + i] - am_[i];
+                    rot(em, ph, relt, tc);
+                    for (int i = 0; i < 3; i++) tc[i] += am_[i];
+                    rot(em, ph, tax, ta);
+                    // segment - segment distance (Ericson 5.1.9)
+                    const double r[3] = {uc[0] - tc[0], uc[1] - tc[1], uc[2] - tc[2]};
+                    const double b = ua[0] * ta[0] + ua[1] * ta[1] + ua[2] * ta[2], c = ua[0] * r[0] + ua[1] * r[1] + ua[2] * r[2], f = ta[0] * r[0] + ta[1] * r[1] + ta[2] * r[2];
+                    const double den = 1.0 - b * b, hu = gu[JB_G_SIZE + 1], ht = gth[JB_G_SIZE + 1];
+                    double sq = den > 1e-12 ? (b * f - c) / den : 0.0;
+                    sq = sq < -hu ? -hu : (sq > hu ? hu : sq);
+                    double tq = b * sq + f;
+                    if (tq < -ht || tq > ht) { tq = tq < -ht ? -ht : ht; sq = b * tq - c; sq = sq < -hu ? -hu : (sq > hu ? hu : sq); }
+                    double d2 = 0;
+                    for (int i = 0; i < 3; i++) { const double dd = r[i] + sq * ua[i] - tq * ta[i]; d2 += dd * dd; }
+                    if (d2 < lim * lim) near = true;
+                }
+            }
+        }
+        if (near) out[LM_PE_IS + 1] = -out[LM_PE_IS + 1];
+    }
     {   // broadphase boxes (LM_BX): oriented boxes around the lane's root-body geoms; motor-body geoms (lane 3) get one
         // axis-aligned cube centred on the motor axis (invariant under the motor angle).  Unused boxes have negative sizes.
         for (int k = 0; k < 2; k++) {

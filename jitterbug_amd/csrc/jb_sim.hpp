@@ -96,8 +96,12 @@ enum LM : int {
     // the eccentric-mass ellipsoid (motor body) for EVERY lane: its contact with the lane's own upper-leg cylinder (PAIR kernels: the
     // one geom-geom pair that touches on randomised models)
     LM_PE_C = LM_X_ONM + 4 /*3: centre*/, LM_PE_R = LM_PE_C + 3 /*9: rotation, columns = semi-axes directions*/, LM_PE_S = LM_PE_R + 9 /*3: semi-axes*/,
-    LM_PE_IS = LM_PE_S + 3 /*3: 1 / (semi-axis + cylinder radius + 0.2 mm): the broad phase tests the leg's axis against this inflated ellipsoid; <= 0: no pair*/,
-    LM_COUNT = LM_PE_IS + 3,
+    LM_PE_IS = LM_PE_S + 3 /*3: 1 / (semi-axis + cylinder radius + 0.2 mm): the broad phase tests the leg's axis against this inflated ellipsoid; x <= 0: no pair.
+                             The SIGN of the y entry is a flag of its own: negative = this lane's upper leg can come near the motor-axis thread (LM_PT below)*/,
+    // the motor-axis thread (geom 20, a cylinder on the motor body) for EVERY lane: its contact with the lane's own upper-leg cylinder (PAIR kernels: the second
+    // geom-geom pair randomised models can bring together; read only by lanes whose LM_PE_IS flag is set - 0.2 % of the reference's draws)
+    LM_PT_C = LM_PE_IS + 3 /*3: centre*/, LM_PT_AX = LM_PT_C + 3 /*3: unit axis*/, LM_PT_R = LM_PT_AX + 3, LM_PT_H = LM_PT_R + 1,
+    LM_COUNT = LM_PT_H + 1,
 
     // Entries [0, LM_INV) (global options, root body, motor body) are the same for the 4 lanes of an env and are stored
     // once; the rest is stored per lane.  Packed table: [LM_INV] then [LM_COUNT - LM_INV][4]  = LM_TABLE floats per env.
@@ -1478,6 +1482,71 @@ JB_HD typename lane_traits<V>::mask pair_narrow_warm(const Vec3<V>& ce, const Ma
     return conv;
 }
 
+// ----------------------------------------------------------------------------- the second geom-geom pair: motor-axis thread against the own upper-leg cylinder
+// (oracle/jb_oracle.c pair_thread_geometric states the definition: the point of the LEG's axis segment with the smallest signed distance to
+// the thread cylinder, the thread's nearest surface point and outward normal there.)  Signed distance of a point to a finite cylinder with
+// flat caps (centre tc, unit axis ta, radius R, half length H), branch-free: q = nearest surface point, nrm = outward normal.
+template <typename V>
+JB_HD V cyl_nearest(const Vec3<V>& tc, const Vec3<V>& ta, const V& R, const V& H, const Vec3<V>& x, Vec3<V>& q, Vec3<V>& nrm) {
+    const Vec3<V> y = x - tc;
+    const V z = dot(y, ta);
+    const Vec3<V> rv = y - ta * z;
+    const V rho2 = dot(rv, rv), irho = vrsqrt(vmax(rho2, V(1e-30))), rho = rho2 * irho;
+    const Vec3<V> er = rv * irho;                                    // (on the axis itself: a zero vector - the side is never the nearest surface there unless R < H... see below)
+    const V dr = rho - R, az = vabs(z), dz = az - H, sz = sel(lt(z, V(0)), V(-1), V(1));
+    const auto rim = mand(gt(dr, V(0)), gt(dz, V(0))), side = mand(mnot(rim), gt(dr, dz));
+    const V d2 = dr * dr + dz * dz, id = vrsqrt(vmax(d2, V(1e-30))), drim = d2 * id;
+    const Vec3<V> q_side = tc + er * R + ta * z, q_rim = tc + er * R + ta * (sz * H), q_cap = tc + rv + ta * (sz * H);
+    const Vec3<V> n_rim = er * (dr * id) + ta * (sz * dz * id), n_cap = ta * sz;
+    q = sel_v3(rim, q_rim, sel_v3(side, q_side, q_cap));
+    nrm = sel_v3(rim, n_rim, sel_v3(side, er, n_cap));
+    return sel(rim, drim, sel(side, dr, dz));
+}
+// smallest distance between the segments c1 + s u1 (|s| <= h1) and c2 + t u2 (|t| <= h2), unit directions (Ericson 5.1.9, with selects)
+template <typename V>
+JB_HD V segment_distance(const Vec3<V>& c1, const Vec3<V>& u1, const V& h1, const Vec3<V>& c2, const Vec3<V>& u2, const V& h2) {
+    const Vec3<V> r = c1 - c2;
+    const V b = dot(u1, u2), c = dot(u1, r), f = dot(u2, r), den = V(1) - b * b;
+    V s = sel(gt(den, V(1e-12)), (b * f - c) * vrcp(vmax(den, V(1e-12))), V(0));
+    s = vmin(vmax(s, -h1), h1);
+    V t = b * s + f;
+    const auto lo = lt(t, -h2), hi = gt(t, h2);
+    const V tcl = vmin(vmax(t, -h2), h2);
+    const V s2 = vmin(vmax(b * tcl - c, -h1), h1);
+    s = sel(mor(lo, hi), s2, s);
+    t = tcl;
+    const Vec3<V> dd = r + u1 * s - u2 * t;
+    const V d2 = dot(dd, dd);
+    return d2 * vrsqrt(vmax(d2, V(1e-30)));
+}
+#ifndef JB_THREAD_BISECT
+#define JB_THREAD_BISECT 26
+#endif
+// the contact: dist (< 0: overlap), mo = the thread's outward normal at the contact (thread -> leg), pos; all in root coordinates
+template <typename V>
+JB_HD void thread_narrow(const Vec3<V>& tc, const Vec3<V>& ta, const V& R, const V& H, const Vec3<V>& cc, const Vec3<V>& ua, const V& rad, const V& half,
+                         V& dist, Vec3<V>& mo, Vec3<V>& pos) {
+    Vec3<V> q, nrm;
+    V ta_ = -half, tb_ = half;
+    (void)cyl_nearest<V>(tc, ta, R, H, cc + ua * ta_, q, nrm);
+    const auto at_a = mnot(lt(dot(nrm, ua), V(0)));          // the signed distance already grows at the lower end: the minimiser is that end
+    (void)cyl_nearest<V>(tc, ta, R, H, cc + ua * tb_, q, nrm);
+    const auto at_b = mnot(gt(dot(nrm, ua), V(0)));
+#pragma unroll 1
+    for (int it = 0; it < JB_THREAD_BISECT; it++) {           // f(t) = m(x(t)) . u is monotone (the signed distance to a convex body is convex along a line)
+        const V t = V(0.5) * (ta_ + tb_);
+        (void)cyl_nearest<V>(tc, ta, R, H, cc + ua * t, q, nrm);
+        const auto neg = lt(dot(nrm, ua), V(0));
+        ta_ = sel(neg, t, ta_); tb_ = sel(neg, tb_, t);
+    }
+    const V t = sel(at_a, -half, sel(at_b, half, V(0.5) * (ta_ + tb_)));
+    const Vec3<V> x = cc + ua * t;
+    const V sd = cyl_nearest<V>(tc, ta, R, H, x, q, nrm);
+    dist = sd - rad;
+    mo = nrm;
+    pos = (q + x - nrm * rad) * V(0.5);
+}
+
 #if !defined(__HIPCC__)
 inline long g_pair_narrow_stats[2] = {0, 0};      // host harness only: substeps whose narrow phase was entirely warm-started / needed the cold scheme
 #endif
@@ -2181,7 +2250,8 @@ JB_HD bool substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
                 // ellipsoid's unit-sphere coordinates the segment is still a segment: its closest point to the origin decides.
                 const Vec3<V> isv = ldc3(m, LM_PE_IS);
                 const Vec3<V> cl = mulT(Re, uc - pe), ul = mulT(Re, ua);
-                const Vec3<V> cs = v3<V>(cl.x * isv.x, cl.y * isv.y, cl.z * isv.z), us = v3<V>(ul.x * isv.x, ul.y * isv.y, ul.z * isv.z);
+                const V isvy = vabs(isv.y);          // (the sign carries the thread flag, below)
+                const Vec3<V> cs = v3<V>(cl.x * isv.x, cl.y * isvy, cl.z * isv.z), us = v3<V>(ul.x * isv.x, ul.y * isvy, ul.z * isv.z);
                 const V tpr = vmin(vmax(-dot(cs, us) * vrcp(dot(us, us)), -uh), uh);
                 const Vec3<V> pcl = cs + us * tpr;
                 const MK near_pair = mand(gt(isv.x, V(0)), lt(dot(pcl, pcl), V(1)));
@@ -2209,16 +2279,38 @@ JB_HD bool substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
                     }
                     sc.st(sc.pd + 9, wt); sc.st(sc.pd + 10, wlam);
                     pon = mand(near_pair, lt(pdist, V(0)));
-                    if (any_lane(pon)) {
-                        // contact frame: MuJoCo's mju_makeFrame on the WORLD normal (y = world y unless the normal is within 60 degrees of
-                        // it, then world z), expressed in root coordinates like everything else
-                        const Vec3<V> wy = v3<V>(R.m[3], R.m[4], R.m[5]);
-                        const V ny = dot(pn, wy);
-                        const Vec3<V> ys = sel_v3(lt(vabs(ny), V(0.5)), wy, nb);
-                        Vec3<V> t1 = ys - pn * dot(pn, ys);
-                        t1 = t1 * vrsqrt(vmax(dot(t1, t1), V(1e-30)));
-                        sc.st3(sc.pd, pn); sc.st3(sc.pd + 3, t1); sc.st3(sc.pd + 6, cross(pn, t1));
+                }
+                // The second pair: the motor-axis thread against the own upper leg (flagged lanes only: the model builder marks the legs the
+                // thread can come near at all - 0.2 % of the reference's draws; broad phase: the two AXES within r_thread + r_leg + 0.2 mm).
+                // It shares the pair slot - rows jac(leg) - jac(motor) either way; should both pairs of one leg overlap at once (1e-5 of the
+                // draws), the deeper contact takes the slot (the oracle simulates both: a stated deviation).
+                MK use_t = lt(V(1), V(0));
+                const MK tflag = lt(isv.y, V(0));
+                if (any_lane(tflag)) {
+                    const Vec3<V> tcw = am + mul(Rm, ldc3(m, LM_PT_C) - am), taw = mul(Rm, ldc3(m, LM_PT_AX));
+                    const V tr = ldc(m, LM_PT_R), thh = ldc(m, LM_PT_H), ur = ldc(m, LM_UC_R);
+                    const MK tnear = mand(tflag, lt(segment_distance<V>(uc, ua, uh, tcw, taw, thh), tr + ur + V(2e-4)));
+                    if (any_lane(tnear)) {
+                        V tdist;
+                        Vec3<V> tm, tpos;
+                        thread_narrow<V>(tcw, taw, tr, thh, uc, ua, ur, uh, tdist, tm, tpos);
+                        use_t = mand(mand(tnear, lt(tdist, V(0))), mnot(mand(pon, lt(pdist, tdist))));
+                        pdist = sel(use_t, tdist, pdist); ppos = sel_v3(use_t, tpos, ppos); pn = sel_v3(use_t, tm, pn);
+                        pon = mor(pon, use_t);
                     }
+                }
+                if (any_lane(pon)) {
+                    // contact frame: MuJoCo's mju_makeFrame on the WORLD normal (y = world y unless the normal is within 60 degrees of
+                    // it, then world z), expressed in root coordinates like everything else.  Mass pair: normal mass -> leg (geom1 = the
+                    // ellipsoid), rows jac(leg) - jac(motor).  Thread pair: MuJoCo's normal runs leg -> thread (geom1 = the leg's cylinder,
+                    // the lower geom id) with rows jac(motor) - jac(leg): the same rows with the frame (n, t1, t2) negated - stored here as
+                    // (m, -t1, m x t1) with m = -n the thread's outward normal (t1 is even in the normal's sign, t2 = n x t1 odd).
+                    const Vec3<V> wy = v3<V>(R.m[3], R.m[4], R.m[5]);
+                    const V ny = dot(pn, wy);
+                    const Vec3<V> ys = sel_v3(lt(vabs(ny), V(0.5)), wy, nb);
+                    Vec3<V> t1 = ys - pn * dot(pn, ys);
+                    t1 = t1 * vrsqrt(vmax(dot(t1, t1), V(1e-30)));
+                    sc.st3(sc.pd, pn); sc.st3(sc.pd + 3, sel_v3(use_t, -t1, t1)); sc.st3(sc.pd + 6, cross(pn, t1));
                 }
                 sc.st(sc.pd + 11, sel(near_pair, V(1), V(0)));          // the next substep may start from this one's solution (only while the pair stays near)
                 live_slots |= cand_store(sc, live_slots, SLOT_PAIR, ppos, pdist, pon);

@@ -55,7 +55,8 @@
 #define MAXCON 64
 #define MAXROW (4 * MAXCON)
 #define WARM_PAIR (JB_NGEOM * 16 + JB_NV)    /* then 4 x 4: pyramid forces of the mass - upper-leg contact of leg l */
-#define WARM_SIZE (JB_NGEOM * 16 + JB_NV + 16)   /* pyramid forces by (geom,slot,edge) + last qacc + the geom-geom contacts */
+#define WARM_PAIR2 (WARM_PAIR + 16)          /* then 4 x 4: pyramid forces of the thread - upper-leg contact of leg l */
+#define WARM_SIZE (JB_NGEOM * 16 + JB_NV + 32)   /* pyramid forces by (geom,slot,edge) + last qacc + the geom-geom contacts */
 
 static const int PARENT[NB] = {-1, 0, 1, 0, 3, 0, 5, 0, 7, 0};
 
@@ -68,7 +69,7 @@ typedef struct {
     int feet_only;       /* 1: only the 4 foot spheres collide                     */
     int solver;          /* 0: dual PGS, 1: primal Newton with exact line search   */
                          /*    (MuJoCo 2.0's default solver; same unique optimum)  */
-    int pair_contacts;   /* 1: the geom-geom pairs that can touch on randomised models - the eccentric-mass ellipsoid against the
+    int pair_contacts;   /* bit 0 (1): the geom-geom pairs that can touch on randomised models - the eccentric-mass ellipsoid against the
                             upper-leg cylinder of each leg - collide like MuJoCo's mjc_Convex would make them (0: floor only) */
 } jbo_opts;
 
@@ -588,6 +589,78 @@ static int pair_geometric(const CGeom* e, const CGeom* c, double* dist, double* 
     for (int i = 0; i < 3; i++) pos[i] += e->c[i];
     return 1;
 }
+/* ---- the second geom-geom pair randomised models can bring together: the motor-axis THREAD (geom 20, a cylinder of 1 mm
+ * radius on the motor body, coaxial with the motor hinge) against the upper-leg cylinders.  MuJoCo sends cylinder - cylinder through
+ * mjc_Convex = MPR like the pair above; what is simulated is again the geometric contact, with the leg - a thin rod, radius 0.61 mm - taken
+ * as its axis segment:
+ *     x* = the point of the LEG's axis segment with the smallest SIGNED distance sd to the thread cylinder (flat caps, closed form below),
+ *     q* the thread's nearest surface point,  m = the thread's outward normal there,
+ *     dist = sd - r_leg,   pos = midpoint of q* and the leg surface point x* - r_leg m,   normal (geom1 = leg -> geom2 = thread) = -m.
+ * The signed distance to a convex body is convex along a line, so f(t) = m(x(t)) . u is monotone: bisection on its sign. */
+/* signed distance of y (cylinder's own axes, z = its axis) to a finite cylinder (radius R, half length H); q: nearest surface point, nrm: outward normal */
+static double cylinder_nearest(double R, double H, const double* y, double* q, double* nrm) {
+    double rho = sqrt(y[0] * y[0] + y[1] * y[1]), er[2] = {1, 0};
+    if (rho > 1e-300) { er[0] = y[0] / rho; er[1] = y[1] / rho; }
+    double dr = rho - R, az = fabs(y[2]), dz = az - H, sz = y[2] < 0 ? -1.0 : 1.0;
+    if (dr > 0 && dz > 0) {          /* beyond the rim */
+        double d = sqrt(dr * dr + dz * dz);
+        q[0] = R * er[0]; q[1] = R * er[1]; q[2] = sz * H;
+        nrm[0] = dr * er[0] / d; nrm[1] = dr * er[1] / d; nrm[2] = sz * dz / d;
+        return d;
+    }
+    if (dr > dz) { q[0] = R * er[0]; q[1] = R * er[1]; q[2] = y[2]; nrm[0] = er[0]; nrm[1] = er[1]; nrm[2] = 0; return dr; }      /* the side is nearest (outside or inside) */
+    q[0] = y[0]; q[1] = y[1]; q[2] = sz * H; nrm[0] = 0; nrm[1] = 0; nrm[2] = sz;
+    return dz;                                                                                                                      /* a cap is nearest */
+}
+#ifndef JB_THREAD_BISECT
+#define JB_THREAD_BISECT 26      /* bisection steps on the leg's axis parameter: the HIP kernel (jb_sim.hpp thread_narrow) runs the same fixed count */
+#endif
+/* th: the thread cylinder, c: the leg cylinder (world poses); returns dist, n (leg -> thread), pos in world axes */
+static void pair_thread_geometric(const CGeom* th, const CGeom* c, int steps, double* dist, double* n, double* pos) {
+    double cl[3], ul[3], d[3], ax[3] = {c->R[2], c->R[5], c->R[8]};
+    for (int i = 0; i < 3; i++) d[i] = c->c[i] - th->c[i];
+    matTvec3(cl, th->R, d);
+    matTvec3(ul, th->R, ax);
+    const double h = c->sz[1], R = th->sz[0], H = th->sz[1];
+    double x[3], q[3], m[3], ta = -h, tb = h, t;
+    for (int i = 0; i < 3; i++) x[i] = cl[i] + ta * ul[i];
+    cylinder_nearest(R, H, x, q, m);
+    double fa = dot3(m, ul);
+    for (int i = 0; i < 3; i++) x[i] = cl[i] + tb * ul[i];
+    cylinder_nearest(R, H, x, q, m);
+    double fb = dot3(m, ul);
+    if (!(fa < 0)) t = ta;
+    else if (!(fb > 0)) t = tb;
+    else {
+        for (int it = 0; it < steps; it++) {
+            t = 0.5 * (ta + tb);
+            for (int i = 0; i < 3; i++) x[i] = cl[i] + t * ul[i];
+            cylinder_nearest(R, H, x, q, m);
+            if (dot3(m, ul) < 0) ta = t; else tb = t;
+        }
+        t = 0.5 * (ta + tb);
+    }
+    for (int i = 0; i < 3; i++) x[i] = cl[i] + t * ul[i];
+    double sd = cylinder_nearest(R, H, x, q, m), pl[3], nl[3];
+    *dist = sd - c->sz[0];
+    for (int i = 0; i < 3; i++) { pl[i] = 0.5 * (q[i] + x[i] - c->sz[0] * m[i]); nl[i] = -m[i]; }
+    matvec3(n, th->R, nl);
+    matvec3(pos, th->R, pl);
+    for (int i = 0; i < 3; i++) pos[i] += th->c[i];
+}
+/* smallest distance between two segments c1 + s u1 (|s| <= h1), c2 + t u2 (|t| <= h2), unit directions (Ericson, Real-Time Collision Detection 5.1.9) */
+static double segment_distance(const double* c1, const double* u1, double h1, const double* c2, const double* u2, double h2) {
+    double r[3] = {c1[0] - c2[0], c1[1] - c2[1], c1[2] - c2[2]};
+    double b = dot3(u1, u2), c = dot3(u1, r), f = dot3(u2, r), den = 1.0 - b * b, s, t;
+    s = den > 1e-12 ? (b * f - c) / den : 0.0;
+    s = s < -h1 ? -h1 : (s > h1 ? h1 : s);
+    t = b * s + f;
+    if (t < -h2) { t = -h2; s = b * t - c; s = s < -h1 ? -h1 : (s > h1 ? h1 : s); }
+    else if (t > h2) { t = h2; s = b * t - c; s = s < -h1 ? -h1 : (s > h1 ? h1 : s); }
+    double dd[3];
+    for (int i = 0; i < 3; i++) dd[i] = r[i] + s * u1[i] - t * u2[i];
+    return sqrt(dot3(dd, dd));
+}
 static void cgeom_world(const double* P, const Kin* k, int g, CGeom* out) {
     const double* G = P + JB_P_GEOM + g * JB_GEOM_STRIDE;
     int b = (int)G[JB_G_BODY];
@@ -698,7 +771,35 @@ static int collide(const double* P, const Kin* k, int feet_only, int pair_contac
         }
         if (n == MAXCON && n0 != n) *overflow = 1;
     }
-    if (pair_contacts && !feet_only) {
+    if ((pair_contacts & 2) && !feet_only) {
+        /* the motor-axis thread (geom 20) against the upper-leg cylinders: geom1 = the leg's cylinder (lower geom id), geom2 = the thread; the
+         * normal points from the leg to the thread, the row is jac(motor body) - jac(upper leg).  MuJoCo's bounding-sphere filter first; then a
+         * tight one of this oracle's own (the two AXES within r_thread + r_leg + 0.2 mm of each other - the HIP kernel's broad phase makes the same
+         * test) that only spares the narrow phase where the answer is "apart". */
+        CGeom th, c;
+        cgeom_world(P, k, 20, &th);
+        for (int l = 0; l < JB_NLEG; l++) {
+            int g = 4 + 4 * l;
+            cgeom_world(P, k, g, &c);
+            double d[3] = {c.c[0] - th.c[0], c.c[1] - th.c[1], c.c[2] - th.c[2]};
+            if (sqrt(dot3(d, d)) > cgeom_rbound(&th) + cgeom_rbound(&c)) continue;
+            double axc[3] = {c.R[2], c.R[5], c.R[8]}, axt[3] = {th.R[2], th.R[5], th.R[8]};
+            if (segment_distance(c.c, axc, c.sz[1], th.c, axt, th.sz[1]) >= th.sz[0] + c.sz[0] + 2e-4) { MARGIN(2e-4); continue; }
+            double dist, dir[3], pos[3];
+            pair_thread_geometric(&th, &c, JB_THREAD_BISECT, &dist, dir, pos);
+            MARGIN(dist);
+            if (dist < -c.sz[0]) MARGIN(0.0);          /* the leg's AXIS inside the thread: counted as ill-conditioned for the fp32 comparison, like the pair below */
+            if (dist < 0) {
+                if (n < MAXCON) {
+                    con[n].dist = dist; memcpy(con[n].pos, pos, 24); memcpy(con[n].n, dir, 24);
+                    con[n].body = (int)P[JB_P_GEOM + 20 * JB_GEOM_STRIDE + JB_G_BODY]; con[n].body2 = (int)P[JB_P_GEOM + g * JB_GEOM_STRIDE + JB_G_BODY];
+                    con[n].geom = JB_NGEOM + 4 + l; con[n].slot = 0; con[n].wslot = WARM_PAIR2 + 4 * l;
+                    n++;
+                } else *overflow = 1;
+            }
+        }
+    }
+    if ((pair_contacts & 1) && !feet_only) {
         /* The geom pairs that can touch (on randomised models the eccentric-mass ellipsoid, geom 21 on the motor body,
          * reaches the upper-leg cylinders; every other pair MuJoCo's filters let through keeps its distance in every regime
          * measured).  MuJoCo orders a pair by geom type (ellipsoid < cylinder), so geom1 = the ellipsoid and the normal points from
@@ -983,7 +1084,7 @@ static void substep(const double* P, double* qpos, double* qvel, double ctrl, co
         for (int d = 0; d < NV; d++) { double s = 0; for (int r = 0; r < nr; r++) s += J[r][d] * f[r]; qfc[d] = s; }
         if (warm) {
             memset(warm, 0, sizeof(double) * JB_NGEOM * 16);
-            memset(warm + WARM_PAIR, 0, sizeof(double) * 16);
+            memset(warm + WARM_PAIR, 0, sizeof(double) * 32);
             for (int c = 0; c < ncon; c++) for (int e = 0; e < 4; e++) warm[con[c].wslot + e] = f[4 * c + e];
         }
         if (dbg) {
@@ -1001,7 +1102,7 @@ static void substep(const double* P, double* qpos, double* qvel, double ctrl, co
         free(J); free(MJ); free(A); free(b); free(Rr); free(f); free(aref);
     } else if (warm) {
         memset(warm, 0, sizeof(double) * JB_NGEOM * 16);
-        memset(warm + WARM_PAIR, 0, sizeof(double) * 16);
+        memset(warm + WARM_PAIR, 0, sizeof(double) * 32);
     }
     if (st) { st->ncon_last = ncon; if (ncon > st->ncon_max) st->ncon_max = ncon; if (overflow) st->overflow = 1; }
     if (dbg) memcpy(dbg->qfrc_constraint, qfc, sizeof qfc);
@@ -1038,7 +1139,7 @@ static void substep(const double* P, double* qpos, double* qvel, double ctrl, co
 
 /* ------------------------------------------------------------------ public: physics */
 void jbo_default_opts(jbo_opts* o) {
-    o->contacts = 1; o->implicit_damp = 1; o->solver_iters = 20000; o->solver_tol = 1e-12; o->warmstart = 1; o->feet_only = 0; o->solver = 1; o->pair_contacts = 1;
+    o->contacts = 1; o->implicit_damp = 1; o->solver_iters = 20000; o->solver_tol = 1e-12; o->warmstart = 1; o->feet_only = 0; o->solver = 1; o->pair_contacts = 3;
 }
 
 /* nsub substeps with constant ctrl (reference: control.Environment.step, 50 substeps) */
@@ -1082,6 +1183,19 @@ int jbo_pair_geometric_exact(const double* P, const double* qpos_in, int leg, do
     cgeom_world(P, &k, 21, &e);
     cgeom_world(P, &k, 4 + 4 * leg, &c);
     return pair_geometric_exact(&e, &c, out, out + 1, out + 4);
+}
+/* the thread (geom 20) against the upper-leg cylinder of `leg`: out = [dist, n (leg -> thread, 3), pos (3), distance of the two axis segments] */
+int jbo_pair_thread_geometric(const double* P, const double* qpos_in, int leg, int steps, double* out) {
+    Kin k; double qpos[NQ];
+    memcpy(qpos, qpos_in, sizeof qpos);
+    kinematics(P, qpos, &k);
+    CGeom th, c;
+    cgeom_world(P, &k, 20, &th);
+    cgeom_world(P, &k, 4 + 4 * leg, &c);
+    pair_thread_geometric(&th, &c, steps > 0 ? steps : JB_THREAD_BISECT, out, out + 1, out + 4);
+    double axc[3] = {c.R[2], c.R[5], c.R[8]}, axt[3] = {th.R[2], th.R[5], th.R[8]};
+    out[7] = segment_distance(c.c, axc, c.sz[1], th.c, axt, th.sz[1]);
+    return 1;
 }
 int jbo_pair_geometric(const double* P, const double* qpos_in, int leg, double* out) {
     Kin k; double qpos[NQ];

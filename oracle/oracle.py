@@ -14,7 +14,7 @@ _SO = os.path.join(_HERE, "_build", "libjb_oracle.so")
 
 NQ, NV, NGEOM = 16, 15, 22
 NPARAM = 612
-WARM_SIZE = NGEOM * 16 + NV + 16
+WARM_SIZE = NGEOM * 16 + NV + 32          # (jb_oracle.c WARM_SIZE: floor contacts, last qacc, the two geom-geom pairs of each leg)
 MAXCON = 64
 MAXROW = 4 * MAXCON
 TASKS = ("move_from_origin", "face_direction", "move_in_direction", "move_to_position", "move_to_pose")
@@ -220,10 +220,20 @@ def pair_geometric(P, qpos, leg, exact=False):
     return bool(ok), out[0], out[1:4].copy(), out[4:7].copy()
 
 
+def pair_thread_geometric(P, qpos, leg, steps=0):
+    """The simulated contact of the motor-axis thread (geom 20) with the upper-leg cylinder of `leg` (jb_oracle.c pair_thread_geometric):
+    -> (dist, normal leg -> thread, position, distance of the two axis segments).  steps: bisection steps (0: the kernel's fixed count)."""
+    out = np.zeros(8)
+    L = lib()
+    L.jbo_pair_thread_geometric.argtypes = [_dp, _dp, C.c_int, C.c_int, _dp]
+    L.jbo_pair_thread_geometric(_p(np.ascontiguousarray(P, dtype=np.float64)), _p(np.ascontiguousarray(qpos, dtype=np.float64)), int(leg), int(steps), _p(out))
+    return out[0], out[1:4].copy(), out[4:7].copy(), out[7]
+
+
 def pair_clearance(P, qpos, skip_simulated=False):
     """Minimum distance over the geom pairs MuJoCo's filters would test (jb_clearance.c).  qpos [16] -> (distance, (gi, gj));
     qpos [n,16] -> (distances [n], pairs [n,2]); P may be one table or one per row.  skip_simulated: leave out the pairs the simulator
-    collides itself (mass ellipsoid against the upper-leg cylinders)."""
+    collides itself (mass ellipsoid and motor-axis thread against the upper-leg cylinders)."""
     P = np.ascontiguousarray(P, dtype=np.float64)
     q = np.ascontiguousarray(qpos, dtype=np.float64)
     one = q.ndim == 1
