@@ -455,7 +455,7 @@ def main(argv=None):
                                      "value_over_ceiling": (n * total / wall) / (epw * min(simds, len(wc)) / (float(wc.mean()) / total)),
                                      "what": "per-wave lifetimes of the launch (s_memrealtime): the launch lasts as long as its slowest wave; `ceiling_mean_wave` = envs per wave / mean wave time x waves in flight - what the launch would reach if no wave were slower than the mean.  A robot that has tipped over stays tipped for the rest of its episode (tools/tip_persistence.py), so the slowest wave is the one whose robot tipped first"}
             return out
-        rollout_fused = {"k1000": fused(1000, "tape", episodes=3), "k100": fused(100, "tape"), "k1000_policy": fused(1000, "policy"), "k1000_const1": fused(1000, "const1"),
+        rollout_fused = {"k1000": fused(1000, "tape", episodes=3), "k100": fused(100, "tape", episodes=3), "k1000_policy": fused(1000, "policy"), "k1000_const1": fused(1000, "const1"),
                          "per_step_full_episode": None if full_episode is None else full_episode["value"],
                          "what": "jb_step_many_device: K control steps per launch, bit-identical to K single-step launches (tests/test_gpu_rollout.py); `value` above stays the per-step path"}
 

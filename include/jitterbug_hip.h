@@ -66,8 +66,8 @@ typedef struct jb_handle jb_handle;
                                   jitterbug_amd.variants / DESIGN.md 4.  A combination it cannot run (a model that needs the pair contact
                                   unless that is one model per env at 4 envs per wave) is refused with JB_E_INVALID, never run silently as
                                   the ordinary kernel; jb_kernel_variant() reports what a handle launches */
-#define JB_FLAG_PAIR        4   /* always run the kernel variant with the geom-geom contact (eccentric-mass ellipsoid against the upper-leg
-                                  cylinders, reference jitterbug.xml:44-107: every jitterbug geom collides).  Without the flag the variant
+#define JB_FLAG_PAIR        4   /* always run the kernel variant with the geom-geom contacts (eccentric-mass ellipsoid, and - round 5 - the motor-axis
+                                  thread, against the upper-leg cylinders; reference jitterbug.xml:44-107: every jitterbug geom collides).  Without the flag the variant
                                   is chosen by the model: on for one-model-per-env batches and for a shared table whose mass comes within
                                   0.5 mm of a leg, off for the nominal model (whose mass clears the legs by 3 mm) */
 #define JB_FLAG_NO_PAIR     8   /* never: floor contacts only (rounds 1-2 behaviour; diagnostic) */

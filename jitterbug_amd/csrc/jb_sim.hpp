@@ -39,7 +39,9 @@
 
 #if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
 #define JB_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define JB_ASM_MARK(txt) asm volatile("; " txt)
 #else
+#define JB_ASM_MARK(txt) ((void)0)
 #define JB_NO_DEVICE_PROF 1
 #define JB_SCHED_FENCE() ((void)0)
 #endif
@@ -2130,9 +2132,6 @@ JB_HD bool substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
         if (any_lane(mand(lane_ok, mor(gt(vabs(s.th1), V(0.9)), gt(vabs(s.th2), V(0.9)))))) { s1 = vsin(s.th1); c1 = vcos(s.th1); s2 = vsin(s.th2); c2 = vcos(s.th2); }
         V sp, cp;
         vsincos_pi(s.phi, sp, cp);
-#ifdef JB_EXP_NO_MOTOR      // (measurement only, wrong physics: what the replicated motor-body work costs a substep)
-        sp = V(0); cp = V(1);
-#endif
         if (o.aux) { s1 = sel(ax_motor, sp, s1); c1 = sel(ax_motor, cp, c1); }      // the motor's angle is wrapped to [-pi, pi): its own sine / cosine routine
         Mat3<V> R1 = rodrigues(e1, s1, c1);
         Mat3<V> R12 = mul(R1, rodrigues(ldv3(m, LM_E2), s2, c2));
@@ -2479,6 +2478,7 @@ JB_HD bool substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
     // wave-mates keep the bits of the first solve.  The code sits in a cold block outside the Newton loop: the other substeps - all but a
     // few in ten million - pay one scalar branch.
     if (__builtin_expect(redone, false)) {
+        JB_ASM_MARK("jb-cold-solve-begin");          // (a comment in the ISA: tools/asm_spills.py tells the cold block's register spills from the hot loop's)
         const U cf = group_sum_u<V>(sc, mbit(capped));      // every lane group learns which envs it concerns (helper lanes contribute zeros)
         V zr[6], zl[2], zm;
         MK capped2 = lt(V(1), V(0));
@@ -2495,6 +2495,7 @@ JB_HD bool substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
 #if !defined(__HIPCC__)
         if (is_main) g_ls_stats[0]++;
 #endif
+        JB_ASM_MARK("jb-cold-solve-end");
 #if defined(JB_CAPTURE) && defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
         if (o.capture && is_main) {      // the substep's entry state of an env that stayed unconverged (LEAN: not supported by this diagnostic)
             const bool bad = mand(re, neq_u(cf2, zero_u<V>()));

@@ -35,15 +35,23 @@ for (i0, name), i1 in zip(starts, ends):
     inner = [ab for ab in loops[1:] if ab[0] >= outer[0] and ab[1] <= outer[1]]
     sub = inner[0] if inner else outer
 
-    def count(pred, lo, hi):
-        return sum(1 for j in inst_idx if lo <= j <= hi and pred(body[j]))
+    # the cold block of the substep loop - the line-searched second contact solve (jb_sim.hpp substep_impl) - is bracketed by comments in the ISA
+    cb = [j for j, l in enumerate(body) if "jb-cold-solve-begin" in l]
+    ce = [j for j, l in enumerate(body) if "jb-cold-solve-end" in l]
+    cold = (cb[0], ce[-1]) if cb and ce else None
 
-    def report(lo, hi):
+    def count(pred, lo, hi, skip=None):
+        return sum(1 for j in inst_idx if lo <= j <= hi and pred(body[j]) and not (skip and skip[0] <= j <= skip[1]))
+
+    def report(lo, hi, skip=None):
         return "insts %6d  scratch %4d  writelane %4d  readlane %4d  accvgpr %4d" % (
-            count(lambda l: True, lo, hi), count(lambda l: "scratch_" in l, lo, hi), count(lambda l: "v_writelane" in l, lo, hi),
-            count(lambda l: "v_readlane" in l, lo, hi), count(lambda l: "v_accvgpr" in l, lo, hi))
+            count(lambda l: True, lo, hi, skip), count(lambda l: "scratch_" in l, lo, hi, skip), count(lambda l: "v_writelane" in l, lo, hi, skip),
+            count(lambda l: "v_readlane" in l, lo, hi, skip), count(lambda l: "v_accvgpr" in l, lo, hi, skip))
 
     short = re.sub(r"^_ZN12_GLOBAL__N_1\d+", "", name)[:44]
     print("%-44s whole        %s" % (short, report(0, len(body))))
     print("%-44s step loop    %s" % ("", report(*outer)))
     print("%-44s substep loop %s" % ("", report(*sub)))
+    if cold:
+        print("%-44s  - hot part  %s   (the loop without its cold block: the line-searched second solve)" % ("", report(sub[0], sub[1], cold)))
+        print("%-44s  - cold block %s" % ("", report(*cold)))

@@ -4,7 +4,7 @@ src, prefix = sys.argv[1], sys.argv[2]
 KERNEL = "jb_step_kernel"
 def find(d, pat):
     r = glob.glob(os.path.join(src, d, "**", pat), recursive=True)
-    return r[0] if r else None
+    return max(r, key=os.path.getmtime) if r else None          # (gpurun merges into a directory that may still hold an earlier run's files: take the newest)
 out = {}
 st = find("stats", "*kernel_stats.csv")
 if st:

@@ -6,7 +6,7 @@ N = int(sys.argv[4]) if len(sys.argv) > 4 else 4096
 KERNEL = "jb_step_kernel"
 def find(d, pat):
     r = glob.glob(os.path.join(src, d, "**", pat), recursive=True)
-    return r[0] if r else None
+    return max(r, key=os.path.getmtime) if r else None          # (gpurun merges into a directory that may still hold an earlier run's files: take the newest)
 out = {"what": "ONE launch of jb_step_kernel<4> advancing %d envs by K = %d control steps (jb_step_many_device; BASELINE configs[2], uniform action tape, seed 0, steps 0-%d of the episode, auto-reset included)" % (N, K, K), "K": K, "n_envs": N}
 st = find("stats", "*kernel_stats.csv")
 if st:
