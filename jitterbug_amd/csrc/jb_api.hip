@@ -37,6 +37,7 @@ using namespace jb;
 
 namespace {
 
+constexpr int OVC_FLOATS_PER_LANE = 4 * (NSLOT - ROW_K) + 9;      // LEAN kernels' per-wave block in global memory: overflow candidates + the second pair contact's frame
 enum RootF : int { RF_P = 0, RF_Q = 3, RF_V = 7, RF_W = 10, RF_PHI = 13, RF_PHID = 14, RF_TURNS = 15, RF_WA = 16, RF_WL = 19, RF_WM = 22, RF_FAIL = 23, RF_TGT = 24, RF_LO = 27 /*5: low-order words of z and the quaternion*/, ROOT_F = 32 };
 enum LegF : int { LF_TH1 = 0, LF_TH2 = 1, LF_THD1 = 2, LF_THD2 = 3, LF_WJ0 = 4, LF_WJ1 = 5, LEG_F = 6 };
 
@@ -256,9 +257,10 @@ __device__ __forceinline__ void step_body(KArgs a, StepIO io) {
     scr.p = lds + lane_in_grp;
     scr.stride = MAIN;
     scr.grp = grp; scr.ngrp = NGRP; scr.gstride = MAIN;
-    if (LEAN) { scr.ovc = a.ovc_buf + (size_t)lblock * (4 * (NSLOT - ROW_K) * MAIN) + lane_in_grp; scr.red_lds = false; }
-    else { scr.ovc = lds + SC_OVC * MAIN + lane_in_grp; scr.red_lds = true; }
-    scr.ovc_stride = MAIN;
+    // (LEAN: per wave a block in global memory - the overflow candidates, then the second pair contact's frame: rare paths both)
+    if (LEAN) { scr.ovc = a.ovc_buf + (size_t)lblock * (OVC_FLOATS_PER_LANE * MAIN) + lane_in_grp; scr.pd2 = scr.ovc + 4 * (NSLOT - ROW_K) * MAIN; scr.red_lds = false; }
+    else { scr.ovc = lds + SC_OVC * MAIN + lane_in_grp; scr.pd2 = lds + SC_PD2 * MAIN + lane_in_grp; scr.red_lds = true; }
+    scr.ovc_stride = MAIN; scr.pd2_stride = MAIN;
     scr.pd = LEAN ? SC_PD_LEAN : SC_PD;
     scr.aux_lane = aux_on && grp >= 2;
 #ifdef JB_WAVE_STATS
@@ -1143,7 +1145,7 @@ static int launch_step(jb_handle* h, StepIO io, int packed_rows) {
     const size_t lds_bytes_x = lds_bytes;
 #endif
     if (use_lean && !h->d_ovc) {      // the LEAN variant's overflow candidates (beyond the row cache): one block per wave
-        const size_t waves = (size_t)grid.x, fl = waves * 4 * (NSLOT - ROW_K) * 4 * h->ka.epw;
+        const size_t waves = (size_t)grid.x, fl = waves * OVC_FLOATS_PER_LANE * 4 * h->ka.epw;
         JB_HIP(hipMalloc(&h->d_ovc, fl * sizeof(float)));
         h->ka.ovc_buf = h->d_ovc;
     }

@@ -333,7 +333,7 @@ template <typename V> struct LaneState {
 // this is LDS with element i of lane L at lds[i*stride + L] (conflict free); on the host a plain array.  Helper lanes use
 // the addresses of the main lane they mirror.  (Lane-private long-lived values - model constants, the joint-space system -
 // are kept in registers instead, see LaneConsts / StarSys.)
-constexpr int NSLOT = 29, SLOT_PAIR = 28;
+constexpr int NSLOT = 30, SLOT_PAIR = 28, SLOT_PAIR2 = 29;      // 28: mass ellipsoid against the lane's upper leg, 29: motor-axis thread against it (PAIR kernels)
 constexpr int ROW_F = 13;            // floats per cached contact: x(3), w (the candidate's effective distance until the row is built, then the weight D), jsh(3), j7(3), ahat(3)
 constexpr int ROW_K = JB_ROW_K;      // cached live slots per substep: a leg lying on the floor has 8-9 live (10 measured +1.4 % / +3.4 % over 8 for uniform / flat-out actions; 9 is what lets eight
                                      // LEAN waves share a CU's 160 KB of LDS); the contacts
@@ -355,7 +355,8 @@ enum SC : int {
     SC_OVC = SC_RED + 56 /*(NSLOT - ROW_K) x 4: candidates of the live slots beyond the row cache (sc.ovc points here)*/,
     SC_PD = SC_OVC + 4 * (NSLOT - ROW_K) /*9 + 3: contact frame (n, t1, t2) of the pair contact, root coordinates; then the narrow phase's warm start
                    for the next substep of the same control step: axis parameter, multiplier, valid flag*/,
-    SC_ZERO = SC_PD + 12 /*56 zeros, written once per kernel: what the replica group reads where the main lanes read the reduction's totals (SimOpts::offload)*/,
+    SC_PD2 = SC_PD + 12 /*9: contact frame of the second pair contact (slot 29: the thread), stored NEGATED - see substep_impl (sc.pd2 points here; LEAN: global memory)*/,
+    SC_ZERO = SC_PD2 + 9 /*56 zeros, written once per kernel: what the replica group reads where the main lanes read the reduction's totals (SimOpts::offload)*/,
     SC_COUNT = SC_ZERO + 56,
     // ---- LEAN kernel variant (two waves per SIMD: 20 KB of LDS per wave): long-lived values that the one-wave-per-SIMD kernel keeps in
     // registers are parked here between the phases that use them; no reduction hand-over (the totals are combined in registers), the
@@ -374,6 +375,8 @@ template <typename V> struct LaneScratch {
     V* ovc;                   // candidates of the live slots beyond the row cache: [i * ovc_stride], LDS (SC_OVC) or, in the LEAN variant, global memory
     int ovc_stride;
     int pd;                   // where the pair contact's frame lives (SC_PD, or SC_PD_LEAN in the LEAN layout)
+    V* pd2;                   // the second pair contact's frame (9 values): [i * pd2_stride], LDS (SC_PD2) or, in the LEAN variant, global memory (rare path: 0.2 % of the robots)
+    int pd2_stride;
     bool aux_lane = false;    // this lane is an AUX lane (SimOpts::aux): it runs phase A on a body of its own and must not write the scratch of the leg it mirrors
     bool red_lds;             // the group reduction hands its totals over through SC_RED (false: combined in registers, the LEAN variant has no room for the buffer)
     JB_HD V ld(int i) const { return p[i * stride]; }
@@ -616,7 +619,7 @@ template <typename V> struct RowVals { Vec3<V> x; V D; V jsh[3], j7[3], ah[3]; }
 // The pair contact's rows: relative motion of the upper leg (geom2's body: + shoulder column) and the motor body (geom1's: - motor
 // column) at the contact point along the pair's own frame (sc.pd); the root columns cancel (contact_apply masks them).
 template <typename V>
-JB_HD void pair_row_values(const LaneModel<V>& m, const LaneScratch<V>& sc, const Vec3<V>& x, const V& dist, RowVals<V>& r) {
+JB_HD void pair_row_values(const LaneModel<V>& m, const LaneScratch<V>& sc, const Vec3<V>& x, const V& dist, RowVals<V>& r, const bool second = false) {
     const V thd1 = sc.ld(SC_ST + 3), phid = sc.ld(SC_ST + 5);
     const V mu = m.c[LM_MU];
     const auto valid = lt(dist, V(0));
@@ -628,7 +631,7 @@ JB_HD void pair_row_values(const LaneModel<V>& m, const LaneScratch<V>& sc, cons
     const Vec3<V> pm = cross(ldv3(m, LM_EM), x - ldv3(m, LM_AM));              // em x (x - am)
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-        const Vec3<V> d = sc.ld3(sc.pd + 3 * k);
+        const Vec3<V> d = second ? v3<V>(sc.pd2[(3 * k) * sc.pd2_stride], sc.pd2[(3 * k + 1) * sc.pd2_stride], sc.pd2[(3 * k + 2) * sc.pd2_stride]) : sc.ld3(sc.pd + 3 * k);
         r.jsh[k] = dot(d, p1); r.j7[k] = -dot(d, pm);
         r.ah[k] = -m.c[LM_BB] * (r.jsh[k] * thd1 + r.j7[k] * phid);
         if (k == 0) r.ah[k] = r.ah[k] - m.c[LM_KK] * imp * dist;
@@ -638,7 +641,7 @@ JB_HD void pair_row_values(const LaneModel<V>& m, const LaneScratch<V>& sc, cons
 // position x and effective distance of a candidate -> its row values
 template <typename V, bool PAIR = false>
 JB_HD void row_values(const LaneModel<V>& m, const LaneScratch<V>& sc, bool xtra, int slot, const Vec3<V>& x, const V& dist, RowVals<V>& r) {
-    if (PAIR && slot == SLOT_PAIR) { pair_row_values<V>(m, sc, x, dist, r); return; }
+    if (PAIR && slot >= SLOT_PAIR) { pair_row_values<V>(m, sc, x, dist, r, slot == SLOT_PAIR2); return; }
     const Vec3<V> w = sc.ld3(SC_ST);
     const V thd1 = sc.ld(SC_ST + 3), thd2 = sc.ld(SC_ST + 4), phid = sc.ld(SC_ST + 5);
     const int level = slot_level(slot);
@@ -754,7 +757,12 @@ JB_HD void contact_apply(const RowVals<V>& rv, const Vec3<V> (&dk)[3], const V& 
         U bits = (mbit(a1) + mbit(a2) * 2u + mbit(a3) * 4u + mbit(a4) * 8u + 16u);
         if (slot < 5) acc.bw0 = acc.bw0 + selu(valid, bits, zero_u<V>()) * (1u << (5 * slot));
         else if (slot < 10) acc.bw1 = acc.bw1 + selu(valid, bits, zero_u<V>()) * (1u << (5 * (slot - 5)));
-        else acc.xh = acc.xh * 0x9E3779B1u + selu(valid, bits, zero_u<V>() + 7u);
+        else {
+            // (the lane groups' records are ADDED up - contact_sweep: a per-slot odd multiplier keeps a change in one group's slot from
+            //  cancelling against the opposite change in another group's, which a plain sum of the 5-bit fields would allow)
+            const unsigned sk = (((unsigned)slot * 0x9E3779B1u) ^ (((unsigned)slot * 0x85EBCA6Bu) >> 13)) | 1u;
+            acc.xh = acc.xh * 0x9E3779B1u + selu(valid, bits, zero_u<V>() + 7u) * sk;
+        }
     }
     if (mode == 2) return;
     V f1 = sel(a1, V(1), V(0)), f2 = sel(a2, V(1), V(0)), f3 = sel(a3, V(1), V(0)), f4 = sel(a4, V(1), V(0));
@@ -1023,7 +1031,7 @@ template <int G, int NG> struct GroupMask {
 JB_HD unsigned group_mask(int g, int ngroups) {
     if (ngroups == 4) return g == 0 ? GroupMask<0, 4>::value : g == 1 ? GroupMask<1, 4>::value : g == 2 ? GroupMask<2, 4>::value : GroupMask<3, 4>::value;
     if (ngroups == 2) return g == 0 ? GroupMask<0, 2>::value : GroupMask<1, 2>::value;
-    return 0x1FFFFFFFu;
+    return (1u << NSLOT) - 1u;
 }
 
 // How the live slots of a substep are shared out: group g works through the live slots of ITS static subset, one per round.
@@ -2279,41 +2287,51 @@ JB_HD bool substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
                     sc.st(sc.pd + 9, wt); sc.st(sc.pd + 10, wlam);
                     pon = mand(near_pair, lt(pdist, V(0)));
                 }
-                // The second pair: the motor-axis thread against the own upper leg (flagged lanes only: the model builder marks the legs the
-                // thread can come near at all - 0.2 % of the reference's draws; broad phase: the two AXES within r_thread + r_leg + 0.2 mm).
-                // It shares the pair slot - rows jac(leg) - jac(motor) either way; should both pairs of one leg overlap at once (1e-5 of the
-                // draws), the deeper contact takes the slot (the oracle simulates both: a stated deviation).
-                MK use_t = lt(V(1), V(0));
+                if (any_lane(pon)) {
+                    // contact frame: MuJoCo's mju_makeFrame on the WORLD normal (y = world y unless the normal is within 60 degrees of
+                    // it, then world z), expressed in root coordinates like everything else.  Normal mass -> leg (geom1 = the ellipsoid),
+                    // rows jac(leg) - jac(motor).
+                    const Vec3<V> wy = v3<V>(R.m[3], R.m[4], R.m[5]);
+                    const V ny = dot(pn, wy);
+                    const Vec3<V> ys = sel_v3(lt(vabs(ny), V(0.5)), wy, nb);
+                    Vec3<V> t1 = ys - pn * dot(pn, ys);
+                    t1 = t1 * vrsqrt(vmax(dot(t1, t1), V(1e-30)));
+                    sc.st3(sc.pd, pn); sc.st3(sc.pd + 3, t1); sc.st3(sc.pd + 6, cross(pn, t1));
+                }
+                sc.st(sc.pd + 11, sel(near_pair, V(1), V(0)));          // the next substep may start from this one's solution (only while the pair stays near)
+                live_slots |= cand_store(sc, live_slots, SLOT_PAIR, ppos, pdist, pon);      // (stored before the second pair's narrow phase: its values die here)
+                any_con = mor(any_con, pon);
+                // The second pair (slot 29): the motor-axis thread against the own upper leg, flagged lanes only - the model builder marks the legs
+                // the thread can come near at all (0.2 % of the reference's draws); broad phase: the two AXES within r_thread + r_leg + 0.2 mm.
+                MK ton = lt(V(1), V(0));
+                V tdist = V(1);
+                Vec3<V> tpos = uc;
                 const MK tflag = lt(isv.y, V(0));
                 if (any_lane(tflag)) {
                     const Vec3<V> tcw = am + mul(Rm, ldc3(m, LM_PT_C) - am), taw = mul(Rm, ldc3(m, LM_PT_AX));
                     const V tr = ldc(m, LM_PT_R), thh = ldc(m, LM_PT_H), ur = ldc(m, LM_UC_R);
                     const MK tnear = mand(tflag, lt(segment_distance<V>(uc, ua, uh, tcw, taw, thh), tr + ur + V(2e-4)));
                     if (any_lane(tnear)) {
-                        V tdist;
-                        Vec3<V> tm, tpos;
+                        Vec3<V> tm;
                         thread_narrow<V>(tcw, taw, tr, thh, uc, ua, ur, uh, tdist, tm, tpos);
-                        use_t = mand(mand(tnear, lt(tdist, V(0))), mnot(mand(pon, lt(pdist, tdist))));
-                        pdist = sel(use_t, tdist, pdist); ppos = sel_v3(use_t, tpos, ppos); pn = sel_v3(use_t, tm, pn);
-                        pon = mor(pon, use_t);
+                        ton = mand(tnear, lt(tdist, V(0)));
+                        if (any_lane(ton) && !sc.aux_lane) {
+                            // MuJoCo's normal runs leg -> thread (geom1 = the leg's cylinder, the lower geom id) with rows jac(motor) - jac(leg):
+                            // the rows of the mass pair with the frame (n, t1, t2) negated - stored as (m, -t1, m x t1) with m = -n the thread's
+                            // outward normal (t1 is even in the normal's sign, t2 = n x t1 odd).
+                            const Vec3<V> wy = v3<V>(R.m[3], R.m[4], R.m[5]);
+                            const Vec3<V> ys = sel_v3(lt(vabs(dot(tm, wy)), V(0.5)), wy, nb);
+                            Vec3<V> t1 = ys - tm * dot(tm, ys);
+                            t1 = t1 * vrsqrt(vmax(dot(t1, t1), V(1e-30)));
+                            const Vec3<V> t2 = cross(tm, t1);
+                            const V fr[9] = {tm.x, tm.y, tm.z, -t1.x, -t1.y, -t1.z, t2.x, t2.y, t2.z};
+#pragma unroll
+                            for (int i = 0; i < 9; i++) sc.pd2[i * sc.pd2_stride] = fr[i];
+                        }
                     }
                 }
-                if (any_lane(pon)) {
-                    // contact frame: MuJoCo's mju_makeFrame on the WORLD normal (y = world y unless the normal is within 60 degrees of
-                    // it, then world z), expressed in root coordinates like everything else.  Mass pair: normal mass -> leg (geom1 = the
-                    // ellipsoid), rows jac(leg) - jac(motor).  Thread pair: MuJoCo's normal runs leg -> thread (geom1 = the leg's cylinder,
-                    // the lower geom id) with rows jac(motor) - jac(leg): the same rows with the frame (n, t1, t2) negated - stored here as
-                    // (m, -t1, m x t1) with m = -n the thread's outward normal (t1 is even in the normal's sign, t2 = n x t1 odd).
-                    const Vec3<V> wy = v3<V>(R.m[3], R.m[4], R.m[5]);
-                    const V ny = dot(pn, wy);
-                    const Vec3<V> ys = sel_v3(lt(vabs(ny), V(0.5)), wy, nb);
-                    Vec3<V> t1 = ys - pn * dot(pn, ys);
-                    t1 = t1 * vrsqrt(vmax(dot(t1, t1), V(1e-30)));
-                    sc.st3(sc.pd, pn); sc.st3(sc.pd + 3, sel_v3(use_t, -t1, t1)); sc.st3(sc.pd + 6, cross(pn, t1));
-                }
-                sc.st(sc.pd + 11, sel(near_pair, V(1), V(0)));          // the next substep may start from this one's solution (only while the pair stays near)
-                live_slots |= cand_store(sc, live_slots, SLOT_PAIR, ppos, pdist, pon);
-                any_con = mor(any_con, pon);
+                live_slots |= cand_store(sc, live_slots, SLOT_PAIR2, tpos, tdist, ton);
+                any_con = mor(any_con, ton);
             }
             any_contact = any_lane(any_con);
             env_con = neq_u(quad_sum_u(mbit(any_con)), zero_u<V>());
