@@ -258,9 +258,9 @@ __device__ __forceinline__ void step_body(KArgs a, StepIO io) {
     scr.stride = MAIN;
     scr.grp = grp; scr.ngrp = NGRP; scr.gstride = MAIN;
     // (LEAN: per wave a block in global memory - the overflow candidates, then the second pair contact's frame: rare paths both)
-    if (LEAN) { scr.ovc = a.ovc_buf + (size_t)lblock * (OVC_FLOATS_PER_LANE * MAIN) + lane_in_grp; scr.pd2 = scr.ovc + 4 * (NSLOT - ROW_K) * MAIN; scr.red_lds = false; }
-    else { scr.ovc = lds + SC_OVC * MAIN + lane_in_grp; scr.pd2 = lds + SC_PD2 * MAIN + lane_in_grp; scr.red_lds = true; }
-    scr.ovc_stride = MAIN; scr.pd2_stride = MAIN;
+    if (LEAN) { scr.ovc = a.ovc_buf + (size_t)lblock * (OVC_FLOATS_PER_LANE * MAIN) + lane_in_grp; scr.pd2 = 4 * (NSLOT - ROW_K); scr.red_lds = false; }
+    else { scr.ovc = lds + SC_OVC * MAIN + lane_in_grp; scr.pd2 = SC_PD2 - SC_OVC; scr.red_lds = true; }
+    scr.ovc_stride = MAIN;
     scr.pd = LEAN ? SC_PD_LEAN : SC_PD;
     scr.aux_lane = aux_on && grp >= 2;
 #ifdef JB_WAVE_STATS

@@ -333,7 +333,7 @@ template <typename V> struct LaneState {
 // this is LDS with element i of lane L at lds[i*stride + L] (conflict free); on the host a plain array.  Helper lanes use
 // the addresses of the main lane they mirror.  (Lane-private long-lived values - model constants, the joint-space system -
 // are kept in registers instead, see LaneConsts / StarSys.)
-constexpr int NSLOT = 30, SLOT_PAIR = 28, SLOT_PAIR2 = 29;      // 28: mass ellipsoid against the lane's upper leg, 29: motor-axis thread against it (PAIR kernels)
+constexpr int NSLOT = 30, SLOT_THREAD = 28, SLOT_MASS = 29;     // PAIR kernels - 28: motor-axis thread against the lane's upper leg, 29: mass ellipsoid against it
 constexpr int ROW_F = 13;            // floats per cached contact: x(3), w (the candidate's effective distance until the row is built, then the weight D), jsh(3), j7(3), ahat(3)
 constexpr int ROW_K = JB_ROW_K;      // cached live slots per substep: a leg lying on the floor has 8-9 live (10 measured +1.4 % / +3.4 % over 8 for uniform / flat-out actions; 9 is what lets eight
                                      // LEAN waves share a CU's 160 KB of LDS); the contacts
@@ -355,7 +355,7 @@ enum SC : int {
     SC_OVC = SC_RED + 56 /*(NSLOT - ROW_K) x 4: candidates of the live slots beyond the row cache (sc.ovc points here)*/,
     SC_PD = SC_OVC + 4 * (NSLOT - ROW_K) /*9 + 3: contact frame (n, t1, t2) of the pair contact, root coordinates; then the narrow phase's warm start
                    for the next substep of the same control step: axis parameter, multiplier, valid flag*/,
-    SC_PD2 = SC_PD + 12 /*9: contact frame of the second pair contact (slot 29: the thread), stored NEGATED - see substep_impl (sc.pd2 points here; LEAN: global memory)*/,
+    SC_PD2 = SC_PD + 12 /*9: contact frame of the thread pair contact (slot 28), stored NEGATED - see substep_impl (sc.pd2 points here; LEAN: global memory)*/,
     SC_ZERO = SC_PD2 + 9 /*56 zeros, written once per kernel: what the replica group reads where the main lanes read the reduction's totals (SimOpts::offload)*/,
     SC_COUNT = SC_ZERO + 56,
     // ---- LEAN kernel variant (two waves per SIMD: 20 KB of LDS per wave): long-lived values that the one-wave-per-SIMD kernel keeps in
@@ -375,8 +375,7 @@ template <typename V> struct LaneScratch {
     V* ovc;                   // candidates of the live slots beyond the row cache: [i * ovc_stride], LDS (SC_OVC) or, in the LEAN variant, global memory
     int ovc_stride;
     int pd;                   // where the pair contact's frame lives (SC_PD, or SC_PD_LEAN in the LEAN layout)
-    V* pd2;                   // the second pair contact's frame (9 values): [i * pd2_stride], LDS (SC_PD2) or, in the LEAN variant, global memory (rare path: 0.2 % of the robots)
-    int pd2_stride;
+    int pd2;                  // the thread pair contact's frame (9 values): sc.ovc[(pd2 + i) * ovc_stride] - behind the overflow candidates, in LDS (SC_PD2 - SC_OVC) or, in the LEAN variant, in global memory (rare path: 0.2 % of the robots)
     bool aux_lane = false;    // this lane is an AUX lane (SimOpts::aux): it runs phase A on a body of its own and must not write the scratch of the leg it mirrors
     bool red_lds;             // the group reduction hands its totals over through SC_RED (false: combined in registers, the LEAN variant has no room for the buffer)
     JB_HD V ld(int i) const { return p[i * stride]; }
@@ -631,7 +630,7 @@ JB_HD void pair_row_values(const LaneModel<V>& m, const LaneScratch<V>& sc, cons
     const Vec3<V> pm = cross(ldv3(m, LM_EM), x - ldv3(m, LM_AM));              // em x (x - am)
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-        const Vec3<V> d = second ? v3<V>(sc.pd2[(3 * k) * sc.pd2_stride], sc.pd2[(3 * k + 1) * sc.pd2_stride], sc.pd2[(3 * k + 2) * sc.pd2_stride]) : sc.ld3(sc.pd + 3 * k);
+        const Vec3<V> d = second ? v3<V>(sc.ovc[(sc.pd2 + 3 * k) * sc.ovc_stride], sc.ovc[(sc.pd2 + 3 * k + 1) * sc.ovc_stride], sc.ovc[(sc.pd2 + 3 * k + 2) * sc.ovc_stride]) : sc.ld3(sc.pd + 3 * k);
         r.jsh[k] = dot(d, p1); r.j7[k] = -dot(d, pm);
         r.ah[k] = -m.c[LM_BB] * (r.jsh[k] * thd1 + r.j7[k] * phid);
         if (k == 0) r.ah[k] = r.ah[k] - m.c[LM_KK] * imp * dist;
@@ -641,7 +640,7 @@ JB_HD void pair_row_values(const LaneModel<V>& m, const LaneScratch<V>& sc, cons
 // position x and effective distance of a candidate -> its row values
 template <typename V, bool PAIR = false>
 JB_HD void row_values(const LaneModel<V>& m, const LaneScratch<V>& sc, bool xtra, int slot, const Vec3<V>& x, const V& dist, RowVals<V>& r) {
-    if (PAIR && slot >= SLOT_PAIR) { pair_row_values<V>(m, sc, x, dist, r, slot == SLOT_PAIR2); return; }
+    if (PAIR && slot >= SLOT_THREAD) { pair_row_values<V>(m, sc, x, dist, r, slot == SLOT_THREAD); return; }
     const Vec3<V> w = sc.ld3(SC_ST);
     const V thd1 = sc.ld(SC_ST + 3), thd2 = sc.ld(SC_ST + 4), phid = sc.ld(SC_ST + 5);
     const int level = slot_level(slot);
@@ -2243,19 +2242,51 @@ JB_HD bool substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
               }
             }
             if (PAIR) {
+                const Vec3<V> uc = a1 + mul(R1, ldc3(m, LM_UC_D)), ua = mul(R1, ldc3(m, LM_UC_AX));
+                const V uh = ldc(m, LM_UC_H);
+                const Vec3<V> isv = ldc3(m, LM_PE_IS);
+                // The thread pair first (slot 28: its values are dead before the mass pair's narrow phase, the register peak of this block): the motor-axis
+                // thread against the own upper leg, flagged lanes only - the model builder marks the legs
+                // the thread can come near at all (0.2 % of the reference's draws); broad phase: the two AXES within r_thread + r_leg + 0.2 mm.
+                MK ton = lt(V(1), V(0));
+                V tdist = V(1);
+                Vec3<V> tpos = uc;
+                const MK tflag = lt(isv.y, V(0));
+                if (any_lane(tflag)) {
+                    const Vec3<V> tcw = am + mul(Rm, ldc3(m, LM_PT_C) - am), taw = mul(Rm, ldc3(m, LM_PT_AX));
+                    const V tr = ldc(m, LM_PT_R), thh = ldc(m, LM_PT_H), ur = ldc(m, LM_UC_R);
+                    const MK tnear = mand(tflag, lt(segment_distance<V>(uc, ua, uh, tcw, taw, thh), tr + ur + V(2e-4)));
+                    if (any_lane(tnear)) {
+                        Vec3<V> tm;
+                        thread_narrow<V>(tcw, taw, tr, thh, uc, ua, ur, uh, tdist, tm, tpos);
+                        ton = mand(tnear, lt(tdist, V(0)));
+                        if (any_lane(ton) && !sc.aux_lane) {
+                            // MuJoCo's normal runs leg -> thread (geom1 = the leg's cylinder, the lower geom id) with rows jac(motor) - jac(leg):
+                            // the rows of the mass pair with the frame (n, t1, t2) negated - stored as (m, -t1, m x t1) with m = -n the thread's
+                            // outward normal (t1 is even in the normal's sign, t2 = n x t1 odd).
+                            const Vec3<V> wy = v3<V>(R.m[3], R.m[4], R.m[5]);
+                            const Vec3<V> ys = sel_v3(lt(vabs(dot(tm, wy)), V(0.5)), wy, nb);
+                            Vec3<V> t1 = ys - tm * dot(tm, ys);
+                            t1 = t1 * vrsqrt(vmax(dot(t1, t1), V(1e-30)));
+                            const Vec3<V> t2 = cross(tm, t1);
+                            const V fr[9] = {tm.x, tm.y, tm.z, -t1.x, -t1.y, -t1.z, t2.x, t2.y, t2.z};
+#pragma unroll
+                            for (int i = 0; i < 9; i++) sc.ovc[(sc.pd2 + i) * sc.ovc_stride] = fr[i];
+                        }
+                    }
+                }
+                live_slots |= cand_store(sc, live_slots, SLOT_THREAD, tpos, tdist, ton);
+                any_con = mor(any_con, ton);
                 // The geom-geom pair: the eccentric-mass ellipsoid (motor body) against the own upper-leg cylinder.  Broad phase: the
                 // ellipsoid's centre within (largest semi-axis + cylinder radius) of the leg's axis segment; the narrow phase runs for
                 // the whole wave when some lane is that close.
-                const Vec3<V> uc = a1 + mul(R1, ldc3(m, LM_UC_D)), ua = mul(R1, ldc3(m, LM_UC_AX));
                 const Vec3<V> pe = am + mul(Rm, ldc3(m, LM_PE_C) - am);
                 Mat3<V> Re0;
 #pragma unroll
                 for (int i = 0; i < 9; i++) Re0.m[i] = ldc(m, LM_PE_R + i);
                 const Mat3<V> Re = mul(Rm, Re0);
-                const V uh = ldc(m, LM_UC_H);
                 // broad phase, exact for what it tests: does the axis segment enter the ellipsoid with semi-axes s + (r_cyl + 0.2 mm)?  In that
                 // ellipsoid's unit-sphere coordinates the segment is still a segment: its closest point to the origin decides.
-                const Vec3<V> isv = ldc3(m, LM_PE_IS);
                 const Vec3<V> cl = mulT(Re, uc - pe), ul = mulT(Re, ua);
                 const V isvy = vabs(isv.y);          // (the sign carries the thread flag, below)
                 const Vec3<V> cs = v3<V>(cl.x * isv.x, cl.y * isvy, cl.z * isv.z), us = v3<V>(ul.x * isv.x, ul.y * isvy, ul.z * isv.z);
@@ -2299,39 +2330,8 @@ JB_HD bool substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
                     sc.st3(sc.pd, pn); sc.st3(sc.pd + 3, t1); sc.st3(sc.pd + 6, cross(pn, t1));
                 }
                 sc.st(sc.pd + 11, sel(near_pair, V(1), V(0)));          // the next substep may start from this one's solution (only while the pair stays near)
-                live_slots |= cand_store(sc, live_slots, SLOT_PAIR, ppos, pdist, pon);      // (stored before the second pair's narrow phase: its values die here)
+                live_slots |= cand_store(sc, live_slots, SLOT_MASS, ppos, pdist, pon);
                 any_con = mor(any_con, pon);
-                // The second pair (slot 29): the motor-axis thread against the own upper leg, flagged lanes only - the model builder marks the legs
-                // the thread can come near at all (0.2 % of the reference's draws); broad phase: the two AXES within r_thread + r_leg + 0.2 mm.
-                MK ton = lt(V(1), V(0));
-                V tdist = V(1);
-                Vec3<V> tpos = uc;
-                const MK tflag = lt(isv.y, V(0));
-                if (any_lane(tflag)) {
-                    const Vec3<V> tcw = am + mul(Rm, ldc3(m, LM_PT_C) - am), taw = mul(Rm, ldc3(m, LM_PT_AX));
-                    const V tr = ldc(m, LM_PT_R), thh = ldc(m, LM_PT_H), ur = ldc(m, LM_UC_R);
-                    const MK tnear = mand(tflag, lt(segment_distance<V>(uc, ua, uh, tcw, taw, thh), tr + ur + V(2e-4)));
-                    if (any_lane(tnear)) {
-                        Vec3<V> tm;
-                        thread_narrow<V>(tcw, taw, tr, thh, uc, ua, ur, uh, tdist, tm, tpos);
-                        ton = mand(tnear, lt(tdist, V(0)));
-                        if (any_lane(ton) && !sc.aux_lane) {
-                            // MuJoCo's normal runs leg -> thread (geom1 = the leg's cylinder, the lower geom id) with rows jac(motor) - jac(leg):
-                            // the rows of the mass pair with the frame (n, t1, t2) negated - stored as (m, -t1, m x t1) with m = -n the thread's
-                            // outward normal (t1 is even in the normal's sign, t2 = n x t1 odd).
-                            const Vec3<V> wy = v3<V>(R.m[3], R.m[4], R.m[5]);
-                            const Vec3<V> ys = sel_v3(lt(vabs(dot(tm, wy)), V(0.5)), wy, nb);
-                            Vec3<V> t1 = ys - tm * dot(tm, ys);
-                            t1 = t1 * vrsqrt(vmax(dot(t1, t1), V(1e-30)));
-                            const Vec3<V> t2 = cross(tm, t1);
-                            const V fr[9] = {tm.x, tm.y, tm.z, -t1.x, -t1.y, -t1.z, t2.x, t2.y, t2.z};
-#pragma unroll
-                            for (int i = 0; i < 9; i++) sc.pd2[i * sc.pd2_stride] = fr[i];
-                        }
-                    }
-                }
-                live_slots |= cand_store(sc, live_slots, SLOT_PAIR2, tpos, tdist, ton);
-                any_con = mor(any_con, ton);
             }
             any_contact = any_lane(any_con);
             env_con = neq_u(quad_sum_u(mbit(any_con)), zero_u<V>());

@@ -53,11 +53,10 @@ static int run(const double* P, double* qpos, double* qvel, double ctrl, int nsu
     m_aux.c.tab = auxtab; m_aux.c.tab_rare = tab + LM_INV; m_aux.c.preload();
     constexpr int SCMAX = SC_COUNT > SC_COUNT_LEAN_PAIR ? SC_COUNT : SC_COUNT_LEAN_PAIR;
     V scratch[SCMAX];                  // (the LEAN variant parks state / system / factorisation where the ordinary one has its reduction buffer and overflow candidates)
-    V ovcbuf[4 * (NSLOT - ROW_K)];     // LEAN: the candidates beyond the row cache live outside the scratch (global memory on the device)
-    V pd2buf[9];                       // ... and so does the second pair contact's frame
+    V ovcbuf[4 * (NSLOT - ROW_K) + 9]; // LEAN: the candidates beyond the row cache live outside the scratch (global memory on the device), and behind them the thread pair contact's frame
     auto set_ovc = [&](LaneScratch<V>& sc) {
         sc.ovc = lean ? ovcbuf : scratch + SC_OVC; sc.ovc_stride = 1; sc.red_lds = !lean; sc.pd = lean ? SC_PD_LEAN : SC_PD;
-        sc.pd2 = lean ? pd2buf : scratch + SC_PD2; sc.pd2_stride = 1;
+        sc.pd2 = lean ? 4 * (NSLOT - ROW_K) : SC_PD2 - SC_OVC;
     };
     normalise_state(s);
     if (ngroups <= 1) {
@@ -196,7 +195,7 @@ static int rollout(const double* P, double* qpos, double* qvel, double* target, 
     auto body = [&](int g) {
         if (ngroups > 1) { g_host_wave = &wave; g_host_grp = g; }
         LaneScratch<V> sc; sc.p = scratch; sc.stride = 1; sc.grp = g; sc.ngrp = ngroups; sc.gstride = ngroups > 1 ? 16 : 4;
-        sc.ovc = scratch + SC_OVC; sc.ovc_stride = 1; sc.red_lds = true; sc.pd = SC_PD; sc.pd2 = scratch + SC_PD2; sc.pd2_stride = 1;
+        sc.ovc = scratch + SC_OVC; sc.ovc_stride = 1; sc.red_lds = true; sc.pd = SC_PD; sc.pd2 = SC_PD2 - SC_OVC;
         sc.aux_lane = o.aux && g >= 2;
         const LaneModel<V>& mg = sc.aux_lane ? m_aux : m;
         const bool rep = g == 0 || (o.offload && g == 1) || sc.aux_lane;          // the lanes that hold the env's state (main, replica, aux)
@@ -306,7 +305,7 @@ extern "C" int jbh_substep_record(const double* P, const float* rec, int max_new
     auto body = [&](int g) {
         if (ngroups > 1) { g_host_wave = &wave; g_host_grp = g; }
         LaneScratch<V> sc; sc.p = scratch; sc.stride = 1; sc.grp = g; sc.ngrp = ngroups; sc.gstride = ngroups > 1 ? 16 : 4;
-        sc.ovc = scratch + SC_OVC; sc.ovc_stride = 1; sc.red_lds = true; sc.pd = SC_PD; sc.pd2 = scratch + SC_PD2; sc.pd2_stride = 1;
+        sc.ovc = scratch + SC_OVC; sc.ovc_stride = 1; sc.red_lds = true; sc.pd = SC_PD; sc.pd2 = SC_PD2 - SC_OVC;
         sc.aux_lane = o.aux && g >= 2;
         const bool rep = g == 0 || (o.offload && g == 1) || sc.aux_lane;
         LaneState<V> s = s0;

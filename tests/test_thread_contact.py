@@ -116,7 +116,7 @@ def test_thread_contact_in_the_dynamics_fp64_host_equals_oracle_and_fp32_is_clos
 
 def test_both_pairs_of_one_leg_at_once_fp64_host_equals_oracle(touching):
     """A robot whose thread reaches a front leg has its motor axis ~7 mm nearer that leg than nominal: when the motor turns, the eccentric mass
-    strikes the same leg.  The thread contact (slot 29) and the mass contact (slot 28) are then live in the same substeps - two pair slots,
+    strikes the same leg.  The thread contact (slot 28) and the mass contact (slot 29) are then live in the same substeps - two pair slots,
     two frames, one shoulder - motor cross term that both add to: the kernel source on the host in fp64 against the oracle, one and four
     lane groups."""
     import tests.build_harness as bh
