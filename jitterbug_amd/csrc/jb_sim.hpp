@@ -2196,45 +2196,58 @@ JB_HD bool substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
                                ldc(m, LM_XC_R), ldc(m, LM_XC_H), nb, s.pz, s.pz_lo, mand(lane_ok, gt(ldc(m, LM_XC_EN), V(0.5))), cy);
                 live_slots |= cand_store_cyl(sc, live_slots, 10, cy, mnot(x_onm));      // (slots in increasing order: 10-13, 14, 15-22, then the motor body's 23-27)
                 any_con = mor(any_con, cy.on[0]);
-                Vec3<V> ellx_m;
-                V elld_m;
-                MK ellon_m;
-                {   // lane ellipsoid: support point in direction -n
-                    Mat3<V> Re0, Re;
+                Vec3<V> ellx_m = c0;
+                V elld_m = V(1);
+                MK ellon_m = lt(V(1), V(0));
+                {   // lane ellipsoid: support point in direction -n.  A sphere of the largest semi-axis around its centre first - when no lane's
+                    // reaches the floor (the usual case: a robot on its side rests on legs and screws) the rotation products are not needed
+                    const Vec3<V> ec0 = ldc3(m, LM_XE_C), sz = ldc3(m, LM_XE_S);
+                    const Vec3<V> ec = sel_v3(x_onm, am + mul(Rm, ec0 - am), ec0);
+                    const MK een = mand(lane_ok, gt(ldc(m, LM_XE_EN), V(0.5)));
+                    const V ech = (s.pz + dot(ec, nb)) + s.pz_lo;
+                    if (any_lane(mand(een, lt(ech, vmax(sz.x, vmax(sz.y, sz.z)))))) {
+                        Mat3<V> Re0, Re;
 #pragma unroll
-                    for (int i = 0; i < 9; i++) Re0.m[i] = ldc(m, LM_XE_R + i);
-                    Mat3<V> Rem = mul(Rm, Re0);
+                        for (int i = 0; i < 9; i++) Re0.m[i] = ldc(m, LM_XE_R + i);
+                        Mat3<V> Rem = mul(Rm, Re0);
 #pragma unroll
-                    for (int i = 0; i < 9; i++) Re.m[i] = sel(x_onm, Rem.m[i], Re0.m[i]);
-                    Vec3<V> ec0 = ldc3(m, LM_XE_C);
-                    Vec3<V> ec = sel_v3(x_onm, am + mul(Rm, ec0 - am), ec0);
-                    Vec3<V> dl = mulT(Re, -nb);
-                    Vec3<V> sz = ldc3(m, LM_XE_S);
-                    V iden = vrsqrt(sz.x * sz.x * dl.x * dl.x + sz.y * sz.y * dl.y * dl.y + sz.z * sz.z * dl.z * dl.z);
-                    Vec3<V> sup = ec + mul(Re, v3<V>(sz.x * sz.x * dl.x * iden, sz.y * sz.y * dl.y * iden, sz.z * sz.z * dl.z * iden));
-                    V elld = (s.pz + dot(sup, nb)) + s.pz_lo;
-                    MK ellon = mand(mand(lane_ok, gt(ldc(m, LM_XE_EN), V(0.5))), lt(elld, V(0)));
-                    Vec3<V> ellx = sup - nb * (elld * V(0.5));
-                    live_slots |= cand_store(sc, live_slots, 14, ellx, elld, mand(ellon, mnot(x_onm)));
-                    ellx_m = ellx; elld_m = elld; ellon_m = mand(ellon, x_onm);
-                    any_con = mor(any_con, ellon);
+                        for (int i = 0; i < 9; i++) Re.m[i] = sel(x_onm, Rem.m[i], Re0.m[i]);
+                        Vec3<V> dl = mulT(Re, -nb);
+                        V iden = vrsqrt(sz.x * sz.x * dl.x * dl.x + sz.y * sz.y * dl.y * dl.y + sz.z * sz.z * dl.z * dl.z);
+                        Vec3<V> sup = ec + mul(Re, v3<V>(sz.x * sz.x * dl.x * iden, sz.y * sz.y * dl.y * iden, sz.z * sz.z * dl.z * iden));
+                        V elld = (s.pz + dot(sup, nb)) + s.pz_lo;
+                        MK ellon = mand(een, lt(elld, V(0)));
+                        Vec3<V> ellx = sup - nb * (elld * V(0.5));
+                        live_slots |= cand_store(sc, live_slots, 14, ellx, elld, mand(ellon, mnot(x_onm)));
+                        ellx_m = ellx; elld_m = elld; ellon_m = mand(ellon, x_onm);
+                        any_con = mor(any_con, ellon);
+                    }
                 }
-                {   // lane box (root body): first 4 penetrating vertices in vertex order
+                {   // lane box (root body): first 4 penetrating vertices in vertex order.  A vertex's height is the centre's plus / minus the three
+                    // half-extents projected on the floor normal; the positions are worked out for penetrating vertices only, and nothing
+                    // at all when the lowest vertex of every lane's box is above the floor
                     Mat3<V> Rb;
 #pragma unroll
                     for (int i = 0; i < 9; i++) Rb.m[i] = ldc(m, LM_XB_R + i);
-                    Vec3<V> bc = ldc3(m, LM_XB_C), bs = ldc3(m, LM_XB_S);
-                    MK ben = mand(lane_ok, gt(ldc(m, LM_XB_EN), V(0.5)));
-                    V cnt = V(0);
+                    const Vec3<V> bc = ldc3(m, LM_XB_C), bs = ldc3(m, LM_XB_S);
+                    const MK ben = mand(lane_ok, gt(ldc(m, LM_XB_EN), V(0.5)));
+                    const Vec3<V> hb = mulT(Rb, nb);
+                    const V hx = bs.x * hb.x, hy = bs.y * hb.y, hz = bs.z * hb.z;
+                    const V bch = dot(bc, nb);
+                    if (any_lane(mand(ben, lt((s.pz + (bch - (vabs(hx) + vabs(hy) + vabs(hz)))) + s.pz_lo, V(0))))) {
+                        V cnt = V(0);
 #pragma unroll
-                    for (int vtx = 0; vtx < 8; vtx++) {
-                        Vec3<V> l = v3<V>((vtx & 1) ? bs.x : -bs.x, (vtx & 2) ? bs.y : -bs.y, (vtx & 4) ? bs.z : -bs.z);
-                        Vec3<V> pnt = bc + mul(Rb, l);
-                        V d = (s.pz + dot(pnt, nb)) + s.pz_lo;
-                        MK on = mand(mand(ben, lt(d, V(0))), lt(cnt, V(3.5)));
-                        cnt = cnt + sel(on, V(1), V(0));
-                        live_slots |= cand_store(sc, live_slots, 15 + vtx, pnt - nb * (d * V(0.5)), d, on);
-                        any_con = mor(any_con, on);
+                        for (int vtx = 0; vtx < 8; vtx++) {
+                            const V d = (s.pz + (bch + (((vtx & 1) ? hx : -hx) + ((vtx & 2) ? hy : -hy) + ((vtx & 4) ? hz : -hz)))) + s.pz_lo;
+                            const MK on = mand(mand(ben, lt(d, V(0))), lt(cnt, V(3.5)));
+                            cnt = cnt + sel(on, V(1), V(0));
+                            if (any_lane(on)) {
+                                const Vec3<V> l = v3<V>((vtx & 1) ? bs.x : -bs.x, (vtx & 2) ? bs.y : -bs.y, (vtx & 4) ? bs.z : -bs.z);
+                                const Vec3<V> pnt = bc + mul(Rb, l);
+                                live_slots |= cand_store(sc, live_slots, 15 + vtx, pnt - nb * (d * V(0.5)), d, on);
+                            }
+                            any_con = mor(any_con, on);
+                        }
                     }
                 }
                 live_slots |= cand_store_cyl(sc, live_slots, 23, cy, x_onm);
