@@ -576,7 +576,7 @@ def main(argv=None):
                                     "mean_active_lanes_per_valu_inst": lanes,
                                     "fp32_tflops_full_wave": wave_ops * 64.0 / k_s / 1e12,          # rocprof-compute's convention: every instruction counted at 64 lanes
                                     "fp32_tflops_active_lanes": (wave_ops * lanes / k_s / 1e12) if lanes else None,
-                                    "active_lanes_note": "active lanes are NOT useful lanes: since round 3 lane group 1 repeats the main lanes' phase A / C (it needs the joint-space system for the damping factorisation it takes off the critical path) and the solves run unmasked in all four groups; one env's physics occupies 4 lanes",
+                                    "active_lanes_note": "active lanes are NOT useful lanes: since round 3 lane group 1 repeats the main lanes' phase A / C (it needs the joint-space system for the damping factorisation it takes off the critical path) and the solves run unmasked in all four groups; since round 5 lane groups 2 and 3 run phase A / C on the motor body and the root body's own mass (group 3 repeating group 2 for the replica); one env's physics occupies 4 + 2 of its 16 lanes",
                                     "fp32_peak_tflops": 157.3,
                                     "fp32_frac_of_peak_active_lanes": (wave_ops * lanes / k_s / 1e12 / 157.3) if lanes else None})
                 prof_note = "%s, same build (sha256 %s...)" % (PROFILE, lib_sha[:12])
