@@ -168,6 +168,38 @@ def test_helper_groups_fp64_equal_single_group_and_oracle(gstep, params):
     assert n_multi > 40 and worst_groups < 1e-11 and worst_oracle < 1e-10
 
 
+def test_every_geom_type_with_lane_groups_fp64_equals_oracle(gstep, params):
+    """test_every_geom_type_fp64_equals_oracle's random orientations pushed into the floor, with TWO and FOUR lane groups: the body slots
+    (root box vertices, screws, motor-body geoms: slots 10-27) are dealt to different groups, whose accumulators and active-set records
+    are combined across groups every pass - up to fourteen contacts at once, four substeps, against the oracle."""
+    rng = np.random.default_rng(5)
+    seen, most, worst = set(), 0, 0.0
+    for trial in range(70):
+        q = model.qpos0(params)
+        q[3:7] = rng.normal(size=4); q[3:7] /= np.linalg.norm(q[3:7])
+        q[7:15] = rng.normal(size=8) * 0.03; q[15] = rng.uniform(-3, 3)
+        v = rng.normal(size=15) * np.array([.05] * 3 + [1] * 3 + [1] * 8 + [20])
+        lo, hi = -0.1, 0.2
+        for _ in range(30):
+            mid = 0.5 * (lo + hi); q[2] = mid
+            if O.forward_debug(params, q, v, 0.0)["ncon"] > 0:
+                lo = mid
+            else:
+                hi = mid
+        q[2] = lo - rng.uniform(0.0002, 0.004)
+        u = rng.uniform(-1, 1)
+        d = O.forward_debug(params, q, v, u)
+        seen |= set(d["con_geom"][:d["ncon"]].tolist()); most = max(most, d["ncon"])
+        qo, vo = O.step_physics(params, q, v, u, 4)
+        for groups in (2, 4):
+            qh, vh, cap = gstep(q, v, u, 4, groups=groups, maxn=12)
+            assert cap == 0
+            worst = max(worst, np.abs(qh - qo).max(), (np.abs(vh - vo) / (1 + np.abs(vo))).max())
+    print("random orientations on the floor, 2 and 4 lane groups vs oracle: %.2e (geoms seen %d, most contacts at once %d)" % (worst, len(seen), most))
+    assert len(seen) >= 14 and most >= 7
+    assert worst < 1e-10
+
+
 def test_rank_one_passes_fp64_equal_full_passes_with_groups(gstep, params):
     """Sherman-Morrison on the kept factorisation, reading contact rows that OTHER groups built (the path of round 1's
     uninitialised-row bug), and the rank-one update / downdate of that factorisation after every pass (chains of single-edge

@@ -176,6 +176,54 @@ def test_captured_double_contact_states_with_lane_groups_fp64_host_equals_oracle
     assert worst < 1e-9
 
 
+def test_every_kernel_variant_on_random_orientations_fp64_host_equals_oracle():
+    """Robots whose thread rubs a leg (and the nominal robot) thrown on the floor in random orientations - up to a dozen floor contacts of legs,
+    box vertices, screws and motor-body geoms next to the geom-geom contacts, four substeps: the kernel source in all four layouts
+    (ordinary / LEAN, each with and without the pair contacts; LEAN keeps its overflow candidates and the thread contact's frame outside the
+    scratch) with one and four lane groups, fp64 on the host, against the oracle (the layouts without the pair contacts against the oracle
+    with them switched off)."""
+    import tests.build_harness as bh
+    lib = C.CDLL(bh.build())
+    dp = C.POINTER(C.c_double)
+    names = ("jbh_step_groups", "jbh_step_lean", "jbh_step_pair", "jbh_step_pair_lean")
+    for name in names:
+        getattr(lib, name).argtypes = [dp, dp, dp, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, dp]
+    models = [m[0] for m in _touching_models(6, seed=11)] + [model.default_params()]
+    rng = np.random.default_rng(9)
+    worst, pair_seen, most = 0.0, 0, 0
+    for trial in range(49):
+        params = models[trial % len(models)]
+        P = np.ascontiguousarray(params, dtype=np.float64)
+        q = model.qpos0(params)
+        q[3:7] = rng.normal(size=4); q[3:7] /= np.linalg.norm(q[3:7])
+        q[7:15] = rng.normal(size=8) * 0.03; q[15] = rng.uniform(-3, 3)
+        v = rng.normal(size=15) * np.array([.05] * 3 + [1] * 3 + [1] * 8 + [20])
+        lo, hi = -0.1, 0.2
+        for _ in range(30):          # the height at which the first FLOOR contact appears
+            mid = 0.5 * (lo + hi); q[2] = mid
+            d = O.forward_debug(params, q, v, 0.0)
+            if any(int(g) < model.NGEOM for g in d["con_geom"][:d["ncon"]]):
+                lo = mid
+            else:
+                hi = mid
+        q[2] = lo - rng.uniform(0.0002, 0.004)
+        u = rng.uniform(-1, 1)
+        d = O.forward_debug(params, q, v, u)
+        pair_seen += any(int(g) >= model.NGEOM for g in d["con_geom"][:d["ncon"]]); most = max(most, d["ncon"])
+        with_pairs = O.step_physics(params, q, v, u, 4)
+        without = O.step_physics(params, q, v, u, 4, O.default_opts(pair_contacts=0))
+        for name in names:
+            ref = with_pairs if "pair" in name else without
+            for groups in (1, 4):
+                qq, vv, fail = q.copy(), v.copy(), np.zeros(1)
+                assert getattr(lib, name)(P.ctypes.data_as(dp), qq.ctypes.data_as(dp), vv.ctypes.data_as(dp), float(u), 4, 1, 12, 0, groups, 1, fail.ctypes.data_as(dp)) == 0
+                assert fail[0] == 0
+                worst = max(worst, np.abs(qq - ref[0]).max(), (np.abs(vv - ref[1]) / (1 + np.abs(ref[1]))).max())
+    print("four layouts x 1 / 4 lane groups on random orientations: host fp64 vs oracle %.2e (states with a geom-geom contact %d of 49, most contacts at once %d)" % (worst, pair_seen, most))
+    assert pair_seen >= 30 and most >= 8
+    assert worst < 1e-10
+
+
 def _small_actions(rng, n):
     """The motor held within a few degrees of its rest angle: on these robots - their motor axis sits 7 mm nearer a front leg than nominal - a
     turning mass would strike that leg too (by millimetres: the deep-overlap class of tests/test_pair_contact.py); held back, the thread is
