@@ -167,9 +167,14 @@ def main(argv=None):
     ap.add_argument("--actions", default="uniform", help="uniform (default, the metric's workload) | const1 (motor flat out: about half the robots tip over - diagnostic)")
     ap.add_argument("--seed", type=int, default=0, help="reset / action stream seed (the committed numbers use 0)")
     ap.add_argument("--dist-backend", default="nccl", help="--collective torch only: nccl (= RCCL through PyTorch); gloo is a CPU-staged rehearsal of the N>1 control flow")
-    ap.add_argument("--collective", default="cabi", choices=["cabi", "torch"],
-                    help="N > 1: who moves the rows.  cabi (default): the library's own RCCL binding (jb_comm_init / jb_gather_rows_device; torch.distributed carries only control traffic over gloo); "
-                         "torch: torch.distributed's gather.  If the chosen path fails the other is tried, then the shards are timed without any collective and the line says degraded")
+    ap.add_argument("--collective", default="torch", choices=["cabi", "torch"],
+                    help="N > 1: who moves the rows.  torch (default): torch.distributed's gather over RCCL - the path PyTorch has run on many ranks; cabi: the library's own RCCL binding "
+                         "(jb_comm_init / jb_scatter_actions_device / jb_gather_rows_device; torch.distributed then carries only control traffic over gloo) - it has never seen two GPUs, so it is "
+                         "opt-in until a multi-GPU box has run it.  If the chosen path fails the other is tried, then the shards are timed without any collective and the line says degraded")
+    ap.add_argument("--actions-from", default="local", choices=["local", "rank0"],
+                    help="N > 1: where a step's actions come from.  local (default): resident on every rank before the timed region; rank0: rank 0 holds the actions of the whole batch and "
+                         "every step scatters them (jb_scatter_actions_device / torch.distributed.scatter): the timed region is then scatter -> step -> gather, the reference's whole per-step "
+                         "round trip (benchmarks/benchmark.py:161-171); the line says which it timed")
     ap.add_argument("--task", default=TASK, help="default move_from_origin (the BASELINE metric); move_to_pose is BASELINE configs[3]'s task")
     ap.add_argument("--augmented", action="store_true", help="one randomised model per env (BASELINE configs[4], augment_Jitterbug semantics)")
     ap.add_argument("--no-steady", action="store_true", help="skip the steady-state (steps 100-400) and full-episode blocks measured next to the headline")
@@ -272,7 +277,11 @@ def main(argv=None):
             setup = run_setup(contacts, steps, warmup, gather)
         except Exception as e:
             failure, setup = e, None
-        sync_point(failure)
+        try:
+            sync_point(failure)
+        except Exception:
+            close_quietly(setup)
+            raise
         env, sh, one, drain, obs, last = setup
         t0 = time.perf_counter()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -286,13 +295,29 @@ def main(argv=None):
         except Exception as e:
             failure = e
         wall = time.perf_counter() - t0
-        sync_point(failure)
+        try:
+            sync_point(failure)
+        except Exception:
+            close_quietly(setup)          # a failed attempt leaves no communicator, stream or handle behind before the next mode is tried
+            raise
         try:
             out = run_finish(env, sh, obs, last, wall, ev0.elapsed_time(ev1))
         except Exception as e:
             failure, out = e, None
+            close_quietly(setup)
         sync_point(failure)
         return out
+
+    def close_quietly(setup):
+        if not setup:
+            return
+        env, sh = setup[0], setup[1]
+        for obj in (sh, env):
+            try:
+                if obj is not None:
+                    obj.close()
+            except Exception:
+                pass
 
     def run_setup(contacts, steps, warmup, gather):
         g = torch.Generator(device=dev)
@@ -324,11 +349,17 @@ def main(argv=None):
         env.reset_device(None, obs.data_ptr())
         last = [None]
 
+        actions_all = None
+        if sh is not None and args.actions_from == "rank0" and rank == 0:          # the whole batch's actions on rank 0 (resident in ITS HBM), scattered every step
+            actions_all = torch.rand((steps + warmup, n * world), generator=g, device=dev, dtype=torch.float32) * 2 - 1
+            actions_all[:, :n] = actions
+
         def one(i):
             if sh is None:
                 env.step_device(actions[i].data_ptr(), obs.data_ptr(), rew.data_ptr(), done.data_ptr())
             else:
-                r = sh.step(local_actions=actions[i])          # a PendingRows handle for step i-1: nothing waits unless asked
+                # a PendingRows handle for step i-1: nothing waits unless asked
+                r = sh.step(local_actions=actions[i]) if args.actions_from == "local" else sh.step(None if actions_all is None else actions_all[i])
                 if r is not None:
                     last[0] = r
 
@@ -363,7 +394,10 @@ def main(argv=None):
         if sh is not None and rank == 0:                # the gathered block of the last step really holds every rank's rows
             ob_all, rw_all, dn_all = last[0].get()
             finite = finite and ob_all.shape[0] == n * world and bool(torch.isfinite(ob_all).all().item()) and bool((ob_all[:n] == sh.last_local_rows()[:, :D]).all().item())
-        env.close()
+        if sh is not None:
+            sh.close()          # flush, both streams idle, the library's communicator destroyed (cabi), then the env
+        else:
+            env.close()
         return wall, dev_ms, float(cap.sum()), finite
 
     measured = None
@@ -493,9 +527,14 @@ def main(argv=None):
             rollout_fused = {"k100_sharded": {"value": total_envs * 1000 / wf, "unit": "env steps/s", "ms_per_step": wf * 1e3 / 1000, "launches": 10, "steps_per_launch": 100,
                                               "gathers": 10, "rows_per_gather": [100, n, D + 2], "finite": ok, "collective": use_gather,
                                               "what": "ShardedJitterbugEnv.rollout(100): one fused 100-step launch per rank, then one gather of [100, N_local, D+2] rows to rank 0; x 10 = a whole episode"}}
-            sh.env.close()
+            sh.close()
         except Exception as e:            # (RanksDisagree on every rank, or a local error after the last sync point: recorded, the headline stands)
             rollout_fused = {"k100_sharded": {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}}
+            try:
+                if sh is not None:
+                    sh.close()
+            except Exception:
+                pass
 
     def config_label(contacts):
         """which BASELINE.json config this workload is, if any"""
@@ -532,6 +571,17 @@ def main(argv=None):
             env.step(acts[i % 64])
         host_rate = {"value": n * kh / (time.perf_counter() - t0), "unit": "env steps/s", "steps": kh,
                      "what": "jb_step with host buffers through the Python VecEnv (H2D actions + kernel + D2H obs/reward/done + sync + numpy copies per step)"}
+        # the same through step_async / step_wait (jb_step_async: pinned staging, the copies and the kernel queued at once, an event to wait on) with
+        # the caller's own work between the halves - here: drawing the next step's actions, what a policy would be doing
+        env.step_async(acts[0]); env.step_wait()
+        t0 = time.perf_counter()
+        nxt = acts[0]
+        for i in range(kh):
+            env.step_async(nxt)
+            nxt = acts[(i + 1) % 64] * 1.0          # host work that overlaps the step
+            env.step_wait(copy=False)
+        host_rate["async"] = {"value": n * kh / (time.perf_counter() - t0), "unit": "env steps/s", "steps": kh,
+                              "what": "step_async -> (host prepares the next actions) -> step_wait(copy=False): pinned buffers, no stream sync inside the call, results read in place"}
         env.close()
 
     if rank == 0:
@@ -595,6 +645,8 @@ def main(argv=None):
         elif world > 1 or dist is not None:
             how = {"cabi": "the library's own RCCL communicator (jb_gather_rows_device: grouped ncclSend / ncclRecv)", "torch": "torch.distributed (%s)" % ("RCCL" if args.dist_backend != "gloo" else "gloo rehearsal, staged through the host")}[use_gather]
             gather_txt = ", gather of [N,D+2] rows to rank 0 every step through %s, issued one step late from a side stream, three row buffers (jitterbug_amd.distributed.ShardedJitterbugEnv, pipeline_depth=2)" % how
+            gather_txt += {"local": "; actions resident on every rank (the timed region is step -> gather)",
+                           "rank0": "; actions of the whole batch on rank 0, scattered every step (the timed region is scatter -> step -> gather: the whole per-step round trip)"}[args.actions_from]
         res = {
             "metric": "env steps/s at N_envs=%d, %s" % (n, task),
             "value": None if degraded else value, "unit": "env steps/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -614,7 +666,7 @@ def main(argv=None):
                          "note": "path is fp32-VALU/latency bound, not HBM bound (SURVEY.md §8d): 317 B per env step vs ~1e5-1e6 dependent flops",
                          "compute": compute, "profile": prof_note},
             "solver_cap_hits": cap_hits, "finite": finite, "lib_sha256": lib_sha, "src_sha256": _lib.load().jb_source_sha256().decode(), "kernel_variant": used_variant[0], "dist_notes": dist_notes,
-            "data_path_collective": (None if dist is None else (use_gather or False)), "degraded": degraded,
+            "data_path_collective": (None if dist is None else (use_gather or False)), "degraded": degraded, "actions_from": (None if dist is None else args.actions_from),
         }
         if degraded:          # a multi-GPU line without the gather is NOT the multi-GPU result: no headline value, the shards' rate on the side, rc 3
             res["value_independent_shards"] = value

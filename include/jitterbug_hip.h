@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define JB_ABI_VERSION 4
+#define JB_ABI_VERSION 5
 
 #define JB_OK            0
 #define JB_E_INVALID    -1   /* bad argument */
@@ -106,6 +106,15 @@ int jb_destroy(jb_handle* h);
 /* host-buffer entry points (synchronous) */
 int jb_reset(jb_handle* h, const uint8_t* mask /*[N] nullable = all*/, float* obs_out /*[N,D] nullable*/);
 int jb_step(jb_handle* h, const float* action /*[N]*/, float* obs_out /*[N,D]*/, float* reward_out /*[N]*/, uint8_t* done_out /*[N]*/);
+/* The same step in two halves - the step_async / step_wait split of the VecEnv the reference trains against (stable-baselines
+ * SubprocVecEnv, reference benchmarks/benchmark.py:146-171: the workers step while the caller goes on).  jb_step_async copies the actions
+ * into pinned staging owned by the handle and queues H2D copy -> step kernel -> D2H copies of obs / reward / done into pinned buffers ->
+ * an event on the handle's stream, and returns at once; jb_step_wait waits for that event and copies the results into the caller's buffers
+ * (each nullable).  jb_step_views hands out the pinned result buffers themselves (valid until the next jb_step_async): a caller that
+ * reads them in place needs no copy at all.  Exactly one jb_step_wait per jb_step_async; results are bit-identical to jb_step's. */
+int jb_step_async(jb_handle* h, const float* action /*[N]*/);
+int jb_step_wait(jb_handle* h, float* obs_out /*[N,D] nullable*/, float* reward_out /*[N] nullable*/, uint8_t* done_out /*[N] nullable*/);
+int jb_step_views(jb_handle* h, const float** obs /*[N,D]*/, const float** reward /*[N]*/, const uint8_t** done /*[N]*/);
 int jb_observe(jb_handle* h, float* obs_out /*[N,D]*/, float* reward_out /*[N] nullable*/);
 int jb_get_state(jb_handle* h, double* qpos /*[N,16]*/, double* qvel /*[N,15]*/, double* target /*[N,3]*/);
 int jb_set_state(jb_handle* h, const double* qpos, const double* qvel, const double* target);   /* any may be NULL = keep */
@@ -194,13 +203,16 @@ int jb_step_many_device(jb_handle* h, int32_t n_steps, const float* d_actions, f
 /* host-buffer form (synchronous): actions [K, N] or NULL = in-kernel policy, rows_out [K, N, D+2] nullable; the device staging belongs to the
  * handle and only grows (no allocation from the second call of a size on) */
 int jb_step_many(jb_handle* h, int32_t n_steps, const float* actions, float* rows_out);
+/* frees the device staging jb_step_many / jb_rollout_policy have grown (K x N x (D+2) floats: 4-5 GB after one rollout(1000) of 65 536 envs);
+ * the next call of either allocates what it needs again */
+int jb_release_staging(jb_handle* h);
 /* seconds each wave of the LAST step launch was alive (one wave = jb_envs_per_wave envs), out[0 .. min(n_waves, max_waves)); returns the
  * number of waves.  Mean against maximum is the load imbalance of the launch (roofline). */
 int jb_wave_clocks(jb_handle* h, double* out, int32_t max_waves);
 /* Rows between GPUs without Python: one RCCL communicator per handle, RCCL bound at run time (dlopen: no link-time
  * dependency; a process that already holds an RCCL, e.g. PyTorch-ROCm's, keeps that one).  Rank 0 makes the id, the host distributes
  * its JB_COMM_ID_BYTES to every rank by its own means, every rank calls jb_comm_init (collective).  jb_gather_rows_device sends this
- * rank's packed rows [N_local, D+2] (what jb_step_rows_device wrote; N_local equal on every rank) to rank 0, which receives
+ * rank's packed rows [N_local, D+2] (what jb_step_rows_device wrote; N_local equal on every rank, or jb_comm_set_shards) to rank 0, which receives
  * [n_ranks, N_local, D+2] - grouped ncclSend / ncclRecv: on 8 MI355X seven concurrent single-hop xGMI transfers, no ring.  It is
  * asynchronous on `stream` (use_stream = 1) or on the handle's stream; issue it from a side stream one step late, like
  * jitterbug_amd.distributed.ShardedJitterbugEnv does, so that it overlaps the next step kernel instead of delaying it. */
@@ -208,7 +220,20 @@ int jb_wave_clocks(jb_handle* h, double* out, int32_t max_waves);
 int jb_comm_unique_id(void* id_out /*[JB_COMM_ID_BYTES]*/);
 int jb_comm_init(jb_handle* h, int32_t n_ranks, int32_t rank, const void* id);
 int jb_comm_destroy(jb_handle* h);
-int jb_gather_rows_device(jb_handle* h, const float* d_rows, float* d_all /*rank 0: [n_ranks, N_local, D+2]; others: NULL*/, void* stream, int32_t use_stream);
+/* Uneven shards (ABI 5): the number of envs EVERY rank holds, the same list on every rank (the host knows the partition: contiguous ranges
+ * of a global batch).  The exchanges below then move blocks of the LONGEST shard - rows buffers are [n_max, D+2], rank 0 receives
+ * [n_ranks, n_max, D+2] and reads shard r's first shard_envs[r] rows; action blocks are [n_max] - so that every rank posts transfers of the
+ * same size whatever its own shard.  JB_E_INVALID when shard_envs[rank] is not this handle's n_envs: a partition the ranks do not agree
+ * on is refused HERE, on the host, instead of hanging RCCL in the first exchange.  Without this call every rank must hold the same number
+ * of envs (ABI 4's contract). */
+int jb_comm_set_shards(jb_handle* h, const int32_t* shard_envs /*[n_ranks]*/);
+int jb_gather_rows_device(jb_handle* h, const float* d_rows /*[n_max, D+2]*/, float* d_all /*rank 0: [n_ranks, n_max, D+2]; others: NULL*/, void* stream, int32_t use_stream);
+/* The action half of the per-step round trip (SURVEY.md 8e "actions flow the other way as a scatter of [N_local] fp32"; the reference sends
+ * every worker its actions every step, benchmarks/benchmark.py:161-171 SubprocVecEnv.step_async): rank 0 holds the actions of every shard,
+ * d_all [n_ranks, count] (shard r's block at r * count), and every rank receives its block into d_local [count] - grouped ncclSend x n_ranks
+ * on rank 0, one ncclRecv everywhere: seven concurrent single-hop xGMI transfers on 8 MI355X.  count must be the same on every rank (n_max
+ * with uneven shards); asynchronous on `stream` (use_stream = 1) or on the handle's stream. */
+int jb_scatter_actions_device(jb_handle* h, const float* d_all /*rank 0: [n_ranks, count]; others: NULL*/, float* d_local /*[count]*/, int64_t count, void* stream, int32_t use_stream);
 /* the same exchange for `count` floats per rank (equal on every rank): the [K, N_local, D+2] block a fused K-step rollout returns (jb_step_many_device) */
 int jb_gather_block_device(jb_handle* h, const float* d_src, float* d_all /*rank 0: [n_ranks, count]; others: NULL*/, int64_t count, void* stream, int32_t use_stream);
 

@@ -22,7 +22,10 @@ SOURCES = ["jb_api.hip"]
 SRC_EXT = (".hip", ".hpp", ".h")
 # -fno-slp-vectorize: the SLP vectoriser turns the small fixed-size linear algebra into v_pk_fma_f32 fed by hundreds of
 # register-shuffling v_mov (a third of the contact loop); scalar v_fma code is ~10 % shorter and has no such moves.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-fno-slp-vectorize", "-Wno-unused-value"]
+# -mllvm -disable-vector-combine: the packed-fp32 pairs of jb_lane.hpp's Pk2 are built from scalars that come out of small arrays (the
+# preloaded constants); VectorCombine widens such a scalar load into a 2-wide load of TWO NEIGHBOURING array elements and overwrites one of
+# them, overlapping loads that keep the array on the stack (72 scratch operations in the substep loop).  The pass has nothing else to do here.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-fno-slp-vectorize", "-mllvm", "-disable-vector-combine", "-Wno-unused-value"]
 _TAG = b"JB_SRC_SHA256="
 
 

@@ -714,6 +714,11 @@ struct jb_handle {
     JbNominalSpec* d_spec;           // nominal (uncompiled) model for the randomiser
     void* comm;                      // RCCL communicator (jb_comm_init), null until asked for
     int comm_ranks, comm_rank;
+    int comm_nmax;                   // envs of the longest shard (jb_comm_set_shards); 0: every rank holds cfg.n_envs
+    // jb_step_async / jb_step_wait: pinned host staging (allocated at the first jb_step_async) and the event behind the D2H copies
+    float *p_action, *p_obs, *p_reward; unsigned char* p_done;
+    hipEvent_t async_done;
+    bool async_pending;
     float* d_terms;
     float* d_enc_params; float* d_code;
 };
@@ -1008,9 +1013,12 @@ int jb_destroy(jb_handle* h) {
     jb::DeviceGuard<HipDeviceApi> guard;
     guard.enter(h->cfg.device_id);
     if (h->stream || !h->own_stream) hipStreamSynchronize(h->stream);
-    if (h->comm && g_rccl.CommDestroy) { g_rccl.CommDestroy(h->comm); h->comm = nullptr; }
+    if (h->comm && g_rccl.CommDestroy) { hipDeviceSynchronize(); g_rccl.CommDestroy(h->comm); h->comm = nullptr; }      // (device-wide: exchanges may be queued on streams of the caller's)
     void* bufs[] = {h->d_tape, h->d_rows_stage, h->d_rew_stage, h->d_capture, h->d_capture_count, h->d_resolve, h->d_wave_order, h->d_wave_clock, h->d_ovc, h->d_terms, h->d_spec, h->d_root, h->d_leg, h->d_model, h->d_step, h->d_episode, h->d_action, h->d_obs, h->d_reward, h->d_done, h->d_mask, h->d_qpos, h->d_qvel, h->d_target, h->d_wave_stats, h->d_enc_params, h->d_code};
     for (void* b : bufs) if (b) hipFree(b);
+    void* pinned[] = {h->p_action, h->p_obs, h->p_reward, h->p_done};
+    for (void* b : pinned) if (b) hipHostFree(b);
+    if (h->async_done) hipEventDestroy(h->async_done);
     if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
     delete h;
     return JB_OK;
@@ -1152,6 +1160,10 @@ static int launch_step(jb_handle* h, StepIO io, int packed_rows) {
 #define JB_LAUNCH_STEP(E) hipLaunchKernelGGL(jb_step_kernel<E>, grid, dim3(64), lds_bytes_x, h->stream, h->ka, io)
 #define JB_LAUNCH_LEAN(E) hipLaunchKernelGGL(jb_step_kernel_lean<E>, grid, dim3(64), lds_bytes_x, h->stream, h->ka, io)
 #define JB_LAUNCH_PAIR(E) hipLaunchKernelGGL(jb_step_kernel_pair<E>, grid, dim3(64), lds_bytes_x, h->stream, h->ka, io)
+#ifdef JB_DEV_ONLY4      // development builds: the one instantiation the headline runs (a fifth of the compile time)
+    if (variant != JB_VARIANT_ORDINARY || h->ka.epw != 4) return fail(JB_E_INVALID, "JB_DEV_ONLY4 build: only the ordinary kernel at 4 envs per wave");
+    JB_LAUNCH_STEP(4);
+#else
     if (lean_pair) {
         hipLaunchKernelGGL(jb_step_kernel_lean_pair<4>, grid, dim3(64), lds_bytes_x, h->stream, h->ka, io);
     } else if (variant == JB_VARIANT_PAIR) {
@@ -1175,6 +1187,7 @@ static int launch_step(jb_handle* h, StepIO io, int packed_rows) {
         default: JB_LAUNCH_STEP(8); break;
         }
     }
+#endif
 #undef JB_LAUNCH_STEP
 #undef JB_LAUNCH_LEAN
 #undef JB_LAUNCH_PAIR
@@ -1247,6 +1260,14 @@ int jb_step_many(jb_handle* h, int32_t n_steps, const float* actions, float* row
     if (!rc && e != hipSuccess) rc = fail(JB_E_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(e));
     return rc;
 }
+int jb_release_staging(jb_handle* h) {
+    JB_ENTER(h);
+    JB_HIP(hipStreamSynchronize(h->stream));
+    float** bufs[] = {&h->d_tape, &h->d_rows_stage, &h->d_rew_stage};
+    size_t* caps[] = {&h->tape_cap, &h->rows_cap, &h->rew_cap};
+    for (int i = 0; i < 3; i++) { if (*bufs[i]) hipFree(*bufs[i]); *bufs[i] = nullptr; *caps[i] = 0; }
+    return JB_OK;
+}
 // how long each wave of the last step launch lived, in seconds (s_memrealtime, 100 MHz): out[0 .. n_waves); returns the number of waves
 int jb_wave_clocks(jb_handle* h, double* out, int32_t max_waves) {
     if (!h || !out) return fail(JB_E_INVALID, "handle/out is NULL");
@@ -1268,6 +1289,7 @@ int jb_observe_device(jb_handle* h, float* d_obs_out, float* d_reward_out) {
 
 int jb_reset(jb_handle* h, const uint8_t* mask, float* obs_out) {
     JB_ENTER(h);
+    if (h->async_pending) return fail(JB_E_INVALID, "jb_reset: a jb_step_async is pending (jb_step_wait first)");
     const size_t N = (size_t)h->cfg.n_envs;
     if (mask) JB_HIP(hipMemcpyAsync(h->d_mask, mask, N, hipMemcpyHostToDevice, h->stream));
     int rc = jb_reset_device(h, mask ? h->d_mask : nullptr, obs_out ? h->d_obs : nullptr);
@@ -1279,6 +1301,7 @@ int jb_reset(jb_handle* h, const uint8_t* mask, float* obs_out) {
 int jb_step(jb_handle* h, const float* action, float* obs_out, float* reward_out, uint8_t* done_out) {
     if (!h || !action) return fail(JB_E_INVALID, "handle/action is NULL");
     JB_ENTER(h);
+    if (h->async_pending) return fail(JB_E_INVALID, "jb_step: a jb_step_async is pending (jb_step_wait first)");
     RoctxRange range("jb_step_host_buffers");
     const size_t N = (size_t)h->cfg.n_envs;
     JB_HIP(hipMemcpyAsync(h->d_action, action, sizeof(float) * N, hipMemcpyHostToDevice, h->stream));
@@ -1288,6 +1311,52 @@ int jb_step(jb_handle* h, const float* action, float* obs_out, float* reward_out
     if (reward_out) JB_HIP(hipMemcpyAsync(reward_out, h->d_reward, sizeof(float) * N, hipMemcpyDeviceToHost, h->stream));
     if (done_out) JB_HIP(hipMemcpyAsync(done_out, h->d_done, N, hipMemcpyDeviceToHost, h->stream));
     JB_HIP(hipStreamSynchronize(h->stream));
+    return JB_OK;
+}
+// jb_step in two halves (header: the VecEnv's step_async / step_wait).  Pinned staging: a copy from or to pageable memory would make
+// hipMemcpyAsync wait for the stream; with pinned buffers the call returns as soon as the four operations are queued.
+int jb_step_async(jb_handle* h, const float* action) {
+    if (!h || !action) return fail(JB_E_INVALID, "handle/action is NULL");
+    JB_ENTER(h);
+    if (h->async_pending) return fail(JB_E_INVALID, "jb_step_async: the previous step has not been waited for (jb_step_wait)");
+    const size_t N = (size_t)h->cfg.n_envs;
+    if (!h->p_action) {
+        JB_HIP(hipHostMalloc((void**)&h->p_action, sizeof(float) * N, hipHostMallocDefault));
+        JB_HIP(hipHostMalloc((void**)&h->p_obs, sizeof(float) * N * h->D, hipHostMallocDefault));
+        JB_HIP(hipHostMalloc((void**)&h->p_reward, sizeof(float) * N, hipHostMallocDefault));
+        JB_HIP(hipHostMalloc((void**)&h->p_done, N, hipHostMallocDefault));
+        JB_HIP(hipEventCreateWithFlags(&h->async_done, hipEventDisableTiming));
+    }
+    RoctxRange range("jb_step_async");
+    std::memcpy(h->p_action, action, sizeof(float) * N);
+    JB_HIP(hipMemcpyAsync(h->d_action, h->p_action, sizeof(float) * N, hipMemcpyHostToDevice, h->stream));
+    int rc = jb_step_device(h, h->d_action, h->d_obs, h->d_reward, h->d_done);
+    if (rc) return rc;
+    JB_HIP(hipMemcpyAsync(h->p_obs, h->d_obs, sizeof(float) * N * h->D, hipMemcpyDeviceToHost, h->stream));
+    JB_HIP(hipMemcpyAsync(h->p_reward, h->d_reward, sizeof(float) * N, hipMemcpyDeviceToHost, h->stream));
+    JB_HIP(hipMemcpyAsync(h->p_done, h->d_done, N, hipMemcpyDeviceToHost, h->stream));
+    JB_HIP(hipEventRecord(h->async_done, h->stream));
+    h->async_pending = true;
+    return JB_OK;
+}
+int jb_step_wait(jb_handle* h, float* obs_out, float* reward_out, uint8_t* done_out) {
+    if (!h) return fail(JB_E_INVALID, "handle is NULL");
+    if (!h->async_pending) return fail(JB_E_INVALID, "jb_step_wait: no jb_step_async is pending");
+    JB_ENTER(h);
+    h->async_pending = false;          // (whatever happens below, the pairing async -> wait is used up)
+    JB_HIP(hipEventSynchronize(h->async_done));
+    const size_t N = (size_t)h->cfg.n_envs;
+    if (obs_out) std::memcpy(obs_out, h->p_obs, sizeof(float) * N * h->D);
+    if (reward_out) std::memcpy(reward_out, h->p_reward, sizeof(float) * N);
+    if (done_out) std::memcpy(done_out, h->p_done, N);
+    return JB_OK;
+}
+int jb_step_views(jb_handle* h, const float** obs, const float** reward, const uint8_t** done) {
+    if (!h) return fail(JB_E_INVALID, "handle is NULL");
+    if (!h->p_action) return fail(JB_E_INVALID, "jb_step_views: no jb_step_async yet (the pinned buffers come into being with the first one)");
+    if (obs) *obs = h->p_obs;
+    if (reward) *reward = h->p_reward;
+    if (done) *done = h->p_done;
     return JB_OK;
 }
 int jb_observe(jb_handle* h, float* obs_out, float* reward_out) {
@@ -1556,12 +1625,27 @@ int jb_comm_init(jb_handle* h, int32_t n_ranks, int32_t rank, const void* id) {
     RcclApi::IdBlob blob;
     std::memcpy(blob.b, id, sizeof blob.b);
     JB_NCCL(g_rccl.CommInitRank(&h->comm, n_ranks, blob, rank));
-    h->comm_ranks = n_ranks; h->comm_rank = rank;
+    h->comm_ranks = n_ranks; h->comm_rank = rank; h->comm_nmax = 0;
+    return JB_OK;
+}
+int jb_comm_set_shards(jb_handle* h, const int32_t* shard_envs) {
+    if (!h || !shard_envs) return fail(JB_E_INVALID, "handle/shard_envs is NULL");
+    if (!h->comm) return fail(JB_E_INVALID, "no communicator (jb_comm_init)");
+    int nmax = 0;
+    for (int r = 0; r < h->comm_ranks; r++) {
+        if (shard_envs[r] < 1) return fail(JB_E_INVALID, "shard_envs[" + std::to_string(r) + "] < 1");
+        nmax = shard_envs[r] > nmax ? shard_envs[r] : nmax;
+    }
+    if (shard_envs[h->comm_rank] != h->cfg.n_envs)
+        return fail(JB_E_INVALID, "shard_envs[" + std::to_string(h->comm_rank) + "] = " + std::to_string(shard_envs[h->comm_rank]) + " but this handle steps " + std::to_string(h->cfg.n_envs) +
+                                  " envs: the ranks do not agree on the partition");
+    h->comm_nmax = nmax;
     return JB_OK;
 }
 int jb_comm_destroy(jb_handle* h) {
     if (!h) return fail(JB_E_INVALID, "handle is NULL");
-    if (h->comm) { JB_ENTER(h); hipStreamSynchronize(h->stream); JB_NCCL(g_rccl.CommDestroy(h->comm)); h->comm = nullptr; }
+    // the exchanges run on streams of the caller's choosing (ShardedJitterbugEnv: a side stream): wait for the whole device, not just the handle's stream
+    if (h->comm) { JB_ENTER(h); hipDeviceSynchronize(); JB_NCCL(g_rccl.CommDestroy(h->comm)); h->comm = nullptr; h->comm_nmax = 0; }
     return JB_OK;
 }
 // the same exchange for a block of `count` floats per rank (equal on every rank): what a fused K-step rollout returns, [K, N_local, D+2]
@@ -1588,7 +1672,8 @@ int jb_gather_rows_device(jb_handle* h, const float* d_rows, float* d_all, void*
     JB_ENTER(h);
     RoctxRange range("jb_gather_rows");
     hipStream_t st = use_stream ? (hipStream_t)stream : h->stream;
-    const size_t count = (size_t)h->cfg.n_envs * (size_t)(h->D + 2);
+    // every rank posts blocks of the longest shard (jb_comm_set_shards; without it the shards are equal by contract)
+    const size_t count = (size_t)(h->comm_nmax > 0 ? h->comm_nmax : h->cfg.n_envs) * (size_t)(h->D + 2);
     JB_NCCL(g_rccl.GroupStart());
     int err = 0;              // a failed Send/Recv must not leave the RCCL group open: close it, then report the first error
     if (h->comm_rank == 0)
@@ -1596,6 +1681,24 @@ int jb_gather_rows_device(jb_handle* h, const float* d_rows, float* d_all, void*
     if (!err) err = g_rccl.Send(d_rows, count, 7 /*ncclFloat*/, 0, h->comm, st);
     const int end = g_rccl.GroupEnd();
     if (err || end) return fail(JB_E_HIP, std::string("RCCL row gather: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(err ? err : end) : "RCCL error"));
+    return JB_OK;
+}
+int jb_scatter_actions_device(jb_handle* h, const float* d_all, float* d_local, int64_t count, void* stream, int32_t use_stream) {
+    if (!h || !d_local || count < 1) return fail(JB_E_INVALID, "handle/local is NULL or count < 1");
+    if (!h->comm) return fail(JB_E_INVALID, "no communicator (jb_comm_init)");
+    if (h->comm_rank == 0 && !d_all) return fail(JB_E_INVALID, "rank 0 needs the send buffer [n_ranks, count]");
+    if (count < (int64_t)h->cfg.n_envs || (h->comm_nmax > 0 && count != (int64_t)h->comm_nmax))
+        return fail(JB_E_INVALID, "jb_scatter_actions_device: count must be the longest shard's envs (" + std::to_string(h->comm_nmax > 0 ? h->comm_nmax : h->cfg.n_envs) + "), the same on every rank");
+    JB_ENTER(h);
+    RoctxRange range("jb_scatter_actions");
+    hipStream_t st = use_stream ? (hipStream_t)stream : h->stream;
+    JB_NCCL(g_rccl.GroupStart());
+    int err = 0;              // (as in the gathers: the group is closed before an error is reported)
+    if (h->comm_rank == 0)
+        for (int r = 0; r < h->comm_ranks && !err; r++) err = g_rccl.Send(d_all + (size_t)r * (size_t)count, (size_t)count, 7 /*ncclFloat*/, r, h->comm, st);
+    if (!err) err = g_rccl.Recv(d_local, (size_t)count, 7 /*ncclFloat*/, 0, h->comm, st);
+    const int end = g_rccl.GroupEnd();
+    if (err || end) return fail(JB_E_HIP, std::string("RCCL action scatter: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(err ? err : end) : "RCCL error"));
     return JB_OK;
 }
 

@@ -15,6 +15,7 @@
 #pragma once
 #include <cmath>
 #include <cstdint>
+#include <type_traits>
 #if !defined(__HIPCC__)
 #include <atomic>
 #include <thread>
@@ -385,6 +386,45 @@ template <typename T> inline Quad<T> vmin(const Quad<T>& a, const Quad<T>& b) { 
 template <typename T> inline Quad<T> vmax(const Quad<T>& a, const Quad<T>& b) { Quad<T> r; for (int i = 0; i < 4; i++) r.v[i] = vmax(a.v[i], b.v[i]); return r; }
 template <typename T> struct lane_traits<Quad<T>> { using mask = Mask4; using uint = UQuad; using real = T; };
 #endif
+
+// ----------------------------------------------------------------------------- two values per lane: packed fp32
+// W = Pk2<V> holds TWO independent values of lane type V that go through the same arithmetic - the upper and the lower body of a leg in
+// phase A of jb_sim.hpp, the two tangential directions of a contact in phase B.  On the device (V = float) it is a 2-wide vector in an
+// aligned register pair and every + - * (and the multiply-adds the compiler fuses from them) is ONE v_pk_add_f32 / v_pk_mul_f32 /
+// v_pk_fma_f32: a lone wave issues those at the rate of their scalar forms (profiles/r03_pk_issue_microbench.txt), so a pair costs one
+// issue slot instead of two.  A value used for both halves (W(x, x)) needs no register of its own: the packed forms read either half of any
+// pair for either result (op_sel).  The halves never meet inside a packed operation - they are two IEEE operations side by side.
+// On the host (V = Quad<T>) it is a struct of two V: the fp64 harness runs the very same source.
+template <typename V> struct Pk2 {
+    V lo, hi;
+    Pk2() = default;
+    template <typename S, typename = typename std::enable_if<std::is_arithmetic<S>::value>::type>
+    JB_HD Pk2(S s) : lo(V((typename lane_traits<V>::real)s)), hi(V((typename lane_traits<V>::real)s)) {}
+    JB_HD Pk2(const V& a, const V& b) : lo(a), hi(b) {}
+};
+template <typename V> JB_HD Pk2<V> operator+(const Pk2<V>& a, const Pk2<V>& b) { return Pk2<V>(a.lo + b.lo, a.hi + b.hi); }
+template <typename V> JB_HD Pk2<V> operator-(const Pk2<V>& a, const Pk2<V>& b) { return Pk2<V>(a.lo - b.lo, a.hi - b.hi); }
+template <typename V> JB_HD Pk2<V> operator*(const Pk2<V>& a, const Pk2<V>& b) { return Pk2<V>(a.lo * b.lo, a.hi * b.hi); }
+template <typename V> JB_HD Pk2<V> operator-(const Pk2<V>& a) { return Pk2<V>(-a.lo, -a.hi); }
+template <typename V> JB_HD V pk_lo(const Pk2<V>& a) { return a.lo; }
+template <typename V> JB_HD V pk_hi(const Pk2<V>& a) { return a.hi; }
+#if defined(__HIPCC__)
+typedef float jb_f32x2 __attribute__((ext_vector_type(2)));
+template <> struct Pk2<float> {
+    jb_f32x2 v;
+    Pk2() = default;
+    JB_HD Pk2(float s) : v{s, s} {}
+    JB_HD Pk2(float a, float b) : v{a, b} {}          // (one build-vector: element-wise stores into the uninitialised member leave loads SROA cannot split)
+    JB_HD explicit Pk2(jb_f32x2 q) : v(q) {}
+};
+JB_HD Pk2<float> operator+(const Pk2<float>& a, const Pk2<float>& b) { return Pk2<float>(a.v + b.v); }
+JB_HD Pk2<float> operator-(const Pk2<float>& a, const Pk2<float>& b) { return Pk2<float>(a.v - b.v); }
+JB_HD Pk2<float> operator*(const Pk2<float>& a, const Pk2<float>& b) { return Pk2<float>(a.v * b.v); }
+JB_HD Pk2<float> operator-(const Pk2<float>& a) { return Pk2<float>(-a.v); }
+JB_HD float pk_lo(const Pk2<float>& a) { return a.v.x; }
+JB_HD float pk_hi(const Pk2<float>& a) { return a.v.y; }
+#endif
+template <typename V> struct lane_traits<Pk2<V>> { using mask = typename lane_traits<V>::mask; using uint = typename lane_traits<V>::uint; using real = typename lane_traits<V>::real; };
 
 // unsigned helpers
 JB_HD unsigned umulv(unsigned a, unsigned b) { return a * b; }

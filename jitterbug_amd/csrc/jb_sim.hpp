@@ -306,6 +306,44 @@ template <typename V> JB_HD Mat3<V> quat2mat(const V& w, const V& x, const V& y,
     return R;
 }
 
+// ---- two bodies per lane (jb_lane.hpp Pk2): pack two vectors / matrices into one of pairs, take the halves out again, use one for both halves.
+// On the device taking a half out is free (a pair IS two registers) and so is `both` (the packed instructions read either half of any pair).
+template <typename V> JB_HD Vec3<Pk2<V>> pk(const Vec3<V>& a, const Vec3<V>& b) { return v3<Pk2<V>>(Pk2<V>(a.x, b.x), Pk2<V>(a.y, b.y), Pk2<V>(a.z, b.z)); }
+template <typename V> JB_HD Vec3<Pk2<V>> both(const Vec3<V>& a) { return pk(a, a); }
+template <typename V> JB_HD Vec3<V> lo(const Vec3<Pk2<V>>& w) { return v3<V>(pk_lo(w.x), pk_lo(w.y), pk_lo(w.z)); }
+template <typename V> JB_HD Vec3<V> hi(const Vec3<Pk2<V>>& w) { return v3<V>(pk_hi(w.x), pk_hi(w.y), pk_hi(w.z)); }
+template <typename V> JB_HD Mat3<Pk2<V>> pk(const Mat3<V>& a, const Mat3<V>& b) {
+    Mat3<Pk2<V>> r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.m[i] = Pk2<V>(a.m[i], b.m[i]);
+    return r;
+}
+template <typename V> JB_HD Mat3<Pk2<V>> both(const Mat3<V>& a) { return pk(a, a); }
+template <typename V> JB_HD Mat3<V> lo(const Mat3<Pk2<V>>& w) {
+    Mat3<V> r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.m[i] = pk_lo(w.m[i]);
+    return r;
+}
+template <typename V> JB_HD Mat3<V> hi(const Mat3<Pk2<V>>& w) {
+    Mat3<V> r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.m[i] = pk_hi(w.m[i]);
+    return r;
+}
+template <typename V> JB_HD Sym3<Pk2<V>> pk(const Sym3<V>& a, const Sym3<V>& b) {
+    Sym3<Pk2<V>> s;
+    s.xx = Pk2<V>(a.xx, b.xx); s.yy = Pk2<V>(a.yy, b.yy); s.zz = Pk2<V>(a.zz, b.zz); s.xy = Pk2<V>(a.xy, b.xy); s.xz = Pk2<V>(a.xz, b.xz); s.yz = Pk2<V>(a.yz, b.yz);
+    return s;
+}
+template <typename V> JB_HD Sym3<V> lo(const Sym3<Pk2<V>>& w) { Sym3<V> s; s.xx = pk_lo(w.xx); s.yy = pk_lo(w.yy); s.zz = pk_lo(w.zz); s.xy = pk_lo(w.xy); s.xz = pk_lo(w.xz); s.yz = pk_lo(w.yz); return s; }
+template <typename V> JB_HD Sym3<V> hi(const Sym3<Pk2<V>>& w) { Sym3<V> s; s.xx = pk_hi(w.xx); s.yy = pk_hi(w.yy); s.zz = pk_hi(w.zz); s.xy = pk_hi(w.xy); s.xz = pk_hi(w.xz); s.yz = pk_hi(w.yz); return s; }
+// centripetal term  w x (w x r) = w (w.r) - r |w|^2  (9 flops + a shared |w|^2 instead of two cross products)
+template <typename V> JB_HD Vec3<V> wxwx(const Vec3<V>& ww, const V& ww2, const Vec3<V>& r) {
+    V d = dot(ww, r);
+    return v3<V>(ww.x * d - r.x * ww2, ww.y * d - r.y * ww2, ww.z * d - r.z * ww2);
+}
+
 // ----------------------------------------------------------------------------- lane state
 template <typename V> struct LaneState {
     // replicated in the 4 lanes of a quad
@@ -2131,23 +2169,31 @@ JB_HD bool substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
         Vec3<V> u = mulT(R, v3<V>(s.vx, s.vy, s.vz));
         Vec3<V> AO = -mulT(R, ldv3(m, LM_GRAV));                    // fictitious root acceleration = -g (root coords)
 
-        // ---- own leg kinematics
+        // ---- own leg kinematics.  The upper and the lower body of a leg go through the same formulas on different data: from here to the end of
+        // phase A they travel as PAIRS (W: lo = shoulder / upper leg, hi = knee / lower leg), one packed instruction for the two of them.
+        using W = Pk2<V>;
         Vec3<V> a1 = ldv3(m, LM_A1), e1 = ldv3(m, LM_E1);
         V s1, c1, s2, c2;
-        sincos_small(s.th1, s1, c1);
-        sincos_small(s.th2, s2, c2);
+        {
+            W sn, cs;
+            sincos_small(W(s.th1, s.th2), sn, cs);
+            s1 = pk_lo(sn); s2 = pk_hi(sn); c1 = pk_lo(cs); c2 = pk_hi(cs);
+        }
         if (any_lane(mand(lane_ok, mor(gt(vabs(s.th1), V(0.9)), gt(vabs(s.th2), V(0.9)))))) { s1 = vsin(s.th1); c1 = vcos(s.th1); s2 = vsin(s.th2); c2 = vcos(s.th2); }
         V sp, cp;
         vsincos_pi(s.phi, sp, cp);
         if (o.aux) { s1 = sel(ax_motor, sp, s1); c1 = sel(ax_motor, cp, c1); }      // the motor's angle is wrapped to [-pi, pi): its own sine / cosine routine
-        Mat3<V> R1 = rodrigues(e1, s1, c1);
-        Mat3<V> R12 = mul(R1, rodrigues(ldv3(m, LM_E2), s2, c2));
-        Vec3<V> a2 = a1 + mul(R1, ldv3(m, LM_DA2));
-        Vec3<V> e2 = mul(R1, ldv3(m, LM_E2));
-        Vec3<V> cc1 = a1 + mul(R1, ldv3(m, LM_DC1));
-        Vec3<V> cc2 = a2 + mul(R12, ldv3(m, LM_DC2));
-        Sym3<V> I1 = rotate(R1, ldsym(m, LM_I1));
-        Sym3<V> I2 = rotate(R12, ldsym(m, LM_I2));
+        const Mat3<W> Rj = rodrigues(pk(e1, ldv3(m, LM_E2)), W(s1, s2), W(c1, c2));      // the two hinge rotations
+        const Mat3<V> R1 = lo(Rj);
+        const Mat3<V> R12 = mul(R1, hi(Rj));
+        const Mat3<W> RR = pk(R1, R12);                                      // body rotations: (upper, lower)
+        const Vec3<W> t_ae = mul(both(R1), pk(ldv3(m, LM_DA2), ldv3(m, LM_E2)));       // (knee anchor - a1, knee axis)
+        Vec3<V> a2 = a1 + lo(t_ae);
+        Vec3<V> e2 = hi(t_ae);
+        const Vec3<W> aw = pk(a1, a2), ew = pk(e1, e2);                      // hinge anchors and axes of the two bodies
+        const Vec3<W> ccw = aw + mul(RR, pk(ldv3(m, LM_DC1), ldv3(m, LM_DC2)));        // centres of mass
+        const Vec3<V> cc2 = hi(ccw);
+        const Sym3<W> Iw = rotate(RR, pk(ldsym(m, LM_I1), ldsym(m, LM_I2)));           // inertias about the centres of mass, root axes
         const V m1 = m.c[LM_M1], m2 = m.c[LM_M2];
 
         // ---- motor body kinematics (replicated in every lane - unless the aux lanes have the motor body: SimOpts::aux)
@@ -2168,22 +2214,26 @@ JB_HD bool substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
         //      kinematic quantities are still live)
         if (o.contacts) {
             U own = zero_u<V>();            // the leg slots in which this lane's leg has a contact
-            Vec3<V> foot = a2 + mul(R12, ldv3(m, LM_DFOOT));
+            const Vec3<W> t_fl = both(a2) + mul(both(R12), pk(ldv3(m, LM_DFOOT), ldv3(m, LM_LC_D)));      // (foot centre, lower cylinder's centre)
+            const Vec3<W> t_ax = mul(both(R12), pk(ldv3(m, LM_LC_AX), ldv3(m, LM_LC_XA)));               // (the cylinder's axis, its x axis)
+            Vec3<V> foot = lo(t_fl);
             V fdist = (s.pz + dot(foot, nb) - m.c[LM_FOOT_R]) + s.pz_lo;
             MK fon = mand(lane_ok, lt(fdist, V(0)));
             live_slots |= cand_store(sc, live_slots, 0, foot - nb * (m.c[LM_FOOT_R] + fdist * V(0.5)), fdist, fon, &own);
             CylContacts<V> lc;
             MK all_on = lane_ok;
-            cylinder_floor(a2 + mul(R12, ldv3(m, LM_LC_D)), mul(R12, ldv3(m, LM_LC_AX)), mul(R12, ldv3(m, LM_LC_XA)), m.c[LM_LC_R], m.c[LM_LC_H], nb, s.pz, s.pz_lo, all_on, lc);
+            cylinder_floor(hi(t_fl), lo(t_ax), hi(t_ax), m.c[LM_LC_R], m.c[LM_LC_H], nb, s.pz, s.pz_lo, all_on, lc);
             live_slots |= cand_store_cyl(sc, live_slots, 1, lc, all_on, &own);
             MK any_con = mor(fon, lc.on[0]);
             if (xtra) {
                 // every remaining geom of the model against the floor
                 CylContacts<V> cy;
-                cylinder_floor(a1 + mul(R1, ldc3(m, LM_UC_D)), mul(R1, ldc3(m, LM_UC_AX)), mul(R1, ldc3(m, LM_UC_XA)), ldc(m, LM_UC_R), ldc(m, LM_UC_H), nb, s.pz, s.pz_lo, all_on, cy);
+                const Vec3<W> t_ut = both(a1) + mul(both(R1), pk(ldc3(m, LM_UC_D), ldc3(m, LM_DTIP)));          // (upper cylinder's centre, knee tip)
+                const Vec3<W> t_ux = mul(both(R1), pk(ldc3(m, LM_UC_AX), ldc3(m, LM_UC_XA)));
+                cylinder_floor(lo(t_ut), lo(t_ux), hi(t_ux), ldc(m, LM_UC_R), ldc(m, LM_UC_H), nb, s.pz, s.pz_lo, all_on, cy);
                 live_slots |= cand_store_cyl(sc, live_slots, 5, cy, all_on, &own);
                 any_con = mor(any_con, cy.on[0]);
-                Vec3<V> tip = a1 + mul(R1, ldc3(m, LM_DTIP));
+                Vec3<V> tip = hi(t_ut);
                 V tipd = (s.pz + dot(tip, nb) - ldc(m, LM_TIP_R)) + s.pz_lo;
                 live_slots |= cand_store(sc, live_slots, 9, tip - nb * (ldc(m, LM_TIP_R) + tipd * V(0.5)), tipd, mand(lane_ok, lt(tipd, V(0))), &own);
                 any_con = mor(any_con, mand(lane_ok, lt(tipd, V(0))));
@@ -2255,7 +2305,8 @@ JB_HD bool substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
               }
             }
             if (PAIR) {
-                const Vec3<V> uc = a1 + mul(R1, ldc3(m, LM_UC_D)), ua = mul(R1, ldc3(m, LM_UC_AX));
+                const Vec3<W> t_uc = mul(both(R1), pk(ldc3(m, LM_UC_D), ldc3(m, LM_UC_AX)));
+                const Vec3<V> uc = a1 + lo(t_uc), ua = hi(t_uc);
                 const V uh = ldc(m, LM_UC_H);
                 const Vec3<V> isv = ldc3(m, LM_PE_IS);
                 // The thread pair first (slot 28: its values are dead before the mass pair's narrow phase, the register peak of this block): the motor-axis
@@ -2367,19 +2418,25 @@ JB_HD bool substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
         JB_SCHED_FENCE();
 
         // ---- composite rigid bodies -> star system of M (into the scratch)
-        Vec3<V> h2 = cc2 * m2, h1 = cc1 * m1;
-        Sym3<V> J2 = about_origin(I2, m2, cc2);
-        Sym3<V> J12 = about_origin(I1, m1, cc1) + J2;
-        Vec3<V> h12 = h1 + h2;
-        V m12 = m1 + m2;
-        Vec3<V> sK = cross(a2, e2), sS = cross(a1, e1);          // linear part of the joint motion vectors
-        Vec3<V> fK = sK * m2 + cross(e2, h2), nK = mul(J2, e2) + cross(h2, sK);
-        Vec3<V> fS = sS * m12 + cross(e1, h12), nS = mul(J12, e1) + cross(h12, sS);
+        const W mw = W(m1, m2);
+        const Vec3<W> hw = ccw * mw;                                  // first moments (upper, lower)
+        const Sym3<W> Jo = about_origin(Iw, mw, ccw);                 // inertias about the root origin (upper, lower)
+        const Sym3<V> J2 = hi(Jo);
+        const Sym3<V> J12 = lo(Jo) + J2;
+        const Vec3<V> h2 = hi(hw), h12 = lo(hw) + h2;
+        const V m12 = m1 + m2;
+        // the joint motion vectors and what each hinge moves: the shoulder both bodies (m12, h12, J12), the knee the lower one
+        const Vec3<W> sw = cross(aw, ew);                             // linear part of the joint motion vectors (shoulder, knee)
+        const Vec3<W> hcw = pk(h12, h2);
+        const Vec3<W> fw = sw * W(m12, m2) + cross(ew, hcw), nw = mul(pk(J12, J2), ew) + cross(hcw, sw);
+        const Vec3<V> fS = lo(fw), fK = hi(fw), nS = lo(nw), nK = hi(nw);
         sys.B[0][0] = nS.x; sys.B[1][0] = nS.y; sys.B[2][0] = nS.z; sys.B[3][0] = fS.x; sys.B[4][0] = fS.y; sys.B[5][0] = fS.z;
         sys.B[0][1] = nK.x; sys.B[1][1] = nK.y; sys.B[2][1] = nK.z; sys.B[3][1] = fK.x; sys.B[4][1] = fK.y; sys.B[5][1] = fK.z;
-        sys.C[0] = dot(e1, nS) + dot(sS, fS);
-        sys.C[1] = dot(e1, nK) + dot(sS, fK);
-        sys.C[2] = dot(e2, nK) + dot(sK, fK);
+        {
+            const W cd = dot(ew, nw) + dot(sw, fw);
+            sys.C[0] = pk_lo(cd); sys.C[2] = pk_hi(cd);
+            sys.C[1] = dot(e1, nK) + dot(lo(sw), fK);
+        }
         // the legs' sums over the quad; in the aux quads the same instructions sum the motor body and the root body's own mass
         const Vec3<V> h12q = qsum(h12);
         const Sym3<V> J12q = qsum(J12);
@@ -2421,29 +2478,29 @@ JB_HD bool substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
 
         // ---- bias forces (Newton-Euler with qacc = 0 in MuJoCo coordinates) and applied forces
         {
-            // centripetal term  w x (w x r) = w (w.r) - r |w|^2  (9 flops + a shared |w|^2 instead of two cross products)
-            auto wxwx = [](const Vec3<V>& ww, const V& ww2, const Vec3<V>& r) { V d = dot(ww, r); return v3<V>(ww.x * d - r.x * ww2, ww.y * d - r.y * ww2, ww.z * d - r.z * ww2); };
             const V w_2 = dot(w, w);
             auto accel_at = [&](const Vec3<V>& x) { return AO + wxwx(w, w_2, x); };
-            // own leg
-            Vec3<V> Aa1 = accel_at(a1);
-            Vec3<V> w1 = w + e1 * s.thd1;
-            Vec3<V> al1 = cross(w, e1) * s.thd1;
-            Vec3<V> r1 = cc1 - a1;
-            const V w1_2 = dot(w1, w1);
-            Vec3<V> F1 = (Aa1 + cross(al1, r1) + wxwx(w1, w1_2, r1)) * m1;
-            Vec3<V> N1 = mul(I1, al1) + cross(w1, mul(I1, w1));
-            Vec3<V> r12 = a2 - a1;
-            Vec3<V> Aa2 = Aa1 + cross(al1, r12) + wxwx(w1, w1_2, r12);
-            Vec3<V> w2 = w1 + e2 * s.thd2;
-            Vec3<V> al2 = al1 + cross(w1, e2) * s.thd2;
-            Vec3<V> r2 = cc2 - a2;
-            Vec3<V> F2 = (Aa2 + cross(al2, r2) + wxwx(w2, dot(w2, w2), r2)) * m2;
-            Vec3<V> N2 = mul(I2, al2) + cross(w2, mul(I2, w2));
-            V cK = dot(e2, N2 + cross(r2, F2));
-            V cS = dot(e1, N1 + cross(r1, F1) + N2 + cross(cc2 - a1, F2));
-            Vec3<V> legF = F1 + F2;
-            Vec3<V> legN = N1 + cross(cc1, F1) + N2 + cross(cc2, F2);
+            // own leg.  Angular velocities, angular accelerations and the hinge anchors' linear accelerations are a short chain (the lower body
+            // rides on the upper one); forces and moments of the two bodies are then the same formulas on pairs.
+            const Vec3<V> Aa1 = accel_at(a1);
+            const Vec3<V> w1 = w + e1 * s.thd1, w2 = w1 + e2 * s.thd2;
+            const Vec3<W> www = pk(w1, w2);
+            const Vec3<W> dal = cross(pk(w, w1), ew) * W(s.thd1, s.thd2);      // (al1, al2 - al1)
+            const Vec3<V> al1 = lo(dal), al2 = al1 + hi(dal);
+            const Vec3<W> alw = pk(al1, al2);
+            const Vec3<W> rw = ccw - aw;                                       // centres of mass from the own hinge anchors
+            const W w2w = dot(www, www);
+            const Vec3<V> r12 = a2 - a1;
+            const Vec3<V> Aa2 = Aa1 + cross(al1, r12) + wxwx(w1, pk_lo(w2w), r12);
+            const Vec3<W> Fw = (pk(Aa1, Aa2) + cross(alw, rw) + wxwx(www, w2w, rw)) * mw;
+            const Vec3<W> Nw = mul(Iw, alw) + cross(www, mul(Iw, www));
+            const Vec3<W> tw = Nw + cross(rw, Fw);                             // moments about the own hinge anchors
+            const Vec3<V> F2 = hi(Fw);
+            V cK = dot(e2, hi(tw));
+            V cS = dot(e1, lo(tw) + hi(Nw) + cross(cc2 - a1, F2));
+            Vec3<V> legF = lo(Fw) + F2;
+            const Vec3<W> Now = Nw + cross(ccw, Fw);                           // moments about the root origin
+            Vec3<V> legN = lo(Now) + hi(Now);
             const Vec3<V> legFq = qsum(legF), legNq = qsum(legN);
             Vec3<V> bl, ba;
             V cM;

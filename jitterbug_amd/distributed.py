@@ -97,13 +97,17 @@ class PendingRows:
 
 
 class _EventPending:
-    """the `work` handle of a gather issued through the C ABI: wait() makes the CURRENT stream wait for the event recorded behind it"""
+    """the `work` handle of a gather issued through the C ABI: wait() makes the CURRENT stream wait for the event recorded behind it,
+    wait_on(stream) a stream of the caller's choosing.  The event belongs to the row buffer and is re-recorded by its next gather."""
 
     def __init__(self, ops, event):
         self._ops, self._event = ops, event
 
     def wait(self):
         self._ops.wait_event(self._ops.current_stream(), self._event)
+
+    def wait_on(self, stream):
+        self._ops.wait_event(stream, self._event)
 
 
 class _CudaStreamOps:
@@ -117,7 +121,11 @@ class _CudaStreamOps:
         return self.torch.cuda.Stream(device=self.device)
 
     def event(self):
-        return self.torch.cuda.Event()
+        with self.torch.cuda.device(self.device):
+            return self.torch.cuda.Event()
+
+    def synchronize(self, stream):
+        stream.synchronize()
 
     def record(self, event, stream):
         event.record(stream)
@@ -191,12 +199,13 @@ class ShardedJitterbugEnv:
         if self._cabi:
             if not self._device_rows:
                 raise ValueError("collective='cabi' needs the device path (a GPU env with step_rows_device)")
-            if min(self.sizes) != max(self.sizes):
-                raise ValueError("collective='cabi': jb_gather_rows_device moves equal blocks - n_global must divide by the world size (got shards %s)" % self.sizes)
             # the communicator id: made by rank 0, handed round once over the process group (control traffic; 128 bytes)
             box = [self.env.comm_unique_id() if self.rank == 0 else None]
             dist.broadcast_object_list(box, src=0, group=group)
             self.env.comm_init(self.world, self.rank, box[0])
+            # the partition, the same list on every rank: the exchanges move blocks of the longest shard (uneven splits pad to it), and a rank
+            # whose env does not hold what the list says is refused here instead of hanging the first exchange
+            self.env.comm_set_shards(self.sizes)
             self._ops = stream_ops if stream_ops is not None else _CudaStreamOps(self.device)
         # (in the row-buffer logic below "nccl" means: rows stay on the device and the gather is ordered by streams - true of both RCCL paths)
         self._nccl = self._device_rows and (self._cabi or dist.get_backend(group) == "nccl")
@@ -220,6 +229,12 @@ class ShardedJitterbugEnv:
                 self._env_stream = self._ops.env_stream(self.env) if hasattr(self._ops, "env_stream") else (torch.cuda.ExternalStream(int(self.env.stream), device=self.device) if self.env.stream else torch.cuda.default_stream(self.device))
                 self._nvtx = False
                 self._step_done = [self._ops.event() for _ in range(self._NB)] if self._side is not None else None
+                # one "gather done" event per row buffer and one for rollouts, re-recorded: nothing is created per step
+                self._gather_done = [self._ops.event() for _ in range(self._NB)]
+                self._rollout_done = self._ops.event()
+                # the action half of the round trip (jb_scatter_actions_device): rank 0 stages every shard's block, every rank receives its own
+                self._act_local = torch.zeros((nmax,), device=self.device, dtype=torch.float32)
+                self._act_all = torch.zeros((self.world, nmax), device=self.device, dtype=torch.float32) if self.rank == 0 else None
             else:
                 self._side = torch.cuda.Stream(device=self.device) if (self._nccl and self.depth == 2) else None
                 # The step kernel runs on the ENV's stream (the one captured when it was built, or its own): events are recorded on, and
@@ -275,9 +290,8 @@ class ShardedJitterbugEnv:
             if self._side is not None:
                 ops.wait_event(self._side, self._step_done[b])
             self.env.gather_rows_device(self._rows[b].data_ptr(), self._blocks[b].data_ptr() if self.rank == 0 else None, ops.raw(st))
-            ev = ops.event()
-            ops.record(ev, st)
-            self._pending[b] = _EventPending(ops, ev)
+            ops.record(self._gather_done[b], st)
+            self._pending[b] = _EventPending(ops, self._gather_done[b])
             return
         if self._side is not None:
             with torch.cuda.stream(self._side):
@@ -313,7 +327,7 @@ class ShardedJitterbugEnv:
         b = i % self._NB
         if self._pending[b] is not None:                 # the buffer is rewritten only after the gather that read it:
             if self._cabi:                               # the ENV's stream (where the kernel that rewrites it runs) waits for that gather
-                self._ops.wait_event(self._env_stream, self._pending[b]._event)
+                self._pending[b].wait_on(self._env_stream)
             else:
                 with torch.cuda.stream(self._env_stream):
                     self._pending[b].wait()
@@ -384,9 +398,8 @@ class ShardedJitterbugEnv:
         if self._cabi:          # ONE block gather through the library's own communicator, on the env's stream behind the launch
             blk = torch.empty((self.world, K, nmax, D2), device=rows.device, dtype=torch.float32) if self.rank == 0 else None
             self.env.gather_block_device(rows.data_ptr(), None if blk is None else blk.data_ptr(), K * nmax * D2, self._ops.raw(self._env_stream))
-            ev = self._ops.event()
-            self._ops.record(ev, self._env_stream)
-            self._ops.wait_event(self._ops.current_stream(), ev)
+            self._ops.record(self._rollout_done, self._env_stream)
+            self._ops.wait_event(self._ops.current_stream(), self._rollout_done)
             if self.rank != 0:
                 return None
             out = torch.cat([blk[r][:, :n] for r, n in enumerate(self.sizes)], 1)          # [K, N_global, D+2]
@@ -399,6 +412,55 @@ class ShardedJitterbugEnv:
             return None
         out = torch.cat([b[:, :n] for b, n in zip(bufs, self.sizes)], 1).to(self.device)          # [K, N_global, D+2]
         return out[..., :-2], out[..., -2], out[..., -1] > 0.5
+
+    def _scatter_cabi(self, actions_global):
+        """The action half of the round trip through the library's own communicator (jb_scatter_actions_device: grouped ncclSend x world on
+        rank 0, one ncclRecv everywhere), on the env's stream - the step kernel that reads the block is queued right behind it.  Rank 0
+        passes the actions of all N_global envs (numpy array or tensor, host or device); the other ranks pass None."""
+        import torch
+        nmax = self._act_local.shape[0]
+        if self.rank == 0:
+            a = torch.as_tensor(np.asarray(actions_global) if not torch.is_tensor(actions_global) else actions_global, dtype=torch.float32).reshape(-1)
+            if a.shape[0] != self.n_global:
+                raise ValueError("rank 0 passes one action per env of the global batch (%d), got %d" % (self.n_global, a.shape[0]))
+            cur = self._ops.current_stream() if a.is_cuda else None
+            if cur is not None and self._ops.raw(cur) != self._ops.raw(self._env_stream):
+                self._env_stream.wait_stream(cur)              # device actions produced on the caller's stream
+            with self._stream_ctx(self._env_stream):
+                if min(self.sizes) == nmax:
+                    self._act_all.view(-1).copy_(a, non_blocking=True)
+                else:                                          # uneven shards: every block is padded to the longest
+                    lo = 0
+                    for r, n in enumerate(self.sizes):
+                        self._act_all[r, :n].copy_(a[lo:lo + n], non_blocking=True)
+                        lo += n
+        self.env.scatter_actions_device(None if self._act_all is None else self._act_all.data_ptr(), self._act_local.data_ptr(), nmax, self._ops.raw(self._env_stream))
+        return self._act_local[:self.n_local]
+
+    def _stream_ctx(self, stream):
+        import contextlib
+        import torch
+        return torch.cuda.stream(stream) if self.on_gpu else contextlib.nullcontext()
+
+    def close(self):
+        """Drains what is in flight (the late gather of depth 2), waits for the side stream and the env's stream, destroys the library's
+        communicator (if this object made one) and then the env.  Safe to call twice; the object is unusable afterwards."""
+        env = getattr(self, "env", None)
+        if env is None:
+            return
+        try:
+            if getattr(self, "_device_rows", False):
+                try:
+                    self.flush()
+                finally:
+                    for st in (getattr(self, "_side", None), getattr(self, "_env_stream", None)):
+                        if st is not None:
+                            (self._ops.synchronize(st) if self._cabi else st.synchronize())
+            if getattr(self, "_cabi", False):
+                env.comm_destroy()
+        finally:
+            self.env = None
+            env.close()
 
     def flush(self):
         """depth 2: the results of the last step issued (None if there is none pending)"""
@@ -419,6 +481,8 @@ class ShardedJitterbugEnv:
         import torch
         if local_actions is not None:
             a = local_actions
+        elif self._cabi:
+            a = self._scatter_cabi(actions_global)
         else:
             a = scatter_actions(actions_global, self.sizes, self.device, 0, self.group)
         if self._device_rows:

@@ -100,6 +100,7 @@ class JitterbugVecEnv:
         self._rew = np.zeros(self.num_envs, dtype=np.float32)
         self._done = np.zeros(self.num_envs, dtype=np.uint8)
         self._pending = None
+        self._views = None               # numpy views of the pinned result buffers of step_async / step_wait
         self._params = None              # host copy of the per-env / shared parameter table(s) when set_model_params was used
         self._rnd = None                 # randomise_models without fetched tables: what model_params() needs to rebuild one on the host
         self.state_version = 0           # bumped by every call that changes the simulator state (Physics caches on it)
@@ -140,12 +141,36 @@ class JitterbugVecEnv:
         return LazyInfos(self.num_envs)
 
     def step_async(self, actions):
-        self._pending = actions
+        """First half of step() (the VecEnv split the reference's SubprocVecEnv workers give its trainer, benchmarks/benchmark.py:146-171):
+        the actions go into pinned staging, H2D copy -> step kernel -> D2H copies are queued on the handle's stream, and the call
+        returns while the GPU works (jb_step_async)."""
+        a = np.ascontiguousarray(np.broadcast_to(np.asarray(actions, dtype=np.float32).reshape(-1), (self.num_envs,)))
+        _lib.check(self._L.jb_step_async(self._h, _lib.ptr(a)))
+        self._pending = True
+        self.state_version += 1
 
-    def step_wait(self):
-        out = self.step(self._pending)
+    def step_wait(self, copy=True):
+        """Second half: waits for the event behind the copies (jb_step_wait) and hands out (obs, reward, done, infos) - the very
+        arrays step() would have returned.  copy=False: views of the handle's pinned buffers, valid until the next step_async."""
+        if not self._pending:
+            raise RuntimeError("step_wait() without a step_async() before it")
         self._pending = None
-        return out
+        if copy:
+            _lib.check(self._L.jb_step_wait(self._h, _lib.ptr(self._obs), _lib.ptr(self._rew), _lib.ptr(self._done)))
+            return self._obs.copy(), self._rew.copy(), self._done.astype(bool), self._empty_infos()
+        _lib.check(self._L.jb_step_wait(self._h, None, None, None))
+        if self._views is None:
+            po, pr, pd = C.c_void_p(), C.c_void_p(), C.c_void_p()
+            _lib.check(self._L.jb_step_views(self._h, C.byref(po), C.byref(pr), C.byref(pd)))
+            n, d = self.num_envs, self.obs_dim
+            self._views = (np.ctypeslib.as_array(C.cast(po, C.POINTER(C.c_float)), shape=(n, d)), np.ctypeslib.as_array(C.cast(pr, C.POINTER(C.c_float)), shape=(n,)),
+                           np.ctypeslib.as_array(C.cast(pd, C.POINTER(C.c_uint8)), shape=(n,)))
+        o, r, dn = self._views
+        return o, r, dn.view(np.bool_), self._empty_infos()
+
+    def release_staging(self):
+        """Frees the device staging that host-buffer rollouts have grown (jb_release_staging): K x N x (D+2) floats stay with the handle otherwise."""
+        _lib.check(self._L.jb_release_staging(self._h))
 
     def observe(self):
         _lib.check(self._L.jb_observe(self._h, _lib.ptr(self._obs), _lib.ptr(self._rew)))
@@ -374,6 +399,15 @@ class JitterbugVecEnv:
     def comm_destroy(self):
         _lib.check(self._L.jb_comm_destroy(self._h))
 
+    def comm_set_shards(self, sizes):
+        """The envs every rank holds (the same list on every rank): the exchanges then move blocks of the longest shard (jb_comm_set_shards)."""
+        a = np.ascontiguousarray(sizes, dtype=np.int32)
+        _lib.check(self._L.jb_comm_set_shards(self._h, a.ctypes.data))
+
+    def scatter_actions_device(self, all_ptr, local_ptr, count, stream=None):
+        """Rank 0's [n_ranks, count] action blocks to every rank's [count] (grouped ncclSend / ncclRecv, jb_scatter_actions_device)."""
+        _lib.check(self._L.jb_scatter_actions_device(self._h, all_ptr, local_ptr, int(count), stream, 0 if stream is None else 1))
+
     def gather_rows_device(self, rows_ptr, all_ptr=None, stream=None):
         """This rank's packed rows [N, D+2] to rank 0's [n_ranks, N, D+2] (grouped ncclSend / ncclRecv); asynchronous on `stream` (a raw
         hipStream_t) or, when None, on the handle's stream."""
@@ -441,8 +475,10 @@ class MonitoredVecEnv:
         return obs
 
     def step(self, actions):
+        return self._account(*self.venv.step(actions)[:3])
+
+    def _account(self, obs, rew, done):
         import time
-        obs, rew, done, _ = self.venv.step(actions)
         self._ret += rew
         self._len += 1
         infos = [{} for _ in range(self.num_envs)]
@@ -461,10 +497,10 @@ class MonitoredVecEnv:
         return obs, rew, done, infos
 
     def step_async(self, actions):
-        self._pending = actions
+        self.venv.step_async(actions)
 
     def step_wait(self):
-        return self.step(self._pending)
+        return self._account(*self.venv.step_wait()[:3])
 
     def close(self):
         if self._fh:

@@ -24,7 +24,9 @@ for depth in (1, 2):
     expected = []
     for t in range(9):
         acts = rng.uniform(-1, 1, size=n).astype(np.float32)
-        res = sh.step(local_actions=torch.as_tensor(acts, device="cuda:0"))
+        # odd steps: the whole round trip through the library - rank 0 brings every env's action (host array, or a device tensor made on the
+        # caller's stream) and jb_scatter_actions_device hands them out; even steps: actions already resident on the rank
+        res = sh.step(acts if t % 4 == 1 else torch.as_tensor(acts, device="cuda:0")) if t % 2 else sh.step(local_actions=torch.as_tensor(acts, device="cuda:0"))
         expected.append(whole.step(acts))
         if depth == 2:
             if t == 0:
@@ -45,7 +47,8 @@ for depth in (1, 2):
     for k in range(K):
         w = whole.step(tape[k])
         assert np.array_equal(o[k], w[0]) and np.array_equal(r[k], w[1]) and np.array_equal(d[k], w[2].astype(bool)), "rollout step %d differs" % k
-    sh.env.close(); whole.close()
+    sh.close(); sh.close(); whole.close()          # close(): flush, both streams idle, jb_comm_destroy, then the env (twice is harmless)
+    assert sh.env is None
 try:
     ShardedJitterbugEnv(n, task, seed=4, device="cuda:0", flags=2)          # variant="auto" + JB_FLAG_LEAN in flags: refused, not silently cleared
     raise SystemExit("variant='auto' with JB_FLAG_LEAN in flags was accepted")

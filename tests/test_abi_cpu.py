@@ -28,7 +28,7 @@ def test_exports_every_declared_symbol(lib):
 
 
 def test_device_free_queries(lib):
-    assert lib.jb_abi_version() == 4
+    assert lib.jb_abi_version() == 5
     assert [lib.jb_obs_dim(i) for i in range(5)] == [15, 16, 19, 18, 19]
     assert lib.jb_obs_dim(5) == -1 and lib.jb_obs_dim(-1) == -1
     np.testing.assert_array_equal(_lib.default_model_params(), model.default_params())

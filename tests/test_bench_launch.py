@@ -180,9 +180,9 @@ sys.exit(rc)
 @pytest.mark.gpu
 def test_bench_gpus_2_over_rccl_on_one_gpu_succeeds_or_fails_cleanly():
     """Rehearsal of what the driver's 8-GPU tier does first, as far as a one-GPU box allows: `bench.py --gpus 2` with the DEFAULT data path
-    (--collective cabi: the library's own RCCL communicator; control over gloo) and both ranks on device 0.  RCCL may accept two ranks on one
-    device or refuse them (ncclInvalidUsage / "Duplicate GPU detected" - what this pool's does: cabi fails, torch's RCCL is tried and fails
-    the same way, the ranks then time their shards alone and say `degraded`).  Either way the run must end by itself well inside the
+    (--collective torch: torch.distributed's gather over RCCL) and both ranks on device 0.  RCCL may accept two ranks on one
+    device or refuse them (ncclInvalidUsage / "Duplicate GPU detected" - what this pool's does: torch's RCCL fails, the library's own is tried
+    and fails the same way, the ranks then time their shards alone and say `degraded`).  Either way the run must end by itself well inside the
     watchdog's limit - with one result line (rc 0: gathered; rc 3: degraded) or with another rc and no line - and never hang."""
     import time
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
@@ -214,9 +214,11 @@ def test_bench_one_rank_through_the_librarys_own_collective():
     jb_gather_block_device - through real RCCL calls on a one-GPU box, and the line names the collective that ran."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     env.update({"JB_BENCH_FORCE_DIST": "1", "WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29631"})
-    p = subprocess.run([sys.executable, BENCH, "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-also", "--no-host-rate"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    p = subprocess.run([sys.executable, BENCH, "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-also", "--no-host-rate", "--collective", "cabi", "--actions-from", "rank0"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert p.returncode == 0, p.stderr[-3000:]
     d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
     assert d["data_path_collective"] == "cabi" and d["degraded"] is False and d["finite"] is True and d["value"] > 0
+    assert d["actions_from"] == "rank0" and "scatter -> step -> gather" in d["config"]["parallelism"]          # the whole round trip was inside the timed region
     assert "the library's own RCCL communicator" in d["dist_notes"][-1] and "jb_gather_rows_device" in d["config"]["parallelism"]
     assert d["rollout_fused"]["k100_sharded"]["finite"] is True and d["rollout_fused"]["k100_sharded"]["collective"] == "cabi"

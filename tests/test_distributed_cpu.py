@@ -217,7 +217,7 @@ def test_sharded_rollout_one_gather_of_k_steps_matches_single_process_gloo():
 
 
 # ---- collective="cabi": the control flow of the library's own row gather with a STUB library (no GPU here)
-def _cabi_worker(rank, world, port, n_global, steps, q, depth):
+def _cabi_worker(rank, world, port, n_global, steps, q, depth, from_rank0=False):
     """The stub stands in for libjitterbug_hip.so's C ABI: step_rows_device / step_many_device write packed rows through raw pointers (the
     CPU oracle computes them), comm_unique_id / comm_init record the exchange, gather_rows_device / gather_block_device move `count` floats
     to rank 0 (over gloo, where the library uses grouped ncclSend / ncclRecv).  Streams and events are recorded, not executed: the test
@@ -256,6 +256,27 @@ def _cabi_worker(rank, world, port, n_global, steps, q, depth):
             self.comm = (n_ranks, r)
             log.append(("comm_init", n_ranks, r))
 
+        def comm_set_shards(self, sizes):
+            assert self.comm is not None and list(sizes)[rank] == self.n          # (what jb_comm_set_shards refuses otherwise)
+            self.nmax = max(sizes)
+            log.append(("set_shards", tuple(int(x) for x in sizes)))
+
+        def comm_destroy(self):
+            assert self.comm is not None
+            self.comm = None
+            log.append(("comm_destroy",))
+
+        def close(self):
+            log.append(("close",))
+
+        def scatter_actions_device(self, all_ptr, local_ptr, count, stream=None):
+            assert self.comm == (world, rank) and count == self.nmax
+            log.append(("scatter", count, stream))
+            out = torch.empty(count, dtype=torch.float32)
+            chunks = [torch.from_numpy(view(all_ptr, world * count).reshape(world, count)[r].copy()) for r in range(world)] if rank == 0 else None
+            dist.scatter(out, chunks, src=0)
+            view(local_ptr, count)[:] = out.numpy()
+
         def _rows(self, a):
             o, r, d = self.e.step(a)
             return np.concatenate([o, r[:, None], d[:, None].astype(np.float64)], 1).astype(np.float32)
@@ -282,7 +303,7 @@ def _cabi_worker(rank, world, port, n_global, steps, q, depth):
 
         def gather_rows_device(self, rows_ptr, all_ptr=None, stream=None):
             log.append(("gather", rows_ptr, stream))
-            self._gather(rows_ptr, all_ptr, self.n * (self.obs_dim + 2), stream)
+            self._gather(rows_ptr, all_ptr, self.nmax * (self.obs_dim + 2), stream)          # blocks of the longest shard, like jb_gather_rows_device after jb_comm_set_shards
 
         def gather_block_device(self, src_ptr, all_ptr, count, stream=None):
             log.append(("gather_block", count, stream))
@@ -314,14 +335,22 @@ def _cabi_worker(rank, world, port, n_global, steps, q, depth):
         def raw(self, stream):
             return stream
 
-    env = ShardedJitterbugEnv(n_global, "move_to_pose", seed=4, local_env_factory=lambda n, off: StubLib(n, off), pipeline_depth=depth, collective="cabi", stream_ops=StubOps())
-    assert log[0] == ("comm_init", world, rank)
+        def synchronize(self, stream):
+            log.append(("sync", stream))
+
+    ops = StubOps()
+    env = ShardedJitterbugEnv(n_global, "move_to_pose", seed=4, local_env_factory=lambda n, off: StubLib(n, off), pipeline_depth=depth, collective="cabi", stream_ops=ops)
+    assert log[0] == ("comm_init", world, rank) and log[1] == ("set_shards", tuple(env.sizes))
+    n_ev0 = ops.n_ev
     env.env.reset()
     rng = np.random.default_rng(0)
     outs = []
     for t in range(steps):
-        acts = torch.from_numpy(rng.uniform(-1, 1, size=n_global).astype(np.float32))[env.lo:env.hi].contiguous()
-        r = env.step(local_actions=acts)
+        ag = rng.uniform(-1, 1, size=n_global).astype(np.float32)
+        if from_rank0:          # the whole round trip through the library: rank 0 brings every env's action, jb_scatter_actions_device hands them out
+            r = env.step(ag if rank == 0 else None)
+        else:
+            r = env.step(local_actions=torch.from_numpy(ag)[env.lo:env.hi].contiguous())
         keep = lambda x: None if x is None else tuple(v.clone() for v in x)      # (results are views of the rotating receive buffers: valid until they come round again)
         if depth == 1:
             outs.append(keep(r))
@@ -331,25 +360,32 @@ def _cabi_worker(rank, world, port, n_global, steps, q, depth):
         outs.append(keep(env.flush().get()))
     tape = torch.from_numpy(rng.uniform(-1, 1, size=(4, n_global)).astype(np.float32))[:, env.lo:env.hi].contiguous()
     ro = env.rollout(4, local_actions=tape)
+    assert ops.n_ev == n_ev0, "events are made once, with the buffers: %d were created while stepping" % (ops.n_ev - n_ev0)
+    stub = env.env
+    env.close()
+    env.close()          # (twice is harmless)
+    assert stub.comm is None and log[-2:] == [("comm_destroy",), ("close",)]
     if rank == 0:
         q.put(([(o.numpy(), r.numpy(), d.numpy()) for o, r, d in outs], (ro[0].numpy(), ro[1].numpy(), ro[2].numpy()), log))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.timeout(300)
-@pytest.mark.parametrize("depth", [1, 2])
-def test_sharded_env_cabi_collective_control_flow_with_a_stub_library(depth):
-    """ShardedJitterbugEnv(collective='cabi'): id exchange, jb_comm_init, one jb_gather_rows_device per step (depth 2: one step late, on the
-    side stream, behind the event of the step that wrote the rows; three rotating buffers, a buffer rewritten only after its gather's
-    event), one jb_gather_block_device per rollout - and the results equal one unsharded env."""
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("depth,world,n_global,from_rank0", [(1, 2, 12, False), (2, 2, 12, False), (2, 2, 11, True), (1, 8, 4097, True), (2, 8, 41, True)])
+def test_sharded_env_cabi_collective_control_flow_with_a_stub_library(depth, world, n_global, from_rank0):
+    """ShardedJitterbugEnv(collective='cabi'): id exchange, jb_comm_init, jb_comm_set_shards, one jb_gather_rows_device per step (depth 2: one
+    step late, on the side stream, behind the event of the step that wrote the rows; three rotating buffers, a buffer rewritten only after
+    its gather's event), one jb_gather_block_device per rollout, no event made per step, close() - and the results equal one unsharded env.
+    from_rank0: the actions travel through jb_scatter_actions_device (the whole round trip of a step through the library).  World 8 with
+    uneven splits (4097 = 7 x 512 + 513; 41 = 1 x 6 + 7 x 5): ranks >= 2, blocks padded to the longest shard."""
     import torch.multiprocessing as mp
     from oracle import oracle as O
-    n_global, steps, world = 12, 5, 2
+    steps = 5 if n_global < 1000 else 3
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_cabi_worker, args=(r, world, port, n_global, steps, q, depth)) for r in range(world)]
+    procs = [ctx.Process(target=_cabi_worker, args=(r, world, port, n_global, steps, q, depth, from_rank0)) for r in range(world)]
     for p in procs:
         p.start()
     outs, ro, log = q.get(timeout=240)
@@ -375,6 +411,12 @@ def test_sharded_env_cabi_collective_control_flow_with_a_stub_library(depth):
     i_steps = [i for i, e in enumerate(log) if e[0] == "step"]
     i_gathers = [i for i, e in enumerate(log) if e[0] == "gather"]
     assert len(i_steps) == steps and len(i_gathers) == steps and sum(e[0] == "gather_block" for e in log) == 1
+    i_scatters = [i for i, e in enumerate(log) if e[0] == "scatter"]
+    if from_rank0:          # one scatter per step, on the env's stream, right in front of the kernel that reads the block
+        assert len(i_scatters) == steps and all(log[i][2] == "env" and log[i][1] == -(-n_global // world) for i in i_scatters)
+        assert all(i_s < i_k and not any(log[j][0] == "step" for j in range(i_s, i_k)) for i_s, i_k in zip(i_scatters, i_steps))
+    else:
+        assert not i_scatters
     if depth == 2:
         bufs = [log[i][1] for i in i_steps]
         assert len(set(bufs[:3])) == 3 and bufs[3] == bufs[0] and bufs[4] == bufs[1]                 # three row buffers, rotating

@@ -90,6 +90,67 @@ def test_vec_env_shapes_and_done_flags():
     env.close()
 
 
+def test_step_async_overlaps_host_work_and_equals_step():
+    """step_async / step_wait are two real halves (reference benchmarks/benchmark.py:146-171: SubprocVecEnv's workers step while the
+    trainer goes on): 200 steps with 2 ms of host work between the halves must take max(host, device) - not their sum - within 5 %,
+    and hand out the very arrays step() returns.  Views of the pinned buffers (copy=False) and MonitoredVecEnv ride the same path."""
+    import time
+    from jitterbug_amd.vec_env import JitterbugVecEnv, MonitoredVecEnv
+    n, steps, host_s = 4096, 200, 0.002
+    rng = np.random.default_rng(0)
+    acts = rng.uniform(-1, 1, size=(steps, n)).astype(np.float32)
+    a_env, s_env = JitterbugVecEnv(n, "move_from_origin", seed=3), JitterbugVecEnv(n, "move_from_origin", seed=3)
+    a_env.reset(), s_env.reset()
+
+    def busy(seconds):
+        t = time.perf_counter()
+        while time.perf_counter() - t < seconds:
+            pass
+
+    for k in range(20):          # warm-up (first launch, pinned allocation); both envs stay in step
+        a_env.step_async(acts[k]); ra = a_env.step_wait(); rs = s_env.step(acts[k])
+        assert all(np.array_equal(x, y) for x, y in zip(ra[:3], rs[:3]))
+    with pytest.raises(RuntimeError):
+        a_env.step_wait()                                        # no step pending
+    a_env.step_async(acts[0])
+    with pytest.raises(Exception):
+        a_env.step(acts[0])                                      # jb_step refuses while a step is in flight
+    a_env.step_wait(); s_env.step(acts[0])
+    t0 = time.perf_counter()
+    for k in range(20, steps):
+        s_env.step(acts[k])
+    dev_s = (time.perf_counter() - t0) / (steps - 20)           # one synchronous step, device + copies
+    outs = []
+    t0 = time.perf_counter()
+    for k in range(20, steps):
+        a_env.step_async(acts[k])
+        busy(host_s)                                             # the caller's own work (a policy's forward pass, say)
+        o, r, d, _ = a_env.step_wait(copy=False)
+        outs.append((o.copy(), r.copy(), d.copy()))
+    both_s = (time.perf_counter() - t0) / (steps - 20) - 0.0     # per step, including the three copies made for the comparison below
+    copies_s = 0.0
+    t0 = time.perf_counter()
+    for _ in range(50):
+        (o.copy(), r.copy(), d.copy())
+    copies_s = (time.perf_counter() - t0) / 50
+    assert both_s - copies_s <= 1.05 * max(host_s, dev_s) + 2e-5, "async step %.3f ms vs host %.3f ms / device %.3f ms: the halves add up instead of overlapping" % (1e3 * (both_s - copies_s), 1e3 * host_s, 1e3 * dev_s)
+    ref = JitterbugVecEnv(n, "move_from_origin", seed=3)
+    ref.reset()
+    for k in list(range(20)) + [0]:
+        ref.step(acts[k])
+    for k in range(20, steps):
+        o, r, d, _ = ref.step(acts[k])
+        assert np.array_equal(o, outs[k - 20][0]) and np.array_equal(r, outs[k - 20][1]) and np.array_equal(d, outs[k - 20][2]), k
+    m = MonitoredVecEnv(JitterbugVecEnv(16, "move_from_origin", seed=1, time_limit=0.04))
+    m.reset()
+    for t in range(4):
+        m.step_async(np.full(16, 0.5))
+        obs, rew, done, infos = m.step_wait()
+    assert done.all() and all(i["episode"]["l"] == 4 for i in infos)
+    for e in (a_env, s_env, ref, m):
+        e.close()
+
+
 def test_monitored_vec_env(tmp_path):
     from jitterbug_amd.vec_env import JitterbugVecEnv, MonitoredVecEnv
     env = MonitoredVecEnv(JitterbugVecEnv(10, "move_from_origin", seed=1, time_limit=0.04), filename=str(tmp_path / "run"))
@@ -325,6 +386,21 @@ def test_c_abi_row_gather_over_rccl_one_rank():
             r = allrows[0].cpu().numpy()
             assert np.array_equal(r[:, :D], ob) and np.array_equal(r[:, D], rw) and np.array_equal(r[:, D + 1] > 0.5, dn.astype(bool)), t
         _lib.check(L.jb_gather_rows_device(env._h, rows.data_ptr(), allrows.data_ptr(), None, 0)); env.synchronize()   # on the handle's stream
+        # ABI 5: the action half of the round trip, and the partition check
+        bad = np.array([n + 1], dtype=np.int32)
+        assert L.jb_comm_set_shards(env._h, bad.ctypes.data) == -1 and b"do not agree" in L.jb_last_error()      # a partition this handle does not fit: refused on the host
+        _lib.check(L.jb_comm_set_shards(env._h, np.array([n], dtype=np.int32).ctypes.data))
+        a_all = torch.rand((1, n), device=dev) * 2 - 1
+        a_loc = torch.zeros(n, device=dev)
+        torch.cuda.synchronize()
+        _lib.check(L.jb_scatter_actions_device(env._h, a_all.data_ptr(), a_loc.data_ptr(), n, side.cuda_stream, 1)); side.synchronize()
+        assert torch.equal(a_loc, a_all[0])
+        assert L.jb_scatter_actions_device(env._h, a_all.data_ptr(), a_loc.data_ptr(), n - 1, None, 0) == -1     # a block shorter than the shard
+        env.step_rows_device(a_loc.data_ptr(), rows.data_ptr())
+        _lib.check(L.jb_gather_rows_device(env._h, rows.data_ptr(), allrows.data_ptr(), None, 0)); env.synchronize()
+        ob, rw, dn, _ = ref.step(a_all[0].cpu().numpy())
+        r = allrows[0].cpu().numpy()
+        assert np.array_equal(r[:, :D], ob) and np.array_equal(r[:, D], rw)
         _lib.check(L.jb_comm_destroy(env._h))
         assert L.jb_gather_rows_device(env._h, rows.data_ptr(), allrows.data_ptr(), None, 0) == -1                    # no communicator any more
         env.close(); ref.close()

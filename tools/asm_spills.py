@@ -1,6 +1,6 @@
 """Where do a step kernel's register spills sit - in the substep loop (hot) or only around it (once per control step / per launch)?
 
-    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -w -S --cuda-device-only -o /tmp/jb.s jitterbug_amd/csrc/jb_api.hip
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -mllvm -disable-vector-combine -w -S --cuda-device-only -o /tmp/jb.s jitterbug_amd/csrc/jb_api.hip
     python tools/asm_spills.py /tmp/jb.s [kernel-name-substring]
 
 For every step kernel: static instruction count, and the scratch_ / v_writelane / v_readlane operations split by the loop they are in.

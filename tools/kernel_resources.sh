@@ -2,7 +2,7 @@
 # Register / scratch / occupancy report of every kernel in jb_api.hip (compiler remarks; no GPU needed).
 #   tools/kernel_resources.sh [extra hipcc flags]
 cd "$(dirname "$0")/.." || exit 1
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -Wno-unused-value -c --cuda-device-only \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -mllvm -disable-vector-combine -Wno-unused-value -c --cuda-device-only \
     -Rpass-analysis=kernel-resource-usage "$@" -o /tmp/jb_res.o jitterbug_amd/csrc/jb_api.hip 2>&1 | python3 -c '
 import re, sys
 name, rows = None, {}
