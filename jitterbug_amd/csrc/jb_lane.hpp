@@ -401,6 +401,7 @@ template <typename V> struct Pk2 {
     template <typename S, typename = typename std::enable_if<std::is_arithmetic<S>::value>::type>
     JB_HD Pk2(S s) : lo(V((typename lane_traits<V>::real)s)), hi(V((typename lane_traits<V>::real)s)) {}
     JB_HD Pk2(const V& a, const V& b) : lo(a), hi(b) {}
+    JB_HD explicit Pk2(const V& both) : lo(both), hi(both) {}
 };
 template <typename V> JB_HD Pk2<V> operator+(const Pk2<V>& a, const Pk2<V>& b) { return Pk2<V>(a.lo + b.lo, a.hi + b.hi); }
 template <typename V> JB_HD Pk2<V> operator-(const Pk2<V>& a, const Pk2<V>& b) { return Pk2<V>(a.lo - b.lo, a.hi - b.hi); }

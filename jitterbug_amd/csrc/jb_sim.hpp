@@ -441,15 +441,38 @@ template <typename V> JB_HD typename lane_traits<V>::uint group_sum_u(const Lane
 template <typename V> JB_HD int ls_mailbox(const LaneScratch<V>& sc) { return sc.red_lds ? (int)SC_RED : (int)SC_FAC; }
 JB_HD constexpr int tri(int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
 
+// ---- packed layouts of the solver (jb_lane.hpp Pk2: one packed instruction for two values)
+// A symmetric 6x6 block (the root block of M, of the Newton system, its Schur complement and Cholesky factor): the LOWER triangle, stored
+// by COLUMNS in pairs of ROWS - pair (ip, j) holds rows 2 ip and 2 ip + 1 of column j, for 2 ip + 1 >= j: 12 pairs.  Three low halves lie
+// above the diagonal (rows 0 / 2 / 4 of columns 1 / 3 / 5): they carry the mirrored element or junk and are never read as part of the
+// triangle.  Everything the solver does to such a block is "pair of rows op one column element": rank-3 updates from contact rows, the
+// Schur complement's updates, right-looking Cholesky and the forward substitution all run on pairs, no horizontal sums.
+// A 6-vector is three pairs of rows; the 6 x 2 leg coupling is [row pair][column].
+JB_HD constexpr int s6base(int j) { return j == 0 ? 0 : j == 1 ? 3 : j == 2 ? 6 : j == 3 ? 8 : j == 4 ? 10 : 11; }
+JB_HD constexpr int s6p(int ip, int j) { return s6base(j) + ip - j / 2; }
+template <typename V> struct Sym6P { Pk2<V> p[12]; };
+template <typename V> JB_HD V pk_half(const Pk2<V>& w, int h) { return h ? pk_hi(w) : pk_lo(w); }
+template <typename V> JB_HD Pk2<V> pk_with(const Pk2<V>& w, int h, const V& x) { return h ? Pk2<V>(pk_lo(w), x) : Pk2<V>(x, pk_hi(w)); }
+template <typename V> JB_HD V s6get(const Sym6P<V>& S, int i, int j) { return i >= j ? pk_half(S.p[s6p(i >> 1, j)], i & 1) : pk_half(S.p[s6p(j >> 1, i)], j & 1); }
+template <typename V> JB_HD void s6set(Sym6P<V>& S, int i, int j, const V& x) { S.p[s6p(i >> 1, j)] = pk_with(S.p[s6p(i >> 1, j)], i & 1, x); }      // i >= j
+template <typename V> JB_HD V v6get(const Pk2<V> (&v)[3], int i) { return pk_half(v[i >> 1], i & 1); }
+template <typename V> JB_HD void v6set(Pk2<V> (&v)[3], int i, const V& x) { v[i >> 1] = pk_with(v[i >> 1], i & 1, x); }
+template <typename V> JB_HD V b6get(const Pk2<V> (&B)[3][2], int i, int c) { return pk_half(B[i >> 1][c], i & 1); }
+template <typename V, typename MKT> JB_HD Pk2<V> selw(const MKT& k, const Pk2<V>& a, const Pk2<V>& b) { return Pk2<V>(sel(k, pk_lo(a), pk_lo(b)), sel(k, pk_hi(a), pk_hi(b))); }
+template <typename V> JB_HD Pk2<V> qsum2(const Pk2<V>& a) { return Pk2<V>(quad_sum(pk_lo(a)), quad_sum(pk_hi(a))); }
+// ... of a pair whose low half lies above the diagonal (left as it is)
+template <typename V> JB_HD Pk2<V> qsum_hi(const Pk2<V>& a) { return Pk2<V>(pk_lo(a), quad_sum(pk_hi(a))); }
+JB_HD constexpr bool s6_junk_lo(int ip, int j) { return 2 * ip < j; }
+
 // Accumulator of the contact terms of the Newton system for the lane (everything here is ADDED to M / tau,
 // which stay in the scratch)
 template <typename V> struct NewtonAcc {
-    V A[21];                 // lane-private additive part of the root block
-    V B[6][2];               // additive part of the leg coupling
+    Sym6P<V> A;              // lane-private additive part of the root block
+    Pk2<V> B[3][2];          // additive part of the leg coupling
     V C11, C12, C22;
     V X;                     // PAIR kernels: the own shoulder - motor cross term of the pair contact (mass against the own upper leg)
-    V Bm[6], Cm;             // lane-private additive part of the motor branch
-    V rr[6], rl[2], rm;      // additive rhs parts
+    Pk2<V> Bm[3]; V Cm;      // lane-private additive part of the motor branch
+    Pk2<V> rr[3]; V rl[2], rm;      // additive rhs parts
     typename lane_traits<V>::uint bw0, bw1;   // active-set records of the leg slots: 5 bits (4 pyramid edges + valid) each, exact; bw0: slots 0-4, bw1: slots 5-9
     typename lane_traits<V>::uint xh;      // polynomial hash of the records of the rarely-evaluated slots (lane-private, never summed across lanes)
     V ls_g, ls_h, ls_a;      // line search (sweeps of mode 3): sums over this lane's contacts and pyramid edges of D min(0, r + alpha s) s, of D s^2 over the
@@ -458,10 +481,11 @@ template <typename V> struct NewtonAcc {
 // direction and step of the line search, handed to the sweeps of mode 3
 template <typename V> struct LineDir { V dr[6], dl[2], dm, alpha; };
 template <typename V> JB_HD void acc_clear(NewtonAcc<V>& acc) {
+    using W = Pk2<V>;
 #pragma unroll
-    for (int i = 0; i < 21; i++) acc.A[i] = V(0);
+    for (int i = 0; i < 12; i++) acc.A.p[i] = W(0);
 #pragma unroll
-    for (int i = 0; i < 6; i++) { acc.B[i][0] = V(0); acc.B[i][1] = V(0); acc.Bm[i] = V(0); acc.rr[i] = V(0); }
+    for (int i = 0; i < 3; i++) { acc.B[i][0] = W(0); acc.B[i][1] = W(0); acc.Bm[i] = W(0); acc.rr[i] = W(0); }
     acc.C11 = V(0); acc.C12 = V(0); acc.C22 = V(0); acc.Cm = V(0); acc.X = V(0);
     acc.rl[0] = V(0); acc.rl[1] = V(0); acc.rm = V(0);
     acc.bw0 = zero_u<V>(); acc.bw1 = zero_u<V>(); acc.xh = zero_u<V>();
@@ -470,16 +494,25 @@ template <typename V> JB_HD void acc_clear(NewtonAcc<V>& acc) {
 // the 52 additive values of the accumulator as a flat list (and back); PAIR kernels carry X as value 52 (callers pad to 56)
 template <typename V> JB_HD void acc_pack(const NewtonAcc<V>& a, V* v) {
 #pragma unroll
-    for (int i = 0; i < 21; i++) v[i] = a.A[i];
+    for (int i = 0; i < 6; i++)
 #pragma unroll
-    for (int i = 0; i < 6; i++) { v[21 + 2 * i] = a.B[i][0]; v[22 + 2 * i] = a.B[i][1]; v[36 + i] = a.Bm[i]; v[43 + i] = a.rr[i]; }
+        for (int j = 0; j <= i; j++) v[tri(i, j)] = s6get(a.A, i, j);
+#pragma unroll
+    for (int i = 0; i < 6; i++) { v[21 + 2 * i] = b6get(a.B, i, 0); v[22 + 2 * i] = b6get(a.B, i, 1); v[36 + i] = v6get(a.Bm, i); v[43 + i] = v6get(a.rr, i); }
     v[33] = a.C11; v[34] = a.C12; v[35] = a.C22; v[42] = a.Cm; v[49] = a.rl[0]; v[50] = a.rl[1]; v[51] = a.rm;
 }
 template <typename V> JB_HD void acc_unpack(const V* v, NewtonAcc<V>& a) {
+    using W = Pk2<V>;
+    // (the halves above the diagonal take the mirrored element: defined values, never read)
 #pragma unroll
-    for (int i = 0; i < 21; i++) a.A[i] = v[i];
+    for (int j = 0; j < 6; j++)
 #pragma unroll
-    for (int i = 0; i < 6; i++) { a.B[i][0] = v[21 + 2 * i]; a.B[i][1] = v[22 + 2 * i]; a.Bm[i] = v[36 + i]; a.rr[i] = v[43 + i]; }
+        for (int ip = j / 2; ip < 3; ip++) a.A.p[s6p(ip, j)] = W(v[tri(2 * ip, j)], v[tri(2 * ip + 1, j)]);
+#pragma unroll
+    for (int ip = 0; ip < 3; ip++) {
+        a.B[ip][0] = W(v[21 + 4 * ip], v[23 + 4 * ip]); a.B[ip][1] = W(v[22 + 4 * ip], v[24 + 4 * ip]);
+        a.Bm[ip] = W(v[36 + 2 * ip], v[37 + 2 * ip]); a.rr[ip] = W(v[43 + 2 * ip], v[44 + 2 * ip]);
+    }
     a.C11 = v[33]; a.C12 = v[34]; a.C22 = v[35]; a.Cm = v[42]; a.rl[0] = v[49]; a.rl[1] = v[50]; a.rm = v[51];
 }
 
@@ -487,21 +520,21 @@ template <typename V> JB_HD void acc_unpack(const V* v, NewtonAcc<V>& a) {
 // (solves, final pass), so it lives in registers - in practice in the otherwise unused accumulation registers, one move
 // away - instead of making ~130 LDS round trips per substep.
 template <typename V> struct StarSys {
-    V A[21];        // root block, tri() order
-    V B[6][2];      // own leg coupling
-    V C[3];         // own leg block: 11, 12, 22
-    V Bm[6], Cm;    // motor coupling and block
-    V tr[6], tl[2], tm;   // applied + bias forces: root, own leg, motor
+    Sym6P<V> A;           // root block
+    Pk2<V> B[3][2];       // own leg coupling, [row pair][column: shoulder, knee]
+    V C[3];               // own leg block: 11, 12, 22
+    Pk2<V> Bm[3]; V Cm;   // motor coupling and block
+    Pk2<V> tr[3]; V tl[2], tm;   // applied + bias forces: root, own leg, motor
 };
 
 // Factorisation of H = M + contact terms (+ hb on the leg diagonal): the leg 2x2 and motor 1x1 blocks inverted, the 6x6 Schur
 // complement Cholesky-factored (reciprocal pivots on the diagonal).  Kept by the caller between Newton passes: a pass
 // whose active set differs from the factored one by a single pyramid edge is a rank-one update of this factorisation.
 template <typename V> struct StarFactor {
-    V S[21];
-    V B[6][2];
+    Sym6P<V> S;
+    Pk2<V> B[3][2];
     V i11, i12, i22;
-    V bm[6], icm;
+    Pk2<V> bm[3]; V icm;
     V cx0, cx1;     // PAIR kernels: C^-1 [X, 0]^T, the leg block's answer to the shoulder - motor cross term
 };
 // WITH_ACC = false: no contact terms (the final pass): the factorisation of M + hb alone; `acc` is not read.
@@ -511,101 +544,121 @@ template <typename V> struct StarFactor {
 //     y_leg = C^-1 (r_leg - B^T y_root) - (C^-1 x) y_motor.
 template <typename V, bool WITH_ACC = true, bool PAIR = false>
 JB_HD void star_factor(const StarSys<V>& M, const NewtonAcc<V>& acc, const V& hb1, const V& hb2, StarFactor<V>& F) {
+    using W = Pk2<V>;
 #pragma unroll
-    for (int i = 0; i < 6; i++) {
-        F.B[i][0] = WITH_ACC ? M.B[i][0] + acc.B[i][0] : M.B[i][0];
-        F.B[i][1] = WITH_ACC ? M.B[i][1] + acc.B[i][1] : M.B[i][1];
+    for (int ip = 0; ip < 3; ip++) {
+        F.B[ip][0] = WITH_ACC ? M.B[ip][0] + acc.B[ip][0] : M.B[ip][0];
+        F.B[ip][1] = WITH_ACC ? M.B[ip][1] + acc.B[ip][1] : M.B[ip][1];
     }
     V C11 = M.C[0] + hb1, C12 = M.C[1], C22 = M.C[2] + hb2;
     if (WITH_ACC) { C11 = M.C[0] + acc.C11 + hb1; C12 = M.C[1] + acc.C12; C22 = M.C[2] + acc.C22 + hb2; }
     V idet = vrcp(C11 * C22 - C12 * C12);
     F.i11 = C22 * idet; F.i12 = -C12 * idet; F.i22 = C11 * idet;
-    V (&S)[21] = F.S;
+    Sym6P<V>& S = F.S;
+    W g[3][2];          // B C^-1, row pairs
 #pragma unroll
-    for (int i = 0; i < 6; i++) {
-        V g0 = F.B[i][0] * F.i11 + F.B[i][1] * F.i12, g1 = F.B[i][0] * F.i12 + F.B[i][1] * F.i22;
+    for (int ip = 0; ip < 3; ip++) {
+        g[ip][0] = F.B[ip][0] * W(F.i11) + F.B[ip][1] * W(F.i12);
+        g[ip][1] = F.B[ip][0] * W(F.i12) + F.B[ip][1] * W(F.i22);
+    }
 #pragma unroll
-        for (int j = 0; j <= i; j++) {
-            if (WITH_ACC) S[tri(i, j)] = quad_sum(acc.A[tri(i, j)] - (g0 * F.B[j][0] + g1 * F.B[j][1])) + M.A[tri(i, j)];
-            else S[tri(i, j)] = M.A[tri(i, j)] - quad_sum(g0 * F.B[j][0] + g1 * F.B[j][1]);
+    for (int j = 0; j < 6; j++) {
+        const V bj0 = b6get(F.B, j, 0), bj1 = b6get(F.B, j, 1);
+#pragma unroll
+        for (int ip = j / 2; ip < 3; ip++) {
+            const W leg = g[ip][0] * W(bj0) + g[ip][1] * W(bj1);
+            const int k = s6p(ip, j);
+            if (WITH_ACC) { const W t = acc.A.p[k] - leg; S.p[k] = (s6_junk_lo(ip, j) ? qsum_hi(t) : qsum2(t)) + M.A.p[k]; }
+            else S.p[k] = M.A.p[k] - (s6_junk_lo(ip, j) ? qsum_hi(leg) : qsum2(leg));
         }
     }
     // motor branch
     V cm = M.Cm;
 #pragma unroll
-    for (int i = 0; i < 6; i++) F.bm[i] = M.Bm[i];
+    for (int ip = 0; ip < 3; ip++) F.bm[ip] = M.Bm[ip];
     if (WITH_ACC) {
 #pragma unroll
-        for (int i = 0; i < 6; i++) F.bm[i] = F.bm[i] + quad_sum(acc.Bm[i]);
+        for (int ip = 0; ip < 3; ip++) F.bm[ip] = F.bm[ip] + qsum2(acc.Bm[ip]);
         cm = cm + quad_sum(acc.Cm);
     }
     F.cx0 = V(0); F.cx1 = V(0);
     if (WITH_ACC && PAIR) {
         F.cx0 = F.i11 * acc.X; F.cx1 = F.i12 * acc.X;
 #pragma unroll
-        for (int i = 0; i < 6; i++) F.bm[i] = F.bm[i] - quad_sum(F.B[i][0] * F.cx0 + F.B[i][1] * F.cx1);
+        for (int ip = 0; ip < 3; ip++) F.bm[ip] = F.bm[ip] - qsum2(F.B[ip][0] * W(F.cx0) + F.B[ip][1] * W(F.cx1));
         cm = cm - quad_sum(acc.X * F.cx0);
     }
     F.icm = vrcp(cm);
+    {
+        W gm[3];
 #pragma unroll
-    for (int i = 0; i < 6; i++) {
-        V g = F.bm[i] * F.icm;
+        for (int ip = 0; ip < 3; ip++) gm[ip] = F.bm[ip] * W(F.icm);
 #pragma unroll
-        for (int j = 0; j <= i; j++) S[tri(i, j)] = S[tri(i, j)] - g * F.bm[j];
+        for (int j = 0; j < 6; j++) {
+            const V bmj = v6get(F.bm, j);
+#pragma unroll
+            for (int ip = j / 2; ip < 3; ip++) S.p[s6p(ip, j)] = S.p[s6p(ip, j)] - gm[ip] * W(bmj);
+        }
     }
-    // Cholesky S = L L^T (in place, reciprocal pivots on the diagonal)
+    // Cholesky S = L L^T in place, right-looking: column j is finished (reciprocal pivot on the diagonal, the rest scaled), then taken off
+    // the columns to its right - pairs of rows times one element of column j.  Every element sees the subtractions of the left-looking form
+    // in the same order.
 #pragma unroll
     for (int j = 0; j < 6; j++) {
-        V t = S[tri(j, j)];
+        const int jp = j >> 1;
+        const V id = vrsqrt(s6get(S, j, j));
+        if ((j & 1) == 0) S.p[s6p(jp, j)] = W(id, pk_hi(S.p[s6p(jp, j)]) * id);
+        else S.p[s6p(jp, j)] = W(pk_lo(S.p[s6p(jp, j)]), id);
 #pragma unroll
-        for (int k = 0; k < j; k++) t = t - S[tri(j, k)] * S[tri(j, k)];
-        V id = vrsqrt(t);
-        S[tri(j, j)] = id;
+        for (int ip = jp + 1; ip < 3; ip++) S.p[s6p(ip, j)] = S.p[s6p(ip, j)] * W(id);
 #pragma unroll
-        for (int i = j + 1; i < 6; i++) {
-            V u = S[tri(i, j)];
+        for (int c = j + 1; c < 6; c++) {
+            const V lcj = s6get(S, c, j);
 #pragma unroll
-            for (int k = 0; k < j; k++) u = u - S[tri(i, k)] * S[tri(j, k)];
-            S[tri(i, j)] = u * id;
+            for (int ip = c / 2; ip < 3; ip++) S.p[s6p(ip, c)] = S.p[s6p(ip, c)] - S.p[s6p(ip, j)] * W(lcj);
         }
     }
 }
 // H y = rhs with the factorisation above.  rr: lane-private parts of the root rhs (summed over the quad), tr: replicated
 // root rhs (added once), rl0/rl1: own leg rhs, rmt: total motor rhs (replicated).
 template <typename V, bool PAIR = false>
-JB_HD void star_subst(const StarFactor<V>& F, const V (&rr)[6], const V (&tr)[6], const V& rl0, const V& rl1, const V& rmt_in, V (&yr)[6], V (&yl)[2], V& ym) {
-    const V (&S)[21] = F.S;
-    V r[6];
+JB_HD void star_subst(const StarFactor<V>& F, const Pk2<V> (&rr)[3], const Pk2<V> (&tr)[3], const V& rl0, const V& rl1, const V& rmt_in, Pk2<V> (&yr)[3], V (&yl)[2], V& ym) {
+    using W = Pk2<V>;
+    const Sym6P<V>& S = F.S;
+    W r[3];
     V rmt = rmt_in;
     if (PAIR) rmt = rmt_in - quad_sum(F.cx0 * rl0 + F.cx1 * rl1);
 #pragma unroll
-    for (int i = 0; i < 6; i++) {
-        V g0 = F.B[i][0] * F.i11 + F.B[i][1] * F.i12, g1 = F.B[i][0] * F.i12 + F.B[i][1] * F.i22;
-        r[i] = quad_sum(rr[i] - (g0 * rl0 + g1 * rl1)) + tr[i];
+    for (int ip = 0; ip < 3; ip++) {
+        const W g0 = F.B[ip][0] * W(F.i11) + F.B[ip][1] * W(F.i12), g1 = F.B[ip][0] * W(F.i12) + F.B[ip][1] * W(F.i22);
+        r[ip] = qsum2(rr[ip] - (g0 * W(rl0) + g1 * W(rl1))) + tr[ip];
     }
 #pragma unroll
-    for (int i = 0; i < 6; i++) {
-        V g = F.bm[i] * F.icm;
-        r[i] = r[i] - g * rmt;
-    }
+    for (int ip = 0; ip < 3; ip++) r[ip] = r[ip] - (F.bm[ip] * W(F.icm)) * W(rmt);
+    // L z = r, column by column: z_j leaves, and column j times z_j comes off the rows below (the pair that holds row j itself goes along:
+    // its slot is not read again)
+    V y[6];
 #pragma unroll
-    for (int i = 0; i < 6; i++) {
-        V t = r[i];
+    for (int j = 0; j < 6; j++) {
+        y[j] = v6get(r, j) * s6get(S, j, j);
 #pragma unroll
-        for (int k = 0; k < i; k++) t = t - S[tri(i, k)] * yr[k];
-        yr[i] = t * S[tri(i, i)];
+        for (int ip = (j + 1) / 2; ip < 3; ip++) r[ip] = r[ip] - S.p[s6p(ip, j)] * W(y[j]);
     }
+    // L^T y = z
 #pragma unroll
     for (int i = 5; i >= 0; i--) {
-        V t = yr[i];
+        V t = y[i];
 #pragma unroll
-        for (int k = i + 1; k < 6; k++) t = t - S[tri(k, i)] * yr[k];
-        yr[i] = t * S[tri(i, i)];
+        for (int k = i + 1; k < 6; k++) t = t - s6get(S, k, i) * y[k];
+        y[i] = t * s6get(S, i, i);
     }
-    // back-substitute the branches
-    V t0 = rl0, t1 = rl1, tmm = rmt;
 #pragma unroll
-    for (int i = 0; i < 6; i++) { t0 = t0 - F.B[i][0] * yr[i]; t1 = t1 - F.B[i][1] * yr[i]; tmm = tmm - F.bm[i] * yr[i]; }
+    for (int ip = 0; ip < 3; ip++) yr[ip] = W(y[2 * ip], y[2 * ip + 1]);
+    // back-substitute the branches
+    W u0 = F.B[0][0] * yr[0], u1 = F.B[0][1] * yr[0], um = F.bm[0] * yr[0];
+#pragma unroll
+    for (int ip = 1; ip < 3; ip++) { u0 = u0 + F.B[ip][0] * yr[ip]; u1 = u1 + F.B[ip][1] * yr[ip]; um = um + F.bm[ip] * yr[ip]; }
+    const V t0 = rl0 - (pk_lo(u0) + pk_hi(u0)), t1 = rl1 - (pk_lo(u1) + pk_hi(u1)), tmm = rmt - (pk_lo(um) + pk_hi(um));
     ym = tmm * F.icm;
     yl[0] = F.i11 * t0 + F.i12 * t1;
     yl[1] = F.i12 * t0 + F.i22 * t1;
@@ -618,7 +671,7 @@ JB_HD void star_subst(const StarFactor<V>& F, const V (&rr)[6], const V (&tr)[6]
 // The own leg (2x2) and the motor (1x1) are eliminated onto the 6 root dofs; the 6x6 Schur complement is
 // Cholesky-factored redundantly by the 4 lanes.
 template <typename V, bool PAIR = false>
-JB_HD void star_solve(const StarSys<V>& M, const NewtonAcc<V>& acc, const V& hb1, const V& hb2, StarFactor<V>& F, V (&yr)[6], V (&yl)[2], V& ym) {
+JB_HD void star_solve(const StarSys<V>& M, const NewtonAcc<V>& acc, const V& hb1, const V& hb2, StarFactor<V>& F, Pk2<V> (&yr)[3], V (&yl)[2], V& ym) {
     star_factor<V, true, PAIR>(M, acc, hb1, hb2, F);
     star_subst<V, PAIR>(F, acc.rr, M.tr, M.tl[0] + acc.rl[0], M.tl[1] + acc.rl[1], M.tm + quad_sum(acc.rm), yr, yl, ym);
 }
@@ -741,48 +794,103 @@ JB_HD void line_terms(const V& D, const V& mu, const V (&rho)[3], const V (&sg)[
     }
 }
 
+// A contact's three rows of B (normal, two tangents) as pairs of COLUMNS: (ang.x, ang.y) (ang.z, d.x) (d.y, d.z) (J_shoulder, J_7) - what the
+// packed accumulation below multiplies with single elements of W B.
+template <typename V> struct RowPairs { Pk2<V> b[3][4]; V ah[3]; };
+template <typename V, bool PAIR = false>
+JB_HD void row_pairs(const RowVals<V>& rv, const Vec3<V> (&dk)[3], const V& lin, const V (&jsh)[3], const V (&j7)[3], const V (&ah)[3], RowPairs<V>& R) {
+    using W = Pk2<V>;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const Vec3<V> ang = cross(rv.x, dk[k]);    // (recomputed from the position: 6 instructions against 3 LDS reads and 9 floats of row cache)
+        R.b[k][0] = W(ang.x, ang.y); R.b[k][1] = W(ang.z, dk[k].x); R.b[k][2] = W(dk[k].y, dk[k].z); R.b[k][3] = W(jsh[k], j7[k]);
+        if (PAIR) {
+#pragma unroll
+            for (int q = 0; q < 3; q++) R.b[k][q] = R.b[k][q] * W(lin);
+        }
+        R.ah[k] = ah[k];
+    }
+}
+// residuals rho_k = B_k y - ahat_k of the three rows at the iterate (root part as row pairs, then the two joint columns)
+template <typename V> JB_HD void row_residuals(const RowPairs<V>& R, const Pk2<V> (&yr)[3], const Pk2<V>& yj, V (&rho)[3]) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        Pk2<V> t = R.b[k][0] * yr[0];
+        t = t + R.b[k][1] * yr[1]; t = t + R.b[k][2] * yr[2]; t = t + R.b[k][3] * yj;
+        rho[k] = (pk_lo(t) - R.ah[k]) + pk_hi(t);
+    }
+}
+// W B for the active set (weights of the pyramid edges folded into a 3 x 3 weight matrix), column pairs like B
+template <typename V> struct WeightedRows { Pk2<V> wb[3][4]; V wa[3]; };
+template <typename V>
+JB_HD void weighted_rows(const RowPairs<V>& R, const V& D, const V& mu, const V& f1, const V& f2, const V& f3, const V& f4, WeightedRows<V>& Q) {
+    using W = Pk2<V>;
+    const V Wnn = D * (f1 + f2 + f3 + f4), Wn1 = D * mu * (f1 - f2), Wn2 = D * mu * (f3 - f4), W11 = D * mu * mu * (f1 + f2), W22 = D * mu * mu * (f3 + f4);
+    Q.wa[0] = Wnn * R.ah[0] + Wn1 * R.ah[1] + Wn2 * R.ah[2];
+    Q.wa[1] = Wn1 * R.ah[0] + W11 * R.ah[1];
+    Q.wa[2] = Wn2 * R.ah[0] + W22 * R.ah[2];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        Q.wb[0][q] = W(Wnn) * R.b[0][q] + W(Wn1) * R.b[1][q] + W(Wn2) * R.b[2][q];
+        Q.wb[1][q] = W(Wn1) * R.b[0][q] + W(W11) * R.b[1][q];
+        Q.wb[2][q] = W(Wn2) * R.b[0][q] + W(W22) * R.b[2][q];
+    }
+}
+// element c (a column of B, 0-7) of row k
+template <typename V> JB_HD V wb_get(const WeightedRows<V>& Q, int k, int c) { return pk_half(Q.wb[k][c >> 1], c & 1); }
+template <typename V> JB_HD V rb_get(const RowPairs<V>& R, int k, int c) { return pk_half(R.b[k][c >> 1], c & 1); }
+// the root block's share  A += B^T W B,  rr += B^T W ahat : pairs of rows of B^T (= column pairs of B) times single elements of W B
+template <typename V> JB_HD void acc_root(const RowPairs<V>& R, const WeightedRows<V>& Q, NewtonAcc<V>& acc) {
+    using W = Pk2<V>;
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        const W w0 = W(wb_get(Q, 0, j)), w1 = W(wb_get(Q, 1, j)), w2 = W(wb_get(Q, 2, j));
+#pragma unroll
+        for (int ip = j / 2; ip < 3; ip++) acc.A.p[s6p(ip, j)] = fma3(acc.A.p[s6p(ip, j)], R.b[0][ip], w0, R.b[1][ip], w1, R.b[2][ip], w2);
+    }
+#pragma unroll
+    for (int ip = 0; ip < 3; ip++) acc.rr[ip] = fma3(acc.rr[ip], R.b[0][ip], W(Q.wa[0]), R.b[1][ip], W(Q.wa[1]), R.b[2][ip], W(Q.wa[2]));
+}
+// init + sum_k B_k[c] (W B)_k[row pair ip]: what column c of B adds to a coupling block's row pair (and to a single element, to a right-hand side)
+template <typename V> JB_HD Pk2<V> col_times_wb(const RowPairs<V>& R, const WeightedRows<V>& Q, int c, int ip, const Pk2<V>& init) {
+    using W = Pk2<V>;
+    return fma3(init, W(rb_get(R, 0, c)), Q.wb[0][ip], W(rb_get(R, 1, c)), Q.wb[1][ip], W(rb_get(R, 2, c)), Q.wb[2][ip]);
+}
+template <typename V> JB_HD V col_times_col(const RowPairs<V>& R, const WeightedRows<V>& Q, int c, int d, const V& init) {
+    return fma3(init, rb_get(R, 0, c), wb_get(Q, 0, d), rb_get(R, 1, c), wb_get(Q, 1, d), rb_get(R, 2, c), wb_get(Q, 2, d));
+}
+template <typename V> JB_HD V col_times_wa(const RowPairs<V>& R, const WeightedRows<V>& Q, int c, const V& init) {
+    return fma3(init, rb_get(R, 0, c), Q.wa[0], rb_get(R, 1, c), Q.wa[1], rb_get(R, 2, c), Q.wa[2]);
+}
+
 // One cached contact against the iterate y.  mode 0: accumulate the Newton matrix / rhs terms for the active set at y;
 // mode 2: only record the active set (the cheap convergence check); mode 3 (LS instantiations only): the contact's share of the
 // line search's phi' and phi'' at y + ld->alpha * (ld's direction).
 template <typename V, bool PAIR = false, bool LS = false>
 JB_HD void contact_apply(const RowVals<V>& rv, const Vec3<V> (&dk)[3], const V& mu, int slot, bool lane_on, int mode,
-                         const V (&yr)[6], const V (&yl)[2], const V& ym, NewtonAcc<V>& acc, const LineDir<V>* ld = nullptr) {
+                         const Pk2<V> (&yr)[3], const V (&yl)[2], const V& ym, NewtonAcc<V>& acc, const LineDir<V>* ld = nullptr) {
     using U = typename lane_traits<V>::uint;
+    using W = Pk2<V>;
     const int level = slot_level(slot);
     const bool is_pair = PAIR && level == 4;
     const bool has_sh = (level == 1 || level == 2 || is_pair), has_kn = (level == 2), has_m = (level == 3 || is_pair);
     const V lin = V(is_pair ? 0.0f : 1.0f);        // the pair contact has no root columns (the cached angular part is zero, the shared linear part is masked)
-    V Bj[3][8], rho[3], ahat[3];
+    V rho[3];
     const V D = lane_on ? rv.D : V(0);             // a lane without a slot in this round contributes nothing
     const V y7 = has_kn ? yl[1] : ym;              // levels 0/1 have a zero column 7
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-        const Vec3<V> ang = cross(rv.x, dk[k]);    // (recomputed from the position: 6 instructions against 3 LDS reads and 9 floats of row cache)
-        Bj[k][0] = ang.x; Bj[k][1] = ang.y; Bj[k][2] = ang.z;
-        Bj[k][3] = dk[k].x; Bj[k][4] = dk[k].y; Bj[k][5] = dk[k].z;
-        if (PAIR) {
-#pragma unroll
-            for (int i = 0; i < 6; i++) Bj[k][i] = Bj[k][i] * lin;
-        }
-        Bj[k][6] = rv.jsh[k]; Bj[k][7] = rv.j7[k]; ahat[k] = rv.ah[k];
-    }
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-        V t = Bj[k][0] * yr[0] - ahat[k];
-        t = t + Bj[k][1] * yr[1]; t = t + Bj[k][2] * yr[2]; t = t + Bj[k][3] * yr[3]; t = t + Bj[k][4] * yr[4]; t = t + Bj[k][5] * yr[5];
-        t = t + Bj[k][6] * yl[0];
-        rho[k] = t + Bj[k][7] * y7;
-    }
+    RowPairs<V> R;
+    row_pairs<V, PAIR>(rv, dk, lin, rv.jsh, rv.j7, rv.ah, R);
+    row_residuals<V>(R, yr, W(yl[0], y7), rho);
     const auto valid = gt(D, V(0));
     if (LS && mode == 3) {
         const V d7 = has_kn ? ld->dl[1] : ld->dm;
+        const W dq[3] = {W(ld->dr[0], ld->dr[1]), W(ld->dr[2], ld->dr[3]), W(ld->dr[4], ld->dr[5])};
         V sg[3];
 #pragma unroll
         for (int k = 0; k < 3; k++) {
-            V t = Bj[k][0] * ld->dr[0];
-            t = t + Bj[k][1] * ld->dr[1]; t = t + Bj[k][2] * ld->dr[2]; t = t + Bj[k][3] * ld->dr[3]; t = t + Bj[k][4] * ld->dr[4]; t = t + Bj[k][5] * ld->dr[5];
-            t = t + Bj[k][6] * ld->dl[0];
-            sg[k] = t + Bj[k][7] * d7;
+            W t = R.b[k][0] * dq[0];
+            t = t + R.b[k][1] * dq[1]; t = t + R.b[k][2] * dq[2]; t = t + R.b[k][3] * W(ld->dl[0], d7);
+            sg[k] = pk_lo(t) + pk_hi(t);
         }
         line_terms<V>(D, mu, rho, sg, ld->alpha, acc);
         return;
@@ -803,44 +911,28 @@ JB_HD void contact_apply(const RowVals<V>& rv, const Vec3<V> (&dk)[3], const V& 
     }
     if (mode == 2) return;
     V f1 = sel(a1, V(1), V(0)), f2 = sel(a2, V(1), V(0)), f3 = sel(a3, V(1), V(0)), f4 = sel(a4, V(1), V(0));
-    V Wnn = D * (f1 + f2 + f3 + f4), Wn1 = D * mu * (f1 - f2), Wn2 = D * mu * (f3 - f4), W11 = D * mu * mu * (f1 + f2), W22 = D * mu * mu * (f3 + f4);
-    {
-        V wa0 = Wnn * ahat[0] + Wn1 * ahat[1] + Wn2 * ahat[2];
-        V wa1 = Wn1 * ahat[0] + W11 * ahat[1];
-        V wa2 = Wn2 * ahat[0] + W22 * ahat[2];
-        V WB[3][8];
+    WeightedRows<V> Q;
+    weighted_rows<V>(R, D, mu, f1, f2, f3, f4, Q);
+    acc_root<V>(R, Q, acc);
+    if (has_sh) {
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            WB[0][i] = Wnn * Bj[0][i] + Wn1 * Bj[1][i] + Wn2 * Bj[2][i];
-            WB[1][i] = Wn1 * Bj[0][i] + W11 * Bj[1][i];
-            WB[2][i] = Wn2 * Bj[0][i] + W22 * Bj[2][i];
-        }
+        for (int ip = 0; ip < 3; ip++) acc.B[ip][0] = col_times_wb<V>(R, Q, 6, ip, acc.B[ip][0]);
+        acc.C11 = col_times_col<V>(R, Q, 6, 6, acc.C11);
+        acc.rl[0] = col_times_wa<V>(R, Q, 6, acc.rl[0]);
+    }
+    if (has_kn) {
 #pragma unroll
-        for (int i = 0; i < 6; i++) {
+        for (int ip = 0; ip < 3; ip++) acc.B[ip][1] = col_times_wb<V>(R, Q, 7, ip, acc.B[ip][1]);
+        acc.C12 = col_times_col<V>(R, Q, 6, 7, acc.C12);
+        acc.C22 = col_times_col<V>(R, Q, 7, 7, acc.C22);
+        acc.rl[1] = col_times_wa<V>(R, Q, 7, acc.rl[1]);
+    }
+    if (is_pair) acc.X = col_times_col<V>(R, Q, 6, 7, acc.X);
+    if (has_m) {
 #pragma unroll
-            for (int j = 0; j <= i; j++) acc.A[tri(i, j)] = fma3(acc.A[tri(i, j)], Bj[0][i], WB[0][j], Bj[1][i], WB[1][j], Bj[2][i], WB[2][j]);
-            acc.rr[i] = fma3(acc.rr[i], Bj[0][i], wa0, Bj[1][i], wa1, Bj[2][i], wa2);
-        }
-        if (has_sh) {
-#pragma unroll
-            for (int i = 0; i < 6; i++) acc.B[i][0] = fma3(acc.B[i][0], Bj[0][6], WB[0][i], Bj[1][6], WB[1][i], Bj[2][6], WB[2][i]);
-            acc.C11 = fma3(acc.C11, Bj[0][6], WB[0][6], Bj[1][6], WB[1][6], Bj[2][6], WB[2][6]);
-            acc.rl[0] = fma3(acc.rl[0], Bj[0][6], wa0, Bj[1][6], wa1, Bj[2][6], wa2);
-        }
-        if (has_kn) {
-#pragma unroll
-            for (int i = 0; i < 6; i++) acc.B[i][1] = fma3(acc.B[i][1], Bj[0][7], WB[0][i], Bj[1][7], WB[1][i], Bj[2][7], WB[2][i]);
-            acc.C12 = fma3(acc.C12, Bj[0][6], WB[0][7], Bj[1][6], WB[1][7], Bj[2][6], WB[2][7]);
-            acc.C22 = fma3(acc.C22, Bj[0][7], WB[0][7], Bj[1][7], WB[1][7], Bj[2][7], WB[2][7]);
-            acc.rl[1] = fma3(acc.rl[1], Bj[0][7], wa0, Bj[1][7], wa1, Bj[2][7], wa2);
-        }
-        if (is_pair) acc.X = fma3(acc.X, Bj[0][6], WB[0][7], Bj[1][6], WB[1][7], Bj[2][6], WB[2][7]);
-        if (has_m) {
-#pragma unroll
-            for (int i = 0; i < 6; i++) acc.Bm[i] = fma3(acc.Bm[i], Bj[0][7], WB[0][i], Bj[1][7], WB[1][i], Bj[2][7], WB[2][i]);
-            acc.Cm = fma3(acc.Cm, Bj[0][7], WB[0][7], Bj[1][7], WB[1][7], Bj[2][7], WB[2][7]);
-            acc.rm = fma3(acc.rm, Bj[0][7], wa0, Bj[1][7], wa1, Bj[2][7], wa2);
-        }
+        for (int ip = 0; ip < 3; ip++) acc.Bm[ip] = col_times_wb<V>(R, Q, 7, ip, acc.Bm[ip]);
+        acc.Cm = col_times_col<V>(R, Q, 7, 7, acc.Cm);
+        acc.rm = col_times_wa<V>(R, Q, 7, acc.rm);
     }
 }
 
@@ -920,36 +1012,31 @@ template <typename V> JB_HD typename lane_traits<V>::uint quad_seg_sum_u(const t
 // of the iterate of leg it.src.
 template <typename V, bool LS = false>
 JB_HD void contact_apply_leg(const RowVals<V>& rv, const Vec3<V> (&dk)[3], const V& mu, const SpreadItem<V>& it, int mode,
-                             const V (&yr)[6], const V (&yl)[2], NewtonAcc<V>& acc, const LineDir<V>* ld = nullptr, const V* dls = nullptr) {
+                             const Pk2<V> (&yr)[3], const V (&yl)[2], NewtonAcc<V>& acc, const LineDir<V>* ld = nullptr, const V* dls = nullptr) {
     using U = typename lane_traits<V>::uint;
     using MK = typename lane_traits<V>::mask;
-    V Bj[3][8], rho[3], ahat[3];
+    using W = Pk2<V>;
+    V rho[3];
     const V D = sel(it.valid, rv.D, V(0));
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-        const Vec3<V> ang = cross(rv.x, dk[k]);
-        Bj[k][0] = ang.x; Bj[k][1] = ang.y; Bj[k][2] = ang.z;
-        Bj[k][3] = dk[k].x; Bj[k][4] = dk[k].y; Bj[k][5] = dk[k].z;
+    RowPairs<V> R;
+    {
         // (a lane without a contact this round reads the first live slot's entry of its own leg: position and distance are there, the
         //  rest of a row is only built for contacts - selects, not a zero weight, keep whatever the entry holds out of the sums)
-        Bj[k][6] = sel(it.valid, rv.jsh[k], V(0)); Bj[k][7] = sel(it.valid, rv.j7[k], V(0)); ahat[k] = sel(it.valid, rv.ah[k], V(0));
-    }
+        V jsh[3], j7[3], ah[3];
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
-        V t = Bj[k][0] * yr[0] - ahat[k];
-        t = t + Bj[k][1] * yr[1]; t = t + Bj[k][2] * yr[2]; t = t + Bj[k][3] * yr[3]; t = t + Bj[k][4] * yr[4]; t = t + Bj[k][5] * yr[5];
-        t = t + Bj[k][6] * yl[0];
-        rho[k] = t + Bj[k][7] * yl[1];
+        for (int k = 0; k < 3; k++) { jsh[k] = sel(it.valid, rv.jsh[k], V(0)); j7[k] = sel(it.valid, rv.j7[k], V(0)); ah[k] = sel(it.valid, rv.ah[k], V(0)); }
+        row_pairs<V, false>(rv, dk, V(1), jsh, j7, ah, R);
     }
+    row_residuals<V>(R, yr, W(yl[0], yl[1]), rho);
     const MK valid = gt(D, V(0));
     if (LS && mode == 3) {      // line search (see contact_apply); dls: the joint part of the direction for leg it.src
+        const W dq[3] = {W(ld->dr[0], ld->dr[1]), W(ld->dr[2], ld->dr[3]), W(ld->dr[4], ld->dr[5])};
         V sg[3];
 #pragma unroll
         for (int k = 0; k < 3; k++) {
-            V t = Bj[k][0] * ld->dr[0];
-            t = t + Bj[k][1] * ld->dr[1]; t = t + Bj[k][2] * ld->dr[2]; t = t + Bj[k][3] * ld->dr[3]; t = t + Bj[k][4] * ld->dr[4]; t = t + Bj[k][5] * ld->dr[5];
-            t = t + Bj[k][6] * dls[0];
-            sg[k] = t + Bj[k][7] * dls[1];
+            W t = R.b[k][0] * dq[0];
+            t = t + R.b[k][1] * dq[1]; t = t + R.b[k][2] * dq[2]; t = t + R.b[k][3] * W(dls[0], dls[1]);
+            sg[k] = pk_lo(t) + pk_hi(t);
         }
         line_terms<V>(D, mu, rho, sg, ld->alpha, acc);
         return;
@@ -969,36 +1056,23 @@ JB_HD void contact_apply_leg(const RowVals<V>& rv, const Vec3<V> (&dk)[3], const
     }
     if (mode == 2) return;
     V f1 = sel(a1, V(1), V(0)), f2 = sel(a2, V(1), V(0)), f3 = sel(a3, V(1), V(0)), f4 = sel(a4, V(1), V(0));
-    V Wnn = D * (f1 + f2 + f3 + f4), Wn1 = D * mu * (f1 - f2), Wn2 = D * mu * (f3 - f4), W11 = D * mu * mu * (f1 + f2), W22 = D * mu * mu * (f3 + f4);
-    V wa0 = Wnn * ahat[0] + Wn1 * ahat[1] + Wn2 * ahat[2];
-    V wa1 = Wn1 * ahat[0] + W11 * ahat[1];
-    V wa2 = Wn2 * ahat[0] + W22 * ahat[2];
-    V WB[3][8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        WB[0][i] = Wnn * Bj[0][i] + Wn1 * Bj[1][i] + Wn2 * Bj[2][i];
-        WB[1][i] = Wn1 * Bj[0][i] + W11 * Bj[1][i];
-        WB[2][i] = Wn2 * Bj[0][i] + W22 * Bj[2][i];
-    }
-#pragma unroll
-    for (int i = 0; i < 6; i++) {
-#pragma unroll
-        for (int j = 0; j <= i; j++) acc.A[tri(i, j)] = fma3(acc.A[tri(i, j)], Bj[0][i], WB[0][j], Bj[1][i], WB[1][j], Bj[2][i], WB[2][j]);
-        acc.rr[i] = fma3(acc.rr[i], Bj[0][i], wa0, Bj[1][i], wa1, Bj[2][i], wa2);
-    }
+    WeightedRows<V> Q;
+    weighted_rows<V>(R, D, mu, f1, f2, f3, f4, Q);
+    acc_root<V>(R, Q, acc);
     // the leg block of leg it.src: computed here, added in the lane of that leg
     const V m0 = sel(k0, V(1), V(0)), m1 = sel(k1, V(1), V(0)), m2 = sel(k2, V(1), V(0)), m3 = sel(k3, V(1), V(0));
     const V Z = V(0);
+    auto seg2 = [&](const W& t) { return W(quad_seg_sum(pk_lo(t), m0, m1, m2, m3), quad_seg_sum(pk_hi(t), m0, m1, m2, m3)); };
 #pragma unroll
-    for (int i = 0; i < 6; i++) {
-        acc.B[i][0] = acc.B[i][0] + quad_seg_sum(fma3(Z, Bj[0][6], WB[0][i], Bj[1][6], WB[1][i], Bj[2][6], WB[2][i]), m0, m1, m2, m3);
-        acc.B[i][1] = acc.B[i][1] + quad_seg_sum(fma3(Z, Bj[0][7], WB[0][i], Bj[1][7], WB[1][i], Bj[2][7], WB[2][i]), m0, m1, m2, m3);
+    for (int ip = 0; ip < 3; ip++) {
+        acc.B[ip][0] = acc.B[ip][0] + seg2(col_times_wb<V>(R, Q, 6, ip, W(0)));
+        acc.B[ip][1] = acc.B[ip][1] + seg2(col_times_wb<V>(R, Q, 7, ip, W(0)));
     }
-    acc.C11 = acc.C11 + quad_seg_sum(fma3(Z, Bj[0][6], WB[0][6], Bj[1][6], WB[1][6], Bj[2][6], WB[2][6]), m0, m1, m2, m3);
-    acc.C12 = acc.C12 + quad_seg_sum(fma3(Z, Bj[0][6], WB[0][7], Bj[1][6], WB[1][7], Bj[2][6], WB[2][7]), m0, m1, m2, m3);
-    acc.C22 = acc.C22 + quad_seg_sum(fma3(Z, Bj[0][7], WB[0][7], Bj[1][7], WB[1][7], Bj[2][7], WB[2][7]), m0, m1, m2, m3);
-    acc.rl[0] = acc.rl[0] + quad_seg_sum(fma3(Z, Bj[0][6], wa0, Bj[1][6], wa1, Bj[2][6], wa2), m0, m1, m2, m3);
-    acc.rl[1] = acc.rl[1] + quad_seg_sum(fma3(Z, Bj[0][7], wa0, Bj[1][7], wa1, Bj[2][7], wa2), m0, m1, m2, m3);
+    acc.C11 = acc.C11 + quad_seg_sum(col_times_col<V>(R, Q, 6, 6, Z), m0, m1, m2, m3);
+    acc.C12 = acc.C12 + quad_seg_sum(col_times_col<V>(R, Q, 6, 7, Z), m0, m1, m2, m3);
+    acc.C22 = acc.C22 + quad_seg_sum(col_times_col<V>(R, Q, 7, 7, Z), m0, m1, m2, m3);
+    acc.rl[0] = acc.rl[0] + quad_seg_sum(col_times_wa<V>(R, Q, 6, Z), m0, m1, m2, m3);
+    acc.rl[1] = acc.rl[1] + quad_seg_sum(col_times_wa<V>(R, Q, 7, Z), m0, m1, m2, m3);
 }
 
 // Rank-one Newton pass.  The active set at y differs from the factored one by ONE pyramid edge e of one cached contact of
@@ -1012,8 +1086,9 @@ template <typename V, bool PAIR = false>
 JB_HD void rank_one_pass(const LaneScratch<V>& sc, const StarFactor<V>& F, const Vec3<V> (&dk)[3], const V& mu,
                          const typename lane_traits<V>::uint& entry, const typename lane_traits<V>::mask& is_flip, const typename lane_traits<V>::mask& plus,
                          const typename lane_traits<V>::mask& tan2, const typename lane_traits<V>::mask& on,
-                         const V (&yr)[6], const V (&yl)[2], const V& ym, V (&nyr)[6], V (&nyl)[2], V& nym) {
+                         const Pk2<V> (&yr)[3], const V (&yl)[2], const V& ym, Pk2<V> (&nyr)[3], V (&nyl)[2], V& nym) {
     using U = typename lane_traits<V>::uint;
+    using W = Pk2<V>;
     const U e0 = entry * (unsigned)ROW_F + (unsigned)SC_ROWS;
     const V sg = sel(plus, mu, -mu);                    // e = B_n + sg * B_t
     V e[8];
@@ -1028,18 +1103,20 @@ JB_HD void rank_one_pass(const LaneScratch<V>& sc, const StarFactor<V>& F, const
     const V sD = sel(is_flip, sel(on, sc.ldv(e0 + 3u), -sc.ldv(e0 + 3u)), V(0));
 #pragma unroll
     for (int i = 0; i < 8; i++) e[i] = sel(is_flip, e[i], V(0));
-    V rr[6], zero6[6], zr[6], zl[2], zm;
+    W ep[3], zero3[3], zr[3];
+    V zl[2], zm;
 #pragma unroll
-    for (int i = 0; i < 6; i++) { rr[i] = e[i]; zero6[i] = V(0); }
-    star_subst<V, PAIR>(F, rr, zero6, e[6], e[7], V(0), zr, zl, zm);
-    V ety = e[6] * yl[0] + e[7] * yl[1], etz = e[6] * zl[0] + e[7] * zl[1];
+    for (int ip = 0; ip < 3; ip++) { ep[ip] = W(e[2 * ip], e[2 * ip + 1]); zero3[ip] = W(0); }
+    star_subst<V, PAIR>(F, ep, zero3, e[6], e[7], V(0), zr, zl, zm);
+    W ty = ep[0] * yr[0], tz = ep[0] * zr[0];
 #pragma unroll
-    for (int i = 0; i < 6; i++) { ety = ety + e[i] * yr[i]; etz = etz + e[i] * zr[i]; }
+    for (int ip = 1; ip < 3; ip++) { ty = ty + ep[ip] * yr[ip]; tz = tz + ep[ip] * zr[ip]; }
+    const V ety = (e[6] * yl[0] + e[7] * yl[1]) + (pk_lo(ty) + pk_hi(ty)), etz = (e[6] * zl[0] + e[7] * zl[1]) + (pk_lo(tz) + pk_hi(tz));
     // (selects, not products with a zero weight: a lane without the flip may hold anything in these temporaries)
     const V num = quad_sum(sel(is_flip, sD * (ah - ety), V(0))), den = V(1) + quad_sum(sel(is_flip, sD * etz, V(0)));
     const V c = num * vrcp(den);
 #pragma unroll
-    for (int i = 0; i < 6; i++) nyr[i] = yr[i] + c * zr[i];
+    for (int ip = 0; ip < 3; ip++) nyr[ip] = yr[ip] + W(c) * zr[ip];
     nyl[0] = yl[0] + c * zl[0]; nyl[1] = yl[1] + c * zl[1]; nym = ym + c * zm;
 }
 
@@ -1217,9 +1294,10 @@ JB_HD int contact_sweep(const LaneModel<V>& m, const LaneScratch<V>& sc, bool xt
         ldir.dl[0] = sc.ld(box + 6); ldir.dl[1] = sc.ld(box + 7); ldir.dm = sc.ld(box + 8); ldir.alpha = sc.ld(box + 9);
     }
     const V mu = m.c[LM_MU];
-    V yr[6], yl[2], ym;
+    Pk2<V> yr[3];
+    V yl[2], ym;
 #pragma unroll
-    for (int i = 0; i < 6; i++) yr[i] = sc.ld(SC_Y + i);
+    for (int ip = 0; ip < 3; ip++) yr[ip] = Pk2<V>(sc.ld(SC_Y + 2 * ip), sc.ld(SC_Y + 2 * ip + 1));
     yl[0] = sc.ld(SC_Y + 6); yl[1] = sc.ld(SC_Y + 7); ym = sc.ld(SC_Y + 8);
     const int g = plan.grouped ? sc.grp : 0;
     unsigned rest_mine = plan.mine;
@@ -1294,12 +1372,11 @@ JB_HD int contact_sweep(const LaneModel<V>& m, const LaneScratch<V>& sc, bool xt
                 if (PAIR) acc.X = v[52];
             }
         } else if (mode == 0) {
+            V v[52];
+            acc_pack(acc, v);
 #pragma unroll
-            for (int i = 0; i < 21; i++) acc.A[i] = group_sum(sc, acc.A[i]);
-#pragma unroll
-            for (int i = 0; i < 6; i++) { acc.B[i][0] = group_sum(sc, acc.B[i][0]); acc.B[i][1] = group_sum(sc, acc.B[i][1]); acc.Bm[i] = group_sum(sc, acc.Bm[i]); acc.rr[i] = group_sum(sc, acc.rr[i]); }
-            acc.C11 = group_sum(sc, acc.C11); acc.C12 = group_sum(sc, acc.C12); acc.C22 = group_sum(sc, acc.C22); acc.Cm = group_sum(sc, acc.Cm);
-            acc.rl[0] = group_sum(sc, acc.rl[0]); acc.rl[1] = group_sum(sc, acc.rl[1]); acc.rm = group_sum(sc, acc.rm);
+            for (int i = 0; i < 52; i++) v[i] = group_sum(sc, v[i]);
+            acc_unpack(v, acc);
             if (PAIR) acc.X = group_sum(sc, acc.X);
             if (g1z) acc_clear(acc);
         }
@@ -1647,24 +1724,35 @@ template <typename V> inline void stats_hist(const SimOpts&, const LaneScratch<V
 // ---- LEAN variant: park / fetch long-lived values in the lane's scratch (lane-private columns: no hand-over between lanes)
 // (the root block [[J, [h]x], [[h]x^T, m 1]] is parked as its 10 distinct values: J (6), h (3), m)
 template <typename V> JB_HD void sys_store(const LaneScratch<V>& sc, const StarSys<V>& y) {
-    sc.st(SC_SYS + 0, y.A[tri(0, 0)]); sc.st(SC_SYS + 1, y.A[tri(1, 0)]); sc.st(SC_SYS + 2, y.A[tri(1, 1)]);
-    sc.st(SC_SYS + 3, y.A[tri(2, 0)]); sc.st(SC_SYS + 4, y.A[tri(2, 1)]); sc.st(SC_SYS + 5, y.A[tri(2, 2)]);
-    sc.st(SC_SYS + 6, y.A[tri(4, 2)]) /*hx*/; sc.st(SC_SYS + 7, y.A[tri(5, 0)]) /*hy*/; sc.st(SC_SYS + 8, y.A[tri(3, 1)]) /*hz*/; sc.st(SC_SYS + 9, y.A[tri(3, 3)]) /*m*/;
+    sc.st(SC_SYS + 0, s6get(y.A, 0, 0)); sc.st(SC_SYS + 1, s6get(y.A, 1, 0)); sc.st(SC_SYS + 2, s6get(y.A, 1, 1));
+    sc.st(SC_SYS + 3, s6get(y.A, 2, 0)); sc.st(SC_SYS + 4, s6get(y.A, 2, 1)); sc.st(SC_SYS + 5, s6get(y.A, 2, 2));
+    sc.st(SC_SYS + 6, s6get(y.A, 4, 2)) /*hx*/; sc.st(SC_SYS + 7, s6get(y.A, 5, 0)) /*hy*/; sc.st(SC_SYS + 8, s6get(y.A, 3, 1)) /*hz*/; sc.st(SC_SYS + 9, s6get(y.A, 3, 3)) /*m*/;
 #pragma unroll
-    for (int i = 0; i < 6; i++) { sc.st(SC_SYS + 10 + 2 * i, y.B[i][0]); sc.st(SC_SYS + 11 + 2 * i, y.B[i][1]); sc.st(SC_SYS + 25 + i, y.Bm[i]); sc.st(SC_SYS + 32 + i, y.tr[i]); }
+    for (int i = 0; i < 6; i++) { sc.st(SC_SYS + 10 + 2 * i, b6get(y.B, i, 0)); sc.st(SC_SYS + 11 + 2 * i, b6get(y.B, i, 1)); sc.st(SC_SYS + 25 + i, v6get(y.Bm, i)); sc.st(SC_SYS + 32 + i, v6get(y.tr, i)); }
     sc.st(SC_SYS + 22, y.C[0]); sc.st(SC_SYS + 23, y.C[1]); sc.st(SC_SYS + 24, y.C[2]); sc.st(SC_SYS + 31, y.Cm);
     sc.st(SC_SYS + 38, y.tl[0]); sc.st(SC_SYS + 39, y.tl[1]); sc.st(SC_SYS + 40, y.tm);
 }
+// the root block [[J, [h]x], [[h]x^T, m 1]] with [h]x = [[0,-hz,hy],[hz,0,-hx],[-hy,hx,0]] from its 10 distinct values, as column pairs
+template <typename V> JB_HD void root_block(const Sym3<V>& J, const Vec3<V>& h, const V& mt, Sym6P<V>& A) {
+    using W = Pk2<V>;
+    const V Z = V(0);
+    A.p[s6p(0, 0)] = W(J.xx, J.xy); A.p[s6p(1, 0)] = W(J.xz, Z);    A.p[s6p(2, 0)] = W(-h.z, h.y);
+    A.p[s6p(0, 1)] = W(J.xy, J.yy); A.p[s6p(1, 1)] = W(J.yz, h.z);  A.p[s6p(2, 1)] = W(Z, -h.x);
+    A.p[s6p(1, 2)] = W(J.zz, -h.y); A.p[s6p(2, 2)] = W(h.x, Z);
+    A.p[s6p(1, 3)] = W(-h.y, mt);   A.p[s6p(2, 3)] = W(Z, Z);
+    A.p[s6p(2, 4)] = W(mt, Z);
+    A.p[s6p(2, 5)] = W(Z, mt);
+}
 template <typename V> JB_HD void sys_load(const LaneScratch<V>& sc, StarSys<V>& y) {
-    const V Z = V(0), hx = sc.ld(SC_SYS + 6), hy = sc.ld(SC_SYS + 7), hz = sc.ld(SC_SYS + 8), mt = sc.ld(SC_SYS + 9);
-    y.A[tri(0, 0)] = sc.ld(SC_SYS + 0); y.A[tri(1, 0)] = sc.ld(SC_SYS + 1); y.A[tri(1, 1)] = sc.ld(SC_SYS + 2);
-    y.A[tri(2, 0)] = sc.ld(SC_SYS + 3); y.A[tri(2, 1)] = sc.ld(SC_SYS + 4); y.A[tri(2, 2)] = sc.ld(SC_SYS + 5);
-    y.A[tri(3, 0)] = Z;   y.A[tri(3, 1)] = hz;  y.A[tri(3, 2)] = -hy;
-    y.A[tri(4, 0)] = -hz; y.A[tri(4, 1)] = Z;   y.A[tri(4, 2)] = hx;
-    y.A[tri(5, 0)] = hy;  y.A[tri(5, 1)] = -hx; y.A[tri(5, 2)] = Z;
-    y.A[tri(3, 3)] = mt; y.A[tri(4, 3)] = Z; y.A[tri(4, 4)] = mt; y.A[tri(5, 3)] = Z; y.A[tri(5, 4)] = Z; y.A[tri(5, 5)] = mt;
+    using W = Pk2<V>;
+    Sym3<V> J;
+    J.xx = sc.ld(SC_SYS + 0); J.xy = sc.ld(SC_SYS + 1); J.yy = sc.ld(SC_SYS + 2); J.xz = sc.ld(SC_SYS + 3); J.yz = sc.ld(SC_SYS + 4); J.zz = sc.ld(SC_SYS + 5);
+    root_block<V>(J, v3<V>(sc.ld(SC_SYS + 6), sc.ld(SC_SYS + 7), sc.ld(SC_SYS + 8)), sc.ld(SC_SYS + 9), y.A);
 #pragma unroll
-    for (int i = 0; i < 6; i++) { y.B[i][0] = sc.ld(SC_SYS + 10 + 2 * i); y.B[i][1] = sc.ld(SC_SYS + 11 + 2 * i); y.Bm[i] = sc.ld(SC_SYS + 25 + i); y.tr[i] = sc.ld(SC_SYS + 32 + i); }
+    for (int ip = 0; ip < 3; ip++) {
+        y.B[ip][0] = W(sc.ld(SC_SYS + 10 + 4 * ip), sc.ld(SC_SYS + 12 + 4 * ip)); y.B[ip][1] = W(sc.ld(SC_SYS + 11 + 4 * ip), sc.ld(SC_SYS + 13 + 4 * ip));
+        y.Bm[ip] = W(sc.ld(SC_SYS + 25 + 2 * ip), sc.ld(SC_SYS + 26 + 2 * ip)); y.tr[ip] = W(sc.ld(SC_SYS + 32 + 2 * ip), sc.ld(SC_SYS + 33 + 2 * ip));
+    }
     y.C[0] = sc.ld(SC_SYS + 22); y.C[1] = sc.ld(SC_SYS + 23); y.C[2] = sc.ld(SC_SYS + 24); y.Cm = sc.ld(SC_SYS + 31);
     y.tl[0] = sc.ld(SC_SYS + 38); y.tl[1] = sc.ld(SC_SYS + 39); y.tm = sc.ld(SC_SYS + 40);
 }
@@ -1672,16 +1760,24 @@ template <typename V> JB_HD void fac_store_cx(const LaneScratch<V>& sc, const St
 template <typename V> JB_HD void fac_load_cx(const LaneScratch<V>& sc, StarFactor<V>& F) { F.cx0 = sc.ld(SC_CX_LEAN); F.cx1 = sc.ld(SC_CX_LEAN + 1); }
 template <typename V> JB_HD void fac_store(const LaneScratch<V>& sc, const StarFactor<V>& F) {
 #pragma unroll
-    for (int i = 0; i < 21; i++) sc.st(SC_FAC + i, F.S[i]);
+    for (int i = 0; i < 6; i++)
 #pragma unroll
-    for (int i = 0; i < 6; i++) { sc.st(SC_FAC + 21 + 2 * i, F.B[i][0]); sc.st(SC_FAC + 22 + 2 * i, F.B[i][1]); sc.st(SC_FAC + 36 + i, F.bm[i]); }
+        for (int j = 0; j <= i; j++) sc.st(SC_FAC + tri(i, j), s6get(F.S, i, j));
+#pragma unroll
+    for (int i = 0; i < 6; i++) { sc.st(SC_FAC + 21 + 2 * i, b6get(F.B, i, 0)); sc.st(SC_FAC + 22 + 2 * i, b6get(F.B, i, 1)); sc.st(SC_FAC + 36 + i, v6get(F.bm, i)); }
     sc.st(SC_FAC + 33, F.i11); sc.st(SC_FAC + 34, F.i12); sc.st(SC_FAC + 35, F.i22); sc.st(SC_FAC + 42, F.icm);
 }
 template <typename V> JB_HD void fac_load(const LaneScratch<V>& sc, StarFactor<V>& F) {
+    using W = Pk2<V>;
 #pragma unroll
-    for (int i = 0; i < 21; i++) F.S[i] = sc.ld(SC_FAC + i);
+    for (int j = 0; j < 6; j++)
 #pragma unroll
-    for (int i = 0; i < 6; i++) { F.B[i][0] = sc.ld(SC_FAC + 21 + 2 * i); F.B[i][1] = sc.ld(SC_FAC + 22 + 2 * i); F.bm[i] = sc.ld(SC_FAC + 36 + i); }
+        for (int ip = j / 2; ip < 3; ip++) F.S.p[s6p(ip, j)] = W(sc.ld(SC_FAC + tri(2 * ip, j)), sc.ld(SC_FAC + tri(2 * ip + 1, j)));
+#pragma unroll
+    for (int ip = 0; ip < 3; ip++) {
+        F.B[ip][0] = W(sc.ld(SC_FAC + 21 + 4 * ip), sc.ld(SC_FAC + 23 + 4 * ip)); F.B[ip][1] = W(sc.ld(SC_FAC + 22 + 4 * ip), sc.ld(SC_FAC + 24 + 4 * ip));
+        F.bm[ip] = W(sc.ld(SC_FAC + 36 + 2 * ip), sc.ld(SC_FAC + 37 + 2 * ip));
+    }
     F.i11 = sc.ld(SC_FAC + 33); F.i12 = sc.ld(SC_FAC + 34); F.i22 = sc.ld(SC_FAC + 35); F.icm = sc.ld(SC_FAC + 42);
 }
 template <typename V> JB_HD void state_store(const LaneScratch<V>& sc, const LaneState<V>& s) {
@@ -1813,10 +1909,19 @@ inline void ls_trace_check(int it, const Mask4& unc, const UQuad& b0, const UQua
 template <typename V, bool PAIR, bool LS>
 JB_HD bool newton_phase(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneState<V>& s, const SimOpts& o, const bool xtra, const SlotPlan& plan, const SpreadPlan<V>& spl,
                         const Mat3<V>& Rw, StarSys<V>& sys, const Vec3<V> (&dk)[3], const bool any_contact, const typename lane_traits<V>::mask& env_con,
-                        V (&yr)[6], V (&yl)[2], V& ym, typename lane_traits<V>::mask& capped) {
+                        Pk2<V> (&yr)[3], V (&yl)[2], V& ym, typename lane_traits<V>::mask& capped) {
     using MK = typename lane_traits<V>::mask;
     using U = typename lane_traits<V>::uint;
+    using W = Pk2<V>;
     const V h = m.c[LM_H];
+    auto store_root = [&](int at, const W (&y)[3]) {      // a root 6-vector (three row pairs) into the scratch
+#pragma unroll
+        for (int ip = 0; ip < 3; ip++) { sc.st(at + 2 * ip, pk_lo(y[ip])); sc.st(at + 2 * ip + 1, pk_hi(y[ip])); }
+    };
+    auto load_root = [&](int at, W (&y)[3]) {
+#pragma unroll
+        for (int ip = 0; ip < 3; ip++) y[ip] = W(sc.ld(at + 2 * ip), sc.ld(at + 2 * ip + 1));
+    };
     const bool is_main = (sc.grp == 0);
     const bool g1 = o.offload && sc.grp == 1;       // the replica group (its LDS stores repeat the main lanes': same address, same value)
     const bool rep = is_main || g1;
@@ -1838,10 +1943,9 @@ JB_HD bool newton_phase(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
         if (any_contact) {
             if (is_main) {      // warm start (world linear part rotated into the root frame)
                 Vec3<V> lw = mulT(Rw, v3<V>(s.wl[0], s.wl[1], s.wl[2]));
-                yr[0] = s.wa[0]; yr[1] = s.wa[1]; yr[2] = s.wa[2]; yr[3] = lw.x; yr[4] = lw.y; yr[5] = lw.z;
+                yr[0] = W(s.wa[0], s.wa[1]); yr[1] = W(s.wa[2], lw.x); yr[2] = W(lw.y, lw.z);
                 yl[0] = s.wj[0]; yl[1] = s.wj[1]; ym = s.wm;
-#pragma unroll
-                for (int i = 0; i < 6; i++) sc.st(SC_Y + i, yr[i]);
+                store_root(SC_Y, yr);
                 sc.st(SC_Y + 6, yl[0]); sc.st(SC_Y + 7, yl[1]); sc.st(SC_Y + 8, ym);
             }
             wave_sync();          // the helper groups read the iterate from the scratch
@@ -1884,7 +1988,8 @@ JB_HD bool newton_phase(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
                 // (LS: every lane group comes along - the line search below has hand-over points that all groups must pass; the helper groups'
                 // solve works on whatever their registers hold and nobody reads it)
                 if (o.offload || is_main || LS) {
-                    V nyr[6], nyl[2], nym;
+                    W nyr[3];
+                    V nyl[2], nym;
                     if (o.lean) sys_load(sc, sys);
                     // offload: EVERY lane runs this - the replica on M + h diag(b) (zero accumulator from the sweep, hb on its diagonal), in
                     // every full pass; the other helper groups on whatever their registers hold (nobody reads their result).  No lane
@@ -1897,28 +2002,29 @@ JB_HD bool newton_phase(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
                     MK ls_tiny = lt(V(1), V(0));
                     if (LS && any_contact) {
                         const int box = ls_mailbox(sc);
-                        V dr[6], dl[2], dm;
+                        // (cold code: element by element, out of the packed layouts)
+                        V dr[6], dl[2], dm, ys[6];
 #pragma unroll
-                        for (int i = 0; i < 6; i++) dr[i] = nyr[i] - yr[i];
+                        for (int i = 0; i < 6; i++) { ys[i] = v6get(yr, i); dr[i] = v6get(nyr, i) - ys[i]; }
                         dl[0] = nyl[0] - yl[0]; dl[1] = nyl[1] - yl[1]; dm = nym - ym;
                         auto matvec = [&](const V (&vr)[6], const V (&vl)[2], const V& vm, V (&wr)[6], V (&wl)[2], V& wm) {
                             wl[0] = sys.C[0] * vl[0] + sys.C[1] * vl[1]; wl[1] = sys.C[1] * vl[0] + sys.C[2] * vl[1]; wm = sys.Cm * vm;
 #pragma unroll
                             for (int i = 0; i < 6; i++) {
-                                V t = quad_sum(sys.B[i][0] * vl[0] + sys.B[i][1] * vl[1]) + sys.Bm[i] * vm;
+                                V t = quad_sum(b6get(sys.B, i, 0) * vl[0] + b6get(sys.B, i, 1) * vl[1]) + v6get(sys.Bm, i) * vm;
 #pragma unroll
-                                for (int j = 0; j < 6; j++) t = t + sys.A[tri(i, j)] * vr[j];
+                                for (int j = 0; j < 6; j++) t = t + s6get(sys.A, i, j) * vr[j];
                                 wr[i] = t;
-                                wl[0] = wl[0] + sys.B[i][0] * vr[i]; wl[1] = wl[1] + sys.B[i][1] * vr[i]; wm = wm + sys.Bm[i] * vr[i];
+                                wl[0] = wl[0] + b6get(sys.B, i, 0) * vr[i]; wl[1] = wl[1] + b6get(sys.B, i, 1) * vr[i]; wm = wm + v6get(sys.Bm, i) * vr[i];
                             }
                         };
                         V myr[6], myl[2], mym, mdr[6], mdl[2], mdm;
-                        matvec(yr, yl, ym, myr, myl, mym);
+                        matvec(ys, yl, ym, myr, myl, mym);
                         matvec(dr, dl, dm, mdr, mdl, mdm);
                         V g0 = quad_sum(dl[0] * (myl[0] - sys.tl[0]) + dl[1] * (myl[1] - sys.tl[1])) + dm * (mym - sys.tm);
                         V g1_ = quad_sum(dl[0] * mdl[0] + dl[1] * mdl[1]) + dm * mdm;
 #pragma unroll
-                        for (int i = 0; i < 6; i++) { g0 = g0 + dr[i] * (myr[i] - sys.tr[i]); g1_ = g1_ + dr[i] * mdr[i]; }
+                        for (int i = 0; i < 6; i++) { g0 = g0 + dr[i] * (myr[i] - v6get(sys.tr, i)); g1_ = g1_ + dr[i] * mdr[i]; }
                         if (is_main) {
 #pragma unroll
                             for (int i = 0; i < 6; i++) sc.st(box + i, dr[i]);
@@ -1945,7 +2051,7 @@ JB_HD bool newton_phase(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
                             // 3e-5 |y| after ten passes, and every iteration ends (the error it leaves is bounded by the step it declined to take).
                             V dn = quad_sum(dl[0] * dl[0] + dl[1] * dl[1]) + dm * dm, yn = quad_sum(yl[0] * yl[0] + yl[1] * yl[1]) + ym * ym;
 #pragma unroll
-                            for (int i = 0; i < 6; i++) { dn = dn + dr[i] * dr[i]; yn = yn + yr[i] * yr[i]; }
+                            for (int i = 0; i < 6; i++) { dn = dn + dr[i] * dr[i]; yn = yn + ys[i] * ys[i]; }
                             ls_tiny = lt(dn, V(NEWTON_TINY_STEP * (float)(1u << (it < 30 ? it : 30))) * yn);
                         }
                         // A minimum short of the full step sits on a kink of the cost - an edge's residual crossing zero - and the next pass must be
@@ -1964,22 +2070,25 @@ JB_HD bool newton_phase(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
                             ls_alpha = sel(mor(neq_u(and_u(ls_flags, zero_u<V>() + 4u), zero_u<V>()), ls_tiny), V(1), ls_alpha);
                             const MK part = lt(ls_alpha, V(1));      // (a whole step keeps the pass's own bits)
 #pragma unroll
-                            for (int i = 0; i < 6; i++) nyr[i] = sel(part, yr[i] + ls_alpha * (nyr[i] - yr[i]), nyr[i]);
+                            for (int ip = 0; ip < 3; ip++) nyr[ip] = selw(part, yr[ip] + W(ls_alpha) * (nyr[ip] - yr[ip]), nyr[ip]);
                             nyl[0] = sel(part, yl[0] + ls_alpha * (nyl[0] - yl[0]), nyl[0]); nyl[1] = sel(part, yl[1] + ls_alpha * (nyl[1] - yl[1]), nyl[1]);
                             nym = sel(part, ym + ls_alpha * (nym - ym), nym);
                             ls_flags = mbit(mand(take, part)) + mbit(mand(take, ls_tiny)) * 2u;
 #if !defined(__HIPCC__)
-                            if (g_ls_trace) ls_trace_pass(it, ls_alpha, take, ls_tiny, yr, nyr, yl, nyl, ym, nym);
+                            if (g_ls_trace) {
+                                V ty[6], tn[6];
+                                for (int i = 0; i < 6; i++) { ty[i] = v6get(yr, i); tn[i] = v6get(nyr, i); }
+                                ls_trace_pass(it, ls_alpha, take, ls_tiny, ty, tn, yl, nyl, ym, nym);
+                            }
                             g_ls_stats[1]++;
                             if (any_lane(mand(take, part))) g_ls_stats[2]++;
 #endif
                         }
 #pragma unroll
-                        for (int i = 0; i < 6; i++) yr[i] = sel(take, nyr[i], yr[i]);
+                        for (int ip = 0; ip < 3; ip++) yr[ip] = selw(take, nyr[ip], yr[ip]);
                         yl[0] = sel(take, nyl[0], yl[0]); yl[1] = sel(take, nyl[1], yl[1]); ym = sel(take, nym, ym);
                         fac_valid = mnot(fast_env);         // a rank-one env's factorisation is one edge behind its set
-#pragma unroll
-                        for (int i = 0; i < 6; i++) sc.st(SC_Y + i, yr[i]);
+                        store_root(SC_Y, yr);
                         sc.st(SC_Y + 6, yl[0]); sc.st(SC_Y + 7, yl[1]); sc.st(SC_Y + 8, ym);
                     }
                 }
@@ -2051,11 +2160,12 @@ JB_HD bool newton_phase(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
                             if (LS || !o.rank_one) fast_env = lt(V(1), V(0));      // (the line-searched iteration works on full passes)
                             full = any_lane(mand(unconverged, mnot(fast_env))) ? 1u : 0u;
                             if (!LS && any_lane(fast_env)) {
-                                V fyr[6], fyl[2], fym;
+                                W fyr[3];
+                                V fyl[2], fym;
                                 if (o.lean) { fac_load(sc, fac); if (PAIR) fac_load_cx(sc, fac); }
                                 rank_one_pass<V, PAIR>(sc, fac, dk, m.c[LM_MU], f_entry, f_is, f_plus, f_tan2, f_on, yr, yl, ym, fyr, fyl, fym);
 #pragma unroll
-                                for (int i = 0; i < 6; i++) yr[i] = sel(fast_env, fyr[i], yr[i]);
+                                for (int ip = 0; ip < 3; ip++) yr[ip] = selw(fast_env, fyr[ip], yr[ip]);
                                 yl[0] = sel(fast_env, fyl[0], yl[0]); yl[1] = sel(fast_env, fyl[1], yl[1]); ym = sel(fast_env, fym, ym);
 #ifdef JB_WAVE_STATS
                                 s.st_fast = s.st_fast + V(1);
@@ -2074,8 +2184,7 @@ JB_HD bool newton_phase(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
                     if (final_pass || full_pass) break;
                     if (is_main) {      // rank-one passes only: their iterates go to the scratch for the next check
                         fac_valid = mand(fac_valid, mnot(fast_env));
-#pragma unroll
-                        for (int i = 0; i < 6; i++) sc.st(SC_Y + i, yr[i]);
+                        store_root(SC_Y, yr);
                         sc.st(SC_Y + 6, yl[0]); sc.st(SC_Y + 7, yl[1]); sc.st(SC_Y + 8, ym);
                     }
                     JB_PROF_ADD(o, 3);
@@ -2093,18 +2202,18 @@ JB_HD bool newton_phase(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
         // star_subst adds tau itself, so the contact envs cancel it (replicated parts enter the quad sums as 1/4).
         // An env without contacts has qfrc = 0 exactly, whatever the rest of its wave is doing: plain solve.
         if (have_dfac || rep) {
-            V nyr[6], nyl[2], nym;
+            W nyr[3];
+            V nyl[2], nym;
             if (o.lean) sys_load(sc, sys);
             if (have_dfac) {
                 // Every lane takes the iterate from the scratch (what the main lanes hold in registers) and runs the substitution on whatever
                 // factorisation it holds: the REPLICA's is the one of M + h diag(b), and only its result is handed on.
-#pragma unroll
-                for (int i = 0; i < 6; i++) yr[i] = sc.ld(SC_Y + i);
+                load_root(SC_Y, yr);
                 yl[0] = sc.ld(SC_Y + 6); yl[1] = sc.ld(SC_Y + 7); ym = sc.ld(SC_Y + 8);
             }
             if (any_contact) {
 #pragma unroll
-                for (int i = 0; i < 6; i++) acc.rr[i] = sel(env_con, V(-0.25) * sys.tr[i], V(0));
+                for (int ip = 0; ip < 3; ip++) acc.rr[ip] = selw(env_con, W(-0.25) * sys.tr[ip], W(0));
                 acc.rl[0] = sel(env_con, hb1 * yl[0] - sys.tl[0], V(0));
                 acc.rl[1] = sel(env_con, hb2 * yl[1] - sys.tl[1], V(0));
                 acc.rm = sel(env_con, V(-0.25) * sys.tm, V(0));
@@ -2119,17 +2228,15 @@ JB_HD bool newton_phase(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
             JB_PROF_ADD(o, 6);
             if (have_dfac) {
                 if (g1) {
-#pragma unroll
-                    for (int i = 0; i < 6; i++) sc.st(SC_RED + i, nyr[i]);
+                    store_root(SC_RED, nyr);
                     sc.st(SC_RED + 6, nyl[0]); sc.st(SC_RED + 7, nyl[1]); sc.st(SC_RED + 8, nym);
                 }
                 wave_sync();
-#pragma unroll
-                for (int i = 0; i < 6; i++) nyr[i] = sc.ld(SC_RED + i);
+                load_root(SC_RED, nyr);
                 nyl[0] = sc.ld(SC_RED + 6); nyl[1] = sc.ld(SC_RED + 7); nym = sc.ld(SC_RED + 8);
             }
 #pragma unroll
-            for (int i = 0; i < 6; i++) yr[i] = sel(env_con, yr[i] - nyr[i], nyr[i]);
+            for (int ip = 0; ip < 3; ip++) yr[ip] = selw(env_con, yr[ip] - nyr[ip], nyr[ip]);
             yl[0] = sel(env_con, yl[0] - nyl[0], nyl[0]); yl[1] = sel(env_con, yl[1] - nyl[1], nyl[1]); ym = sel(env_con, ym - nym, nym);
         }
     }
@@ -2430,8 +2537,9 @@ JB_HD bool substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
         const Vec3<W> hcw = pk(h12, h2);
         const Vec3<W> fw = sw * W(m12, m2) + cross(ew, hcw), nw = mul(pk(J12, J2), ew) + cross(hcw, sw);
         const Vec3<V> fS = lo(fw), fK = hi(fw), nS = lo(nw), nK = hi(nw);
-        sys.B[0][0] = nS.x; sys.B[1][0] = nS.y; sys.B[2][0] = nS.z; sys.B[3][0] = fS.x; sys.B[4][0] = fS.y; sys.B[5][0] = fS.z;
-        sys.B[0][1] = nK.x; sys.B[1][1] = nK.y; sys.B[2][1] = nK.z; sys.B[3][1] = fK.x; sys.B[4][1] = fK.y; sys.B[5][1] = fK.z;
+        // (the solver's layout: rows in pairs, one column per hinge - a 2 x 2 transposition of the (shoulder, knee) pairs)
+        sys.B[0][0] = W(nS.x, nS.y); sys.B[1][0] = W(nS.z, fS.x); sys.B[2][0] = W(fS.y, fS.z);
+        sys.B[0][1] = W(nK.x, nK.y); sys.B[1][1] = W(nK.z, fK.x); sys.B[2][1] = W(fK.y, fK.z);
         {
             const W cd = dot(ew, nw) + dot(sw, fw);
             sys.C[0] = pk_lo(cd); sys.C[2] = pk_hi(cd);
@@ -2450,30 +2558,19 @@ JB_HD bool substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
             Jx.xy = xor_get(J12q.xy, axoff); Jx.xz = xor_get(J12q.xz, axoff); Jx.yz = xor_get(J12q.yz, axoff);
             Jt = Jx + J12q;
 #pragma unroll
-            for (int i = 0; i < 6; i++) sys.Bm[i] = xor_get(quad_bcast<0>(sys.B[i][0]), axoff);
+            for (int ip = 0; ip < 3; ip++) sys.Bm[ip] = W(xor_get(quad_bcast<0>(pk_lo(sys.B[ip][0])), axoff), xor_get(quad_bcast<0>(pk_hi(sys.B[ip][0])), axoff));
             sys.Cm = xor_get(quad_bcast<0>(sys.C[0]), axoff);
         } else {
             Vec3<V> sM = cross(am, em);
             Vec3<V> hm = cm * mm;
             Sym3<V> Jm = about_origin(Im, mm, cm);
             Vec3<V> fM = sM * mm + cross(em, hm), nM = mul(Jm, em) + cross(hm, sM);
-            sys.Bm[0] = nM.x; sys.Bm[1] = nM.y; sys.Bm[2] = nM.z; sys.Bm[3] = fM.x; sys.Bm[4] = fM.y; sys.Bm[5] = fM.z;
+            sys.Bm[0] = W(nM.x, nM.y); sys.Bm[1] = W(nM.z, fM.x); sys.Bm[2] = W(fM.y, fM.z);
             sys.Cm = dot(em, nM) + dot(sM, fM);
             ht = c0 * m0 + hm + h12q;
             Jt = about_origin(I0, m0, c0) + Jm + J12q;
         }
-        {
-            V mt = m.c[LM_MTOT];
-            V Z = V(0);
-            // [[J, [h]x], [[h]x^T, m 1]] with [h]x = [[0,-hz,hy],[hz,0,-hx],[-hy,hx,0]]
-            sys.A[tri(0, 0)] = Jt.xx; sys.A[tri(1, 0)] = Jt.xy; sys.A[tri(1, 1)] = Jt.yy;
-            sys.A[tri(2, 0)] = Jt.xz; sys.A[tri(2, 1)] = Jt.yz; sys.A[tri(2, 2)] = Jt.zz;
-            sys.A[tri(3, 0)] = Z;     sys.A[tri(3, 1)] = ht.z;  sys.A[tri(3, 2)] = -ht.y;
-            sys.A[tri(4, 0)] = -ht.z; sys.A[tri(4, 1)] = Z;     sys.A[tri(4, 2)] = ht.x;
-            sys.A[tri(5, 0)] = ht.y;  sys.A[tri(5, 1)] = -ht.x; sys.A[tri(5, 2)] = Z;
-            sys.A[tri(3, 3)] = mt; sys.A[tri(4, 3)] = Z; sys.A[tri(4, 4)] = mt;
-            sys.A[tri(5, 3)] = Z; sys.A[tri(5, 4)] = Z; sys.A[tri(5, 5)] = mt;
-        }
+        root_block<V>(Jt, ht, m.c[LM_MTOT], sys.A);
         JB_SCHED_FENCE();
 
         // ---- bias forces (Newton-Euler with qacc = 0 in MuJoCo coordinates) and applied forces
@@ -2522,7 +2619,7 @@ JB_HD bool substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
                 bl = F0 + Fm + legFq;
                 ba = N0 + cross(c0, F0) + Nm + cross(cm, Fm) + legNq;
             }
-            sys.tr[0] = -ba.x; sys.tr[1] = -ba.y; sys.tr[2] = -ba.z; sys.tr[3] = -bl.x; sys.tr[4] = -bl.y; sys.tr[5] = -bl.z;
+            sys.tr[0] = W(-ba.x, -ba.y); sys.tr[1] = W(-ba.z, -bl.x); sys.tr[2] = W(-bl.y, -bl.z);
             sys.tl[0] = -cS - m.c[LM_K1] * s.th1 - m.c[LM_B1] * s.thd1;
             sys.tl[1] = -cK - m.c[LM_K2] * s.th2 - m.c[LM_B2] * s.thd2;
             V uc = vmin(vmax(ctrl, m.c[LM_CTRL_LO]), m.c[LM_CTRL_HI]);
@@ -2552,9 +2649,10 @@ JB_HD bool substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
         contact_rows_build_all<V, PAIR>(m, sc, xtra, plan, spl);
         JB_PROF_ADD(o, 5);
     }
-    V yr[6], yl[2], ym;
+    Pk2<V> yrp[3];
+    V yl[2], ym;
     MK capped = lt(V(1), V(0));        // main lanes: this env's iteration ran into the cap
-    bool redone = newton_phase<V, PAIR, false>(m, sc, s, o, xtra, plan, spl, Rw, sys, dk, any_contact, env_con, yr, yl, ym, capped);
+    bool redone = newton_phase<V, PAIR, false>(m, sc, s, o, xtra, plan, spl, Rw, sys, dk, any_contact, env_con, yrp, yl, ym, capped);
 #ifdef JB_NO_RESOLVE      // A/B measurements only: the hot instantiation alone (a capped substep keeps its last iterate and is not counted)
     redone = false;
 #endif
@@ -2568,13 +2666,14 @@ JB_HD bool substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
     if (__builtin_expect(redone, false)) {
         JB_ASM_MARK("jb-cold-solve-begin");          // (a comment in the ISA: tools/asm_spills.py tells the cold block's register spills from the hot loop's)
         const U cf = group_sum_u<V>(sc, mbit(capped));      // every lane group learns which envs it concerns (helper lanes contribute zeros)
-        V zr[6], zl[2], zm;
+        Pk2<V> zr[3];
+        V zl[2], zm;
         MK capped2 = lt(V(1), V(0));
         (void)newton_phase<V, PAIR, true>(m, sc, s, o, xtra, plan, spl, Rw, sys, dk, any_contact, env_con, zr, zl, zm, capped2);
         const U cf2 = group_sum_u<V>(sc, mbit(capped2));
         const MK re = neq_u(cf, zero_u<V>());
 #pragma unroll
-        for (int i = 0; i < 6; i++) yr[i] = sel(re, zr[i], yr[i]);
+        for (int ip = 0; ip < 3; ip++) yrp[ip] = selw(re, zr[ip], yrp[ip]);
         yl[0] = sel(re, zl[0], yl[0]); yl[1] = sel(re, zl[1], yl[1]); ym = sel(re, zm, ym);
         // the failure counter records what even the line-searched solve did not settle (LEAN: the state is parked in the scratch)
         const V inc = sel(mand(re, neq_u(cf2, zero_u<V>())), V(1), V(0));
@@ -2609,6 +2708,7 @@ JB_HD bool substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
 
     // ================= phase C: integrate (the replica too: it starts the next substep from the same state)
     if (o.lean) state_load(sc, s);
+    const V yr[6] = {pk_lo(yrp[0]), pk_hi(yrp[0]), pk_lo(yrp[1]), pk_hi(yrp[1]), pk_lo(yrp[2]), pk_hi(yrp[2])};
     Vec3<V> lin = mul(Rw, v3<V>(yr[3], yr[4], yr[5]));
     s.wa[0] = yr[0]; s.wa[1] = yr[1]; s.wa[2] = yr[2]; s.wl[0] = lin.x; s.wl[1] = lin.y; s.wl[2] = lin.z; s.wj[0] = yl[0]; s.wj[1] = yl[1]; s.wm = ym;
     // mj_advance: velocities, then positions with the new velocities

@@ -242,6 +242,11 @@ def test_integration_md_stub_runs_and_matches_vec_env():
         o1, r1, d1, _ = b.step(act)
         o2, r2, d2, _ = v.step(act)
         assert np.array_equal(o1, o2) and np.array_equal(r1, r2) and np.array_equal(d1, d2.astype(bool))
+    act = rng.uniform(-1, 1, size=33).astype(np.float32)
+    b.step_async(act)                             # the stub's step_async / step_wait pair = one step
+    o1, r1, d1, _ = b.step_wait()
+    o2, r2, d2, _ = v.step(act)
+    assert np.array_equal(o1, o2) and np.array_equal(r1, r2) and np.array_equal(d1, d2.astype(bool))
     # the second block of the document: the fused rollout stub (jb_step_many_device), as written
     a2 = src.index("```python", a) + len("```python")
     exec(src[a2:src.index("```", a2)], ns)
