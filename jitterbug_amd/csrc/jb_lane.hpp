@@ -211,6 +211,12 @@ JB_HD void vsincos_pi(float x, float& s, float& c) {
     c = ((q + 1) & 2) ? -b : b;
 }
 JB_HD void vsincos_pi(double x, double& s, double& c) { s = sin(x); c = cos(x); }
+// sine / cosine of a BOUNDED angle (|x| far below 1e4: a hinge angle, a yaw target, the half-angle of a reset pose) by the same
+// quarter-turn reduction: no slow path, so none of libm's private-memory argument reduction ends up in a kernel
+JB_HD float vsin_b(float x) { float s, c; vsincos_pi(x, s, c); return s; }
+JB_HD float vcos_b(float x) { float s, c; vsincos_pi(x, s, c); return c; }
+JB_HD double vsin_b(double x) { return sin(x); }
+JB_HD double vcos_b(double x) { return cos(x); }
 // products / fused products that the compiler may not re-fuse: the error-free transformations of the compensated position
 // state (jb_sim.hpp, two_sum / sq_err) rely on a*b being rounded exactly once
 #if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)

@@ -130,11 +130,13 @@ template <typename T> JB_HD int build_lane_model(const double* P, int leg, T* ou
         put3(LM_PE_C, ge + JB_G_CENTER);
         for (int i = 0; i < 9; i++) out[LM_PE_R + i] = T(ge[JB_G_ROT + i]);
         put3(LM_PE_S, ge + JB_G_SIZE);
-        for (int i = 0; i < 3; i++) out[LM_PE_IS + i] = T((int)ge[JB_G_TYPE] == JB_GEOM_ELLIPSOID ? 1.0 / (ge[JB_G_SIZE + i] + gu[JB_G_SIZE] + 2e-4) : -1.0);
+        // (no ellipsoid: x <= 0 switches the pair off; the y entry stays POSITIVE - its sign is the thread flag's, below, and must not double as this sentinel)
+        for (int i = 0; i < 3; i++) out[LM_PE_IS + i] = T((int)ge[JB_G_TYPE] == JB_GEOM_ELLIPSOID ? 1.0 / (ge[JB_G_SIZE + i] + gu[JB_G_SIZE] + 2e-4) : (i == 1 ? 1.0 : -1.0));
     }
     {   // the motor-axis thread for every lane (PAIR kernels: its contact with the lane's own upper-leg cylinder), and the flag that says whether
         // this lane's leg can come near it at all: the smallest distance of the two AXES over the shoulder angles |th1| <= 0.4 rad (rollouts
-        // stay below 0.15) and a full turn of the motor, against r_thread + r_leg + 1 mm.  The flag is the SIGN of LM_PE_IS + 1.
+        // stay below 0.15) and a full turn of the motor, against r_thread + r_leg + 1 mm.  The flag is the SIGN of LM_PE_IS + 1 (negative = near; the magnitude is the mass pair's scale, or 1 without an ellipsoid).
+        // Outside that envelope of shoulder angles the kernel does not trust the flag: it runs the broad phase (substep_impl).
         const double* gth = geom(20);
         put3(LM_PT_C, gth + JB_G_CENTER);
         const double tax[3] = {gth[JB_G_ROT + 2], gth[JB_G_ROT + 5], gth[JB_G_ROT + 8]};
@@ -183,7 +185,7 @@ template <typename T> JB_HD int build_lane_model(const double* P, int leg, T* ou
                 }
             }
         }
-        if (near) out[LM_PE_IS + 1] = -out[LM_PE_IS + 1];
+        out[LM_PE_IS + 1] = near ? -std::fabs(out[LM_PE_IS + 1]) : std::fabs(out[LM_PE_IS + 1]);
     }
     {   // broadphase boxes (LM_BX): oriented boxes around the lane's root-body geoms; motor-body geoms (lane 3) get one
         // axis-aligned cube centred on the motor axis (invariant under the motor angle).  Unused boxes have negative sizes.

@@ -2286,7 +2286,7 @@ JB_HD bool substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
             sincos_small(W(s.th1, s.th2), sn, cs);
             s1 = pk_lo(sn); s2 = pk_hi(sn); c1 = pk_lo(cs); c2 = pk_hi(cs);
         }
-        if (any_lane(mand(lane_ok, mor(gt(vabs(s.th1), V(0.9)), gt(vabs(s.th2), V(0.9)))))) { s1 = vsin(s.th1); c1 = vcos(s.th1); s2 = vsin(s.th2); c2 = vcos(s.th2); }
+        if (any_lane(mand(lane_ok, mor(gt(vabs(s.th1), V(0.9)), gt(vabs(s.th2), V(0.9)))))) { vsincos_pi(s.th1, s1, c1); vsincos_pi(s.th2, s2, c2); }      // (the quarter-turn reduction: good to 1e-7 for any angle a hinge can reach, and no libm slow path in the kernel)
         V sp, cp;
         vsincos_pi(s.phi, sp, cp);
         if (o.aux) { s1 = sel(ax_motor, sp, s1); c1 = sel(ax_motor, cp, c1); }      // the motor's angle is wrapped to [-pi, pi): its own sine / cosine routine
@@ -2422,7 +2422,8 @@ JB_HD bool substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
                 MK ton = lt(V(1), V(0));
                 V tdist = V(1);
                 Vec3<V> tpos = uc;
-                const MK tflag = lt(isv.y, V(0));
+                // (the builder's flag covers shoulder angles up to 0.4 rad - rollouts stay below 0.15; a leg bent further takes the broad phase whatever the flag says)
+                const MK tflag = mor(lt(isv.y, V(0)), gt(vabs(s.th1), V(0.4)));
                 if (any_lane(tflag)) {
                     const Vec3<V> tcw = am + mul(Rm, ldc3(m, LM_PT_C) - am), taw = mul(Rm, ldc3(m, LM_PT_AX));
                     const V tr = ldc(m, LM_PT_R), thh = ldc(m, LM_PT_H), ur = ldc(m, LM_UC_R);

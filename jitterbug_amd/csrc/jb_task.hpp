@@ -64,14 +64,14 @@ JB_HD void episode_reset(int task, int random_pose, uint64_t seed, uint64_t env,
     e.phi = T(0); e.phid = T(0);
     e.tx = e.ty = e.tpsi = T(0);
     if (task == TASK_FACE_DIRECTION || task == TASK_MOVE_IN_DIRECTION) e.tpsi = yaw;                                  // :618-630
-    else if (task == TASK_MOVE_TO_POSITION) { e.tx = radius * vcos(angle); e.ty = radius * vsin(angle); }             // :632-639
-    else if (task == TASK_MOVE_TO_POSE) { e.tx = radius * vcos(angle); e.ty = radius * vsin(angle); e.tpsi = yaw; }   // :641-648
+    else if (task == TASK_MOVE_TO_POSITION) { e.tx = radius * vcos_b(angle); e.ty = radius * vsin_b(angle); }             // :632-639
+    else if (task == TASK_MOVE_TO_POSE) { e.tx = radius * vcos_b(angle); e.ty = radius * vsin_b(angle); e.tpsi = yaw; }   // :641-648
     if (random_pose) {                                                                                                // :653-664
         T th = u01<T>(r0[3]) * TWO_PI;
         T ax = u01<T>(r1[0]) * T(0.05) - T(0.025), ay = u01<T>(r1[1]) * T(0.05) - T(0.025);
         T inv = T(1) / vsqrt(ax * ax + ay * ay + T(1));
-        T sh = vsin(T(0.5) * th);
-        e.qw = vcos(T(0.5) * th); e.qx = sh * ax * inv; e.qy = sh * ay * inv; e.qz = sh * inv;
+        T sh = vsin_b(T(0.5) * th);
+        e.qw = vcos_b(T(0.5) * th); e.qx = sh * ax * inv; e.qy = sh * ay * inv; e.qz = sh * inv;
     }
 }
 
@@ -96,7 +96,7 @@ template <typename T> JB_HD T angle_to_target(const EnvCore<T>& e) {
     T R10 = T(2) * (e.qx * e.qy + e.qw * e.qz);
     T yaw = vatan2(R10, R00) - T(1.5707963267948966);
     // target quat (cos psi/2, 0, 0, sin psi/2) -> its yaw by the same formula
-    T c = vcos(T(0.5) * e.tpsi), s = vsin(T(0.5) * e.tpsi);
+    T c = vcos_b(T(0.5) * e.tpsi), s = vsin_b(T(0.5) * e.tpsi);
     T tyaw = vatan2(T(2) * c * s, c * c - s * s);
     return wrap_pi(tyaw - yaw);
 }
@@ -126,7 +126,7 @@ template <typename T> JB_HD void framelinvel(const EnvCore<T>& e, T (&o)[3]) {
 // Jitterbug linear velocity (the sensor above) in the target frame   (reference :292-303)
 template <typename T> JB_HD void vel_in_target(const EnvCore<T>& e, T (&o)[3]) {
     JB_NO_CONTRACT
-    T c = vcos(e.tpsi), s = vsin(e.tpsi);
+    T c = vcos_b(e.tpsi), s = vsin_b(e.tpsi);
     T v[3];
     framelinvel(e, v);
     o[0] = c * v[0] + s * v[1]; o[1] = -s * v[0] + c * v[1]; o[2] = v[2];
@@ -142,21 +142,26 @@ template <typename T> JB_HD void observe(int task, const EnvCore<T>& e, T target
     obs[10 * stride] = e.wx * T(1.0 / 35); obs[11 * stride] = e.wy * T(1.0 / 35); obs[12 * stride] = e.wz * T(1.0 / 35);
     obs[13 * stride] = wrap_pi(e.phi + T(1.5707963267948966)) / PI;      // :222-239
     obs[14 * stride] = e.phid * T(1.0 / 180);
+    // the task's extras: worked out into plain values and stored by ONE set of stores (every caller passes room for 19 entries; the ones beyond
+    // the task's width are zeros nobody reads) - stores of their own in every branch end as a choice between addresses, which keeps the
+    // row in private memory
     T t3[3];
+    T x15 = T(0), x16 = T(0), x17 = T(0), x18 = T(0);
     if (task == TASK_FACE_DIRECTION) {
-        obs[15 * stride] = angle_to_target(e) / PI;
+        x15 = angle_to_target(e) / PI;
     } else if (task == TASK_MOVE_IN_DIRECTION) {
-        obs[15 * stride] = angle_to_target(e) / PI;
+        x15 = angle_to_target(e) / PI;
         vel_in_target(e, t3);
-        obs[16 * stride] = t3[0]; obs[17 * stride] = t3[1]; obs[18 * stride] = t3[2];
+        x16 = t3[0]; x17 = t3[1]; x18 = t3[2];
     } else if (task == TASK_MOVE_TO_POSITION) {
         target_in_body(e, target_z, t3);
-        obs[15 * stride] = t3[0] * T(1.0 / 3); obs[16 * stride] = t3[1] * T(1.0 / 3); obs[17 * stride] = t3[2] * T(10);
+        x15 = t3[0] * T(1.0 / 3); x16 = t3[1] * T(1.0 / 3); x17 = t3[2] * T(10);
     } else if (task == TASK_MOVE_TO_POSE) {
         target_in_body(e, target_z, t3);
-        obs[15 * stride] = t3[0] * T(1.0 / 3); obs[16 * stride] = t3[1] * T(1.0 / 3); obs[17 * stride] = t3[2] * T(10);
-        obs[18 * stride] = angle_to_target(e) / PI;
+        x15 = t3[0] * T(1.0 / 3); x16 = t3[1] * T(1.0 / 3); x17 = t3[2] * T(10);
+        x18 = angle_to_target(e) / PI;
     }
+    obs[15 * stride] = x15; obs[16 * stride] = x16; obs[17 * stride] = x17; obs[18 * stride] = x18;
 }
 
 // reference jitterbug.py:840-925.  tolerance() sigmoids with the reference's arguments folded in:
@@ -177,7 +182,7 @@ template <typename T> JB_HD void reward_terms(const EnvCore<T>& e, T target_z, T
     T d = vsqrt(t3[0] * t3[0] + t3[1] * t3[1] + t3[2] * t3[2]), dn = d * T(20);
     out[0] = (d == T(0)) ? T(1) : vexp(LN01 * dn * dn);
     T a = angle_to_target(e), x = vabs(a) / T(1.5707963267948966);
-    out[1] = (a == T(0)) ? T(1) : (x < T(1) ? T(0.5) * (T(1) + vcos(T(3.141592653589793) * x)) : T(0));
+    out[1] = (a == T(0)) ? T(1) : (x < T(1) ? T(0.5) * (T(1) + vcos_b(T(3.141592653589793) * x)) : T(0));
     vel_in_target(e, t3);
     T v = t3[0];
     out[2] = (v >= T(0.1)) ? T(1) : ((T(0.1) - v) * T(10) < T(1) ? T(1) - (T(0.1) - v) * T(10) : T(0));
@@ -200,7 +205,7 @@ template <typename T> JB_HD T reward(int task, const EnvCore<T>& e, T target_z) 
     if (task == TASK_FACE_DIRECTION || task == TASK_MOVE_TO_POSE) {
         T a = angle_to_target(e);
         T x = vabs(a) / T(1.5707963267948966);
-        T H = (a == T(0)) ? T(1) : (x < T(1) ? T(0.5) * (T(1) + vcos(T(3.141592653589793) * x)) : T(0));
+        T H = (a == T(0)) ? T(1) : (x < T(1) ? T(0.5) * (T(1) + vcos_b(T(3.141592653589793) * x)) : T(0));
         r = (task == TASK_FACE_DIRECTION) ? H : r * H;
     }
     if (task == TASK_MOVE_IN_DIRECTION) {

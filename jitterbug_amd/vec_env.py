@@ -155,9 +155,10 @@ class JitterbugVecEnv:
         if not self._pending:
             raise RuntimeError("step_wait() without a step_async() before it")
         self._pending = None
-        if copy:
-            _lib.check(self._L.jb_step_wait(self._h, _lib.ptr(self._obs), _lib.ptr(self._rew), _lib.ptr(self._done)))
-            return self._obs.copy(), self._rew.copy(), self._done.astype(bool), self._empty_infos()
+        if copy:          # straight into arrays of the caller's own (one copy out of the pinned buffers, none on top)
+            o, r, d = np.empty((self.num_envs, self.obs_dim), dtype=np.float32), np.empty(self.num_envs, dtype=np.float32), np.empty(self.num_envs, dtype=np.uint8)
+            _lib.check(self._L.jb_step_wait(self._h, _lib.ptr(o), _lib.ptr(r), _lib.ptr(d)))
+            return o, r, d.view(np.bool_), self._empty_infos()
         _lib.check(self._L.jb_step_wait(self._h, None, None, None))
         if self._views is None:
             po, pr, pd = C.c_void_p(), C.c_void_p(), C.c_void_p()

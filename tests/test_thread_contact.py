@@ -48,6 +48,41 @@ def touching():
     return _touching_models(12, seed=7)
 
 
+def test_thread_flag_keeps_its_sign_apart_from_the_no_ellipsoid_sentinel(touching):
+    """the 'this leg can come near the thread' flag is the SIGN of the lane table's LM_PE_IS + 1 entry, whose magnitude is the mass
+    pair's broad-phase scale - or, for a mass geom that is not an ellipsoid, a sentinel that used to be -1 and inverted the flag.  Checked on
+    the lane tables (host build of the model builder): nominal model - no flag on any leg; a robot drawn to touch - flag on its leg; both
+    again with geom 21 turned into a cylinder: the same flags, the mass pair off (x <= 0)."""
+    import tests.build_harness as bh
+    lib = C.CDLL(bh.build())
+    dp = C.POINTER(C.c_double)
+    lib.jbh_lane_table.argtypes = [dp, C.c_int, dp]
+    n = lib.jbh_lm_count()
+
+    def pe_is(P, leg):
+        out = np.zeros(n)
+        assert lib.jbh_lane_table(np.ascontiguousarray(P).ctypes.data_as(dp), leg, out.ctypes.data_as(dp)) == 0
+        return out[n - 11:n - 8]          # LM_PE_IS (3): followed by LM_PT_C (3), LM_PT_AX (3), LM_PT_R, LM_PT_H
+
+    P0 = model.default_params()
+    Pt, leg, _ = touching[0]
+    for P, flagged_leg in ((P0, None), (Pt, leg)):
+        flags = {}
+        for variant in ("ellipsoid", "cylinder"):
+            Q = np.array(P, dtype=np.float64)
+            if variant == "cylinder":
+                Q[model.P_GEOM + 21 * model.GEOM_STRIDE + model.G_TYPE] = model.GEOM_CYLINDER
+            for l in range(3):          # (leg 3's table holds the mass geom itself and refuses a non-ellipsoid: that model is rejected as a whole)
+                v = pe_is(Q, l)
+                flags[variant, l] = bool(v[1] < 0)
+                assert (v[0] > 0) == (variant == "ellipsoid") and abs(v[1]) > 0, (variant, l, v)
+        assert all(flags["ellipsoid", l] == flags["cylinder", l] for l in range(3)), flags          # the sentinel does not touch the flag
+        if flagged_leg is None:
+            assert not any(flags.values()), flags                    # the nominal thread stays 7 mm clear of every leg
+        else:
+            assert flags["ellipsoid", flagged_leg], flags            # (the flag is conservative: a neighbouring leg may carry it too)
+
+
 def test_thread_narrow_phase_against_exact_gjk():
     """pair_thread_geometric (the leg as its axis segment, the thread as a flat-capped cylinder in closed form): separated, and with the nearest
     point of the leg's axis inside the segment, the gap IS the exact GJK distance of the two cylinders; at the very end of the leg it is the
