@@ -77,6 +77,9 @@ typedef struct jb_handle jb_handle;
 #define JB_FLAG_NO_REORDER  32  /* diagnostic: never reorder the waves of a launch.  By default a batch with more waves than the device holds at once
                                    launches them longest-first, by the wave times the previous launch measured (results do not depend on it) */
 
+#define JB_FLAG_PAIR_WITNESS 64 /* diagnostic, off by default: behind every step launch one pass of the PAIR WITNESS (jb_get_pair_witness below) - for users whose
+                                   randomised models leave the reference's distribution */
+
 typedef struct jb_config {
     int32_t  n_envs;        /* N >= 1 */
     int32_t  task_id;       /* JB_TASK_* */
@@ -126,6 +129,18 @@ int jb_get_counters(jb_handle* h, int32_t* step_count /*[N]*/, uint32_t* episode
 /* how often the plain active-set iteration did not settle within max_newton checks and the substep's contact problem was solved again with
  * the exact line search: wave-substeps (a wave = jb_envs_per_wave envs) since jb_create - a few in ten million */
 int jb_solver_stats(jb_handle* h, uint64_t* resolved_wave_substeps);
+/* The pair witness.  Every jitterbug geom has contype = conaffinity = 1 (reference jitterbug_dmc/jitterbug.xml:44-107): MuJoCo tests the 160
+ * geom pairs whose bodies differ and are not parent and child.  The step kernels collide every geom with the floor and the eight pairs
+ * that do occur on randomised models (mass ellipsoid and motor-axis thread against the upper-leg cylinders); the other 152 never touch on
+ * the reference's model or under the reference's randomisation (measured: tests/test_gpu_clearance.py) - but a caller's sigmas may be
+ * larger.  The witness says so instead of letting bodies pass through each other silently: per env, the exact (GJK, fp64) smallest
+ * distance over the 152 unsimulated pairs in the current state, from the constant tables the step kernel reads; 0 = a pair interpenetrates.
+ *   jb_pair_witness      one pass now: clearance_out [N] metres (nullable), pairs_out [N, 2] geom indices in the reference XML's order
+ *                        (nullable), *n_touching = envs with clearance 0 (nullable).  Synchronous.
+ *   jb_get_pair_witness  handles created with JB_FLAG_PAIR_WITNESS run a pass behind every step launch: overlap_passes [N] = passes that
+ *                        found a pair interpenetrating, min_clearance [N] = smallest clearance seen, both since jb_create (nullable). */
+int jb_pair_witness(jb_handle* h, float* clearance_out, int32_t* pairs_out, int32_t* n_touching);
+int jb_get_pair_witness(jb_handle* h, uint32_t* overlap_passes, float* min_clearance);
 /* n_tables is 1 (shared) or N (one table per env); each table is JB_NPARAM doubles (jitterbug_model.h) */
 int jb_set_model_params(jb_handle* h, const double* params, int32_t n_tables);
 

@@ -14,7 +14,7 @@ JB_OK = 0
 ERR_NAMES = {-1: "JB_E_INVALID", -2: "JB_E_NODEVICE", -3: "JB_E_HIP", -4: "JB_E_MODEL"}
 
 EXPORTS = ["jb_default_config", "jb_create", "jb_destroy", "jb_reset", "jb_step", "jb_observe", "jb_get_state", "jb_set_state",
-           "jb_get_counters", "jb_solver_stats", "jb_set_model_params", "jb_policy", "jb_policy_device", "jb_set_policy_params", "jb_reward_terms", "jb_reward_terms_device", "jb_default_randomise_config", "jb_randomise_models", "jb_model_compile_host", "jb_model_mass_clearance_ok", "jb_model_draw_offsets_host", "jb_comm_unique_id", "jb_comm_init", "jb_comm_destroy", "jb_comm_set_shards", "jb_gather_rows_device", "jb_gather_block_device", "jb_scatter_actions_device", "jb_step_async", "jb_step_wait", "jb_step_views", "jb_release_staging", "jb_rollout_policy_device", "jb_rollout_policy", "jb_step_many_device", "jb_step_many", "jb_wave_clocks", "jb_kernel_variant", "jb_envs_per_wave", "jb_reset_device", "jb_step_device", "jb_step_rows_device", "jb_observe_device", "jb_debug_poison_lds", "jb_set_obs_encoder", "jb_encoded_dim", "jb_encode_device", "jb_encode", "jb_synchronize",
+           "jb_get_counters", "jb_solver_stats", "jb_set_model_params", "jb_policy", "jb_policy_device", "jb_set_policy_params", "jb_reward_terms", "jb_reward_terms_device", "jb_default_randomise_config", "jb_randomise_models", "jb_model_compile_host", "jb_model_mass_clearance_ok", "jb_model_draw_offsets_host", "jb_comm_unique_id", "jb_comm_init", "jb_comm_destroy", "jb_comm_set_shards", "jb_gather_rows_device", "jb_gather_block_device", "jb_scatter_actions_device", "jb_step_async", "jb_step_wait", "jb_step_views", "jb_release_staging", "jb_pair_witness", "jb_get_pair_witness", "jb_rollout_policy_device", "jb_rollout_policy", "jb_step_many_device", "jb_step_many", "jb_wave_clocks", "jb_kernel_variant", "jb_envs_per_wave", "jb_reset_device", "jb_step_device", "jb_step_rows_device", "jb_observe_device", "jb_debug_poison_lds", "jb_set_obs_encoder", "jb_encoded_dim", "jb_encode_device", "jb_encode", "jb_synchronize",
            "jb_stream", "jb_obs_dim", "jb_num_envs", "jb_device_count", "jb_abi_version", "jb_source_sha256", "jb_default_model_params", "jb_last_error"]
 
 
@@ -36,7 +36,7 @@ class RandomiseConfig(C.Structure):
 
 
 VARIANT_NAMES = {0: "ordinary", 1: "pair", 2: "lean", 3: "lean_pair"}      # jb_kernel_variant (JB_VARIANT_*)
-FLAG_NO_RANK_ONE, FLAG_LEAN, FLAG_PAIR, FLAG_NO_PAIR, FLAG_NO_SPREAD, FLAG_NO_REORDER = 1, 2, 4, 8, 16, 32
+FLAG_NO_RANK_ONE, FLAG_LEAN, FLAG_PAIR, FLAG_NO_PAIR, FLAG_NO_SPREAD, FLAG_NO_REORDER, FLAG_PAIR_WITNESS = 1, 2, 4, 8, 16, 32, 64
 NOFFSET = 31
 RND_LEGS, RND_MASS, RND_CORE1_DENSITY, RND_CORE2_DENSITY, RND_GLOBAL_DENSITY, RND_GEAR = 1, 2, 4, 8, 16, 32
 
@@ -132,6 +132,8 @@ def load():
         L.jb_step_wait.argtypes = [vp, fp, fp, u8p]
         L.jb_step_views.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
         L.jb_release_staging.argtypes = [vp]
+        L.jb_pair_witness.argtypes = [vp, fp, vp, vp]
+        L.jb_get_pair_witness.argtypes = [vp, vp, fp]
     if os.environ.get("JITTERBUG_HIP_LIB") is None or hasattr(L, "jb_solver_stats"):
         L.jb_solver_stats.argtypes = [vp, vp]
     L.jb_synchronize.argtypes = [vp]

@@ -28,6 +28,7 @@
 #include "jb_sim.hpp"
 #include "jb_step.hpp"
 #include "jb_task.hpp"
+#include "jb_witness.hpp"
 
 using namespace jb;
 
@@ -512,6 +513,25 @@ __global__ __launch_bounds__(64) void jb_reward_terms_kernel(KArgs a, float* __r
     terms_out[(size_t)env * 4 + leg] = out[leg];
 }
 
+// ---------------------------------------------------------------------------------------------- witness for the unsimulated geom pairs
+// One thread per env (fp64, private memory: a diagnostic pass, jb_witness.hpp): smallest distance over the geom pairs MuJoCo would test and the
+// step kernels do not collide, in the env's current state.  clear_out / pair_out: this pass's result; min_acc / count_acc (nullable): running
+// minimum and the number of passes that found a pair interpenetrating (JB_FLAG_PAIR_WITNESS: one pass behind every step launch).
+__global__ __launch_bounds__(64) void jb_witness_kernel(KArgs a, float* __restrict__ clear_out, int* __restrict__ pair_out, float* __restrict__ min_acc, unsigned* __restrict__ count_acc) {
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= a.n) return;
+    const float* tab = a.lane_model + (a.per_env_model ? (size_t)env * LM_TABLE : 0);
+    const int L = 4 * a.n;
+    double th1[4], th2[4];
+    for (int l = 0; l < 4; l++) { th1[l] = a.leg[LF_TH1 * L + env * 4 + l]; th2[l] = a.leg[LF_TH2 * L + env * 4 + l]; }
+    int pair[2];
+    const double d = witness_clearance<float>(tab, th1, th2, (double)a.root[RF_PHI * a.n + env], pair);
+    if (clear_out) clear_out[env] = (float)d;
+    if (pair_out) { pair_out[2 * env] = pair[0]; pair_out[2 * env + 1] = pair[1]; }
+    if (min_acc) min_acc[env] = fminf(min_acc[env], (float)d);
+    if (count_acc && !(d > 0.0)) count_acc[env] += 1u;
+}
+
 // ---------------------------------------------------------------------------------------------- launch order of the waves
 // order[0 .. n) = the waves sorted by their last measured lifetime, longest first (a 1024-bin counting sort: exact order inside a bin does
 // not matter).  One workgroup; runs on the handle's stream right after a step launch whenever the batch has more waves than the device
@@ -721,6 +741,7 @@ struct jb_handle {
     bool async_pending;
     float* d_terms;
     float* d_enc_params; float* d_code;
+    float *d_wit_clear, *d_wit_min; int* d_wit_pair; unsigned* d_wit_count;      // the pair witness (jb_pair_witness / JB_FLAG_PAIR_WITNESS), allocated at first use
 };
 
 // ---------------------------------------------------------------------------------------------- RCCL, bound at run time
@@ -1014,7 +1035,7 @@ int jb_destroy(jb_handle* h) {
     guard.enter(h->cfg.device_id);
     if (h->stream || !h->own_stream) hipStreamSynchronize(h->stream);
     if (h->comm && g_rccl.CommDestroy) { hipDeviceSynchronize(); g_rccl.CommDestroy(h->comm); h->comm = nullptr; }      // (device-wide: exchanges may be queued on streams of the caller's)
-    void* bufs[] = {h->d_tape, h->d_rows_stage, h->d_rew_stage, h->d_capture, h->d_capture_count, h->d_resolve, h->d_wave_order, h->d_wave_clock, h->d_ovc, h->d_terms, h->d_spec, h->d_root, h->d_leg, h->d_model, h->d_step, h->d_episode, h->d_action, h->d_obs, h->d_reward, h->d_done, h->d_mask, h->d_qpos, h->d_qvel, h->d_target, h->d_wave_stats, h->d_enc_params, h->d_code};
+    void* bufs[] = {h->d_tape, h->d_rows_stage, h->d_rew_stage, h->d_capture, h->d_capture_count, h->d_resolve, h->d_wave_order, h->d_wave_clock, h->d_ovc, h->d_terms, h->d_spec, h->d_root, h->d_leg, h->d_model, h->d_step, h->d_episode, h->d_action, h->d_obs, h->d_reward, h->d_done, h->d_mask, h->d_qpos, h->d_qvel, h->d_target, h->d_wave_stats, h->d_enc_params, h->d_code, h->d_wit_clear, h->d_wit_min, h->d_wit_pair, h->d_wit_count};
     for (void* b : bufs) if (b) hipFree(b);
     void* pinned[] = {h->p_action, h->p_obs, h->p_reward, h->p_done};
     for (void* b : pinned) if (b) hipHostFree(b);
@@ -1106,6 +1127,19 @@ int jb_reset_device(jb_handle* h, const uint8_t* d_mask, float* d_obs_out) {
     JB_HIP(hipGetLastError());
     return JB_OK;
 }
+static int ensure_witness(jb_handle* h) {
+    if (h->d_wit_clear) return JB_OK;
+    const size_t N = (size_t)h->cfg.n_envs;
+    JB_HIP(hipMalloc(&h->d_wit_clear, sizeof(float) * N));
+    JB_HIP(hipMalloc(&h->d_wit_min, sizeof(float) * N));
+    JB_HIP(hipMalloc(&h->d_wit_pair, sizeof(int) * 2 * N));
+    JB_HIP(hipMalloc(&h->d_wit_count, sizeof(unsigned) * N));
+    std::vector<float> inf(N, INFINITY);
+    JB_HIP(hipMemcpyAsync(h->d_wit_min, inf.data(), sizeof(float) * N, hipMemcpyHostToDevice, h->stream));
+    JB_HIP(hipMemsetAsync(h->d_wit_count, 0, sizeof(unsigned) * N, h->stream));
+    JB_HIP(hipStreamSynchronize(h->stream));          // (`inf` goes out of scope)
+    return JB_OK;
+}
 static int launch_step(jb_handle* h, StepIO io, int packed_rows) {
     if (!h) return fail(JB_E_INVALID, "handle is NULL");
     if (io.n_steps < 1) return fail(JB_E_INVALID, "n_steps must be >= 1");
@@ -1194,6 +1228,12 @@ static int launch_step(jb_handle* h, StepIO io, int packed_rows) {
     JB_HIP(hipGetLastError());
     if (reorder) {
         hipLaunchKernelGGL(jb_wave_order_kernel, dim3(1), dim3(1024), 0, h->stream, h->d_wave_clock, h->d_wave_order, (int)grid.x, fold_from);
+        JB_HIP(hipGetLastError());
+    }
+    if (h->cfg.flags & JB_FLAG_PAIR_WITNESS) {      // one witness pass behind every step launch (the state the launch left)
+        int rc = ensure_witness(h);
+        if (rc) return rc;
+        hipLaunchKernelGGL(jb_witness_kernel, dim3((unsigned)((h->cfg.n_envs + 63) / 64)), dim3(64), 0, h->stream, h->ka, (float*)nullptr, (int*)nullptr, h->d_wit_min, h->d_wit_count);
         JB_HIP(hipGetLastError());
     }
     return JB_OK;
@@ -1503,6 +1543,34 @@ int jb_debug_wave_stats(jb_handle* h, unsigned long long* out, int32_t n_waves) 
     return h->ka.epw;
 }
 #endif
+// The witness for the geom pairs the step kernels do not collide (header; jb_witness.hpp): one pass over the current state, results on the host.
+int jb_pair_witness(jb_handle* h, float* clearance_out, int32_t* pairs_out, int32_t* n_touching) {
+    JB_ENTER(h);
+    int rc = ensure_witness(h);
+    if (rc) return rc;
+    const size_t N = (size_t)h->cfg.n_envs;
+    hipLaunchKernelGGL(jb_witness_kernel, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, h->stream, h->ka, h->d_wit_clear, h->d_wit_pair, (float*)nullptr, (unsigned*)nullptr);
+    JB_HIP(hipGetLastError());
+    std::vector<float> host(N);
+    JB_HIP(hipMemcpyAsync(host.data(), h->d_wit_clear, sizeof(float) * N, hipMemcpyDeviceToHost, h->stream));
+    if (pairs_out) JB_HIP(hipMemcpyAsync(pairs_out, h->d_wit_pair, sizeof(int) * 2 * N, hipMemcpyDeviceToHost, h->stream));
+    JB_HIP(hipStreamSynchronize(h->stream));
+    int touching = 0;
+    for (size_t i = 0; i < N; i++) { if (!(host[i] > 0.f)) touching++; if (clearance_out) clearance_out[i] = host[i]; }
+    if (n_touching) *n_touching = touching;
+    return JB_OK;
+}
+int jb_get_pair_witness(jb_handle* h, uint32_t* overlap_passes, float* min_clearance) {
+    JB_ENTER(h);
+    if (!(h->cfg.flags & JB_FLAG_PAIR_WITNESS)) return fail(JB_E_INVALID, "jb_get_pair_witness: the handle was created without JB_FLAG_PAIR_WITNESS (jb_pair_witness gives one pass on demand)");
+    int rc = ensure_witness(h);
+    if (rc) return rc;
+    const size_t N = (size_t)h->cfg.n_envs;
+    JB_HIP(hipStreamSynchronize(h->stream));
+    if (overlap_passes) JB_HIP(hipMemcpy(overlap_passes, h->d_wit_count, sizeof(unsigned) * N, hipMemcpyDeviceToHost));
+    if (min_clearance) JB_HIP(hipMemcpy(min_clearance, h->d_wit_min, sizeof(float) * N, hipMemcpyDeviceToHost));
+    return JB_OK;
+}
 int jb_set_model_params(jb_handle* h, const double* params, int32_t n_tables) {
     if (!h || !params) return fail(JB_E_INVALID, "handle/params is NULL");
     JB_ENTER(h);

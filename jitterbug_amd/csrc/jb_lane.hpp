@@ -431,6 +431,12 @@ JB_HD Pk2<float> operator-(const Pk2<float>& a) { return Pk2<float>(-a.v); }
 JB_HD float pk_lo(const Pk2<float>& a) { return a.v.x; }
 JB_HD float pk_hi(const Pk2<float>& a) { return a.v.y; }
 #endif
+// A value the optimiser may not look through: an error-free sum (jb_sim.hpp comp_add2) needs its addend rounded ONCE, as a value of its
+// own - never folded into a fused multiply-add with the sum that follows.
+template <typename V> JB_HD Pk2<V> pk_pin(const Pk2<V>& a) { return a; }          // (the host builds do not contract across statements)
+#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+JB_HD Pk2<float> pk_pin(const Pk2<float>& a) { jb_f32x2 r = a.v; asm("" : "+v"(r)); return Pk2<float>(r); }
+#endif
 template <typename V> struct lane_traits<Pk2<V>> { using mask = typename lane_traits<V>::mask; using uint = typename lane_traits<V>::uint; using real = typename lane_traits<V>::real; };
 
 // unsigned helpers

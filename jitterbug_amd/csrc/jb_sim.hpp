@@ -1814,6 +1814,15 @@ template <typename V> JB_HD void comp_add(V& hi, V& lo, const V& d, bool big_hi 
     hi = vadd_rn(s, l);
     lo = vadd_rn(l, -vadd_rn(hi, -s));
 }
+// the same for two values at once (a pair of quaternion components): Knuth's two_sum on packed adds - no products in it, so nothing the
+// compiler could fuse once the addend is pinned
+template <typename V> JB_HD void comp_add2(Pk2<V>& hi, Pk2<V>& lo, const Pk2<V>& d_in) {
+    const Pk2<V> d = pk_pin(d_in);
+    const Pk2<V> s = hi + d, bb = s - hi, e = (hi - (s - bb)) + (d - bb);
+    const Pk2<V> l = lo + e, h2 = s + l;
+    lo = l - (h2 - s);
+    hi = h2;
+}
 // |q|^2 - 1 of a quaternion held as hi + lo, to ~1e-14: exact squares (fma residuals) and a compensated sum
 template <typename V> JB_HD V quat_norm_excess(const V (&h)[4], const V (&l)[4]) {
     V p[4], r[4];
@@ -2727,15 +2736,18 @@ JB_HD bool substep_impl(const LaneModel<V>& m, const LaneScratch<V>& sc, LaneSta
         V sc_ = half * (V(1) + a2_ * (V(-1.0 / 6) + a2_ * (V(1.0 / 120) + a2_ * V(-1.0 / 5040))));
         V cm1 = a2_ * (V(-0.5) + a2_ * (V(1.0 / 24) + a2_ * V(-1.0 / 720)));
         V dx = s.wx * sc_, dy = s.wy * sc_, dz = s.wz * sc_;
-        V qh[4] = {s.qw, s.qx, s.qy, s.qz}, ql[4] = {s.qw_lo, s.qx_lo, s.qy_lo, s.qz_lo};
-        const V d0 = qh[0] * cm1 - qh[1] * dx - qh[2] * dy - qh[3] * dz;
-        const V d1 = qh[0] * dx + qh[1] * cm1 + qh[2] * dz - qh[3] * dy;
-        const V d2 = qh[0] * dy - qh[1] * dz + qh[2] * cm1 + qh[3] * dx;
-        const V d3 = qh[0] * dz + qh[1] * dy - qh[2] * dx + qh[3] * cm1;
-        comp_add(qh[0], ql[0], d0); comp_add(qh[1], ql[1], d1); comp_add(qh[2], ql[2], d2); comp_add(qh[3], ql[3], d3);
+        // the four components as two pairs (w, x) (y, z):
+        //   d0 = qw cm1 - qx dx - qy dy - qz dz      d1 = qw dx + qx cm1 + qy dz - qz dy
+        //   d2 = qw dy - qx dz + qy cm1 + qz dx      d3 = qw dz + qx dy - qy dx + qz cm1
+        using W = Pk2<V>;
+        W q01 = W(s.qw, s.qx), q23 = W(s.qy, s.qz), l01 = W(s.qw_lo, s.qx_lo), l23 = W(s.qy_lo, s.qz_lo);
+        const W d01 = W(s.qw) * W(cm1, dx) + W(s.qx) * W(-dx, cm1) + W(s.qy) * W(-dy, dz) + W(s.qz) * W(-dz, -dy);
+        const W d23 = W(s.qw) * W(dy, dz) + W(s.qx) * W(-dz, dy) + W(s.qy) * W(cm1, -dx) + W(s.qz) * W(dx, cm1);
+        comp_add2(q01, l01, d01); comp_add2(q23, l23, d23);
         // (no renormalisation here: the update preserves |q| up to the rounding of the bracket, ~1e-10 per substep; mj_kinematics'
         //  per-step normalisation is applied once per control step by normalise_state() - the difference is below 1e-8 in |q|)
-        s.qw = qh[0]; s.qx = qh[1]; s.qy = qh[2]; s.qz = qh[3]; s.qw_lo = ql[0]; s.qx_lo = ql[1]; s.qy_lo = ql[2]; s.qz_lo = ql[3];
+        s.qw = pk_lo(q01); s.qx = pk_hi(q01); s.qy = pk_lo(q23); s.qz = pk_hi(q23);
+        s.qw_lo = pk_lo(l01); s.qx_lo = pk_hi(l01); s.qy_lo = pk_lo(l23); s.qz_lo = pk_hi(l23);
     }
     s.th1 = s.th1 + h * s.thd1; s.th2 = s.th2 + h * s.thd2;
     {

@@ -57,7 +57,7 @@ class JitterbugVecEnv:
     def __init__(self, n_envs, task="move_from_origin", seed=0, device_id=0, random_pose=True, contacts=True,
                  time_limit=DEFAULT_TIME_LIMIT, control_timestep=DEFAULT_CONTROL_TIMESTEP, auto_reset=True,
                  env_offset=0, max_newton=0, stream=None, params=None, envs_per_wave=0, flags=0, variant=None, per_env_model=False,
-                 envs_per_gpu=None):
+                 envs_per_gpu=None, pair_witness=False):
         """variant: 'auto' | 'ordinary' | 'lean' (jitterbug_amd.variants: 'auto' picks the two-waves-per-SIMD kernel above 4096 envs per
         GPU, from 8192 with one model per env); None keeps `flags` as given (JB_FLAG_LEAN = 2 by hand).  per_env_model: the batch will get
         one model per env (randomise_models / set_model_params with N tables) - 'auto' needs to know at creation.  envs_per_gpu: what
@@ -87,6 +87,8 @@ class JitterbugVecEnv:
         cfg.envs_per_wave = int(envs_per_wave)
         if variant is not None:
             flags = variants.flags_for(variant, self.num_envs if envs_per_gpu is None else envs_per_gpu, per_env_model, flags)
+        if pair_witness:
+            flags = int(flags) | _lib.FLAG_PAIR_WITNESS
         cfg.flags = int(flags)
         cfg.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
         cfg.env_offset = int(env_offset)
@@ -232,6 +234,14 @@ class JitterbugVecEnv:
             cfg.sd_legs[:] = [float(x) for x in sd_legs]
         if sd_mass_pos is not None:
             cfg.sd_mass_pos[:] = [float(x) for x in sd_mass_pos]
+        # the reference's sigmas are the tested distribution (tests/test_gpu_clearance.py: no unsimulated geom pair ever touches); beyond them
+        # bodies may pass through each other where MuJoCo would collide them - the pair witness says whether they do
+        ref_legs, ref_mass = (0.003, 0.003, 0.002), (0.0015, 0.002, 0.001)
+        wide = any(float(x) > r * (1 + 1e-9) for x, r in zip(cfg.sd_legs, ref_legs)) or any(float(x) > r * (1 + 1e-9) for x, r in zip(cfg.sd_mass_pos, ref_mass))
+        if wide and not (int(self.cfg.flags) & _lib.FLAG_PAIR_WITNESS):
+            import warnings
+            warnings.warn("randomise_models: sigmas beyond the reference's (augmented_jitterbug.py:96-98) - only the mass / thread against the upper legs are collided as geom-geom "
+                          "pairs; create the env with pair_witness=True (JB_FLAG_PAIR_WITNESS) or call pair_witness() to see whether one of the other 152 pairs interpenetrates", RuntimeWarning)
         n = self.num_envs
         if return_params is None:
             return_params = n <= 8192
@@ -253,6 +263,22 @@ class JitterbugVecEnv:
         if return_offsets:
             out["offsets"] = off
         return out
+
+    def pair_witness(self):
+        """One pass of the pair witness on the current state (jb_pair_witness): (clearance [N] in metres - the smallest exact distance over the
+        152 geom pairs MuJoCo would test and the simulator does not collide, 0 = a pair interpenetrates -, pairs [N, 2] geom indices)."""
+        d = np.zeros(self.num_envs, dtype=np.float32)
+        pr = np.zeros((self.num_envs, 2), dtype=np.int32)
+        _lib.check(self._L.jb_pair_witness(self._h, _lib.ptr(d), pr.ctypes.data, None))
+        return d, pr
+
+    def pair_witness_counters(self):
+        """Handles made with pair_witness=True (JB_FLAG_PAIR_WITNESS): (passes [N] that found an unsimulated pair interpenetrating - one pass
+        runs behind every step launch -, smallest clearance [N] seen) since the env was created."""
+        c = np.zeros(self.num_envs, dtype=np.uint32)
+        m = np.zeros(self.num_envs, dtype=np.float32)
+        _lib.check(self._L.jb_get_pair_witness(self._h, c.ctypes.data, _lib.ptr(m)))
+        return c, m
 
     def model_params(self, index=0):
         """The parameter table (float64[NPARAM]) env `index` is simulated with."""

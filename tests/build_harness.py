@@ -5,7 +5,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.path.join(HERE, "_build", "libjb_hostsim.so")
 SRC = os.path.join(HERE, "host_harness.cpp")
-DEPS = [SRC] + [os.path.join(HERE, "..", "jitterbug_amd", "csrc", f) for f in ("jb_sim.hpp", "jb_lane.hpp", "jb_step.hpp", "jb_task.hpp", "jb_model_build.hpp", "jb_device_guard.hpp")]
+DEPS = [SRC] + [os.path.join(HERE, "..", "jitterbug_amd", "csrc", f) for f in ("jb_sim.hpp", "jb_lane.hpp", "jb_step.hpp", "jb_task.hpp", "jb_model_build.hpp", "jb_device_guard.hpp", "jb_witness.hpp")]
 
 
 def build(row_k=None):

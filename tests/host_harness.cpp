@@ -342,6 +342,19 @@ extern "C" int jbh_lm_count(void) { return LM_COUNT; }
 // the per-leg constant table (LM_COUNT doubles) for inspection by tests / tools
 extern "C" int jbh_lane_table(const double* P, int leg, double* out) { return build_lane_model<double>(P, leg, out); }
 
+// ---- jb_witness.hpp (the run-time witness for the geom pairs the simulator does not collide) on the host: one configuration, from the
+// float constant table the device kernel reads -> smallest distance over the unsimulated pairs and the geoms that attain it
+#include "../jitterbug_amd/csrc/jb_witness.hpp"
+extern "C" int jbh_witness(const double* P, const double* qpos, int* pair, double* out) {
+    static thread_local float tab[LM_TABLE];
+    const int rc = build_packed_model<float>(P, tab);
+    if (rc) return rc;
+    double th1[4], th2[4];
+    for (int l = 0; l < 4; l++) { th1[l] = qpos[7 + 2 * l]; th2[l] = qpos[8 + 2 * l]; }
+    *out = witness_clearance<float>(tab, th1, th2, qpos[15], pair);
+    return 0;
+}
+
 // ---- jb_device_guard.hpp against a recording stub of hipGetDevice / hipSetDevice (the library instantiates it with the real ones)
 #include "../jitterbug_amd/csrc/jb_device_guard.hpp"
 namespace {

@@ -63,3 +63,58 @@ def test_no_geom_pair_ever_touches(regime):
         assert worst > 0.0, (worst, worst_pair)
     if regime.startswith("flat_out"):
         assert tipped > 0.1                              # the regime really has robots lying on their legs
+
+
+def test_pair_witness_fires_where_the_clearance_oracle_says():
+    """a run-time witness for the 152 geom pairs the simulator does not collide (jb_pair_witness / JB_FLAG_PAIR_WITNESS,
+    reference jitterbug.xml:44-107: every geom collides).  With sigmas TWICE the reference's some robots do push unsimulated pairs into each
+    other: the witness must fire for exactly the envs oracle/jb_clearance.c's exact GJK says, warn the caller who widened the sigmas without
+    it, and stay silent on the reference's own distribution."""
+    import warnings
+    from jitterbug_amd.vec_env import JitterbugVecEnv
+    from oracle import oracle as O
+    n = 2048
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        plain = JitterbugVecEnv(64, "move_to_pose", seed=1)
+        plain.randomise_models(seed=3, sd_legs=(0.006, 0.006, 0.004))
+        assert any("pair_witness" in str(x.message) for x in w), "widened sigmas without the witness must warn"
+        plain.close()
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                      # with the witness on, no warning
+        env = JitterbugVecEnv(n, "move_to_pose", seed=8, time_limit=float("inf"), auto_reset=False, pair_witness=True)
+        out = env.randomise_models(seed=11, sd_legs=(0.006, 0.006, 0.004), sd_mass_pos=(0.003, 0.004, 0.002))
+    P = out["params"]
+    env.reset()
+    rng = np.random.default_rng(5)
+    fired_any = np.zeros(n, bool)
+    agree = checked = 0
+    for t in range(120):
+        env.step(rng.uniform(-1, 1, size=n).astype(np.float32))
+        if t % 20 == 19:
+            d_w, pairs_w = env.pair_witness()
+            q, _, _ = env.get_state()
+            d_o, pairs_o = O.pair_clearance(P, q, skip_simulated=True)
+            clear_cut = np.abs(d_o) > 1e-7                   # (a pair within 0.1 um of touching may fall either side in the float tables)
+            assert np.array_equal((d_w <= 0)[clear_cut | (d_o <= 0)], (d_o <= 0)[clear_cut | (d_o <= 0)])
+            np.testing.assert_allclose(d_w[d_o > 0], d_o[d_o > 0], atol=5e-8)
+            far = d_o > 1e-6
+            assert np.array_equal(pairs_w[far], pairs_o[far])
+            fired_any |= d_w <= 0
+            checked += n
+    counts, dmin = env.pair_witness_counters()
+    print("2 x sigmas: %d of %d envs had an unsimulated pair interpenetrating at a sampled state; counters fired in %d envs (every launch is watched), smallest clearance %.3f mm"
+          % (fired_any.sum(), n, (counts > 0).sum(), 1e3 * dmin.min()))
+    assert fired_any.sum() >= 5                              # the counter fires ...
+    assert np.all(counts[fired_any] > 0) and np.all(dmin[fired_any] == 0)      # ... and the per-launch passes saw every env the samples saw
+    env.close()
+    # the reference's own distribution: nothing to report (4096 robots x 100 steps)
+    ref = JitterbugVecEnv(4096, "move_to_pose", seed=8, pair_witness=True)
+    ref.randomise_models(seed=11, return_params=False)
+    ref.reset()
+    for t in range(100):
+        ref.step(rng.uniform(-1, 1, size=4096).astype(np.float32))
+    counts, dmin = ref.pair_witness_counters()
+    print("reference sigmas: %d envs with an overlap, smallest clearance of an unsimulated pair %.3f mm" % ((counts > 0).sum(), 1e3 * dmin.min()))
+    assert (counts > 0).sum() == 0 and dmin.min() > 0
+    ref.close()

