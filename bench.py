@@ -432,7 +432,7 @@ def main(argv=None):
         ws, ds, _, fs = run(args.contacts, 300, 100, gather=use_gather)
         ws = rank_max(ws)
         steady = {"value": total_envs * 300 / ws, "unit": "env steps/s", "ms_per_step": ws * 1e3 / 300, "launch_ms": ds / 300, "steps": 300, "warmup": 100,
-                  "window": "steps 100-400 of the episode (some robots have tipped over by then; the window of profiles/r05_*)", "finite": fs}
+                  "window": "steps 100-400 of the episode (some robots have tipped over by then; the window of profiles/r06_*)", "finite": fs}
         if world == 1 and dist is None:
             wf, df, _, ff = run(args.contacts, 1000, 0, gather=False)
             full_episode = {"value": total_envs * 1000 / wf, "unit": "env steps/s", "ms_per_step": wf * 1e3 / 1000, "launch_ms": df / 1000, "steps": 1000, "warmup": 0,
@@ -573,15 +573,28 @@ def main(argv=None):
                      "what": "jb_step with host buffers through the Python VecEnv (H2D actions + kernel + D2H obs/reward/done + sync + numpy copies per step)"}
         # the same through step_async / step_wait (jb_step_async: pinned staging, the copies and the kernel queued at once, an event to wait on) with
         # the caller's own work between the halves - here: drawing the next step's actions, what a policy would be doing
+        # A caller with work of its own between the halves (the learner's bookkeeping: here 0.3 ms of numpy per step, independent of the
+        # step's results): with step() the two add up, with step_async / step_wait the GPU steps underneath
+        Wm = rs.normal(size=(256, 256)).astype(np.float32)
+
+        def host_work():
+            x = Wm
+            t_end = time.perf_counter() + 0.0003
+            while time.perf_counter() < t_end:
+                x = np.tanh(x @ Wm * 1e-2)
+            return x
+        t0 = time.perf_counter()
+        for i in range(kh):
+            env.step(acts[i % 64]); host_work()
+        sync_with_work = n * kh / (time.perf_counter() - t0)
         env.step_async(acts[0]); env.step_wait()
         t0 = time.perf_counter()
-        nxt = acts[0]
         for i in range(kh):
-            env.step_async(nxt)
-            nxt = acts[(i + 1) % 64] * 1.0          # host work that overlaps the step
+            env.step_async(acts[i % 64])
+            host_work()
             env.step_wait(copy=False)
-        host_rate["async"] = {"value": n * kh / (time.perf_counter() - t0), "unit": "env steps/s", "steps": kh,
-                              "what": "step_async -> (host prepares the next actions) -> step_wait(copy=False): pinned buffers, no stream sync inside the call, results read in place"}
+        host_rate["async"] = {"value": n * kh / (time.perf_counter() - t0), "unit": "env steps/s", "steps": kh, "sync_with_the_same_host_work": sync_with_work, "host_work_ms_per_step": 0.3,
+                              "what": "step_async -> 0.3 ms of the caller's own numpy work -> step_wait(copy=False) (jb_step_async / jb_step_wait: pinned buffers, copies and kernel queued at once, an event to wait on, results read in place) against step() followed by the same work"}
         env.close()
 
     if rank == 0:
@@ -593,7 +606,7 @@ def main(argv=None):
         lib_sha = hashlib.sha256(open(_lib.LIB_PATH, "rb").read()).hexdigest()
         traffic = None
         compute = None
-        PROFILE = "profiles/r05_pmc_raw.json"
+        PROFILE = "profiles/r06_pmc_raw.json"
         prof_note = "no PMC summary for this build/workload (tools/collect_profiles.sh + tools/summarise_profiles.py write one)"
         try:
             raw = json.load(open(os.path.join(ROOT, PROFILE)))
@@ -622,6 +635,7 @@ def main(argv=None):
                     # fp32 operations per launch: wave-instructions by type (an FMA counts 2) x the lanes that really executed them
                     wave_ops = 2.0 * sq["SQ_INSTS_VALU_FMA_F32"] + sq["SQ_INSTS_VALU_ADD_F32"] + sq["SQ_INSTS_VALU_MUL_F32"] + sq["SQ_INSTS_VALU_TRANS_F32"]
                     lanes = sq["SQ_THREAD_CYCLES_VALU"] / sq["SQ_ACTIVE_INST_VALU"] if sq.get("SQ_THREAD_CYCLES_VALU") and sq.get("SQ_ACTIVE_INST_VALU") else None
+                    compute["packed_note"] = "since round 6 a fifth of the VALU instructions are packed (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two fp32 operations per lane); the SQ_INSTS_VALU_*_F32 counters count each ONCE, so the FLOP figures below are lower bounds"
                     compute.update({"fp32_wave_insts_per_launch": {"fma": sq["SQ_INSTS_VALU_FMA_F32"], "add": sq["SQ_INSTS_VALU_ADD_F32"], "mul": sq["SQ_INSTS_VALU_MUL_F32"], "trans": sq["SQ_INSTS_VALU_TRANS_F32"]},
                                     "mean_active_lanes_per_valu_inst": lanes,
                                     "fp32_tflops_full_wave": wave_ops * 64.0 / k_s / 1e12,          # rocprof-compute's convention: every instruction counted at 64 lanes

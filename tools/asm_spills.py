@@ -3,7 +3,8 @@
     hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -mllvm -disable-vector-combine -w -S --cuda-device-only -o /tmp/jb.s jitterbug_amd/csrc/jb_api.hip
     python tools/asm_spills.py /tmp/jb.s [kernel-name-substring]
 
-For every step kernel: static instruction count, and the scratch_ / v_writelane / v_readlane operations split by the loop they are in.
+For every step kernel: static instruction count, the scratch_ / v_writelane / v_readlane operations and the packed fp32 instructions
+(v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32) split by the loop they are in.
 Loops are found from backward branches (label .LBBn_m defined above its s_cbranch / s_branch); the SUBSTEP loop is taken to be the
 largest loop nested inside the outermost one (the control-step loop)."""
 import re
@@ -44,9 +45,9 @@ for (i0, name), i1 in zip(starts, ends):
         return sum(1 for j in inst_idx if lo <= j <= hi and pred(body[j]) and not (skip and skip[0] <= j <= skip[1]))
 
     def report(lo, hi, skip=None):
-        return "insts %6d  scratch %4d  writelane %4d  readlane %4d  accvgpr %4d" % (
+        return "insts %6d  scratch %4d  writelane %4d  readlane %4d  accvgpr %4d  v_pk_* %4d" % (
             count(lambda l: True, lo, hi, skip), count(lambda l: "scratch_" in l, lo, hi, skip), count(lambda l: "v_writelane" in l, lo, hi, skip),
-            count(lambda l: "v_readlane" in l, lo, hi, skip), count(lambda l: "v_accvgpr" in l, lo, hi, skip))
+            count(lambda l: "v_readlane" in l, lo, hi, skip), count(lambda l: "v_accvgpr" in l, lo, hi, skip), count(lambda l: re.match(r"^\s+v_pk_(fma|mul|add)_f32", l) is not None, lo, hi, skip))
 
     short = re.sub(r"^_ZN12_GLOBAL__N_1\d+", "", name)[:44]
     print("%-44s whole        %s" % (short, report(0, len(body))))
