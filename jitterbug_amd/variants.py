@@ -3,9 +3,9 @@ all resolve `variant="auto"` here).
 
 The reference's harness builds a vectorised env with no knobs (benchmarks/benchmark.py:146-171); so does `variant="auto"`:
 
-  ordinary   one four-env wave per SIMD (256 VGPRs + 220 AGPRs, 26.6 KB of LDS; profiles/r05_kernel_resources.txt): the fastest kernel while a GPU holds at
+  ordinary   one four-env wave per SIMD (256 VGPRs + 256 AGPRs, 26.6 KB of LDS; profiles/r06_kernel_resources.txt): the fastest kernel while a GPU holds at
              most one wave per SIMD
-  lean       two four-env waves per SIMD (256 VGPRs, no AGPRs - the registers it spills are used in its cold second contact solve, profiles/r05_asm_spills.txt -,
+  lean       two four-env waves per SIMD (256 VGPRs, no AGPRs - most of what it spills is used in its cold second contact solve, profiles/r06_asm_spills.txt -,
              <= 20.4 KB of LDS: eight waves per CU, JB_FLAG_LEAN): pays as soon as a GPU has
              more waves than SIMDs, i.e. from 4097 envs with a shared model - the one-wave kernel would need a second round for the
              rest.  While the batch still fits the device at once (up to two waves per SIMD) the library chooses WHO shares a SIMD with

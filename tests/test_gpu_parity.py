@@ -211,7 +211,7 @@ def test_step_teacher_forced_tipped_over_robots():
 
 
 def test_lean_kernel_variant_parity():
-    """JB_FLAG_LEAN: the two-waves-per-SIMD variant of the step kernel (256 VGPRs, no AGPRs - profiles/r05_kernel_resources.txt; state / system / factorisation parked in LDS,
+    """JB_FLAG_LEAN: the two-waves-per-SIMD variant of the step kernel (256 VGPRs, no AGPRs - profiles/r06_kernel_resources.txt; state / system / factorisation parked in LDS,
     20 KB of LDS per four-env wave) under the same protocol, and against the ordinary variant from identical states (the compiler fuses multiply-adds differently in
     the two kernels, so they agree to rounding, not bit for bit - on the host, without contraction, they are identical)."""
     from jitterbug_amd.vec_env import JitterbugVecEnv
