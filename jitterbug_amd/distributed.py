@@ -202,10 +202,17 @@ class ShardedJitterbugEnv:
             # the communicator id: made by rank 0, handed round once over the process group (control traffic; 128 bytes)
             box = [self.env.comm_unique_id() if self.rank == 0 else None]
             dist.broadcast_object_list(box, src=0, group=group)
-            self.env.comm_init(self.world, self.rank, box[0])
-            # the partition, the same list on every rank: the exchanges move blocks of the longest shard (uneven splits pad to it), and a rank
-            # whose env does not hold what the list says is refused here instead of hanging the first exchange
-            self.env.comm_set_shards(self.sizes)
+            try:
+                self.env.comm_init(self.world, self.rank, box[0])
+                # the partition, the same list on every rank: the exchanges move blocks of the longest shard (uneven splits pad to it), and a rank
+                # whose env does not hold what the list says is refused here instead of hanging the first exchange
+                self.env.comm_set_shards(self.sizes)
+            except Exception:
+                env, self.env = self.env, None          # a half-built object leaves nothing behind: no communicator, no handle
+                try:
+                    env.close()
+                finally:
+                    raise
             self._ops = stream_ops if stream_ops is not None else _CudaStreamOps(self.device)
         # (in the row-buffer logic below "nccl" means: rows stay on the device and the gather is ordered by streams - true of both RCCL paths)
         self._nccl = self._device_rows and (self._cabi or dist.get_backend(group) == "nccl")
