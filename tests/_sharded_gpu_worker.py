@@ -1,4 +1,4 @@
-"""Worker of tests/test_gpu_surface.py::test_sharded_env_two_ranks_one_gpu (launched by torch.distributed.run, 2 ranks on cuda:0, gloo)."""
+"""Worker of tests/test_gpu_surface.py::test_sharded_env_two_ranks_one_gpu (launched by torch.distributed.run, 2 or 4 ranks on cuda:0, gloo)."""
 import os, sys
 import numpy as np
 import torch
@@ -28,6 +28,8 @@ for t in range(6):
         assert np.array_equal(o1, o2) and np.array_equal(r1, r2) and np.array_equal(d1, d2.astype(bool)), "step %d differs" % t
     else:
         assert res is None
+sh.close(); sh.close()
+assert sh.env is None
 # the pipelined product path (what bench.py --gpus N times): results arrive one call late, bit-identical
 sh2 = ShardedJitterbugEnv(n, task, seed=4, device="cuda:0", pipeline_depth=2)
 sh2.reset()
@@ -68,6 +70,7 @@ if rank == 0:
     o2, r2, d2, _ = expected[-1]
     o1, r1, d1 = (x.cpu().numpy() for x in res.get())
     assert np.array_equal(o1, o2) and np.array_equal(r1, r2), "pipelined flush differs"
+sh2.close()
 # the fused rollout across shards: K steps in one launch per rank, ONE gather of [K, N_local, D+2]; tape from rank 0, per-rank tapes,
 # and the in-kernel heuristic policy - each bit-identical to the same K steps of one unsharded env
 K = 9
@@ -94,6 +97,7 @@ for mode in ("global_tape", "local_tape", "policy"):
         w.close()
     else:
         assert res is None
+    sh3.close()
 dist.barrier()
 if rank == 0:
     print("SHARDED_OK", flush=True)

@@ -169,13 +169,15 @@ def test_monitored_vec_env(tmp_path):
     assert lines[0].startswith("#{") and lines[1] == "r,l,t" and len(lines) == 22
 
 
-def test_sharded_env_two_ranks_one_gpu():
-    """The N>1 data path (scatter -> jb_step_rows_device -> gather) with two ranks sharing cuda:0 over gloo: bit-identical to
-    one unsharded env.  (RCCL needs one GPU per rank, which the test box does not have; the collectives are staged.)"""
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_env_two_ranks_one_gpu(world):
+    """The N>1 data path (scatter -> jb_step_rows_device -> gather) with two - and four: ranks >= 2, an uneven 251 / 251 / 251 / 250 split -
+    ranks sharing cuda:0 over gloo: bit-identical to one unsharded env, both pipeline depths, fused rollouts, close().  (RCCL needs one GPU
+    per rank, which the test box does not have; the collectives are staged.)"""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29533", os.path.join(root, "tests", "_sharded_gpu_worker.py")]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(29533 + world), os.path.join(root, "tests", "_sharded_gpu_worker.py")]
     r = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "SHARDED_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
 
