@@ -116,24 +116,23 @@ def test_step_async_overlaps_host_work_and_equals_step():
     with pytest.raises(Exception):
         a_env.step(acts[0])                                      # jb_step refuses while a step is in flight
     a_env.step_wait(); s_env.step(acts[0])
-    t0 = time.perf_counter()
+    dev_t = []
     for k in range(20, steps):
+        t0 = time.perf_counter()
         s_env.step(acts[k])
-    dev_s = (time.perf_counter() - t0) / (steps - 20)           # one synchronous step, device + copies
-    outs = []
-    t0 = time.perf_counter()
+        dev_t.append(time.perf_counter() - t0)
+    dev_s = float(np.median(dev_t))                              # one synchronous step, device + copies (medians: a shared box preempts now and then)
+    outs, both_t = [], []
     for k in range(20, steps):
+        t0 = time.perf_counter()
         a_env.step_async(acts[k])
         busy(host_s)                                             # the caller's own work (a policy's forward pass, say)
         o, r, d, _ = a_env.step_wait(copy=False)
+        both_t.append(time.perf_counter() - t0)
         outs.append((o.copy(), r.copy(), d.copy()))
-    both_s = (time.perf_counter() - t0) / (steps - 20) - 0.0     # per step, including the three copies made for the comparison below
-    copies_s = 0.0
-    t0 = time.perf_counter()
-    for _ in range(50):
-        (o.copy(), r.copy(), d.copy())
-    copies_s = (time.perf_counter() - t0) / 50
-    assert both_s - copies_s <= 1.05 * max(host_s, dev_s) + 2e-5, "async step %.3f ms vs host %.3f ms / device %.3f ms: the halves add up instead of overlapping" % (1e3 * (both_s - copies_s), 1e3 * host_s, 1e3 * dev_s)
+    both_s = float(np.median(both_t))
+    assert both_s <= 1.05 * max(host_s, dev_s) + 2e-5, "async step %.3f ms vs host %.3f ms / device %.3f ms: the halves add up instead of overlapping" % (1e3 * both_s, 1e3 * host_s, 1e3 * dev_s)
+    assert both_s < 0.8 * (host_s + dev_s), (both_s, host_s, dev_s)
     ref = JitterbugVecEnv(n, "move_from_origin", seed=3)
     ref.reset()
     for k in list(range(20)) + [0]:
